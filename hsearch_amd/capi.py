@@ -1,0 +1,245 @@
+"""ctypes binding of include/hsearch.h.  No compute here; everything runs in libhsearch_amd.so."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+HS_OK, HS_ERR_INVALID, HS_ERR_NO_DEVICE, HS_ERR_HIP, HS_ERR_CAPACITY, HS_ERR_STATE, \
+    HS_ERR_KEY_COLLISION, HS_ERR_NOMEM = range(8)
+_STATUS = ["HS_OK", "HS_ERR_INVALID", "HS_ERR_NO_DEVICE", "HS_ERR_HIP", "HS_ERR_CAPACITY",
+           "HS_ERR_STATE", "HS_ERR_KEY_COLLISION", "HS_ERR_NOMEM"]
+
+# Row order of the embedding table (include/hs_tables.h HS_CODE_TO_LETTER): BLOSUM order.
+_ALPHABET = "ARNDCQEGHILKMFPSTWYV"
+
+EXPORTS = ["hs_create", "hs_destroy", "hs_last_error", "hs_get_profile", "hs_version",
+           "hs_embed_codes", "hs_hash_codes", "hs_hash_points", "hs_key_string", "hs_index_build",
+           "hs_index_info_get", "hs_query", "hs_query_dev", "hs_bruteforce", "hs_bruteforce_topk"]
+
+
+class HsError(RuntimeError):
+    def __init__(self, status, message):
+        self.status = status
+        name = _STATUS[status] if 0 <= status < len(_STATUS) else str(status)
+        super().__init__("%s: %s" % (name, message))
+
+
+class _Params(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("K", C.c_uint32), ("L", C.c_uint32), ("W", C.c_double),
+                ("device", C.c_int32), ("flags", C.c_uint32)]
+
+
+class _Profile(C.Structure):
+    _fields_ = [("ms_hash", C.c_double), ("ms_sort", C.c_double), ("ms_gather", C.c_double),
+                ("ms_probe", C.c_double), ("ms_verify", C.c_double), ("ms_finalize", C.c_double),
+                ("ms_total", C.c_double), ("candidates", C.c_uint64), ("provisional", C.c_uint64),
+                ("hits", C.c_uint64), ("verify_launches", C.c_uint64)]
+
+
+class _IndexInfo(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("device_bytes", C.c_uint64), ("n_buckets", C.c_uint64 * 32),
+                ("max_bucket", C.c_uint64 * 32), ("key_seed", C.c_uint32)]
+
+
+profile_fields = [f[0] for f in _Profile._fields_]
+
+_lib = None
+
+
+def lib_path():
+    return os.path.join(_HERE, "libhsearch_amd.so")
+
+
+def load():
+    """Load libhsearch_amd.so.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; "
+                              "g.build()'` (or make -C hsearch_amd/csrc)" % path)
+        lib = C.CDLL(path)
+        lib.hs_version.restype = C.c_char_p
+        lib.hs_last_error.restype = C.c_char_p
+        lib.hs_last_error.argtypes = [C.c_void_p]
+        lib.hs_destroy.restype = None
+        lib.hs_destroy.argtypes = [C.c_void_p]
+        lib.hs_key_string.restype = C.c_uint32
+        _lib = lib
+    return _lib
+
+
+def alphabet():
+    return _ALPHABET
+
+
+def codes_from_letters(seqs):
+    """['ARND...', ...] (equal lengths, letters of the 20-letter alphabet) -> uint8 [n][k]."""
+    lut = np.full(256, 255, dtype=np.uint8)
+    for i, ch in enumerate(_ALPHABET):
+        lut[ord(ch)] = i
+    arr = np.frombuffer("".join(seqs).encode(), dtype=np.uint8)
+    codes = lut[arr].reshape(len(seqs), -1)
+    if (codes == 255).any():
+        raise ValueError("letter outside ARNDCQEGHILKMFPSTWYV")
+    return codes
+
+
+def key_string(buckets):
+    b = np.ascontiguousarray(buckets, dtype=np.int32)
+    buf = C.create_string_buffer(12 * len(b) + 1)
+    load().hs_key_string(b.ctypes.data_as(C.c_void_p), C.c_uint32(len(b)), buf, C.c_uint32(len(buf)))
+    return buf.value.decode()
+
+
+def _vp(arr):
+    return arr.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One handle = one GPU + one index.  Mirrors the reference's operator surface:
+    LSH(dim, K, W) x L  ->  Engine(k, K, L, W, a, b);  HashBucketIndex -> hash_points/hash_codes;
+    Search() build loop -> index_build; Search() query loop -> query; noLSH Search() -> bruteforce.
+    """
+
+    def __init__(self, k, K, L, W, a, b, device=0, coords=None):
+        self._lib = load()
+        self.k, self.K, self.L, self.W = int(k), int(K), int(L), float(W)
+        self.d = 8 * self.k
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        assert a.shape == (self.L, self.K, self.d), a.shape
+        assert b.shape == (self.L, self.K), b.shape
+        cptr = None
+        if coords is not None:
+            coords = np.ascontiguousarray(coords, dtype=np.float64)
+            assert coords.shape == (20, 8)
+            cptr = _vp(coords)
+        params = _Params(self.k, self.K, self.L, self.W, int(device), 0)
+        self._h = C.c_void_p()
+        st = self._lib.hs_create(C.byref(params), _vp(a), _vp(b), cptr, C.byref(self._h))
+        if st != HS_OK:
+            msg = self._lib.hs_last_error(self._h).decode() if self._h else ""
+            if self._h:
+                self._lib.hs_destroy(self._h)
+                self._h = C.c_void_p()
+            raise HsError(st, msg or "hs_create failed (is a gfx950 GPU visible?)")
+
+    # -- helpers
+    def _check(self, st):
+        if st != HS_OK:
+            raise HsError(st, self._lib.hs_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.hs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def profile(self):
+        p = _Profile()
+        self._check(self._lib.hs_get_profile(self._h, C.byref(p)))
+        return {f: getattr(p, f) for f in profile_fields}
+
+    def index_info(self):
+        info = _IndexInfo()
+        self._check(self._lib.hs_index_info_get(self._h, C.byref(info)))
+        return dict(n=info.n, device_bytes=info.device_bytes,
+                    n_buckets=list(info.n_buckets)[:self.L], max_bucket=list(info.max_bucket)[:self.L],
+                    key_seed=info.key_seed)
+
+    # -- a2 / a4 / a5
+    def embed_codes(self, codes):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        n = codes.shape[0]
+        out = np.empty((n, self.d), dtype=np.float64)
+        self._check(self._lib.hs_embed_codes(self._h, _vp(codes), C.c_uint64(n), _vp(out)))
+        return out
+
+    def hash_codes(self, codes):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        n = codes.shape[0]
+        assert codes.shape == (n, self.k)
+        out = np.empty((n, self.L, self.K), dtype=np.int32)
+        self._check(self._lib.hs_hash_codes(self._h, _vp(codes), C.c_uint64(n), _vp(out)))
+        return out
+
+    def hash_points(self, pts):
+        pts = np.ascontiguousarray(pts, dtype=np.float64)
+        n = pts.shape[0]
+        assert pts.shape == (n, self.d)
+        out = np.empty((n, self.L, self.K), dtype=np.int32)
+        self._check(self._lib.hs_hash_points(self._h, _vp(pts), C.c_uint64(n), _vp(out)))
+        return out
+
+    # -- a7
+    def index_build(self, codes):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        n = codes.shape[0]
+        assert codes.ndim == 2 and codes.shape[1] == self.k
+        self._check(self._lib.hs_index_build(self._h, _vp(codes), C.c_uint64(n)))
+        return self.index_info()
+
+    # -- a8..a10
+    def query(self, centers, R, cap=None, want_cand=True):
+        centers = np.ascontiguousarray(centers, dtype=np.float64)
+        nq = centers.shape[0]
+        assert centers.shape == (nq, self.d)
+        cap = int(cap) if cap is not None else max(1024, 64 * nq)
+        while True:
+            hq = np.empty(cap, dtype=np.uint32)
+            hid = np.empty(cap, dtype=np.uint32)
+            ht = np.empty(cap, dtype=np.uint32)
+            hd = np.empty(cap, dtype=np.float64)
+            cand = np.zeros((nq, self.L), dtype=np.uint64) if want_cand else None
+            n = C.c_uint64(0)
+            st = self._lib.hs_query(self._h, _vp(centers), C.c_uint64(nq), C.c_double(R), _vp(hq),
+                                    _vp(hid), _vp(ht), _vp(hd), C.c_uint64(cap), C.byref(n),
+                                    _vp(cand) if want_cand else None)
+            if st == HS_ERR_CAPACITY:
+                cap = int(n.value)
+                continue
+            self._check(st)
+            n = int(n.value)
+            return dict(q=hq[:n], id=hid[:n], table=ht[:n], dist=hd[:n], cand=cand)
+
+    def query_dev(self, d_centers_ptr, nq, R, d_q, d_id, d_table, d_dist, cap, d_cand=None):
+        """Raw device-pointer call (ints from torch .data_ptr()).  Returns the number of hits; raises
+        HsError(HS_ERR_CAPACITY) with the required size in .needed when cap is too small."""
+        n = C.c_uint64(0)
+        st = self._lib.hs_query_dev(self._h, C.c_void_p(d_centers_ptr), C.c_uint64(nq), C.c_double(R),
+                                    C.c_void_p(d_q), C.c_void_p(d_id), C.c_void_p(d_table),
+                                    C.c_void_p(d_dist), C.c_uint64(cap), C.byref(n),
+                                    C.c_void_p(d_cand) if d_cand else None)
+        if st == HS_ERR_CAPACITY:
+            e = HsError(st, self._lib.hs_last_error(self._h).decode())
+            e.needed = int(n.value)
+            raise e
+        self._check(st)
+        return int(n.value)
+
+    # -- a11
+    def bruteforce(self, centers, R, cap=None):
+        centers = np.ascontiguousarray(centers, dtype=np.float64)
+        nq = centers.shape[0]
+        cap = int(cap) if cap is not None else max(1024, 64 * nq)
+        while True:
+            hq = np.empty(cap, dtype=np.uint32)
+            hid = np.empty(cap, dtype=np.uint32)
+            hd = np.empty(cap, dtype=np.float64)
+            n = C.c_uint64(0)
+            st = self._lib.hs_bruteforce(self._h, _vp(centers), C.c_uint64(nq), C.c_double(R),
+                                         _vp(hq), _vp(hid), _vp(hd), C.c_uint64(cap), C.byref(n))
+            if st == HS_ERR_CAPACITY:
+                cap = int(n.value)
+                continue
+            self._check(st)
+            n = int(n.value)
+            return dict(q=hq[:n], id=hid[:n], dist=hd[:n])

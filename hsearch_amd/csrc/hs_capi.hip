@@ -1,0 +1,615 @@
+// hs_capi.hip -- the C ABI of include/hsearch.h on top of the gfx950 kernels (hs_kernels.hip) and
+// the device primitives (hs_prims.hip).  One handle = one GPU, one stream, one index.
+//
+// HBM layout of an index (N k-mers of k residues, L tables, PW = ceil(k/25) 16-byte words):
+//   codes       [N][k]      u8   original order (exact fp64 re-evaluation of survivors)
+//   packed_all  [N][PW]     u128 5-bit residues, original order (brute force scans this)
+//   per table l:
+//     ids       [N]         u32  DB ids grouped by bucket, ascending inside a bucket
+//     packed    [N][PW]     u128 the same k-mers in bucket order -> a bucket is ONE contiguous,
+//                                coalesced stream for the verify kernel (no gather at query time)
+//     dir_key   [nb]        u64  sorted fingerprints of the distinct HashKey strings
+//     dir_start [nb+1]      u32  bucket boundaries
+//     dir_tuple [nb][K]     i32  bucket ints of each bucket (exact string check at probe time)
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/hs_tables.h"
+#include "hs_internal.h"
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+enum { EV_COUNT = 10 };
+
+}  // namespace
+
+struct hs_handle {
+  hs_params p;
+  int d = 0, LK = 0, PW = 0;
+  int n_cu = 256;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[EV_COUNT];
+  bool ev_ok = false;
+  DevBuf a, b, coords;
+  // index
+  bool built = false;
+  uint64_t n = 0;
+  uint32_t key_seed = 0;
+  DevBuf codes, packed_all;
+  DevBuf t_dirkey[HS_MAX_L], t_dirstart[HS_MAX_L], t_dirtuple[HS_MAX_L], t_packed[HS_MAX_L],
+      t_ids[HS_MAX_L];
+  hs_tables_dev tabs;
+  hs_index_info info;
+  // query workspace (grown on demand, reused across calls)
+  DevBuf qints, qstart, qcount, nslices, slice_off, tq, prov, hit_key, hit_val, hit_key2, hit_val2,
+      counters, temp, io_centers, io_q, io_id, io_table, io_dist, io_cand, io_codes, io_misc;
+  std::string err;
+  hs_profile prof;
+};
+
+namespace {
+
+hs_status fail(hs_handle* h, hs_status st, const std::string& msg) {
+  if (h) h->err = msg;
+  return st;
+}
+
+#define HS_HIP(h, expr)                                                                      \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(h, e_ == hipErrorOutOfMemory ? HS_ERR_NOMEM : HS_ERR_HIP,                  \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+  } while (0)
+
+float ev_ms(hs_handle* h, int i0, int i1) {
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, h->ev[i0], h->ev[i1]) != hipSuccess) return 0.f;
+  return ms;
+}
+
+// smallest float >= x (x >= 0), then one more ulp: the fp32 filter bound must never undercut.
+float filter_bound(double r2) {
+  double hi = r2 * (1.0 + 1e-5) + 1e-30;
+  float f = (float)hi;
+  if ((double)f < hi) f = nextafterf(f, INFINITY);
+  return nextafterf(f, INFINITY);
+}
+
+hs_status ensure_device(hs_handle* h) {
+  HS_HIP(h, hipSetDevice(h->p.device));
+  return HS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* hs_version(void) { return "hsearch_amd 0.1 (gfx950)"; }
+
+const char* hs_last_error(const hs_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+hs_status hs_get_profile(const hs_handle* h, hs_profile* out) {
+  if (!h || !out) return HS_ERR_INVALID;
+  *out = h->prof;
+  return HS_OK;
+}
+
+uint32_t hs_key_string(const int32_t* buckets, uint32_t K, char* out, uint32_t cap) {
+  if (K > HS_MAX_K) K = HS_MAX_K;
+  char tmp[HS_KEY_CHARS];
+  int n = hs_key_chars(buckets, (int)K, tmp);
+  if (cap) {
+    uint32_t m = std::min<uint32_t>((uint32_t)n, cap - 1);
+    memcpy(out, tmp, m);
+    out[m] = 0;
+  }
+  return (uint32_t)n;
+}
+
+hs_status hs_create(const hs_params* params, const double* a, const double* b, const double* coords,
+                    hs_handle** out) {
+  if (!out) return HS_ERR_INVALID;
+  *out = nullptr;
+  if (!params || !a || !b) return HS_ERR_INVALID;
+  if (params->k < 1 || params->k > 75 || params->K < 1 || params->K > HS_MAX_K || params->L < 1 ||
+      params->L > HS_MAX_L || !(params->W > 0.0) || !isfinite(params->W))
+    return HS_ERR_INVALID;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0 || params->device < 0 ||
+      params->device >= n_dev)
+    return HS_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, params->device) != hipSuccess) return HS_ERR_NO_DEVICE;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return HS_ERR_NO_DEVICE;  // CDNA4 code objects only
+  hs_handle* h = new hs_handle();
+  h->p = *params;
+  h->d = 8 * (int)params->k;
+  h->LK = (int)(params->L * params->K);
+  h->PW = hs_packed_words((int)params->k);
+  h->n_cu = prop.multiProcessorCount;
+  memset(&h->tabs, 0, sizeof(h->tabs));
+  memset(&h->info, 0, sizeof(h->info));
+  memset(&h->prof, 0, sizeof(h->prof));
+  *out = h;  // returned even on failure below so the caller can read hs_last_error, then destroy
+  HS_HIP(h, hipSetDevice(params->device));
+  HS_HIP(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  for (int i = 0; i < EV_COUNT; ++i) HS_HIP(h, hipEventCreate(&h->ev[i]));
+  h->ev_ok = true;
+  const size_t na = (size_t)h->LK * h->d;
+  HS_HIP(h, h->a.reserve(na * 8));
+  HS_HIP(h, h->b.reserve((size_t)h->LK * 8));
+  HS_HIP(h, h->coords.reserve(160 * 8));
+  HS_HIP(h, hipMemcpyAsync(h->a.p, a, na * 8, hipMemcpyHostToDevice, h->stream));
+  HS_HIP(h, hipMemcpyAsync(h->b.p, b, (size_t)h->LK * 8, hipMemcpyHostToDevice, h->stream));
+  HS_HIP(h, hipMemcpyAsync(h->coords.p, coords ? coords : &HS_AA_COORDS[0][0], 160 * 8,
+                           hipMemcpyHostToDevice, h->stream));
+  HS_HIP(h, hipStreamSynchronize(h->stream));
+  return HS_OK;
+}
+
+void hs_destroy(hs_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->p.device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  DevBuf* bufs[] = {&h->a, &h->b, &h->coords, &h->codes, &h->packed_all, &h->qints, &h->qstart,
+                    &h->qcount, &h->nslices, &h->slice_off, &h->tq, &h->prov, &h->hit_key,
+                    &h->hit_val, &h->hit_key2, &h->hit_val2, &h->counters, &h->temp,
+                    &h->io_centers, &h->io_q, &h->io_id, &h->io_table, &h->io_dist, &h->io_cand,
+                    &h->io_codes, &h->io_misc};
+  for (DevBuf* bf : bufs) bf->release();
+  for (int l = 0; l < HS_MAX_L; ++l) {
+    h->t_dirkey[l].release();
+    h->t_dirstart[l].release();
+    h->t_dirtuple[l].release();
+    h->t_packed[l].release();
+    h->t_ids[l].release();
+  }
+  if (h->ev_ok)
+    for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(h->ev[i]);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+// ------------------------------------------------------------------------------ embed / hash
+hs_status hs_embed_codes(hs_handle* h, const uint8_t* codes, uint64_t n, double* out) {
+  if (!h || (n && (!codes || !out))) return HS_ERR_INVALID;
+  if (!n) return HS_OK;
+  for (uint64_t i = 0; i < n * h->p.k; ++i)
+    if (codes[i] >= HS_ALPHABET) return fail(h, HS_ERR_INVALID, "residue code >= 20");
+  hs_status st = ensure_device(h);
+  if (st) return st;
+  const size_t out_bytes = (size_t)n * h->d * 8;
+  HS_HIP(h, h->io_codes.reserve((size_t)n * h->p.k));
+  HS_HIP(h, h->io_misc.reserve(out_bytes));
+  HS_HIP(h, hipMemcpyAsync(h->io_codes.p, codes, (size_t)n * h->p.k, hipMemcpyHostToDevice, h->stream));
+  HS_HIP(h, hs_launch_embed(h->io_codes.as<uint8_t>(), n, (int)h->p.k, h->coords.as<double>(),
+                            h->io_misc.as<double>(), h->stream));
+  HS_HIP(h, hipMemcpyAsync(out, h->io_misc.p, out_bytes, hipMemcpyDeviceToHost, h->stream));
+  HS_HIP(h, hipStreamSynchronize(h->stream));
+  return HS_OK;
+}
+
+hs_status hs_hash_codes(hs_handle* h, const uint8_t* codes, uint64_t n, int32_t* buckets) {
+  if (!h || (n && (!codes || !buckets))) return HS_ERR_INVALID;
+  if (!n) return HS_OK;
+  for (uint64_t i = 0; i < n * h->p.k; ++i)
+    if (codes[i] >= HS_ALPHABET) return fail(h, HS_ERR_INVALID, "residue code >= 20");
+  hs_status st = ensure_device(h);
+  if (st) return st;
+  const size_t out_bytes = (size_t)n * h->LK * 4;
+  HS_HIP(h, h->io_codes.reserve((size_t)n * h->p.k));
+  HS_HIP(h, h->io_misc.reserve(out_bytes));
+  HS_HIP(h, hipMemcpyAsync(h->io_codes.p, codes, (size_t)n * h->p.k, hipMemcpyHostToDevice, h->stream));
+  HS_HIP(h, hipEventRecord(h->ev[0], h->stream));
+  HS_HIP(h, hs_launch_hash_codes(h->io_codes.as<uint8_t>(), n, (int)h->p.k, h->a.as<double>(),
+                                 h->b.as<double>(), h->LK, h->p.W, h->coords.as<double>(),
+                                 h->io_misc.as<int32_t>(), h->LK, h->stream));
+  HS_HIP(h, hipEventRecord(h->ev[1], h->stream));
+  HS_HIP(h, hipMemcpyAsync(buckets, h->io_misc.p, out_bytes, hipMemcpyDeviceToHost, h->stream));
+  HS_HIP(h, hipStreamSynchronize(h->stream));
+  memset(&h->prof, 0, sizeof(h->prof));
+  h->prof.ms_hash = h->prof.ms_total = ev_ms(h, 0, 1);
+  return HS_OK;
+}
+
+hs_status hs_hash_points(hs_handle* h, const double* points, uint64_t n, int32_t* buckets) {
+  if (!h || (n && (!points || !buckets))) return HS_ERR_INVALID;
+  if (!n) return HS_OK;
+  hs_status st = ensure_device(h);
+  if (st) return st;
+  const size_t in_bytes = (size_t)n * h->d * 8, out_bytes = (size_t)n * h->LK * 4;
+  HS_HIP(h, h->io_centers.reserve(in_bytes));
+  HS_HIP(h, h->io_misc.reserve(out_bytes));
+  HS_HIP(h, hipMemcpyAsync(h->io_centers.p, points, in_bytes, hipMemcpyHostToDevice, h->stream));
+  HS_HIP(h, hipEventRecord(h->ev[0], h->stream));
+  HS_HIP(h, hs_launch_hash_points(h->io_centers.as<double>(), n, (int)h->p.k, h->a.as<double>(),
+                                  h->b.as<double>(), h->LK, h->p.W, h->io_misc.as<int32_t>(), h->LK,
+                                  h->stream));
+  HS_HIP(h, hipEventRecord(h->ev[1], h->stream));
+  HS_HIP(h, hipMemcpyAsync(buckets, h->io_misc.p, out_bytes, hipMemcpyDeviceToHost, h->stream));
+  HS_HIP(h, hipStreamSynchronize(h->stream));
+  memset(&h->prof, 0, sizeof(h->prof));
+  h->prof.ms_hash = h->prof.ms_total = ev_ms(h, 0, 1);
+  return HS_OK;
+}
+
+// ------------------------------------------------------------------------------------- build
+static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
+  const uint64_t n = h->n;
+  const int K = (int)h->p.K, L = (int)h->p.L, k = (int)h->p.k, d = h->d, PW = h->PW;
+  *collided = false;
+  // scratch shared by all tables
+  DevBuf ints, keys, keys_sorted, iota, rle_unique, rle_counts, small, sort_temp;
+  struct Guard {
+    DevBuf* b[8];
+    ~Guard() { for (DevBuf* x : b) x->release(); }
+  } guard = {{&ints, &keys, &keys_sorted, &iota, &rle_unique, &rle_counts, &small, &sort_temp}};
+  HS_HIP(h, ints.reserve(std::max<size_t>(16, (size_t)n * K * 4)));
+  HS_HIP(h, keys.reserve(std::max<size_t>(16, (size_t)n * 8)));
+  HS_HIP(h, keys_sorted.reserve(std::max<size_t>(16, (size_t)n * 8)));
+  HS_HIP(h, iota.reserve(std::max<size_t>(16, (size_t)n * 4)));
+  HS_HIP(h, rle_unique.reserve(std::max<size_t>(16, (size_t)n * 8)));
+  HS_HIP(h, rle_counts.reserve(std::max<size_t>(16, (size_t)n * 4)));
+  HS_HIP(h, small.reserve(64));  // [0]=runs [1]=collision flag [2]=max count
+  const size_t temp_bytes = std::max(std::max(hs_sort_pairs_u64_u32_temp(n), hs_rle_u64_temp(n)),
+                                     hs_scan_u32_temp(n + 1)) + 256;
+  HS_HIP(h, sort_temp.reserve(temp_bytes));
+  uint32_t* d_small = small.as<uint32_t>();
+  double ms_hash = 0, ms_sort = 0, ms_gather = 0;
+  for (int l = 0; l < L; ++l) {
+    HS_HIP(h, h->t_ids[l].reserve(std::max<size_t>(16, (size_t)n * 4)));
+    HS_HIP(h, h->t_packed[l].reserve(std::max<size_t>(16, (size_t)n * PW * 16)));
+    HS_HIP(h, hipMemsetAsync(d_small, 0, 64, h->stream));
+    HS_HIP(h, hipEventRecord(h->ev[0], h->stream));
+    HS_HIP(h, hs_launch_hash_codes(h->codes.as<uint8_t>(), n, k, h->a.as<double>() + (size_t)l * K * d,
+                                   h->b.as<double>() + (size_t)l * K, K, h->p.W, h->coords.as<double>(),
+                                   ints.as<int32_t>(), K, h->stream));
+    HS_HIP(h, hs_launch_keys(ints.as<int32_t>(), n, K, K, seed, keys.as<uint64_t>(),
+                             iota.as<uint32_t>(), h->stream));
+    HS_HIP(h, hipEventRecord(h->ev[1], h->stream));
+    uint32_t nb = 0, flag = 0, max_count = 0;
+    if (n) {
+      HS_HIP(h, hs_sort_pairs_u64_u32(sort_temp.p, sort_temp.cap, keys.as<uint64_t>(),
+                                      keys_sorted.as<uint64_t>(), iota.as<uint32_t>(),
+                                      h->t_ids[l].as<uint32_t>(), n, h->stream));
+      HS_HIP(h, hs_launch_check_runs(keys_sorted.as<uint64_t>(), h->t_ids[l].as<uint32_t>(),
+                                     ints.as<int32_t>(), n, K, d_small + 1, h->stream));
+      HS_HIP(h, hs_rle_u64(sort_temp.p, sort_temp.cap, keys_sorted.as<uint64_t>(),
+                           rle_unique.as<uint64_t>(), rle_counts.as<uint32_t>(), d_small, n,
+                           h->stream));
+      uint32_t host_small[3];
+      HS_HIP(h, hipMemcpyAsync(host_small, d_small, 8, hipMemcpyDeviceToHost, h->stream));
+      HS_HIP(h, hipStreamSynchronize(h->stream));
+      nb = host_small[0];
+      flag = host_small[1];
+    }
+    if (flag) {
+      *collided = true;
+      return HS_OK;
+    }
+    HS_HIP(h, h->t_dirkey[l].reserve(std::max<size_t>(16, (size_t)nb * 8)));
+    HS_HIP(h, h->t_dirstart[l].reserve(((size_t)nb + 1) * 4));
+    HS_HIP(h, h->t_dirtuple[l].reserve(std::max<size_t>(16, (size_t)nb * K * 4)));
+    if (nb) {
+      HS_HIP(h, hipMemcpyAsync(h->t_dirkey[l].p, rle_unique.p, (size_t)nb * 8,
+                               hipMemcpyDeviceToDevice, h->stream));
+      HS_HIP(h, hs_exclusive_scan_u32(sort_temp.p, sort_temp.cap, rle_counts.as<uint32_t>(),
+                                      h->t_dirstart[l].as<uint32_t>(), nb, h->stream));
+      HS_HIP(h, hs_launch_max_u32(rle_counts.as<uint32_t>(), nb, d_small + 2, h->stream));
+    }
+    HS_HIP(h, hs_launch_set_u32(h->t_dirstart[l].as<uint32_t>() + nb, (uint32_t)n, h->stream));
+    HS_HIP(h, hs_launch_dir_tuples(h->t_dirstart[l].as<uint32_t>(), h->t_ids[l].as<uint32_t>(),
+                                   ints.as<int32_t>(), nb, K, h->t_dirtuple[l].as<int32_t>(),
+                                   h->stream));
+    HS_HIP(h, hipEventRecord(h->ev[2], h->stream));
+    HS_HIP(h, hs_launch_gather_packed(h->packed_all.as<uint4>(), h->t_ids[l].as<uint32_t>(), n, PW,
+                                      h->t_packed[l].as<uint4>(), h->stream));
+    HS_HIP(h, hipEventRecord(h->ev[3], h->stream));
+    HS_HIP(h, hipMemcpyAsync(&max_count, d_small + 2, 4, hipMemcpyDeviceToHost, h->stream));
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    ms_hash += ev_ms(h, 0, 1);
+    ms_sort += ev_ms(h, 1, 2);
+    ms_gather += ev_ms(h, 2, 3);
+    hs_table_dev& tb = h->tabs.t[l];
+    tb.dir_key = h->t_dirkey[l].as<uint64_t>();
+    tb.dir_start = h->t_dirstart[l].as<uint32_t>();
+    tb.dir_tuple = h->t_dirtuple[l].as<int32_t>();
+    tb.packed = h->t_packed[l].as<uint4>();
+    tb.ids = h->t_ids[l].as<uint32_t>();
+    tb.nb = nb;
+    h->info.n_buckets[l] = nb;
+    h->info.max_bucket[l] = max_count;
+  }
+  h->prof.ms_hash = ms_hash;
+  h->prof.ms_sort = ms_sort;
+  h->prof.ms_gather = ms_gather;
+  return HS_OK;
+}
+
+hs_status hs_index_build(hs_handle* h, const uint8_t* codes, uint64_t n) {
+  if (!h || (n && !codes)) return HS_ERR_INVALID;
+  if (n >= (1ull << 31)) return fail(h, HS_ERR_INVALID, "n must be < 2^31 (ids are 32-bit, as in the reference)");
+  hs_status st = ensure_device(h);
+  if (st) return st;
+  h->built = false;
+  h->n = n;
+  memset(&h->prof, 0, sizeof(h->prof));
+  memset(&h->info, 0, sizeof(h->info));
+  const int k = (int)h->p.k;
+  HS_HIP(h, h->codes.reserve(std::max<size_t>(16, (size_t)n * k)));
+  HS_HIP(h, h->packed_all.reserve(std::max<size_t>(16, (size_t)n * h->PW * 16)));
+  HS_HIP(h, h->counters.reserve(256));
+  HS_HIP(h, hipEventRecord(h->ev[8], h->stream));
+  if (n) {
+    HS_HIP(h, hipMemcpyAsync(h->codes.p, codes, (size_t)n * k, hipMemcpyHostToDevice, h->stream));
+    HS_HIP(h, hipMemsetAsync(h->counters.p, 0, 256, h->stream));
+    HS_HIP(h, hs_launch_pack(h->codes.as<uint8_t>(), n, k, h->packed_all.as<uint4>(),
+                             h->counters.as<uint32_t>(), h->stream));
+    uint32_t bad = 0;
+    HS_HIP(h, hipMemcpyAsync(&bad, h->counters.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    if (bad) return fail(h, HS_ERR_INVALID, "residue code >= 20 in the DB");
+  }
+  bool collided = true;
+  uint32_t seed = 0;
+  for (; seed < 4 && collided; ++seed) {
+    st = build_tables(h, seed, &collided);
+    if (st) return st;
+    if (!collided) break;
+  }
+  if (collided) return fail(h, HS_ERR_KEY_COLLISION, "key fingerprints collided for 4 seeds");
+  h->key_seed = seed;
+  HS_HIP(h, hipEventRecord(h->ev[9], h->stream));
+  HS_HIP(h, hipStreamSynchronize(h->stream));
+  h->prof.ms_total = ev_ms(h, 8, 9);
+  h->info.n = n;
+  h->info.key_seed = seed;
+  uint64_t bytes = h->codes.cap + h->packed_all.cap;
+  for (uint32_t l = 0; l < h->p.L; ++l)
+    bytes += h->t_dirkey[l].cap + h->t_dirstart[l].cap + h->t_dirtuple[l].cap + h->t_packed[l].cap +
+             h->t_ids[l].cap;
+  h->info.device_bytes = bytes;
+  h->built = true;
+  return HS_OK;
+}
+
+hs_status hs_index_info_get(const hs_handle* h, hs_index_info* out) {
+  if (!h || !out) return HS_ERR_INVALID;
+  if (!h->built) return HS_ERR_STATE;
+  *out = h->info;
+  return HS_OK;
+}
+
+// ------------------------------------------------------------------------------------- query
+// Counters block (h->counters): [0] prov_count u32, [1] hit_count u32, [2..3] cand_total u64.
+static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq, uint32_t q_base,
+                             double R, bool brute, uint64_t* d_cand, uint32_t* n_batch_hits) {
+  const int K = (int)h->p.K, L = brute ? 1 : (int)h->p.L, k = (int)h->p.k;
+  const uint32_t nql = nq * (uint32_t)L;
+  const double r2 = R * R;  // motif_both_points.cpp:204
+  const float r2_hi = filter_bound(r2);
+  const int n_blocks = h->n_cu * 8;
+  uint32_t* d_cnt = h->counters.as<uint32_t>();
+  HS_HIP(h, h->tq.reserve((size_t)nq * k * HS_TROW * 4));
+  HS_HIP(h, hipMemsetAsync(d_cnt, 0, 64, h->stream));
+  HS_HIP(h, hipEventRecord(h->ev[0], h->stream));
+  if (!brute) {
+    HS_HIP(h, h->qints.reserve((size_t)nq * h->LK * 4));
+    HS_HIP(h, h->qstart.reserve((size_t)nql * 4));
+    HS_HIP(h, h->qcount.reserve((size_t)nql * 4));
+    HS_HIP(h, h->nslices.reserve(((size_t)nql + 1) * 4));
+    HS_HIP(h, h->slice_off.reserve(((size_t)nql + 1) * 4));
+    HS_HIP(h, h->temp.reserve(hs_scan_u32_temp((size_t)nql + 1) + 256));
+    HS_HIP(h, hs_launch_hash_points(d_centers, nq, k, h->a.as<double>(), h->b.as<double>(), h->LK,
+                                    h->p.W, h->qints.as<int32_t>(), h->LK, h->stream));
+  }
+  HS_HIP(h, hipEventRecord(h->ev[1], h->stream));
+  if (!brute) {
+    HS_HIP(h, hs_launch_set_u32(h->nslices.as<uint32_t>() + nql, 0u, h->stream));
+    HS_HIP(h, hs_launch_probe(h->tabs, h->qints.as<int32_t>(), nq, K, L, h->key_seed,
+                              h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
+                              h->nslices.as<uint32_t>(), d_cand,
+                              reinterpret_cast<unsigned long long*>(d_cnt + 2), h->stream));
+    HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, h->nslices.as<uint32_t>(),
+                                    h->slice_off.as<uint32_t>(), (size_t)nql + 1, h->stream));
+  }
+  HS_HIP(h, hs_launch_qtables(d_centers, nq, k, h->coords.as<double>(), h->tq.as<float>(), h->stream));
+  HS_HIP(h, hipEventRecord(h->ev[2], h->stream));
+  uint32_t prov_cap = (uint32_t)std::max<size_t>(h->prov.cap / 8, std::max<size_t>(1u << 20, 16ull * nq));
+  uint32_t host_cnt[4] = {0, 0, 0, 0};
+  double ms_verify = 0, ms_final = 0;
+  uint32_t launches = 0;
+  for (;;) {  // retried only when a workspace capacity was exceeded
+    HS_HIP(h, h->prov.reserve((size_t)prov_cap * 8));
+    uint32_t hit_cap = (uint32_t)std::max<size_t>(h->hit_key.cap / 8, prov_cap);
+    HS_HIP(h, h->hit_key.reserve((size_t)hit_cap * 8));
+    HS_HIP(h, h->hit_val.reserve((size_t)hit_cap * 8));
+    HS_HIP(h, hipMemsetAsync(d_cnt, 0, 8, h->stream));
+    HS_HIP(h, hipEventRecord(h->ev[3], h->stream));
+    if (brute) {
+      HS_HIP(h, hs_launch_bruteforce(h->packed_all.as<uint4>(), (uint32_t)h->n, h->tq.as<float>(),
+                                     nq, k, r2_hi, d_cnt, prov_cap, h->prov.as<uint2>(), n_blocks,
+                                     h->stream));
+    } else {
+      HS_HIP(h, hs_launch_verify(h->tabs, h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
+                                 h->slice_off.as<uint32_t>(), nql, h->tq.as<float>(), k, L, r2_hi,
+                                 d_cnt, prov_cap, h->prov.as<uint2>(), n_blocks, h->stream));
+    }
+    HS_HIP(h, hipEventRecord(h->ev[4], h->stream));
+    if (brute) {
+      HS_HIP(h, hs_launch_bf_finalize(h->codes.as<uint8_t>(), d_centers, h->coords.as<double>(),
+                                      h->prov.as<uint2>(), d_cnt, prov_cap, k, R, q_base, d_cnt + 1,
+                                      hit_cap, h->hit_key.as<uint64_t>(), h->hit_val.as<uint64_t>(),
+                                      h->stream));
+    } else {
+      HS_HIP(h, hs_launch_finalize(h->tabs, h->codes.as<uint8_t>(), d_centers, h->coords.as<double>(),
+                                   h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
+                                   h->prov.as<uint2>(), d_cnt, prov_cap, k, L, r2, q_base, d_cnt + 1,
+                                   hit_cap, h->hit_key.as<uint64_t>(), h->hit_val.as<uint64_t>(),
+                                   h->stream));
+    }
+    HS_HIP(h, hipEventRecord(h->ev[5], h->stream));
+    HS_HIP(h, hipMemcpyAsync(host_cnt, d_cnt, 16, hipMemcpyDeviceToHost, h->stream));
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    ms_verify += ev_ms(h, 3, 4);
+    ms_final += ev_ms(h, 4, 5);
+    ++launches;
+    if (host_cnt[0] > prov_cap) {
+      prov_cap = host_cnt[0] + host_cnt[0] / 8 + 1024;
+      continue;
+    }
+    break;  // hit_count <= prov_count <= prov_cap <= hit_cap
+  }
+  h->prof.ms_hash += ev_ms(h, 0, 1);
+  h->prof.ms_probe += ev_ms(h, 1, 2);
+  h->prof.ms_verify += ms_verify;
+  h->prof.ms_finalize += ms_final;
+  h->prof.verify_launches += launches;
+  uint64_t cand_total;
+  memcpy(&cand_total, host_cnt + 2, 8);
+  h->prof.candidates += brute ? (uint64_t)nq * h->n : cand_total;
+  h->prof.provisional += host_cnt[0];
+  *n_batch_hits = host_cnt[1];
+  return HS_OK;
+}
+
+static hs_status run_query(hs_handle* h, const double* d_centers, uint64_t nq, double R, bool brute,
+                           uint32_t* d_hit_q, uint32_t* d_hit_id, uint32_t* d_hit_table,
+                           double* d_hit_dist, uint64_t cap, uint64_t* n_hits, uint64_t* d_cand) {
+  if (!h || !n_hits) return HS_ERR_INVALID;
+  *n_hits = 0;
+  if (!h->built) return fail(h, HS_ERR_STATE, "hs_index_build has not been called");
+  if (nq >= (1ull << 27)) return fail(h, HS_ERR_INVALID, "nq must be < 2^27 per call");
+  if (nq && !d_centers) return HS_ERR_INVALID;
+  if (cap && (!d_hit_q || !d_hit_id || !d_hit_dist)) return HS_ERR_INVALID;
+  if (!(R == R)) return fail(h, HS_ERR_INVALID, "R is NaN");
+  hs_status st = ensure_device(h);
+  if (st) return st;
+  memset(&h->prof, 0, sizeof(h->prof));
+  HS_HIP(h, h->counters.reserve(256));
+  HS_HIP(h, hipEventRecord(h->ev[8], h->stream));
+  uint64_t total = 0;
+  if (nq && h->n && !(brute && R < 0)) {
+    const uint32_t QB = 1u << 16;  // queries per batch: bounds the workspace
+    for (uint64_t q0 = 0; q0 < nq; q0 += QB) {
+      const uint32_t nqb = (uint32_t)std::min<uint64_t>(QB, nq - q0);
+      uint32_t nh = 0;
+      st = query_batch(h, d_centers + q0 * h->d, nqb, (uint32_t)q0, R, brute,
+                       d_cand ? d_cand + q0 * h->p.L : nullptr, &nh);
+      if (st) return st;
+      if (nh) {
+        // order of the reference's output: query, table of first sight, ascending id
+        HS_HIP(h, h->hit_key2.reserve((size_t)nh * 8));
+        HS_HIP(h, h->hit_val2.reserve((size_t)nh * 8));
+        HS_HIP(h, h->temp.reserve(hs_sort_pairs_u64_u64_temp(nh) + 256));
+        HS_HIP(h, hipEventRecord(h->ev[6], h->stream));
+        HS_HIP(h, hs_sort_pairs_u64_u64(h->temp.p, h->temp.cap, h->hit_key.as<uint64_t>(),
+                                        h->hit_key2.as<uint64_t>(), h->hit_val.as<uint64_t>(),
+                                        h->hit_val2.as<uint64_t>(), nh, 64, h->stream));
+        if (total + nh <= cap)
+          HS_HIP(h, hs_launch_unpack_hits(h->hit_key2.as<uint64_t>(), h->hit_val2.as<uint64_t>(), nh,
+                                          d_hit_q + total, d_hit_id + total,
+                                          d_hit_table ? d_hit_table + total : nullptr,
+                                          d_hit_dist + total, h->stream));
+        HS_HIP(h, hipEventRecord(h->ev[7], h->stream));
+        HS_HIP(h, hipStreamSynchronize(h->stream));
+        h->prof.ms_finalize += ev_ms(h, 6, 7);
+      }
+      total += nh;
+    }
+  } else if (d_cand && nq && !brute) {
+    HS_HIP(h, hipMemsetAsync(d_cand, 0, (size_t)nq * h->p.L * 8, h->stream));
+  }
+  HS_HIP(h, hipEventRecord(h->ev[9], h->stream));
+  HS_HIP(h, hipStreamSynchronize(h->stream));
+  h->prof.ms_total = ev_ms(h, 8, 9);
+  h->prof.hits = total;
+  *n_hits = total;
+  if (total > cap) return fail(h, HS_ERR_CAPACITY, "hit buffers too small; see *n_hits");
+  return HS_OK;
+}
+
+hs_status hs_query_dev(hs_handle* h, const double* d_centers, uint64_t nq, double R,
+                       uint32_t* d_hit_q, uint32_t* d_hit_id, uint32_t* d_hit_table,
+                       double* d_hit_dist, uint64_t cap, uint64_t* n_hits, uint64_t* d_cand) {
+  return run_query(h, d_centers, nq, R, false, d_hit_q, d_hit_id, d_hit_table, d_hit_dist, cap,
+                   n_hits, d_cand);
+}
+
+static hs_status host_query(hs_handle* h, const double* centers, uint64_t nq, double R, bool brute,
+                            uint32_t* hit_q, uint32_t* hit_id, uint32_t* hit_table, double* hit_dist,
+                            uint64_t cap, uint64_t* n_hits, uint64_t* cand) {
+  if (!h || !n_hits) return HS_ERR_INVALID;
+  if (nq && !centers) return HS_ERR_INVALID;
+  hs_status st = ensure_device(h);
+  if (st) return st;
+  const size_t cbytes = (size_t)nq * h->d * 8;
+  HS_HIP(h, h->io_centers.reserve(std::max<size_t>(16, cbytes)));
+  HS_HIP(h, h->io_q.reserve(std::max<size_t>(16, cap * 4)));
+  HS_HIP(h, h->io_id.reserve(std::max<size_t>(16, cap * 4)));
+  HS_HIP(h, h->io_table.reserve(std::max<size_t>(16, cap * 4)));
+  HS_HIP(h, h->io_dist.reserve(std::max<size_t>(16, cap * 8)));
+  if (cand) HS_HIP(h, h->io_cand.reserve(std::max<size_t>(16, (size_t)nq * h->p.L * 8)));
+  if (cbytes) HS_HIP(h, hipMemcpyAsync(h->io_centers.p, centers, cbytes, hipMemcpyHostToDevice, h->stream));
+  st = run_query(h, h->io_centers.as<double>(), nq, R, brute, h->io_q.as<uint32_t>(),
+                 h->io_id.as<uint32_t>(), h->io_table.as<uint32_t>(), h->io_dist.as<double>(), cap,
+                 n_hits, cand ? h->io_cand.as<uint64_t>() : nullptr);
+  if (st != HS_OK) return st;
+  const uint64_t nh = *n_hits;
+  if (nh) {
+    HS_HIP(h, hipMemcpyAsync(hit_q, h->io_q.p, nh * 4, hipMemcpyDeviceToHost, h->stream));
+    HS_HIP(h, hipMemcpyAsync(hit_id, h->io_id.p, nh * 4, hipMemcpyDeviceToHost, h->stream));
+    if (hit_table)
+      HS_HIP(h, hipMemcpyAsync(hit_table, h->io_table.p, nh * 4, hipMemcpyDeviceToHost, h->stream));
+    HS_HIP(h, hipMemcpyAsync(hit_dist, h->io_dist.p, nh * 8, hipMemcpyDeviceToHost, h->stream));
+  }
+  if (cand && nq)
+    HS_HIP(h, hipMemcpyAsync(cand, h->io_cand.p, (size_t)nq * h->p.L * 8, hipMemcpyDeviceToHost, h->stream));
+  HS_HIP(h, hipStreamSynchronize(h->stream));
+  return HS_OK;
+}
+
+hs_status hs_query(hs_handle* h, const double* centers, uint64_t nq, double R, uint32_t* hit_q,
+                   uint32_t* hit_id, uint32_t* hit_table, double* hit_dist, uint64_t cap,
+                   uint64_t* n_hits, uint64_t* cand) {
+  return host_query(h, centers, nq, R, false, hit_q, hit_id, hit_table, hit_dist, cap, n_hits, cand);
+}
+
+hs_status hs_bruteforce(hs_handle* h, const double* centers, uint64_t nq, double R, uint32_t* hit_q,
+                        uint32_t* hit_id, double* hit_dist, uint64_t cap, uint64_t* n_hits) {
+  return host_query(h, centers, nq, R, true, hit_q, hit_id, nullptr, hit_dist, cap, n_hits, nullptr);
+}
+
+hs_status hs_bruteforce_topk(hs_handle* h, const double* centers, uint64_t nq, uint32_t topk,
+                             uint32_t* nn_id, double* nn_dist2) {
+  (void)centers; (void)nq; (void)topk; (void)nn_id; (void)nn_dist2;
+  return fail(h, HS_ERR_INVALID, "hs_bruteforce_topk: not implemented yet");
+}
+
+}  // extern "C"

@@ -1,0 +1,187 @@
+// hs_internal.h -- declarations shared by the translation units of libhsearch_amd.so.
+// gfx950 (MI355X) only; no CPU fallback anywhere in this directory.
+#ifndef HS_INTERNAL_H
+#define HS_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hsearch.h"
+
+#define HS_MAX_L 32
+#define HS_MAX_K 32
+#define HS_ALPHABET_PAD 32  // table rows addressable by a 5-bit residue code
+#define HS_TROW 32          // floats per row of a per-query distance table (20 used)
+#define HS_SLICE 4096u      // candidates one wavefront scans per work item
+#define HS_KEY_CHARS (11 * HS_MAX_K + 1)
+
+// ---- key fingerprints ---------------------------------------------------------------------------
+// The reference keys a table by the STRING to_string(b_0)+...+to_string(b_{K-1}) (lsh.hpp:51-59).
+// The index keys by a 64-bit fingerprint of exactly that character stream (so tuples whose strings
+// alias, e.g. (1,23) and (12,3), share a fingerprint by construction) and verifies string equality
+// exactly: at build time for every sorted neighbour pair, at probe time against the bucket's tuple.
+__host__ __device__ inline uint64_t hs_key_init(uint32_t seed) {
+  return 0xcbf29ce484222325ull ^ ((uint64_t)(seed + 1) * 0x9e3779b97f4a7c15ull);
+}
+__host__ __device__ inline uint64_t hs_key_put(uint64_t h, uint32_t ch) {
+  return (h ^ ch) * 0x100000001b3ull;
+}
+__host__ __device__ inline uint64_t hs_key_put_int(uint64_t h, int32_t v) {
+  uint32_t m;
+  if (v < 0) {
+    h = hs_key_put(h, '-');
+    m = 0u - (uint32_t)v;
+  } else {
+    m = (uint32_t)v;
+  }
+  uint32_t p = 1;
+  while (m / p >= 10) p *= 10;
+  while (p) {
+    uint32_t dgt = m / p;
+    h = hs_key_put(h, '0' + dgt);
+    m -= dgt * p;
+    p /= 10;
+  }
+  return h;
+}
+__host__ __device__ inline uint64_t hs_key_fin(uint64_t h) {
+  h ^= h >> 33;
+  h *= 0xff51afd7ed558ccdull;
+  h ^= h >> 33;
+  h *= 0xc4ceb9fe1a85ec53ull;
+  h ^= h >> 33;
+  return h;
+}
+__host__ __device__ inline uint64_t hs_key_of(const int32_t* t, int K, uint32_t seed) {
+  uint64_t h = hs_key_init(seed);
+  for (int i = 0; i < K; ++i) h = hs_key_put_int(h, t[i]);
+  return hs_key_fin(h);
+}
+// Decimal characters of the concatenation; returns the length.
+__host__ __device__ inline int hs_key_chars(const int32_t* t, int K, char* out) {
+  int n = 0;
+  for (int i = 0; i < K; ++i) {
+    int32_t v = t[i];
+    uint32_t m;
+    if (v < 0) {
+      out[n++] = '-';
+      m = 0u - (uint32_t)v;
+    } else {
+      m = (uint32_t)v;
+    }
+    uint32_t p = 1;
+    while (m / p >= 10) p *= 10;
+    while (p) {
+      uint32_t dgt = m / p;
+      out[n++] = (char)('0' + dgt);
+      m -= dgt * p;
+      p /= 10;
+    }
+  }
+  return n;
+}
+// HashKey string equality of two K-tuples (fast path: identical tuples).
+__host__ __device__ inline bool hs_key_equal(const int32_t* x, const int32_t* y, int K) {
+  bool same = true;
+  for (int i = 0; i < K; ++i) same = same && (x[i] == y[i]);
+  if (same) return true;
+  char sx[HS_KEY_CHARS], sy[HS_KEY_CHARS];
+  int nx = hs_key_chars(x, K, sx), ny = hs_key_chars(y, K, sy);
+  if (nx != ny) return false;
+  for (int i = 0; i < nx; ++i)
+    if (sx[i] != sy[i]) return false;
+  return true;
+}
+
+// ---- device view of one hash table --------------------------------------------------------------
+struct hs_table_dev {
+  const uint64_t* dir_key;   // [nb] sorted fingerprints of the distinct keys
+  const uint32_t* dir_start; // [nb+1] first sorted position of each bucket
+  const int32_t* dir_tuple;  // [nb][K] bucket ints of the bucket's first member
+  const uint4* packed;       // [n][PW] 5-bit packed residue codes in bucket order
+  const uint32_t* ids;       // [n] DB ids in bucket order (ascending inside a bucket)
+  uint32_t nb;
+  uint32_t pad_;
+};
+struct hs_tables_dev {
+  hs_table_dev t[HS_MAX_L];
+};
+
+// 16-byte words per packed k-mer
+// 25 residues x 5 bits per 16-byte word
+static inline int hs_packed_words(int k) { return (k + 24) / 25; }
+
+// ---- primitive wrappers (hs_prims.hip, rocPRIM behind them) --------------------------------------
+size_t hs_sort_pairs_u64_u32_temp(size_t n);
+hipError_t hs_sort_pairs_u64_u32(void* temp, size_t temp_bytes, const uint64_t* kin, uint64_t* kout,
+                                 const uint32_t* vin, uint32_t* vout, size_t n, hipStream_t s);
+size_t hs_sort_pairs_u64_u64_temp(size_t n);
+hipError_t hs_sort_pairs_u64_u64(void* temp, size_t temp_bytes, const uint64_t* kin, uint64_t* kout,
+                                 const uint64_t* vin, uint64_t* vout, size_t n, int end_bit,
+                                 hipStream_t s);
+size_t hs_scan_u32_temp(size_t n);
+hipError_t hs_exclusive_scan_u32(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out,
+                                 size_t n, hipStream_t s);
+size_t hs_rle_u64_temp(size_t n);
+// unique_out[n], counts_out[n], runs_out[1] (device)
+hipError_t hs_rle_u64(void* temp, size_t temp_bytes, const uint64_t* in, uint64_t* unique_out,
+                      uint32_t* counts_out, uint32_t* runs_out, size_t n, hipStream_t s);
+
+// ---- kernel launchers (hs_kernels.hip) -----------------------------------------------------------
+hipError_t hs_launch_embed(const uint8_t* d_codes, uint64_t n, int k, const double* d_coords,
+                           double* d_out, hipStream_t s);
+// buckets out[i*out_stride + f], f in [0,F): exact reference arithmetic.
+hipError_t hs_launch_hash_codes(const uint8_t* d_codes, uint64_t n, int k, const double* d_a,
+                                const double* d_b, int F, double W, const double* d_coords,
+                                int32_t* d_out, int out_stride, hipStream_t s);
+hipError_t hs_launch_hash_points(const double* d_pts, uint64_t n, int k, const double* d_a,
+                                 const double* d_b, int F, double W, int32_t* d_out, int out_stride,
+                                 hipStream_t s);
+// keys[i] = fingerprint(ints[i*stride .. +K)); ids[i] = i (if ids != null)
+hipError_t hs_launch_keys(const int32_t* d_ints, uint64_t n, int stride, int K, uint32_t seed,
+                          uint64_t* d_keys, uint32_t* d_ids, hipStream_t s);
+// flag |= 1 if two sorted neighbours share a fingerprint but not a key string
+hipError_t hs_launch_check_runs(const uint64_t* d_keys_sorted, const uint32_t* d_ids_sorted,
+                                const int32_t* d_ints, uint64_t n, int K, uint32_t* d_flag,
+                                hipStream_t s);
+hipError_t hs_launch_dir_tuples(const uint32_t* d_dir_start, const uint32_t* d_ids_sorted,
+                                const int32_t* d_ints, uint32_t nb, int K, int32_t* d_dir_tuple,
+                                hipStream_t s);
+hipError_t hs_launch_pack(const uint8_t* d_codes, uint64_t n, int k, uint4* d_packed,
+                          uint32_t* d_bad, hipStream_t s);
+hipError_t hs_launch_gather_packed(const uint4* d_packed_all, const uint32_t* d_ids_sorted,
+                                   uint64_t n, int PW, uint4* d_out, hipStream_t s);
+hipError_t hs_launch_set_u32(uint32_t* d_p, uint32_t v, hipStream_t s);
+hipError_t hs_launch_max_u32(const uint32_t* d_in, uint32_t n, uint32_t* d_out, hipStream_t s);
+
+hipError_t hs_launch_probe(const hs_tables_dev& tabs, const int32_t* d_qints, uint32_t nq, int K,
+                           int L, uint32_t seed, uint32_t* d_qstart, uint32_t* d_qcount,
+                           uint32_t* d_nslices, uint64_t* d_cand_out, unsigned long long* d_cand_total,
+                           hipStream_t s);
+hipError_t hs_launch_qtables(const double* d_centers, uint32_t nq, int k, const double* d_coords,
+                             float* d_tq, hipStream_t s);
+hipError_t hs_launch_verify(const hs_tables_dev& tabs, const uint32_t* d_qstart,
+                            const uint32_t* d_qcount, const uint32_t* d_slice_off, uint32_t nql,
+                            const float* d_tq, int k, int L, float r2_hi, uint32_t* d_prov_count,
+                            uint32_t prov_cap, uint2* d_prov, int n_blocks, hipStream_t s);
+hipError_t hs_launch_finalize(const hs_tables_dev& tabs, const uint8_t* d_codes,
+                              const double* d_centers, const double* d_coords,
+                              const uint32_t* d_qstart, const uint32_t* d_qcount,
+                              const uint2* d_prov, const uint32_t* d_prov_count, uint32_t prov_cap,
+                              int k, int L, double r2, uint32_t q_base, uint32_t* d_hit_count,
+                              uint32_t hit_cap, uint64_t* d_hit_key, uint64_t* d_hit_val,
+                              hipStream_t s);
+hipError_t hs_launch_unpack_hits(const uint64_t* d_key, const uint64_t* d_val, uint32_t n,
+                                 uint32_t* d_q, uint32_t* d_id, uint32_t* d_table, double* d_dist,
+                                 hipStream_t s);
+// brute force
+hipError_t hs_launch_bruteforce(const uint4* d_packed_all, uint32_t n, const float* d_tq,
+                                uint32_t nq, int k, float r2_hi, uint32_t* d_prov_count,
+                                uint32_t prov_cap, uint2* d_prov, int n_blocks, hipStream_t s);
+hipError_t hs_launch_bf_finalize(const uint8_t* d_codes, const double* d_centers,
+                                 const double* d_coords, const uint2* d_prov,
+                                 const uint32_t* d_prov_count, uint32_t prov_cap, int k, double R,
+                                 uint32_t q_base, uint32_t* d_hit_count, uint32_t hit_cap,
+                                 uint64_t* d_hit_key, uint64_t* d_hit_val, hipStream_t s);
+
+#endif

@@ -1,0 +1,644 @@
+// hs_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the motif-search hot path.
+//
+// Built with -ffp-contract=off: the reference evaluates its fp64 sums with separate multiply and
+// add (lsh.hpp:33-42, motif_both_points.cpp:176-183; built ISO C++11 without -march, so never
+// contracted), and the bucket ints / hit sets must match bit for bit.  The exact paths also spell
+// the operations as __dmul_rn/__dadd_rn/__dsub_rn/__ddiv_rn/__dsqrt_rn so no flag can fuse them.
+//
+// Kernels
+//   hs_embed_kernel      a2  codes -> R^{8k} doubles                       (HBM write bound)
+//   hs_hash_kernel       a4+a5 exact fp64 projections + floor((dot+b)/W)   (fp64 VALU bound)
+//   hs_keys_kernel       a6  fingerprint of the HashKey character stream
+//   hs_check_runs_kernel a6  exact string-equality check of fingerprint runs (build)
+//   hs_pack_kernel           5-bit residue packing, 25 residues per 16-byte word
+//   hs_gather_packed_kernel  bucket-ordered packed copies (build)
+//   hs_probe_kernel      a8  directory lookup, exact key-string check
+//   hs_qtables_kernel    a9  per-query tables T[pos][aa] = |c_pos - coord[aa]|^2 (fp32)
+//   hs_verify_kernel     a9  candidate scan: coalesced 16-B loads, tables held ACROSS LANES in
+//                            VGPRs, ds_bpermute lookups, wave ballot compaction    (HBM bound)
+//   hs_finalize_kernel   a8-a10 first-seen dedupe, exact left-to-right fp64 d2, d2 <= R^2
+#include <algorithm>
+
+#include "hs_internal.h"
+
+namespace {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (WAVE - 1)); }
+
+// ------------------------------------------------------------------------------------------ embed
+__global__ __launch_bounds__(256) void hs_embed_kernel(const uint8_t* __restrict__ codes,
+                                                       uint64_t total, const double* __restrict__ coords,
+                                                       double* __restrict__ out) {
+  uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (; idx < total; idx += stride) out[idx] = coords[(int)codes[idx >> 3] * 8 + (int)(idx & 7)];
+}
+
+// ------------------------------------------------------------------------------------------- hash
+// One thread = one point; KC accumulators = KC hash functions at a time.  The plane values are
+// wave-uniform (scalar loads), the point's coordinates come from the 20x8 table in LDS (codes) or
+// from its own row (arbitrary points).  Strict i = 0..d-1 order per function, product rounded,
+// then sum rounded -- lsh.hpp:33-42 -- then floor((dot + b) / W) -- lsh.hpp:44-49.
+template <int KC, bool FROM_CODES>
+__global__ __launch_bounds__(256) void hs_hash_kernel(const uint8_t* __restrict__ codes,
+                                                      const double* __restrict__ pts, uint64_t n,
+                                                      int k, const double* __restrict__ a,
+                                                      const double* __restrict__ b, int F, double W,
+                                                      const double* __restrict__ coords,
+                                                      int32_t* __restrict__ out, int out_stride) {
+  __shared__ double s_coords[HS_ALPHABET_PAD * 8];
+  extern __shared__ uint8_t s_codes[];  // [256][k]
+  const int d = 8 * k;
+  const uint64_t base = (uint64_t)blockIdx.x * 256;
+  const uint64_t i = base + threadIdx.x;
+  const bool valid = i < n;
+  if (FROM_CODES) {
+    for (int t = threadIdx.x; t < HS_ALPHABET_PAD * 8; t += 256) s_coords[t] = t < 160 ? coords[t] : 0.0;
+    const uint64_t lo = base * k;
+    const uint64_t hi = (base + 256 < n ? base + 256 : n) * (uint64_t)k;
+    for (uint64_t t = lo + threadIdx.x; t < lo + 256ull * k; t += 256)
+      s_codes[t - lo] = t < hi ? codes[t] : (uint8_t)0;
+    __syncthreads();
+  }
+  const double* xrow = FROM_CODES ? nullptr : pts + (valid ? i : 0) * (uint64_t)d;
+  for (int fc = 0; fc < F; fc += KC) {
+    double acc[KC];
+#pragma unroll
+    for (int f = 0; f < KC; ++f) acc[f] = 0.0;
+    const double* ap = a + (size_t)fc * d;
+    for (int pos = 0; pos < k; ++pos) {
+      double x[8];
+      if (FROM_CODES) {
+        const int c = s_codes[threadIdx.x * k + pos] & (HS_ALPHABET_PAD - 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = s_coords[c * 8 + j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = xrow[8 * pos + j];
+      }
+#pragma unroll
+      for (int f = 0; f < KC; ++f) {
+        const double* af = ap + (size_t)f * d + 8 * pos;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[f] = __dadd_rn(acc[f], __dmul_rn(x[j], af[j]));
+      }
+    }
+    if (valid) {
+#pragma unroll
+      for (int f = 0; f < KC; ++f) {
+        const double val = __dadd_rn(acc[f], b[fc + f]);
+        out[i * (uint64_t)out_stride + fc + f] = (int32_t)floor(__ddiv_rn(val, W));
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- keys
+__global__ __launch_bounds__(256) void hs_keys_kernel(const int32_t* __restrict__ ints, uint64_t n,
+                                                      int stride, int K, uint32_t seed,
+                                                      uint64_t* __restrict__ keys,
+                                                      uint32_t* __restrict__ ids) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = hs_key_of(ints + i * (uint64_t)stride, K, seed);
+  if (ids) ids[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void hs_check_runs_kernel(const uint64_t* __restrict__ keys,
+                                                            const uint32_t* __restrict__ ids,
+                                                            const int32_t* __restrict__ ints,
+                                                            uint64_t n, int K,
+                                                            uint32_t* __restrict__ flag) {
+  const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x + 1;
+  if (p >= n) return;
+  if (keys[p] != keys[p - 1]) return;
+  int32_t x[HS_MAX_K], y[HS_MAX_K];
+  const int32_t* px = ints + (uint64_t)ids[p] * K;
+  const int32_t* py = ints + (uint64_t)ids[p - 1] * K;
+  bool same = true;
+  for (int j = 0; j < K; ++j) {
+    x[j] = px[j];
+    y[j] = py[j];
+    same = same && (x[j] == y[j]);
+  }
+  if (same) return;
+  if (!hs_key_equal(x, y, K)) atomicOr(flag, 1u);
+}
+
+__global__ __launch_bounds__(256) void hs_dir_tuples_kernel(const uint32_t* __restrict__ dir_start,
+                                                            const uint32_t* __restrict__ ids,
+                                                            const int32_t* __restrict__ ints,
+                                                            uint32_t nb, int K,
+                                                            int32_t* __restrict__ dir_tuple) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (uint64_t)nb * K) return;
+  const uint32_t bkt = (uint32_t)(t / K);
+  const int j = (int)(t % K);
+  dir_tuple[t] = ints[(uint64_t)ids[dir_start[bkt]] * K + j];
+}
+
+// counts[nb] -> starts[nb+1] is done by the scan primitive; this fills the sentinel.
+__global__ void hs_set_u32_kernel(uint32_t* p, uint32_t v) { *p = v; }
+
+__global__ __launch_bounds__(256) void hs_max_u32_kernel(const uint32_t* __restrict__ in, uint32_t n,
+                                                         uint32_t* __restrict__ out) {
+  uint32_t m = 0;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) m = max(m, in[i]);
+  for (int off = 32; off; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+  if (lane_id() == 0) atomicMax(out, m);
+}
+
+// ------------------------------------------------------------------------------------------- pack
+// 25 residues x 5 bits in each 16-byte word (3 pad bits); a k-mer takes ceil(k/25) words.
+__global__ __launch_bounds__(256) void hs_pack_kernel(const uint8_t* __restrict__ codes, uint64_t n,
+                                                      int k, int PW, uint4* __restrict__ packed,
+                                                      uint32_t* __restrict__ bad) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* row = codes + i * (uint64_t)k;
+  uint32_t any_bad = 0;
+  for (int w = 0; w < PW; ++w) {
+    uint32_t v[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int r = 0; r < 25; ++r) {
+      const int p = 25 * w + r;
+      uint32_t c = p < k ? (uint32_t)row[p] : 0u;
+      any_bad |= (c >= 20u);
+      c &= 31u;
+      const int bit = 5 * r, wi = bit >> 5, sh = bit & 31;
+      v[wi] |= c << sh;
+      if (sh > 27) v[wi + 1] |= c >> (32 - sh);
+    }
+    packed[i * (uint64_t)PW + w] = make_uint4(v[0], v[1], v[2], v[3]);
+  }
+  if (any_bad) atomicOr(bad, 1u);
+}
+
+__global__ __launch_bounds__(256) void hs_gather_packed_kernel(const uint4* __restrict__ packed_all,
+                                                               const uint32_t* __restrict__ ids,
+                                                               uint64_t n, int PW,
+                                                               uint4* __restrict__ out) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * (uint64_t)PW) return;
+  const uint64_t p = t / PW;
+  const int w = (int)(t % PW);
+  out[t] = packed_all[(uint64_t)ids[p] * PW + w];
+}
+
+// 4 * residue r of a packed word (the ds_bpermute byte address of lane `residue`)
+template <int R>
+__device__ __forceinline__ int residue_x4(const uint4& p) {
+  constexpr int bit = 5 * R, wi = bit >> 5, sh = bit & 31;
+  const uint32_t lo = wi == 0 ? p.x : wi == 1 ? p.y : wi == 2 ? p.z : p.w;
+  uint32_t v;
+  if (sh > 27) {
+    const uint32_t hi = wi == 0 ? p.y : wi == 1 ? p.z : p.w;
+    v = __funnelshift_r(lo, hi, sh);
+    return (int)((v & 31u) << 2);
+  } else if (sh >= 2) {
+    return (int)((lo >> (sh - 2)) & 0x7cu);
+  } else {
+    return (int)((lo << (2 - sh)) & 0x7cu);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ probe
+__global__ __launch_bounds__(256) void hs_probe_kernel(hs_tables_dev tabs,
+                                                       const int32_t* __restrict__ qints,
+                                                       uint32_t nq, int K, int L, uint32_t seed,
+                                                       uint32_t* __restrict__ qstart,
+                                                       uint32_t* __restrict__ qcount,
+                                                       uint32_t* __restrict__ nslices,
+                                                       uint64_t* __restrict__ cand_out,
+                                                       unsigned long long* __restrict__ cand_total) {
+  const uint32_t ql = blockIdx.x * 256 + threadIdx.x;
+  uint32_t count = 0, start = 0;
+  if (ql < nq * (uint32_t)L) {
+    const int l = (int)(ql % (uint32_t)L);
+    int32_t t[HS_MAX_K];
+    for (int j = 0; j < K; ++j) t[j] = qints[(uint64_t)ql * K + j];
+    const uint64_t key = hs_key_of(t, K, seed);
+    const hs_table_dev& tb = tabs.t[l];
+    uint32_t lo = 0, hi = tb.nb;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (tb.dir_key[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    if (lo < tb.nb && tb.dir_key[lo] == key) {
+      int32_t u[HS_MAX_K];
+      for (int j = 0; j < K; ++j) u[j] = tb.dir_tuple[(uint64_t)lo * K + j];
+      if (hs_key_equal(t, u, K)) {  // HashKey string equality, lsh.hpp:51-59
+        start = tb.dir_start[lo];
+        count = tb.dir_start[lo + 1] - start;
+      }
+    }
+    qstart[ql] = start;
+    qcount[ql] = count;
+    nslices[ql] = (count + HS_SLICE - 1) / HS_SLICE;
+    if (cand_out) cand_out[ql] = count;
+  }
+  unsigned long long c = count;
+  for (int off = 32; off; off >>= 1) c += __shfl_xor(c, off);
+  if (lane_id() == 0 && c) atomicAdd(cand_total, c);
+}
+
+// ---------------------------------------------------------------------------------------- qtables
+// T[q][pos][aa] = sum_j (coord[aa][j] - c[q][8 pos + j])^2, fp64 then rounded to fp32.
+// Rows are HS_TROW floats so a wave reads one with a single coalesced 128-byte load.
+__global__ __launch_bounds__(256) void hs_qtables_kernel(const double* __restrict__ centers,
+                                                         uint32_t nq, int k,
+                                                         const double* __restrict__ coords,
+                                                         float* __restrict__ tq) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (uint64_t)nq * k * HS_TROW) return;
+  const int aa = (int)(t % HS_TROW);
+  const uint64_t qp = t / HS_TROW;  // q*k + pos
+  float v = 0.f;
+  if (aa < 20) {
+    const double* c = centers + qp * 8;
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const double r = coords[aa * 8 + j] - c[j];
+      s += r * r;
+    }
+    v = (float)s;
+  }
+  tq[t] = v;
+}
+
+// ----------------------------------------------------------------------------------------- verify
+// Work item = (query, table, slice of <= HS_SLICE bucket members), one wavefront each, taken
+// grid-stride from the scanned slice counts.  The query's distance table lives in 25*PW VGPRs
+// spread across lanes (lane aa holds T[pos][aa]); a candidate's squared distance is 25*PW
+// ds_bpermute lookups + adds on one coalesced 16-byte load per lane.  Survivors of the fp32 filter
+// (d2 <= R^2 (1 + 1e-5)) are compacted with a wave ballot; hs_finalize_kernel decides them exactly.
+template <int PW, bool BRUTE>
+__global__ __launch_bounds__(256) void hs_verify_kernel(hs_tables_dev tabs,
+                                                        const uint4* __restrict__ brute_packed,
+                                                        uint32_t brute_n,
+                                                        const uint32_t* __restrict__ qstart,
+                                                        const uint32_t* __restrict__ qcount,
+                                                        const uint32_t* __restrict__ slice_off,
+                                                        uint32_t nql, const float* __restrict__ tq,
+                                                        int k, int L, float r2_hi,
+                                                        uint32_t* __restrict__ prov_count,
+                                                        uint32_t prov_cap, uint2* __restrict__ prov) {
+  const int lane = lane_id();
+  const uint32_t waves_per_block = blockDim.x / WAVE;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * waves_per_block + (threadIdx.x >> 6));
+  const uint32_t n_waves = gridDim.x * waves_per_block;
+  const uint32_t total = BRUTE ? nql * ((brute_n + HS_SLICE - 1) / HS_SLICE) : slice_off[nql];
+  for (uint32_t s = wave; s < total; s += n_waves) {
+    uint32_t ql, sl, start, cnt;
+    const uint4* packed;
+    if (BRUTE) {
+      const uint32_t per_q = (brute_n + HS_SLICE - 1) / HS_SLICE;
+      ql = s / per_q;
+      sl = s - ql * per_q;
+      start = sl * HS_SLICE;
+      cnt = min(HS_SLICE, brute_n - start);
+      packed = brute_packed;
+    } else {
+      uint32_t lo = 0, hi = nql;  // largest ql with slice_off[ql] <= s
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (slice_off[mid] <= s) lo = mid; else hi = mid;
+      }
+      ql = lo;
+      sl = s - slice_off[ql];
+      start = qstart[ql] + sl * HS_SLICE;
+      cnt = min(HS_SLICE, qcount[ql] - sl * HS_SLICE);
+      packed = tabs.t[ql % (uint32_t)L].packed;
+    }
+    const uint32_t q = BRUTE ? ql : ql / (uint32_t)L;
+    float T[25 * PW];
+    const float* trow = tq + (uint64_t)q * k * HS_TROW + (lane & (HS_TROW - 1));
+#pragma unroll
+    for (int p = 0; p < 25 * PW; ++p) T[p] = p < k ? trow[p * HS_TROW] : 0.f;
+    const uint32_t iters = (cnt + WAVE - 1) / WAVE;
+    for (uint32_t it = 0; it < iters; ++it) {
+      const uint32_t i = it * WAVE + lane;
+      const bool valid = i < cnt;
+      const uint64_t pos = (uint64_t)start + (valid ? i : cnt - 1);
+      float sum = 0.f;
+#pragma unroll
+      for (int w = 0; w < PW; ++w) {
+        const uint4 pk = packed[pos * PW + w];
+#define HS_LOOKUP(R) \
+  sum += __int_as_float(__builtin_amdgcn_ds_bpermute(residue_x4<R>(pk), __float_as_int(T[25 * w + R])));
+        HS_LOOKUP(0) HS_LOOKUP(1) HS_LOOKUP(2) HS_LOOKUP(3) HS_LOOKUP(4)
+        HS_LOOKUP(5) HS_LOOKUP(6) HS_LOOKUP(7) HS_LOOKUP(8) HS_LOOKUP(9)
+        HS_LOOKUP(10) HS_LOOKUP(11) HS_LOOKUP(12) HS_LOOKUP(13) HS_LOOKUP(14)
+        HS_LOOKUP(15) HS_LOOKUP(16) HS_LOOKUP(17) HS_LOOKUP(18) HS_LOOKUP(19)
+        HS_LOOKUP(20) HS_LOOKUP(21) HS_LOOKUP(22) HS_LOOKUP(23) HS_LOOKUP(24)
+#undef HS_LOOKUP
+      }
+      const bool pass = valid && sum <= r2_hi;
+      const unsigned long long m = __ballot(pass);
+      if (m) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(prov_count, (uint32_t)__popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (pass) {
+          const uint32_t idx = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          if (idx < prov_cap) prov[idx] = make_uint2(ql, (uint32_t)pos);
+        }
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------- finalize
+// motif_both_points.cpp:176-183: d2 = sum_i (x_i - c_i)^2 left to right, x_i from the table.
+__device__ __forceinline__ double exact_dist2(const uint8_t* __restrict__ row,
+                                              const double* __restrict__ c,
+                                              const double* __restrict__ coords, int k) {
+  double d2 = 0.0;
+  for (int p = 0; p < k; ++p) {
+    const double* xc = coords + (int)row[p] * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const double r = __dsub_rn(xc[j], c[8 * p + j]);
+      d2 = __dadd_rn(d2, __dmul_rn(r, r));
+    }
+  }
+  return d2;
+}
+
+// One thread per survivor of the fp32 filter: (1) first-seen dedupe -- the reference reports a DB
+// id in the first table whose bucket holds it (label[] test, motif_both_points.cpp:233); ids are
+// ascending inside a bucket, so membership in an earlier table's bucket is a binary search;
+// (2) exact fp64 d2 and the reference's test d2 <= R*R (:239); (3) emit (q, table, id) key +
+// sqrt(d2) (:241) for the ordering pass.
+__global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
+                                                          const uint8_t* __restrict__ codes,
+                                                          const double* __restrict__ centers,
+                                                          const double* __restrict__ coords,
+                                                          const uint32_t* __restrict__ qstart,
+                                                          const uint32_t* __restrict__ qcount,
+                                                          const uint2* __restrict__ prov,
+                                                          const uint32_t* __restrict__ prov_count,
+                                                          uint32_t prov_cap, int k, int L, double r2,
+                                                          uint32_t q_base,
+                                                          uint32_t* __restrict__ hit_count,
+                                                          uint32_t hit_cap,
+                                                          uint64_t* __restrict__ hit_key,
+                                                          uint64_t* __restrict__ hit_val) {
+  const uint32_t n = min(*prov_count, prov_cap);
+  for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    const uint32_t ql = prov[e].x, pos = prov[e].y;
+    const uint32_t q = ql / (uint32_t)L;
+    const int l = (int)(ql % (uint32_t)L);
+    const uint32_t id = tabs.t[l].ids[pos];
+    bool seen = false;
+    for (int l2 = 0; l2 < l && !seen; ++l2) {
+      const uint32_t c2 = qcount[q * L + l2];
+      if (!c2) continue;
+      const uint32_t* ids2 = tabs.t[l2].ids + qstart[q * L + l2];
+      uint32_t lo = 0, hi = c2;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (ids2[mid] < id) lo = mid + 1; else hi = mid;
+      }
+      seen = lo < c2 && ids2[lo] == id;
+    }
+    if (seen) continue;
+    const double d2 = exact_dist2(codes + (uint64_t)id * k, centers + (uint64_t)q * 8 * k, coords, k);
+    if (d2 <= r2) {
+      const uint32_t idx = atomicAdd(hit_count, 1u);
+      if (idx < hit_cap) {
+        hit_key[idx] = ((uint64_t)(q_base + q) << 37) | ((uint64_t)l << 32) | id;
+        hit_val[idx] = (uint64_t)__double_as_longlong(__dsqrt_rn(d2));
+      }
+    }
+  }
+}
+
+// Brute force (motif_both_points_noLSH.cpp:27-34,44-50): sqrt form, hit iff !(dis > R).
+__global__ __launch_bounds__(256) void hs_bf_finalize_kernel(const uint8_t* __restrict__ codes,
+                                                             const double* __restrict__ centers,
+                                                             const double* __restrict__ coords,
+                                                             const uint2* __restrict__ prov,
+                                                             const uint32_t* __restrict__ prov_count,
+                                                             uint32_t prov_cap, int k, double R,
+                                                             uint32_t q_base,
+                                                             uint32_t* __restrict__ hit_count,
+                                                             uint32_t hit_cap,
+                                                             uint64_t* __restrict__ hit_key,
+                                                             uint64_t* __restrict__ hit_val) {
+  const uint32_t n = min(*prov_count, prov_cap);
+  for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    const uint32_t q = prov[e].x, id = prov[e].y;
+    const double d2 = exact_dist2(codes + (uint64_t)id * k, centers + (uint64_t)q * 8 * k, coords, k);
+    const double dis = __dsqrt_rn(d2);
+    if (!(dis > R)) {
+      const uint32_t idx = atomicAdd(hit_count, 1u);
+      if (idx < hit_cap) {
+        hit_key[idx] = ((uint64_t)(q_base + q) << 37) | id;
+        hit_val[idx] = (uint64_t)__double_as_longlong(dis);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void hs_unpack_hits_kernel(const uint64_t* __restrict__ key,
+                                                             const uint64_t* __restrict__ val,
+                                                             uint32_t n, uint32_t* __restrict__ q,
+                                                             uint32_t* __restrict__ id,
+                                                             uint32_t* __restrict__ table,
+                                                             double* __restrict__ dist) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t kk = key[i];
+  q[i] = (uint32_t)(kk >> 37);
+  if (table) table[i] = (uint32_t)((kk >> 32) & 31u);
+  id[i] = (uint32_t)kk;
+  dist[i] = __longlong_as_double((long long)val[i]);
+}
+
+inline unsigned blocks_for(uint64_t n, unsigned per = 256) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+// ================================================================================= launchers
+hipError_t hs_launch_embed(const uint8_t* d_codes, uint64_t n, int k, const double* d_coords,
+                           double* d_out, hipStream_t s) {
+  const uint64_t total = n * 8ull * k;
+  if (!total) return hipSuccess;
+  unsigned blocks = (unsigned)std::min<uint64_t>(blocks_for(total), 256u * 16u);
+  hs_embed_kernel<<<blocks, 256, 0, s>>>(d_codes, total, d_coords, d_out);
+  return hipGetLastError();
+}
+
+template <bool FROM_CODES>
+static hipError_t launch_hash(const uint8_t* d_codes, const double* d_pts, uint64_t n, int k,
+                              const double* d_a, const double* d_b, int F, double W,
+                              const double* d_coords, int32_t* d_out, int out_stride, hipStream_t s) {
+  if (!n || !F) return hipSuccess;
+  const unsigned blocks = blocks_for(n);
+  const size_t lds = FROM_CODES ? 256u * (size_t)k : 0;
+#define HS_HASH(KC)                                                                              \
+  hs_hash_kernel<KC, FROM_CODES><<<blocks, 256, lds, s>>>(d_codes, d_pts, n, k, d_a, d_b, F, W, \
+                                                          d_coords, d_out, out_stride)
+  if (F % 16 == 0) HS_HASH(16);
+  else if (F % 8 == 0) HS_HASH(8);
+  else if (F % 5 == 0) HS_HASH(5);
+  else if (F % 4 == 0) HS_HASH(4);
+  else if (F % 2 == 0) HS_HASH(2);
+  else HS_HASH(1);
+#undef HS_HASH
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_hash_codes(const uint8_t* d_codes, uint64_t n, int k, const double* d_a,
+                                const double* d_b, int F, double W, const double* d_coords,
+                                int32_t* d_out, int out_stride, hipStream_t s) {
+  return launch_hash<true>(d_codes, nullptr, n, k, d_a, d_b, F, W, d_coords, d_out, out_stride, s);
+}
+hipError_t hs_launch_hash_points(const double* d_pts, uint64_t n, int k, const double* d_a,
+                                 const double* d_b, int F, double W, int32_t* d_out, int out_stride,
+                                 hipStream_t s) {
+  return launch_hash<false>(nullptr, d_pts, n, k, d_a, d_b, F, W, nullptr, d_out, out_stride, s);
+}
+
+hipError_t hs_launch_keys(const int32_t* d_ints, uint64_t n, int stride, int K, uint32_t seed,
+                          uint64_t* d_keys, uint32_t* d_ids, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hs_keys_kernel<<<blocks_for(n), 256, 0, s>>>(d_ints, n, stride, K, seed, d_keys, d_ids);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_check_runs(const uint64_t* d_keys_sorted, const uint32_t* d_ids_sorted,
+                                const int32_t* d_ints, uint64_t n, int K, uint32_t* d_flag,
+                                hipStream_t s) {
+  if (n < 2) return hipSuccess;
+  hs_check_runs_kernel<<<blocks_for(n - 1), 256, 0, s>>>(d_keys_sorted, d_ids_sorted, d_ints, n, K,
+                                                         d_flag);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_dir_tuples(const uint32_t* d_dir_start, const uint32_t* d_ids_sorted,
+                                const int32_t* d_ints, uint32_t nb, int K, int32_t* d_dir_tuple,
+                                hipStream_t s) {
+  if (!nb) return hipSuccess;
+  hs_dir_tuples_kernel<<<blocks_for((uint64_t)nb * K), 256, 0, s>>>(d_dir_start, d_ids_sorted,
+                                                                    d_ints, nb, K, d_dir_tuple);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_set_u32(uint32_t* d_p, uint32_t v, hipStream_t s) {
+  hs_set_u32_kernel<<<1, 1, 0, s>>>(d_p, v);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_max_u32(const uint32_t* d_in, uint32_t n, uint32_t* d_out, hipStream_t s) {
+  if (!n) return hipSuccess;
+  unsigned blocks = std::min(blocks_for(n), 1024u);
+  hs_max_u32_kernel<<<blocks, 256, 0, s>>>(d_in, n, d_out);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_pack(const uint8_t* d_codes, uint64_t n, int k, uint4* d_packed,
+                          uint32_t* d_bad, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hs_pack_kernel<<<blocks_for(n), 256, 0, s>>>(d_codes, n, k, hs_packed_words(k), d_packed, d_bad);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_gather_packed(const uint4* d_packed_all, const uint32_t* d_ids_sorted,
+                                   uint64_t n, int PW, uint4* d_out, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hs_gather_packed_kernel<<<blocks_for(n * (uint64_t)PW), 256, 0, s>>>(d_packed_all, d_ids_sorted, n,
+                                                                       PW, d_out);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_probe(const hs_tables_dev& tabs, const int32_t* d_qints, uint32_t nq, int K,
+                           int L, uint32_t seed, uint32_t* d_qstart, uint32_t* d_qcount,
+                           uint32_t* d_nslices, uint64_t* d_cand_out,
+                           unsigned long long* d_cand_total, hipStream_t s) {
+  if (!nq) return hipSuccess;
+  hs_probe_kernel<<<blocks_for((uint64_t)nq * L), 256, 0, s>>>(tabs, d_qints, nq, K, L, seed,
+                                                               d_qstart, d_qcount, d_nslices,
+                                                               d_cand_out, d_cand_total);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_qtables(const double* d_centers, uint32_t nq, int k, const double* d_coords,
+                             float* d_tq, hipStream_t s) {
+  if (!nq) return hipSuccess;
+  hs_qtables_kernel<<<blocks_for((uint64_t)nq * k * HS_TROW), 256, 0, s>>>(d_centers, nq, k,
+                                                                           d_coords, d_tq);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_verify(const hs_tables_dev& tabs, const uint32_t* d_qstart,
+                            const uint32_t* d_qcount, const uint32_t* d_slice_off, uint32_t nql,
+                            const float* d_tq, int k, int L, float r2_hi, uint32_t* d_prov_count,
+                            uint32_t prov_cap, uint2* d_prov, int n_blocks, hipStream_t s) {
+  if (!nql) return hipSuccess;
+  const int PW = hs_packed_words(k);
+#define HS_VERIFY(P)                                                                              \
+  hs_verify_kernel<P, false><<<n_blocks, 256, 0, s>>>(tabs, nullptr, 0u, d_qstart, d_qcount,      \
+                                                      d_slice_off, nql, d_tq, k, L, r2_hi,         \
+                                                      d_prov_count, prov_cap, d_prov)
+  if (PW == 1) HS_VERIFY(1);
+  else if (PW == 2) HS_VERIFY(2);
+  else if (PW == 3) HS_VERIFY(3);
+  else return hipErrorInvalidValue;
+#undef HS_VERIFY
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_bruteforce(const uint4* d_packed_all, uint32_t n, const float* d_tq,
+                                uint32_t nq, int k, float r2_hi, uint32_t* d_prov_count,
+                                uint32_t prov_cap, uint2* d_prov, int n_blocks, hipStream_t s) {
+  if (!nq || !n) return hipSuccess;
+  const int PW = hs_packed_words(k);
+  hs_tables_dev none = {};
+#define HS_BRUTE(P)                                                                               \
+  hs_verify_kernel<P, true><<<n_blocks, 256, 0, s>>>(none, d_packed_all, n, nullptr, nullptr,      \
+                                                     nullptr, nq, d_tq, k, 1, r2_hi, d_prov_count, \
+                                                     prov_cap, d_prov)
+  if (PW == 1) HS_BRUTE(1);
+  else if (PW == 2) HS_BRUTE(2);
+  else if (PW == 3) HS_BRUTE(3);
+  else return hipErrorInvalidValue;
+#undef HS_BRUTE
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_finalize(const hs_tables_dev& tabs, const uint8_t* d_codes,
+                              const double* d_centers, const double* d_coords,
+                              const uint32_t* d_qstart, const uint32_t* d_qcount,
+                              const uint2* d_prov, const uint32_t* d_prov_count, uint32_t prov_cap,
+                              int k, int L, double r2, uint32_t q_base, uint32_t* d_hit_count,
+                              uint32_t hit_cap, uint64_t* d_hit_key, uint64_t* d_hit_val,
+                              hipStream_t s) {
+  hs_finalize_kernel<<<1024, 256, 0, s>>>(tabs, d_codes, d_centers, d_coords, d_qstart, d_qcount,
+                                          d_prov, d_prov_count, prov_cap, k, L, r2, q_base,
+                                          d_hit_count, hit_cap, d_hit_key, d_hit_val);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_bf_finalize(const uint8_t* d_codes, const double* d_centers,
+                                 const double* d_coords, const uint2* d_prov,
+                                 const uint32_t* d_prov_count, uint32_t prov_cap, int k, double R,
+                                 uint32_t q_base, uint32_t* d_hit_count, uint32_t hit_cap,
+                                 uint64_t* d_hit_key, uint64_t* d_hit_val, hipStream_t s) {
+  hs_bf_finalize_kernel<<<1024, 256, 0, s>>>(d_codes, d_centers, d_coords, d_prov, d_prov_count,
+                                             prov_cap, k, R, q_base, d_hit_count, hit_cap, d_hit_key,
+                                             d_hit_val);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_unpack_hits(const uint64_t* d_key, const uint64_t* d_val, uint32_t n,
+                                 uint32_t* d_q, uint32_t* d_id, uint32_t* d_table, double* d_dist,
+                                 hipStream_t s) {
+  if (!n) return hipSuccess;
+  hs_unpack_hits_kernel<<<blocks_for(n), 256, 0, s>>>(d_key, d_val, n, d_q, d_id, d_table, d_dist);
+  return hipGetLastError();
+}

@@ -1,0 +1,150 @@
+/* hsearch.h -- C ABI of the MI355X-native motif-search hot path (libhsearch_amd.so).
+ *
+ * The reference (acgtun/hsearch) has no FFI or plugin interface: its operator surface is the set of
+ * C++ free functions and the LSH class in hclust/src/hclust/ (SURVEY.md 8b).  This header is the
+ * boundary a maintainer of the reference would bind instead of those functions; each entry point
+ * names the reference interface it replaces.  INTEGRATION.md shows the reference-side call sites.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types; every function returns an hs_status and never
+ *     throws; hs_last_error() gives the message of the last failure on a handle;
+ *   - the caller owns every buffer it passes in; the library owns device memory behind the handle;
+ *   - functions WITHOUT a _dev suffix take HOST pointers and copy over PCIe; the _dev variants
+ *     take DEVICE pointers (HBM-resident inputs/outputs) and are what bench.py times;
+ *   - output capacity is explicit: when results exceed `cap` the call returns HS_ERR_CAPACITY and
+ *     *n_out holds the required capacity (two-call pattern);
+ *   - a handle is bound to one GPU and is not thread-safe; use one handle per GPU / process;
+ *   - requires a gfx950 device: there is no CPU fallback, calls fail with HS_ERR_NO_DEVICE.
+ *
+ * Layouts (all row-major, densely packed)
+ *   codes   [n][k]      uint8   rows of the amino-acid table (0..19), see hs_tables.h
+ *   points  [n][d]      double  d = 8*k
+ *   planes  a[L][K][d], b[L][K] double  (LSH::a, LSH::b of table l -- lsh.hpp:65-66)
+ *   buckets [n][L][K]   int32
+ */
+#ifndef HSEARCH_H
+#define HSEARCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HS_API __attribute__((visibility("default")))
+
+typedef enum hs_status {
+  HS_OK = 0,
+  HS_ERR_INVALID = 1,       /* bad argument */
+  HS_ERR_NO_DEVICE = 2,     /* no usable gfx950 device */
+  HS_ERR_HIP = 3,           /* a HIP runtime call failed (see hs_last_error) */
+  HS_ERR_CAPACITY = 4,      /* output buffer too small; required size reported */
+  HS_ERR_STATE = 5,         /* e.g. query before hs_index_build */
+  HS_ERR_KEY_COLLISION = 6, /* 64-bit key fingerprints collided for every retry seed */
+  HS_ERR_NOMEM = 7
+} hs_status;
+
+/* Replaces the (dimension, hash_K, hash_W) arguments of LSH::LSH (lsh.hpp:10-17) and the
+ * (hash_K, hash_L, hash_W) arguments of Search()/Clustering() (motif_both_points.cpp:195-203,
+ * hclust2.cpp:86-91).  DIMENSION = AACoordinateSize * KMERLENGTH (motif_both_points.cpp:337-338). */
+typedef struct hs_params {
+  uint32_t k;      /* residues per k-mer (KMERLENGTH); d = 8*k */
+  uint32_t K;      /* hash functions per table (hash_K), 1..32 */
+  uint32_t L;      /* hash tables (hash_L), 1..32 */
+  double W;        /* bucket width (hash_W) */
+  int32_t device;  /* HIP device ordinal */
+  uint32_t flags;  /* reserved, 0 */
+} hs_params;
+
+typedef struct hs_handle hs_handle;
+
+/* Phase timings (HIP events on the library's stream) and counters of the LAST call on a handle. */
+typedef struct hs_profile {
+  double ms_hash;        /* projection + bucket ints + key fingerprints */
+  double ms_sort;        /* build: radix sort + directory */
+  double ms_gather;      /* build: bucket-ordered packed-code copies */
+  double ms_probe;       /* query: directory lookup */
+  double ms_verify;      /* query: candidate scan kernel (the dominant kernel) */
+  double ms_finalize;    /* query: dedupe + exact fp64 distance + ordering of hits */
+  double ms_total;       /* whole call, device side */
+  uint64_t candidates;   /* sum over (q, l) of |B_l(q)| scanned by the last query call */
+  uint64_t provisional;  /* candidates that passed the fp32 filter */
+  uint64_t hits;
+  uint64_t verify_launches;
+} hs_profile;
+
+typedef struct hs_index_info {
+  uint64_t n;               /* DB k-mers */
+  uint64_t device_bytes;    /* HBM held by the index */
+  uint64_t n_buckets[32];   /* distinct keys of table l (the reference prints this, :217) */
+  uint64_t max_bucket[32];  /* population of the largest bucket of table l */
+  uint32_t key_seed;        /* fingerprint seed that produced a collision-free directory */
+} hs_index_info;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+
+/* Replaces L constructions of LSH (lsh.hpp:10-31), except that the planes are an INPUT: the
+ * reference draws them from std::random_device (lsh.hpp:19-20), which no caller can reproduce.
+ * coords: [20][8] embedding table, or NULL for HS_AA_COORDS (util.hpp:21-42). */
+HS_API hs_status hs_create(const hs_params* params, const double* a, const double* b,
+                           const double* coords, hs_handle** out);
+HS_API void hs_destroy(hs_handle* h);
+HS_API const char* hs_last_error(const hs_handle* h);
+HS_API hs_status hs_get_profile(const hs_handle* h, hs_profile* out);
+HS_API const char* hs_version(void);
+
+/* ---- embedding + hashing (rows a2, a4, a5, a6) ----------------------------------------------- */
+
+/* KmerToCoordinates (hclust2.cpp:49-62) for n k-mers given as codes: out[n][d]. */
+HS_API hs_status hs_embed_codes(hs_handle* h, const uint8_t* codes, uint64_t n, double* out);
+
+/* LSH::HashBucketIndex (lsh.hpp:44-49) for every (point, table, function): bit-exact ints,
+ * strict left-to-right fp64 with separate multiply and add as lsh.hpp:33-42 evaluates it. */
+HS_API hs_status hs_hash_codes(hs_handle* h, const uint8_t* codes, uint64_t n, int32_t* buckets);
+HS_API hs_status hs_hash_points(hs_handle* h, const double* points, uint64_t n, int32_t* buckets);
+
+/* LSH::HashKey (lsh.hpp:51-59): decimal strings of K ints concatenated without separator.
+ * Host-side helper; returns the length, writes a NUL-terminated string of at most cap-1 chars. */
+HS_API uint32_t hs_key_string(const int32_t* buckets, uint32_t K, char* out, uint32_t cap);
+
+/* ---- index build (row a7) --------------------------------------------------------------------- */
+
+/* Replaces the build loop of Search() (motif_both_points.cpp:206-218) / BuildLSHTalbe
+ * (hclust2.cpp:74-84): L tables keyed by HashKey string equality, ids ascending inside a bucket.
+ * The DB is kept as residue codes (k bytes per k-mer), never as 8k doubles. */
+HS_API hs_status hs_index_build(hs_handle* h, const uint8_t* codes, uint64_t n);
+HS_API hs_status hs_index_info_get(const hs_handle* h, hs_index_info* out);
+
+/* ---- query = probe + dedupe + verify (rows a8, a9, a10) ---------------------------------------- */
+
+/* Replaces the query loop of Search() (motif_both_points.cpp:224-245).  centers[nq][d] are
+ * arbitrary points of R^d.  A hit is (query, DB id, table of first sight, sqrt(d2)) with
+ * d2 = sum (x_i - c_i)^2 evaluated left to right in fp64 (motif_both_points.cpp:176-183) and
+ * d2 <= R*R (:239).  Hits are returned in the reference's output order: query, then table of
+ * first sight, then ascending DB id.  cand[nq][L] (may be NULL) receives |B_l(q)|. */
+HS_API hs_status hs_query(hs_handle* h, const double* centers, uint64_t nq, double R,
+                          uint32_t* hit_q, uint32_t* hit_id, uint32_t* hit_table, double* hit_dist,
+                          uint64_t cap, uint64_t* n_hits, uint64_t* cand);
+/* Same with every pointer except n_hits in device memory (HBM-resident queries and hits). */
+HS_API hs_status hs_query_dev(hs_handle* h, const double* d_centers, uint64_t nq, double R,
+                              uint32_t* d_hit_q, uint32_t* d_hit_id, uint32_t* d_hit_table,
+                              double* d_hit_dist, uint64_t cap, uint64_t* n_hits,
+                              uint64_t* d_cand);
+
+/* ---- brute force (row a11) ---------------------------------------------------------------------- */
+
+/* Replaces Search() of motif_both_points_noLSH.cpp:36-56: every (q, j) with !(sqrt(d2) > R),
+ * query-major, ascending j (the order of the reference's hits file). */
+HS_API hs_status hs_bruteforce(hs_handle* h, const double* centers, uint64_t nq, double R,
+                               uint32_t* hit_q, uint32_t* hit_id, double* hit_dist, uint64_t cap,
+                               uint64_t* n_hits);
+/* Exact k nearest DB k-mers per query (ground truth of recall@k; ties by lower id).
+ * nn_id[nq][topk], nn_dist2[nq][topk] (squared, fp64 left-to-right). */
+HS_API hs_status hs_bruteforce_topk(hs_handle* h, const double* centers, uint64_t nq,
+                                    uint32_t topk, uint32_t* nn_id, double* nn_dist2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HSEARCH_H */
