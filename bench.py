@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""bench.py -- motif queries/s of the LSH search hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): 10 M synthetic 25-mers, L = 8 tables, K = 16, W = 200,
+R = 40, 100 k queries per GPU (DB k-mers with 0..4 substitutions), index resident in HBM.
+A "step" = one pass of the query hot path (hash queries -> probe -> verify -> dedupe/exact
+distance -> ordered hits [-> RCCL all-gather of hits when N > 1]) over the rank's query batch, with
+the queries already resident in HBM.  N > 1: one process per GPU, index replicated, queries
+sharded (weak scaling: 100 k queries per GPU), hits all-gathered.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (hs_verify_kernel) by the
+ALGORITHMIC bytes of SURVEY.md 8(d) over its HIP-event time; `cpu_baseline` times the reference's
+CPU path on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=10_000_000, help="DB k-mers")
+    ap.add_argument("--nq", type=int, default=100_000, help="queries per GPU")
+    ap.add_argument("--k", type=int, default=25)
+    ap.add_argument("--K", type=int, default=16)
+    ap.add_argument("--L", type=int, default=8)
+    ap.add_argument("--W", type=float, default=200.0)
+    ap.add_argument("--R", type=float, default=40.0)
+    ap.add_argument("--recall-queries", type=int, default=256)
+    ap.add_argument("--cpu-n", type=int, default=200_000, help="DB sample of the CPU baseline")
+    ap.add_argument("--cpu-nq", type=int, default=200, help="query sample of the CPU baseline")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def synth_seed_planes():
+    from hsearch_amd import synth
+    return synth.SEED_PLANES
+
+
+def cpu_baseline(args, a, b, codes, centers):
+    """Reference CPU path on a bounded sample: the first cpu_n DB k-mers, the first cpu_nq
+    queries, same planes.  Bucket populations (hence per-query cost) scale linearly with N, so the
+    queries/s at the bench's N is the measured sample rate x (cpu_n / N); both are reported."""
+    from oracle import pyoracle as O
+    n_s = min(args.cpu_n, codes.shape[0])
+    q_s = min(args.cpu_nq, centers.shape[0])
+    db = O.embed_codes(codes[:n_s])
+    cq = centers[:q_s]
+    t0 = time.perf_counter()
+    ix = O.Index(a, b, args.W, db)           # Search() build loop, motif_both_points.cpp:206-218
+    t_build = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    res = ix.query(cq, args.R)               # Search() query loop, :224-245
+    t_query = time.perf_counter() - t0
+    ix.close()
+    qps_sample = q_s / t_query
+    out = {
+        "value": qps_sample * n_s / codes.shape[0],
+        "unit": "queries/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": ("oracle/hs_oracle.cpp (restatement with the reference's cost structure, pinned "
+                   "bit-exact to the compiled reference) on the first %d DB k-mers and first %d "
+                   "queries, same planes: %.1f queries/s measured at N=%d, scaled by %d/%d to the "
+                   "bench N (bucket populations are linear in N); index build %.0f k-mers/s"
+                   % (n_s, q_s, qps_sample, n_s, n_s, codes.shape[0], n_s / t_build)),
+        "measured_qps_at_sample": qps_sample,
+        "sample_n": n_s, "sample_nq": q_s,
+        "build_kmers_per_s": n_s / t_build,
+        "sample_hits": int(len(res["q"])),
+        "sample_seconds": t_build + t_query,
+    }
+    if O.have_ref():
+        # the real compiled reference (oracle/_ref) on the same sample.  Its Search() draws its own
+        # planes (same distributions, seeded through the harness) and is monolithic, so it is timed
+        # with zero centers (build only) and with the sample queries, and the difference is the
+        # query loop.  Reported beside the port, which runs the bench's exact planes.
+        import tempfile
+        fd, path = tempfile.mkstemp()
+        os.close(fd)
+        t = time.perf_counter()
+        O.ref_search(synth_seed_planes(), db, cq[:0], args.K, args.L, args.W, args.R, path)
+        tb = time.perf_counter() - t
+        t = time.perf_counter()
+        O.ref_search(synth_seed_planes(), db, cq, args.K, args.L, args.W, args.R, path)
+        tf = time.perf_counter() - t
+        os.unlink(path)
+        tq = max(tf - tb, 1e-9)
+        out["reference_check"] = {
+            "what": "oracle/_ref: the reference's own Search() compiled from its sources, same "
+                    "sample, planes drawn by its own LSH constructor",
+            "measured_qps_at_sample": q_s / tq, "build_kmers_per_s": n_s / tb,
+            "value_scaled_to_bench_n": q_s / tq * n_s / codes.shape[0]}
+    return out
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    import torch
+    import torch.distributed as dist
+    from hsearch_amd import Engine, HsError, synth
+    from hsearch_amd import dist as hdist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    k, K, L, W, R = args.k, args.K, args.L, args.W, args.R
+    d = 8 * k
+    a, b = synth.make_planes(k, K, L, W)
+    codes = synth.make_db(args.n, k)
+    centers, src = synth.make_queries(codes, args.nq, seed=synth.SEED_QUERIES + 1000 * rank)
+
+    eng = Engine(k, K, L, W, a, b, device=local_rank)
+    t0 = time.perf_counter()
+    info = eng.index_build(codes)
+    t_build = time.perf_counter() - t0
+    build_prof = eng.profile()
+
+    d_centers = torch.from_numpy(centers).to(dev)
+    cap = 16 * args.nq + 4096
+    out = None
+
+    def alloc(c):
+        return dict(q=torch.empty(c, dtype=torch.int32, device=dev),
+                    id=torch.empty(c, dtype=torch.int32, device=dev),
+                    table=torch.empty(c, dtype=torch.int32, device=dev),
+                    dist=torch.empty(c, dtype=torch.float64, device=dev))
+    out = alloc(cap)
+    q_lo = rank * args.nq
+    state = {"cap": cap, "out": out}
+
+    def step():
+        while True:
+            o = state["out"]
+            try:
+                nh = eng.query_dev(d_centers.data_ptr(), args.nq, R, o["q"].data_ptr(),
+                                   o["id"].data_ptr(), o["table"].data_ptr(), o["dist"].data_ptr(),
+                                   state["cap"])
+                break
+            except HsError as e:
+                if getattr(e, "needed", 0) <= state["cap"]:
+                    raise
+                state["cap"] = int(e.needed * 1.25) + 1024
+                state["out"] = alloc(state["cap"])
+        gathered = hdist.allgather_hits(o["q"], o["id"], o["table"], o["dist"], nh, q_offset=q_lo)
+        return nh, gathered
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    verify_ms, cand, hits_local, hash_ms, probe_ms, fin_ms = 0.0, 0, 0, 0.0, 0.0, 0.0
+    launches = 0
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        nh, gathered = step()
+        p = eng.profile()
+        verify_ms += p["ms_verify"]
+        hash_ms += p["ms_hash"]
+        probe_ms += p["ms_probe"]
+        fin_ms += p["ms_finalize"]
+        launches += p["verify_launches"]
+        cand = p["candidates"]
+        hits_local = nh
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    total_hits = int(gathered[0].numel())
+
+    if rank == 0:
+        steps = max(args.steps, 1)
+        ms_step = dt / steps * 1e3
+        value = world * args.nq * steps / dt
+        # ALGORITHMIC bytes of one step on this rank: per scanned bucket entry one
+        # k-byte k-mer + one u32 id, + per query its vector (8d) + L bucket lookups (16 B) +
+        # 16 B per hit.
+        algo_bytes = cand * (k + 4) + args.nq * (8 * d + 16 * L) + 16 * hits_local
+        v_ms = verify_ms / steps
+        achieved = algo_bytes / (v_ms * 1e-3) / 1e9 if v_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("verify_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "motif queries/sec (LSH probe + verify, index resident in HBM)",
+            "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[1]: %d x %d-mers, L=%d K=%d W=%g R=%g, %d queries per GPU, "
+                                   "index replicated per GPU" % (args.n, k, L, K, W, R, args.nq),
+                       "db_kmers": args.n, "k": k, "L": L, "K": K, "W": W, "R": R,
+                       "queries_per_gpu": args.nq, "parallelism": "query-sharded x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "hs_verify_kernel", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic,
+                         "algorithmic_bytes_per_step": algo_bytes,
+                         "kernel_ms_per_step": v_ms,
+                         "launches_per_step": launches / steps,
+                         "packed_stream_bytes_per_step": cand * 16 * ((k + 24) // 25)},
+            "phases_ms_per_step": {"hash_queries": hash_ms / steps, "probe_qtables": probe_ms / steps,
+                                   "verify": v_ms, "finalize_sort": fin_ms / steps},
+            "candidates_per_query": cand / args.nq, "hits_per_step_rank0": hits_local,
+            "hits_gathered": total_hits,
+            "index": {"build_seconds": t_build, "build_kmers_per_s": args.n / t_build,
+                      "device_ms": {f: build_prof[f] for f in ("ms_hash", "ms_sort", "ms_gather", "ms_total")},
+                      "device_bytes": info["device_bytes"], "n_buckets": info["n_buckets"],
+                      "max_bucket": info["max_bucket"]},
+        }
+        # radius recall on a query subsample, ground truth = exhaustive scan on the GPU
+        # (hs_bruteforce, itself parity-tested against the oracle)
+        nr = min(args.recall_queries, args.nq)
+        if nr > 0:
+            sub = centers[:nr]
+            bf = eng.bruteforce(sub, R)
+            lsh = eng.query(sub, R, want_cand=False)
+            truth = set(zip(bf["q"].tolist(), bf["id"].tolist()))
+            found = set(zip(lsh["q"].tolist(), lsh["id"].tolist()))
+            line["radius_recall"] = len(truth & found) / max(len(truth), 1)
+            line["recall_queries"] = nr
+            line["true_neighbours_in_sample"] = len(truth)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, a, b, codes, centers)
+        print(json.dumps(line))
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
