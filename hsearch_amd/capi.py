@@ -15,7 +15,8 @@ _STATUS = ["HS_OK", "HS_ERR_INVALID", "HS_ERR_NO_DEVICE", "HS_ERR_HIP", "HS_ERR_
 _ALPHABET = "ARNDCQEGHILKMFPSTWYV"
 
 EXPORTS = ["hs_create", "hs_destroy", "hs_last_error", "hs_get_profile", "hs_version",
-           "hs_embed_codes", "hs_hash_codes", "hs_hash_points", "hs_key_string", "hs_index_build",
+           "hs_embed_codes", "hs_hash_codes", "hs_hash_points", "hs_key_string", "hs_key_fingerprint",
+           "hs_key_strings_equal", "hs_index_build",
            "hs_index_info_get", "hs_query", "hs_query_dev", "hs_bruteforce", "hs_bruteforce_topk"]
 
 
@@ -67,6 +68,8 @@ def load():
         lib.hs_destroy.restype = None
         lib.hs_destroy.argtypes = [C.c_void_p]
         lib.hs_key_string.restype = C.c_uint32
+        lib.hs_key_fingerprint.restype = C.c_uint64
+        lib.hs_key_strings_equal.restype = C.c_int
         _lib = lib
     return _lib
 
@@ -92,6 +95,20 @@ def key_string(buckets):
     buf = C.create_string_buffer(12 * len(b) + 1)
     load().hs_key_string(b.ctypes.data_as(C.c_void_p), C.c_uint32(len(b)), buf, C.c_uint32(len(buf)))
     return buf.value.decode()
+
+
+def key_fingerprint(buckets, seed=0):
+    b = np.ascontiguousarray(buckets, dtype=np.int32)
+    return int(load().hs_key_fingerprint(b.ctypes.data_as(C.c_void_p), C.c_uint32(len(b)),
+                                         C.c_uint32(seed)))
+
+
+def key_strings_equal(x, y):
+    x = np.ascontiguousarray(x, dtype=np.int32)
+    y = np.ascontiguousarray(y, dtype=np.int32)
+    assert len(x) == len(y)
+    return bool(load().hs_key_strings_equal(x.ctypes.data_as(C.c_void_p),
+                                            y.ctypes.data_as(C.c_void_p), C.c_uint32(len(x))))
 
 
 def _vp(arr):

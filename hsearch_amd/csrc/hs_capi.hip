@@ -132,6 +132,14 @@ uint32_t hs_key_string(const int32_t* buckets, uint32_t K, char* out, uint32_t c
   return (uint32_t)n;
 }
 
+uint64_t hs_key_fingerprint(const int32_t* buckets, uint32_t K, uint32_t seed) {
+  return hs_key_of(buckets, (int)std::min<uint32_t>(K, HS_MAX_K), seed);
+}
+
+int hs_key_strings_equal(const int32_t* x, const int32_t* y, uint32_t K) {
+  return hs_key_equal(x, y, (int)std::min<uint32_t>(K, HS_MAX_K)) ? 1 : 0;
+}
+
 hs_status hs_create(const hs_params* params, const double* a, const double* b, const double* coords,
                     hs_handle** out) {
   if (!out) return HS_ERR_INVALID;

@@ -107,6 +107,11 @@ HS_API hs_status hs_hash_points(hs_handle* h, const double* points, uint64_t n, 
 /* LSH::HashKey (lsh.hpp:51-59): decimal strings of K ints concatenated without separator.
  * Host-side helper; returns the length, writes a NUL-terminated string of at most cap-1 chars. */
 HS_API uint32_t hs_key_string(const int32_t* buckets, uint32_t K, char* out, uint32_t cap);
+/* Diagnostics (host-side, no GPU): the 64-bit fingerprint of that character stream under which the
+ * index groups keys, and the exact HashKey string equality of two K-tuples (the index never trusts
+ * the fingerprint alone: it re-checks equality at build and at probe time). */
+HS_API uint64_t hs_key_fingerprint(const int32_t* buckets, uint32_t K, uint32_t seed);
+HS_API int hs_key_strings_equal(const int32_t* x, const int32_t* y, uint32_t K);
 
 /* ---- index build (row a7) --------------------------------------------------------------------- */
 

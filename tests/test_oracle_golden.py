@@ -1,0 +1,82 @@
+"""The CPU oracle against the golden vectors dumped from the compiled reference
+(tools/gen_golden.py).  This is what pins the oracle on machines where /root/reference is absent."""
+import json
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+
+def _load(golden_dir, name):
+    return json.load(open(os.path.join(golden_dir, name)))
+
+
+def test_hash_dots_buckets_keys(oracle, golden_dir):
+    for case in _load(golden_dir, "hash.json")["cases"]:
+        z = np.load(os.path.join(golden_dir, case["file"]))
+        pts = np.concatenate([oracle.embed_codes(z["codes"]), z["arb"]])
+        for l in range(case["L"]):
+            buckets, dots = oracle.hash_table(z["a"][l], z["b"][l], case["W"], pts, want_dots=True)
+            assert np.array_equal(dots, z["dots"][:, l])          # fp64, same rounding sequence
+            assert np.array_equal(buckets, z["buckets"][:, l])
+            for i in range(len(pts)):
+                assert oracle.key_string(buckets[i]) == case["keys"][i][l]
+
+
+def test_search_hits_order_and_text(oracle, golden_dir):
+    for case in _load(golden_dir, "search.json")["cases"]:
+        z = np.load(os.path.join(golden_dir, case["file"]))
+        res = oracle.search(z["a"], z["b"], case["W"], case["R"], oracle.embed_codes(z["codes"]),
+                            z["centers"])
+        assert np.array_equal(res["q"], z["hit_q"])
+        assert np.array_equal(res["id"], z["hit_id"])
+        with tempfile.TemporaryDirectory() as d:
+            p = os.path.join(d, "hits.txt")
+            oracle.write_hits(p, res["q"], res["id"], res["dist"])
+            text = [line.split()[2] for line in open(p)]
+        assert text == case["hit_dist_text"]
+        # first-seen table order: non-decreasing table inside a query
+        for q in np.unique(res["q"]):
+            t = res["table"][res["q"] == q]
+            assert np.all(np.diff(t.astype(np.int64)) >= 0)
+
+
+def test_pairwise_square(oracle, golden_dir):
+    z = np.load(os.path.join(golden_dir, "pairwise.npz"))
+    got = oracle.pairwise_square(oracle.embed_codes(z["codes"]), z["centers"])
+    assert np.array_equal(got, z["dist2"])
+
+
+def test_bruteforce_consistent_with_pairwise(oracle, golden_dir):
+    z = np.load(os.path.join(golden_dir, "pairwise.npz"))
+    db = oracle.embed_codes(z["codes"])
+    R = 60.0
+    bf = oracle.bruteforce(db, z["centers"], R)
+    want = [(q, j) for q in range(len(z["centers"])) for j in range(len(db))
+            if not (np.sqrt(z["dist2"][q, j]) > R)]
+    assert list(zip(bf["q"].tolist(), bf["id"].tolist())) == want
+    nn, d2 = oracle.bruteforce_topk(db, z["centers"], 10)
+    for q in range(len(z["centers"])):
+        order = np.lexsort((np.arange(len(db)), z["dist2"][q]))[:10]
+        assert np.array_equal(nn[q], order)
+        assert np.array_equal(d2[q], z["dist2"][q][order])
+
+
+def test_clustering_file(oracle, golden_dir):
+    for case in _load(golden_dir, "clustering.json")["cases"]:
+        z = np.load(os.path.join(golden_dir, case["file"]))
+        with tempfile.TemporaryDirectory() as d:
+            p = os.path.join(d, "clusters.txt")
+            oracle.clustering_to_file(z["a"], z["b"], case["W"], case["R"],
+                                      oracle.embed_codes(z["codes"]), p)
+            assert open(p).read() == case["clusters_file"]
+
+
+def test_evaluate(oracle, golden_dir):
+    g = _load(golden_dir, "evaluate.json")
+    with tempfile.TemporaryDirectory() as d:
+        gt, hits = os.path.join(d, "gt"), os.path.join(d, "hits")
+        open(gt, "w").write("\n".join(g["ground_truth"]) + "\n")
+        open(hits, "w").write("\n".join(g["hits"]) + "\n")
+        assert oracle.evaluate(gt, hits, g["R"]) == pytest.approx(g["weighted_recall"], abs=1e-15)

@@ -1,0 +1,73 @@
+"""The CPU oracle against the real reference compiled into oracle/_ref, on fresh seeded inputs.
+Runs only where oracle/_ref exists (the build container, or a box the .so travelled to)."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as O
+
+pytestmark = pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+
+LETTERS = "ARNDCQEGHILKMFPSTWYV"
+
+
+def _data(seed, n, nq, k):
+    r = np.random.default_rng(seed)
+    codes = r.integers(0, 20, (n, k)).astype(np.uint8)
+    qc = codes[r.integers(0, n, nq)].copy()
+    for i in range(nq):
+        for _ in range(r.integers(0, 5)):
+            qc[i, r.integers(0, k)] = r.integers(0, 20)
+    centers = O.embed_codes(qc) + r.normal(0, 0.3, (nq, 8 * k))
+    return codes, centers
+
+
+def test_constants():
+    from hsearch_amd import synth
+    coords, dist2, base = O.ref_constants()
+    assert np.array_equal(coords, synth.coords())
+
+
+@pytest.mark.parametrize("k,K,L,W,R", [(25, 4, 4, 100.0, 40.0), (25, 16, 8, 200.0, 40.0),
+                                       (15, 6, 5, 7.0, 30.0), (39, 4, 3, 0.9, 50.0)])
+def test_hash_and_search(k, K, L, W, R):
+    codes, centers = _data(3, 3000, 150, k)
+    db = O.embed_codes(codes)
+    seqs = ["".join(LETTERS[c] for c in row) for row in codes]
+    assert np.array_equal(db, O.ref_kmer_to_coordinates(seqs, k))
+    a, b = O.ref_planes(11, 8 * k, K, L, W)
+    for l in range(L):
+        bk, dots, keys = O.ref_hash_table(a[l], b[l], W, db[:300], want_keys=True)
+        bo, do = O.hash_table(a[l], b[l], W, db[:300], want_dots=True)
+        assert np.array_equal(bk, bo) and np.array_equal(dots, do)
+        assert all(O.key_string(bo[i]) == keys[i] for i in range(300))
+    rq, rid, rdist = O.ref_search(11, db, centers, K, L, W, R)
+    res = O.search(a, b, W, R, db, centers)
+    assert np.array_equal(rq, res["q"]) and np.array_equal(rid, res["id"])
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "h")
+        O.write_hits(p, res["q"], res["id"], res["dist"])
+        assert [line.split()[2] for line in open(p)] == rdist
+
+
+def test_clustering():
+    r = np.random.default_rng(9)
+    k = 25
+    rows = []
+    for f in r.integers(0, 20, (30, k)):
+        for _ in range(40):
+            row = f.copy()
+            for _ in range(r.integers(0, 5)):
+                row[r.integers(0, k)] = r.integers(0, 20)
+            rows.append(row)
+    rows = np.array(rows, dtype=np.uint8)
+    r.shuffle(rows)
+    seqs = ["".join(LETTERS[c] for c in row) for row in rows]
+    with tempfile.TemporaryDirectory() as d:
+        p1, p2 = os.path.join(d, "ref"), os.path.join(d, "port")
+        O.ref_clustering_file(5, seqs, k, 4, 8, 100.0, 60.0, p1)
+        a, b = O.ref_planes(5, 200, 4, 8, 100.0)
+        O.clustering_to_file(a, b, 100.0, 60.0, O.embed_codes(rows), p2)
+        assert open(p1).read() == open(p2).read()
