@@ -29,7 +29,7 @@ class HsError(RuntimeError):
 
 class _Params(C.Structure):
     _fields_ = [("k", C.c_uint32), ("K", C.c_uint32), ("L", C.c_uint32), ("W", C.c_double),
-                ("device", C.c_int32), ("flags", C.c_uint32)]
+                ("device", C.c_int32), ("alphabet", C.c_uint32)]
 
 
 class _Profile(C.Structure):
@@ -132,9 +132,10 @@ class Engine:
         cptr = None
         if coords is not None:
             coords = np.ascontiguousarray(coords, dtype=np.float64)
-            assert coords.shape == (20, 8)
+            assert coords.ndim == 2 and coords.shape[1] == 8 and 1 <= coords.shape[0] <= 32
             cptr = _vp(coords)
-        params = _Params(self.k, self.K, self.L, self.W, int(device), 0)
+        params = _Params(self.k, self.K, self.L, self.W, int(device),
+                         0 if coords is None else coords.shape[0])
         self._h = C.c_void_p()
         st = self._lib.hs_create(C.byref(params), _vp(a), _vp(b), cptr, C.byref(self._h))
         if st != HS_OK:
@@ -260,3 +261,14 @@ class Engine:
             self._check(st)
             n = int(n.value)
             return dict(q=hq[:n], id=hid[:n], dist=hd[:n])
+
+    def bruteforce_topk(self, centers, topk):
+        """Exact k nearest DB k-mers per query: (ids [nq][topk], squared distances [nq][topk]),
+        ordered by (d2, id); ground truth of recall@k."""
+        centers = np.ascontiguousarray(centers, dtype=np.float64)
+        nq = centers.shape[0]
+        nn = np.empty((nq, topk), dtype=np.uint32)
+        d2 = np.empty((nq, topk), dtype=np.float64)
+        self._check(self._lib.hs_bruteforce_topk(self._h, _vp(centers), C.c_uint64(nq),
+                                                 C.c_uint32(topk), _vp(nn), _vp(d2)))
+        return nn, d2

@@ -50,7 +50,7 @@ enum { EV_COUNT = 10 };
 
 struct hs_handle {
   hs_params p;
-  int d = 0, LK = 0, PW = 0;
+  int d = 0, LK = 0, PW = 0, alphabet = HS_ALPHABET;
   int n_cu = 256;
   hipStream_t stream = nullptr;
   hipEvent_t ev[EV_COUNT];
@@ -146,7 +146,8 @@ hs_status hs_create(const hs_params* params, const double* a, const double* b, c
   *out = nullptr;
   if (!params || !a || !b) return HS_ERR_INVALID;
   if (params->k < 1 || params->k > 75 || params->K < 1 || params->K > HS_MAX_K || params->L < 1 ||
-      params->L > HS_MAX_L || !(params->W > 0.0) || !isfinite(params->W))
+      params->L > HS_MAX_L || !(params->W > 0.0) || !isfinite(params->W) ||
+      params->alphabet > HS_ALPHABET_PAD || (params->alphabet && !coords))
     return HS_ERR_INVALID;
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0 || params->device < 0 ||
@@ -160,6 +161,7 @@ hs_status hs_create(const hs_params* params, const double* a, const double* b, c
   h->d = 8 * (int)params->k;
   h->LK = (int)(params->L * params->K);
   h->PW = hs_packed_words((int)params->k);
+  h->alphabet = params->alphabet ? (int)params->alphabet : HS_ALPHABET;
   h->n_cu = prop.multiProcessorCount;
   memset(&h->tabs, 0, sizeof(h->tabs));
   memset(&h->info, 0, sizeof(h->info));
@@ -172,11 +174,12 @@ hs_status hs_create(const hs_params* params, const double* a, const double* b, c
   const size_t na = (size_t)h->LK * h->d;
   HS_HIP(h, h->a.reserve(na * 8));
   HS_HIP(h, h->b.reserve((size_t)h->LK * 8));
-  HS_HIP(h, h->coords.reserve(160 * 8));
+  HS_HIP(h, h->coords.reserve(HS_ALPHABET_PAD * 8 * 8));
+  HS_HIP(h, hipMemsetAsync(h->coords.p, 0, HS_ALPHABET_PAD * 8 * 8, h->stream));
   HS_HIP(h, hipMemcpyAsync(h->a.p, a, na * 8, hipMemcpyHostToDevice, h->stream));
   HS_HIP(h, hipMemcpyAsync(h->b.p, b, (size_t)h->LK * 8, hipMemcpyHostToDevice, h->stream));
-  HS_HIP(h, hipMemcpyAsync(h->coords.p, coords ? coords : &HS_AA_COORDS[0][0], 160 * 8,
-                           hipMemcpyHostToDevice, h->stream));
+  HS_HIP(h, hipMemcpyAsync(h->coords.p, coords ? coords : &HS_AA_COORDS[0][0],
+                           (size_t)h->alphabet * 8 * 8, hipMemcpyHostToDevice, h->stream));
   HS_HIP(h, hipStreamSynchronize(h->stream));
   return HS_OK;
 }
@@ -209,7 +212,7 @@ hs_status hs_embed_codes(hs_handle* h, const uint8_t* codes, uint64_t n, double*
   if (!h || (n && (!codes || !out))) return HS_ERR_INVALID;
   if (!n) return HS_OK;
   for (uint64_t i = 0; i < n * h->p.k; ++i)
-    if (codes[i] >= HS_ALPHABET) return fail(h, HS_ERR_INVALID, "residue code >= 20");
+    if (codes[i] >= h->alphabet) return fail(h, HS_ERR_INVALID, "residue code outside the alphabet");
   hs_status st = ensure_device(h);
   if (st) return st;
   const size_t out_bytes = (size_t)n * h->d * 8;
@@ -227,7 +230,7 @@ hs_status hs_hash_codes(hs_handle* h, const uint8_t* codes, uint64_t n, int32_t*
   if (!h || (n && (!codes || !buckets))) return HS_ERR_INVALID;
   if (!n) return HS_OK;
   for (uint64_t i = 0; i < n * h->p.k; ++i)
-    if (codes[i] >= HS_ALPHABET) return fail(h, HS_ERR_INVALID, "residue code >= 20");
+    if (codes[i] >= h->alphabet) return fail(h, HS_ERR_INVALID, "residue code outside the alphabet");
   hs_status st = ensure_device(h);
   if (st) return st;
   const size_t out_bytes = (size_t)n * h->LK * 4;
@@ -377,12 +380,12 @@ hs_status hs_index_build(hs_handle* h, const uint8_t* codes, uint64_t n) {
   if (n) {
     HS_HIP(h, hipMemcpyAsync(h->codes.p, codes, (size_t)n * k, hipMemcpyHostToDevice, h->stream));
     HS_HIP(h, hipMemsetAsync(h->counters.p, 0, 256, h->stream));
-    HS_HIP(h, hs_launch_pack(h->codes.as<uint8_t>(), n, k, h->packed_all.as<uint4>(),
+    HS_HIP(h, hs_launch_pack(h->codes.as<uint8_t>(), n, k, h->alphabet, h->packed_all.as<uint4>(),
                              h->counters.as<uint32_t>(), h->stream));
     uint32_t bad = 0;
     HS_HIP(h, hipMemcpyAsync(&bad, h->counters.p, 4, hipMemcpyDeviceToHost, h->stream));
     HS_HIP(h, hipStreamSynchronize(h->stream));
-    if (bad) return fail(h, HS_ERR_INVALID, "residue code >= 20 in the DB");
+    if (bad) return fail(h, HS_ERR_INVALID, "residue code outside the alphabet in the DB");
   }
   bool collided = true;
   uint32_t seed = 0;
@@ -447,7 +450,8 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, h->nslices.as<uint32_t>(),
                                     h->slice_off.as<uint32_t>(), (size_t)nql + 1, h->stream));
   }
-  HS_HIP(h, hs_launch_qtables(d_centers, nq, k, h->coords.as<double>(), h->tq.as<float>(), h->stream));
+  HS_HIP(h, hs_launch_qtables(d_centers, nq, k, h->coords.as<double>(), h->alphabet, h->tq.as<float>(),
+                              h->stream));
   HS_HIP(h, hipEventRecord(h->ev[2], h->stream));
   uint32_t prov_cap = (uint32_t)std::max<size_t>(h->prov.cap / 8, std::max<size_t>(1u << 20, 16ull * nq));
   uint32_t host_cnt[4] = {0, 0, 0, 0};
@@ -462,8 +466,8 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, hipEventRecord(h->ev[3], h->stream));
     if (brute) {
       HS_HIP(h, hs_launch_bruteforce(h->packed_all.as<uint4>(), (uint32_t)h->n, h->tq.as<float>(),
-                                     nq, k, r2_hi, d_cnt, prov_cap, h->prov.as<uint2>(), n_blocks,
-                                     h->stream));
+                                     nq, k, r2_hi, d_cnt, prov_cap, h->prov.as<uint2>(), nullptr,
+                                     nullptr, n_blocks, h->stream));
     } else {
       HS_HIP(h, hs_launch_verify(h->tabs, h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
                                  h->slice_off.as<uint32_t>(), nql, h->tq.as<float>(), k, L, r2_hi,
@@ -616,8 +620,85 @@ hs_status hs_bruteforce(hs_handle* h, const double* centers, uint64_t nq, double
 
 hs_status hs_bruteforce_topk(hs_handle* h, const double* centers, uint64_t nq, uint32_t topk,
                              uint32_t* nn_id, double* nn_dist2) {
-  (void)centers; (void)nq; (void)topk; (void)nn_id; (void)nn_dist2;
-  return fail(h, HS_ERR_INVALID, "hs_bruteforce_topk: not implemented yet");
+  if (!h || (nq && (!centers || !nn_id || !nn_dist2)) || topk < 1 || topk > 1024) return HS_ERR_INVALID;
+  if (!h->built) return fail(h, HS_ERR_STATE, "hs_index_build has not been called");
+  hs_status st = ensure_device(h);
+  if (st) return st;
+  memset(&h->prof, 0, sizeof(h->prof));
+  const int k = (int)h->p.k;
+  const uint32_t n = (uint32_t)h->n;
+  const uint32_t per_q = (n + HS_SLICE - 1) / HS_SLICE;
+  const int n_blocks = h->n_cu * 8;
+  HS_HIP(h, h->counters.reserve(256));
+  uint32_t* d_cnt = h->counters.as<uint32_t>();
+  std::vector<uint64_t> keys, vals;
+  std::vector<std::pair<double, uint32_t>> cand;
+  const uint32_t QB = 4096;  // queries per batch: two scans of the DB per batch
+  for (uint64_t q0 = 0; q0 < nq; q0 += QB) {
+    const uint32_t nqb = (uint32_t)std::min<uint64_t>(QB, nq - q0);
+    for (uint32_t t = 0; t < nqb * topk; ++t) {
+      nn_id[q0 * topk + t] = 0xffffffffu;
+      nn_dist2[q0 * topk + t] = INFINITY;
+    }
+    if (!n) continue;
+    HS_HIP(h, h->io_centers.reserve((size_t)nqb * h->d * 8));
+    HS_HIP(h, h->tq.reserve((size_t)nqb * k * HS_TROW * 4));
+    HS_HIP(h, h->io_misc.reserve((size_t)nqb * per_q * 4 + (size_t)nqb * 4));
+    float* d_slice_min = h->io_misc.as<float>();
+    float* d_thr = d_slice_min + (size_t)nqb * per_q;
+    const double* d_centers = h->io_centers.as<double>();
+    HS_HIP(h, hipMemcpyAsync(h->io_centers.p, centers + q0 * h->d, (size_t)nqb * h->d * 8,
+                             hipMemcpyHostToDevice, h->stream));
+    HS_HIP(h, hs_launch_qtables(d_centers, nqb, k, h->coords.as<double>(), h->alphabet,
+                                h->tq.as<float>(), h->stream));
+    // pass 1: minimum of every 4096-candidate slice; threshold = k-th smallest slice minimum
+    HS_HIP(h, hs_launch_bruteforce(h->packed_all.as<uint4>(), n, h->tq.as<float>(), nqb, k, 0.f, d_cnt,
+                                   0, nullptr, nullptr, d_slice_min, n_blocks, h->stream));
+    HS_HIP(h, hs_launch_kth_min(d_slice_min, nqb, per_q, topk, d_thr, h->stream));
+    // pass 2: everything under the per-query threshold, then exact fp64 distances
+    uint32_t prov_cap = (uint32_t)std::max<size_t>(h->prov.cap / 8, std::max<size_t>(1u << 20, 64ull * nqb * topk));
+    uint32_t n_prov = 0;
+    for (;;) {
+      HS_HIP(h, h->prov.reserve((size_t)prov_cap * 8));
+      HS_HIP(h, hipMemsetAsync(d_cnt, 0, 8, h->stream));
+      HS_HIP(h, hs_launch_bruteforce(h->packed_all.as<uint4>(), n, h->tq.as<float>(), nqb, k, 0.f,
+                                     d_cnt, prov_cap, h->prov.as<uint2>(), d_thr, nullptr, n_blocks,
+                                     h->stream));
+      HS_HIP(h, hipMemcpyAsync(&n_prov, d_cnt, 4, hipMemcpyDeviceToHost, h->stream));
+      HS_HIP(h, hipStreamSynchronize(h->stream));
+      if (n_prov <= prov_cap) break;
+      prov_cap = n_prov + 1024;
+    }
+    HS_HIP(h, h->hit_key.reserve(std::max<size_t>(16, (size_t)n_prov * 8)));
+    HS_HIP(h, h->hit_val.reserve(std::max<size_t>(16, (size_t)n_prov * 8)));
+    HS_HIP(h, hs_launch_topk_exact(h->codes.as<uint8_t>(), d_centers, h->coords.as<double>(),
+                                   h->prov.as<uint2>(), d_cnt, prov_cap, k, h->hit_key.as<uint64_t>(),
+                                   h->hit_val.as<uint64_t>(), h->stream));
+    keys.resize(n_prov);
+    vals.resize(n_prov);
+    if (n_prov) {
+      HS_HIP(h, hipMemcpyAsync(keys.data(), h->hit_key.p, (size_t)n_prov * 8, hipMemcpyDeviceToHost, h->stream));
+      HS_HIP(h, hipMemcpyAsync(vals.data(), h->hit_val.p, (size_t)n_prov * 8, hipMemcpyDeviceToHost, h->stream));
+    }
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    // the per-query selection among the few survivors is host work: (d2, id) ascending
+    std::vector<std::vector<std::pair<double, uint32_t>>> per(nqb);
+    for (uint32_t e = 0; e < n_prov; ++e) {
+      double d2;
+      memcpy(&d2, &vals[e], 8);
+      per[(uint32_t)(keys[e] >> 37)].push_back(std::make_pair(d2, (uint32_t)keys[e]));
+    }
+    for (uint32_t q = 0; q < nqb; ++q) {
+      std::sort(per[q].begin(), per[q].end());
+      for (uint32_t t = 0; t < topk && t < per[q].size(); ++t) {
+        nn_id[(q0 + q) * topk + t] = per[q][t].second;
+        nn_dist2[(q0 + q) * topk + t] = per[q][t].first;
+      }
+    }
+    h->prof.provisional += n_prov;
+    h->prof.candidates += 2ull * nqb * n;
+  }
+  return HS_OK;
 }
 
 }  // extern "C"

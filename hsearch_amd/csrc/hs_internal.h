@@ -147,7 +147,7 @@ hipError_t hs_launch_check_runs(const uint64_t* d_keys_sorted, const uint32_t* d
 hipError_t hs_launch_dir_tuples(const uint32_t* d_dir_start, const uint32_t* d_ids_sorted,
                                 const int32_t* d_ints, uint32_t nb, int K, int32_t* d_dir_tuple,
                                 hipStream_t s);
-hipError_t hs_launch_pack(const uint8_t* d_codes, uint64_t n, int k, uint4* d_packed,
+hipError_t hs_launch_pack(const uint8_t* d_codes, uint64_t n, int k, int alphabet, uint4* d_packed,
                           uint32_t* d_bad, hipStream_t s);
 hipError_t hs_launch_gather_packed(const uint4* d_packed_all, const uint32_t* d_ids_sorted,
                                    uint64_t n, int PW, uint4* d_out, hipStream_t s);
@@ -159,7 +159,7 @@ hipError_t hs_launch_probe(const hs_tables_dev& tabs, const int32_t* d_qints, ui
                            uint32_t* d_nslices, uint64_t* d_cand_out, unsigned long long* d_cand_total,
                            hipStream_t s);
 hipError_t hs_launch_qtables(const double* d_centers, uint32_t nq, int k, const double* d_coords,
-                             float* d_tq, hipStream_t s);
+                             int alphabet, float* d_tq, hipStream_t s);
 hipError_t hs_launch_verify(const hs_tables_dev& tabs, const uint32_t* d_qstart,
                             const uint32_t* d_qcount, const uint32_t* d_slice_off, uint32_t nql,
                             const float* d_tq, int k, int L, float r2_hi, uint32_t* d_prov_count,
@@ -177,7 +177,14 @@ hipError_t hs_launch_unpack_hits(const uint64_t* d_key, const uint64_t* d_val, u
 // brute force
 hipError_t hs_launch_bruteforce(const uint4* d_packed_all, uint32_t n, const float* d_tq,
                                 uint32_t nq, int k, float r2_hi, uint32_t* d_prov_count,
-                                uint32_t prov_cap, uint2* d_prov, int n_blocks, hipStream_t s);
+                                uint32_t prov_cap, uint2* d_prov, const float* d_q_thr,
+                                float* d_slice_min, int n_blocks, hipStream_t s);
+hipError_t hs_launch_kth_min(const float* d_slice_min, uint32_t nq, uint32_t per_q, uint32_t topk,
+                             float* d_thr, hipStream_t s);
+hipError_t hs_launch_topk_exact(const uint8_t* d_codes, const double* d_centers,
+                                const double* d_coords, const uint2* d_prov,
+                                const uint32_t* d_prov_count, uint32_t prov_cap, int k,
+                                uint64_t* d_key, uint64_t* d_val, hipStream_t s);
 hipError_t hs_launch_bf_finalize(const uint8_t* d_codes, const double* d_centers,
                                  const double* d_coords, const uint2* d_prov,
                                  const uint32_t* d_prov_count, uint32_t prov_cap, int k, double R,

@@ -27,6 +27,10 @@ constexpr int WAVE = 64;
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (WAVE - 1)); }
 
+__device__ __forceinline__ double exact_dist2(const uint8_t* __restrict__ row,
+                                              const double* __restrict__ c,
+                                              const double* __restrict__ coords, int k);
+
 // ------------------------------------------------------------------------------------------ embed
 __global__ __launch_bounds__(256) void hs_embed_kernel(const uint8_t* __restrict__ codes,
                                                        uint64_t total, const double* __restrict__ coords,
@@ -55,7 +59,7 @@ __global__ __launch_bounds__(256) void hs_hash_kernel(const uint8_t* __restrict_
   const uint64_t i = base + threadIdx.x;
   const bool valid = i < n;
   if (FROM_CODES) {
-    for (int t = threadIdx.x; t < HS_ALPHABET_PAD * 8; t += 256) s_coords[t] = t < 160 ? coords[t] : 0.0;
+    for (int t = threadIdx.x; t < HS_ALPHABET_PAD * 8; t += 256) s_coords[t] = coords[t];
     const uint64_t lo = base * k;
     const uint64_t hi = (base + 256 < n ? base + 256 : n) * (uint64_t)k;
     for (uint64_t t = lo + threadIdx.x; t < lo + 256ull * k; t += 256)
@@ -153,7 +157,8 @@ __global__ __launch_bounds__(256) void hs_max_u32_kernel(const uint32_t* __restr
 // ------------------------------------------------------------------------------------------- pack
 // 25 residues x 5 bits in each 16-byte word (3 pad bits); a k-mer takes ceil(k/25) words.
 __global__ __launch_bounds__(256) void hs_pack_kernel(const uint8_t* __restrict__ codes, uint64_t n,
-                                                      int k, int PW, uint4* __restrict__ packed,
+                                                      int k, int PW, uint32_t alphabet,
+                                                      uint4* __restrict__ packed,
                                                       uint32_t* __restrict__ bad) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(256) void hs_pack_kernel(const uint8_t* __restrict_
     for (int r = 0; r < 25; ++r) {
       const int p = 25 * w + r;
       uint32_t c = p < k ? (uint32_t)row[p] : 0u;
-      any_bad |= (c >= 20u);
+      any_bad |= (c >= alphabet);
       c &= 31u;
       const int bit = 5 * r, wi = bit >> 5, sh = bit & 31;
       v[wi] |= c << sh;
@@ -192,12 +197,10 @@ template <int R>
 __device__ __forceinline__ int residue_x4(const uint4& p) {
   constexpr int bit = 5 * R, wi = bit >> 5, sh = bit & 31;
   const uint32_t lo = wi == 0 ? p.x : wi == 1 ? p.y : wi == 2 ? p.z : p.w;
-  uint32_t v;
-  if (sh > 27) {
+  if constexpr (sh > 27) {
     const uint32_t hi = wi == 0 ? p.y : wi == 1 ? p.z : p.w;
-    v = __funnelshift_r(lo, hi, sh);
-    return (int)((v & 31u) << 2);
-  } else if (sh >= 2) {
+    return (int)((__funnelshift_r(lo, hi, sh) & 31u) << 2);
+  } else if constexpr (sh >= 2) {
     return (int)((lo >> (sh - 2)) & 0x7cu);
   } else {
     return (int)((lo << (2 - sh)) & 0x7cu);
@@ -250,13 +253,13 @@ __global__ __launch_bounds__(256) void hs_probe_kernel(hs_tables_dev tabs,
 __global__ __launch_bounds__(256) void hs_qtables_kernel(const double* __restrict__ centers,
                                                          uint32_t nq, int k,
                                                          const double* __restrict__ coords,
-                                                         float* __restrict__ tq) {
+                                                         int alphabet, float* __restrict__ tq) {
   const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= (uint64_t)nq * k * HS_TROW) return;
   const int aa = (int)(t % HS_TROW);
   const uint64_t qp = t / HS_TROW;  // q*k + pos
   float v = 0.f;
-  if (aa < 20) {
+  if (aa < alphabet) {
     const double* c = centers + qp * 8;
     double s = 0.0;
 #pragma unroll
@@ -285,7 +288,9 @@ __global__ __launch_bounds__(256) void hs_verify_kernel(hs_tables_dev tabs,
                                                         uint32_t nql, const float* __restrict__ tq,
                                                         int k, int L, float r2_hi,
                                                         uint32_t* __restrict__ prov_count,
-                                                        uint32_t prov_cap, uint2* __restrict__ prov) {
+                                                        uint32_t prov_cap, uint2* __restrict__ prov,
+                                                        const float* __restrict__ q_thr,
+                                                        float* __restrict__ slice_min) {
   const int lane = lane_id();
   const uint32_t waves_per_block = blockDim.x / WAVE;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * waves_per_block + (threadIdx.x >> 6));
@@ -319,6 +324,9 @@ __global__ __launch_bounds__(256) void hs_verify_kernel(hs_tables_dev tabs,
 #pragma unroll
     for (int p = 0; p < 25 * PW; ++p) T[p] = p < k ? trow[p * HS_TROW] : 0.f;
     const uint32_t iters = (cnt + WAVE - 1) / WAVE;
+    // brute-force top-k support: per-query thresholds, or a pure min pass over the slice
+    const float thr = (BRUTE && q_thr) ? q_thr[q] : r2_hi;
+    float run_min = INFINITY;
     for (uint32_t it = 0; it < iters; ++it) {
       const uint32_t i = it * WAVE + lane;
       const bool valid = i < cnt;
@@ -336,7 +344,11 @@ __global__ __launch_bounds__(256) void hs_verify_kernel(hs_tables_dev tabs,
         HS_LOOKUP(20) HS_LOOKUP(21) HS_LOOKUP(22) HS_LOOKUP(23) HS_LOOKUP(24)
 #undef HS_LOOKUP
       }
-      const bool pass = valid && sum <= r2_hi;
+      if (BRUTE && slice_min) {
+        run_min = fminf(run_min, valid ? sum : INFINITY);
+        continue;
+      }
+      const bool pass = valid && sum <= thr;
       const unsigned long long m = __ballot(pass);
       if (m) {
         uint32_t base = 0;
@@ -348,6 +360,85 @@ __global__ __launch_bounds__(256) void hs_verify_kernel(hs_tables_dev tabs,
         }
       }
     }
+    if (BRUTE && slice_min) {
+      for (int off = 32; off; off >>= 1) run_min = fminf(run_min, __shfl_xor(run_min, off));
+      if (lane == 0) slice_min[s] = run_min;  // s = q * slices_per_query + slice
+    }
+  }
+}
+
+// thr[q] = k-th smallest of the query's slice minima, widened by the fp32 filter band: at least k
+// candidates (the slice minima themselves) pass it, and every true top-k member does (its fp32 sum
+// is within 1.6e-6 relative of its exact d2).  Fewer than k slices -> +inf (small DBs: keep all).
+__global__ __launch_bounds__(256) void hs_kth_min_kernel(const float* __restrict__ slice_min,
+                                                         uint32_t per_q, uint32_t topk,
+                                                         float* __restrict__ thr) {
+  __shared__ float s_best[4];
+  __shared__ uint32_t s_idx[4];
+  const uint32_t q = blockIdx.x;
+  const float* v = slice_min + (uint64_t)q * per_q;
+  if (per_q < topk) {
+    if (threadIdx.x == 0) thr[q] = INFINITY;
+    return;
+  }
+  float last = -1.f;
+  uint32_t last_idx = 0;
+  bool first = true;
+  for (uint32_t r = 0; r < topk; ++r) {
+    // smallest (value, index) strictly greater than (last, last_idx)
+    float best = INFINITY;
+    uint32_t bi = 0xffffffffu;
+    for (uint32_t i = threadIdx.x; i < per_q; i += 256) {
+      const float x = v[i];
+      const bool after = first || x > last || (x == last && i > last_idx);
+      if (after && (x < best || (x == best && i < bi))) {
+        best = x;
+        bi = i;
+      }
+    }
+    for (int off = 32; off; off >>= 1) {
+      const float ob = __shfl_xor(best, off);
+      const uint32_t oi = (uint32_t)__shfl_xor((int)bi, off);
+      if (ob < best || (ob == best && oi < bi)) {
+        best = ob;
+        bi = oi;
+      }
+    }
+    if (lane_id() == 0) {
+      s_best[threadIdx.x >> 6] = best;
+      s_idx[threadIdx.x >> 6] = bi;
+    }
+    __syncthreads();
+    best = s_best[0];
+    bi = s_idx[0];
+    for (int w = 1; w < 4; ++w)
+      if (s_best[w] < best || (s_best[w] == best && s_idx[w] < bi)) {
+        best = s_best[w];
+        bi = s_idx[w];
+      }
+    __syncthreads();
+    last = best;
+    last_idx = bi;
+    first = false;
+  }
+  if (threadIdx.x == 0) thr[q] = last * (1.0f + 1e-5f) + 1e-30f;
+}
+
+// exact squared distance of every survivor of a top-k filter pass: key = (q, id), val = d2 bits
+__global__ __launch_bounds__(256) void hs_topk_exact_kernel(const uint8_t* __restrict__ codes,
+                                                            const double* __restrict__ centers,
+                                                            const double* __restrict__ coords,
+                                                            const uint2* __restrict__ prov,
+                                                            const uint32_t* __restrict__ prov_count,
+                                                            uint32_t prov_cap, int k,
+                                                            uint64_t* __restrict__ out_key,
+                                                            uint64_t* __restrict__ out_val) {
+  const uint32_t n = min(*prov_count, prov_cap);
+  for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    const uint32_t q = prov[e].x, id = prov[e].y;
+    const double d2 = exact_dist2(codes + (uint64_t)id * k, centers + (uint64_t)q * 8 * k, coords, k);
+    out_key[e] = ((uint64_t)q << 37) | id;
+    out_val[e] = (uint64_t)__double_as_longlong(d2);
   }
 }
 
@@ -541,10 +632,11 @@ hipError_t hs_launch_max_u32(const uint32_t* d_in, uint32_t n, uint32_t* d_out, 
   return hipGetLastError();
 }
 
-hipError_t hs_launch_pack(const uint8_t* d_codes, uint64_t n, int k, uint4* d_packed,
+hipError_t hs_launch_pack(const uint8_t* d_codes, uint64_t n, int k, int alphabet, uint4* d_packed,
                           uint32_t* d_bad, hipStream_t s) {
   if (!n) return hipSuccess;
-  hs_pack_kernel<<<blocks_for(n), 256, 0, s>>>(d_codes, n, k, hs_packed_words(k), d_packed, d_bad);
+  hs_pack_kernel<<<blocks_for(n), 256, 0, s>>>(d_codes, n, k, hs_packed_words(k), (uint32_t)alphabet,
+                                               d_packed, d_bad);
   return hipGetLastError();
 }
 
@@ -568,10 +660,10 @@ hipError_t hs_launch_probe(const hs_tables_dev& tabs, const int32_t* d_qints, ui
 }
 
 hipError_t hs_launch_qtables(const double* d_centers, uint32_t nq, int k, const double* d_coords,
-                             float* d_tq, hipStream_t s) {
+                             int alphabet, float* d_tq, hipStream_t s) {
   if (!nq) return hipSuccess;
   hs_qtables_kernel<<<blocks_for((uint64_t)nq * k * HS_TROW), 256, 0, s>>>(d_centers, nq, k,
-                                                                           d_coords, d_tq);
+                                                                           d_coords, alphabet, d_tq);
   return hipGetLastError();
 }
 
@@ -584,7 +676,7 @@ hipError_t hs_launch_verify(const hs_tables_dev& tabs, const uint32_t* d_qstart,
 #define HS_VERIFY(P)                                                                              \
   hs_verify_kernel<P, false><<<n_blocks, 256, 0, s>>>(tabs, nullptr, 0u, d_qstart, d_qcount,      \
                                                       d_slice_off, nql, d_tq, k, L, r2_hi,         \
-                                                      d_prov_count, prov_cap, d_prov)
+                                                      d_prov_count, prov_cap, d_prov, nullptr, nullptr)
   if (PW == 1) HS_VERIFY(1);
   else if (PW == 2) HS_VERIFY(2);
   else if (PW == 3) HS_VERIFY(3);
@@ -595,14 +687,15 @@ hipError_t hs_launch_verify(const hs_tables_dev& tabs, const uint32_t* d_qstart,
 
 hipError_t hs_launch_bruteforce(const uint4* d_packed_all, uint32_t n, const float* d_tq,
                                 uint32_t nq, int k, float r2_hi, uint32_t* d_prov_count,
-                                uint32_t prov_cap, uint2* d_prov, int n_blocks, hipStream_t s) {
+                                uint32_t prov_cap, uint2* d_prov, const float* d_q_thr,
+                                float* d_slice_min, int n_blocks, hipStream_t s) {
   if (!nq || !n) return hipSuccess;
   const int PW = hs_packed_words(k);
   hs_tables_dev none = {};
 #define HS_BRUTE(P)                                                                               \
   hs_verify_kernel<P, true><<<n_blocks, 256, 0, s>>>(none, d_packed_all, n, nullptr, nullptr,      \
                                                      nullptr, nq, d_tq, k, 1, r2_hi, d_prov_count, \
-                                                     prov_cap, d_prov)
+                                                     prov_cap, d_prov, d_q_thr, d_slice_min)
   if (PW == 1) HS_BRUTE(1);
   else if (PW == 2) HS_BRUTE(2);
   else if (PW == 3) HS_BRUTE(3);
@@ -640,5 +733,21 @@ hipError_t hs_launch_unpack_hits(const uint64_t* d_key, const uint64_t* d_val, u
                                  hipStream_t s) {
   if (!n) return hipSuccess;
   hs_unpack_hits_kernel<<<blocks_for(n), 256, 0, s>>>(d_key, d_val, n, d_q, d_id, d_table, d_dist);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_kth_min(const float* d_slice_min, uint32_t nq, uint32_t per_q, uint32_t topk,
+                             float* d_thr, hipStream_t s) {
+  if (!nq) return hipSuccess;
+  hs_kth_min_kernel<<<nq, 256, 0, s>>>(d_slice_min, per_q, topk, d_thr);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_topk_exact(const uint8_t* d_codes, const double* d_centers,
+                                const double* d_coords, const uint2* d_prov,
+                                const uint32_t* d_prov_count, uint32_t prov_cap, int k,
+                                uint64_t* d_key, uint64_t* d_val, hipStream_t s) {
+  hs_topk_exact_kernel<<<1024, 256, 0, s>>>(d_codes, d_centers, d_coords, d_prov, d_prov_count,
+                                            prov_cap, k, d_key, d_val);
   return hipGetLastError();
 }

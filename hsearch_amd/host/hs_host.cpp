@@ -1,0 +1,261 @@
+// hs_host.cpp -- see hs_host.hpp.  Host logic only: parsing, formatting, planes, evaluation; every
+// number on the search path is computed on the GPU behind include/hsearch.h.
+#include "hs_host.hpp"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <fstream>
+#include <map>
+#include <random>
+#include <sstream>
+#include <unordered_map>
+
+#include "../../include/hsearch.h"
+
+namespace hsearch {
+
+Planes DrawPlanes(uint32_t dim, uint32_t K, uint32_t L, double W, uint32_t seed) {
+  Planes p;
+  p.dim = dim;
+  p.K = K;
+  p.L = L;
+  p.W = W;
+  p.a.resize((size_t)L * K * dim);
+  p.b.resize((size_t)L * K);
+  for (uint32_t l = 0; l < L; ++l) {
+    // one engine and one pair of distributions per table, as one LSH object owns them
+    std::default_random_engine generator(seed + l);
+    std::normal_distribution<double> normal(0.0, 1.0);
+    std::uniform_real_distribution<double> width(0, W);
+    for (uint32_t k = 0; k < K; ++k) {
+      double* row = &p.a[((size_t)l * K + k) * dim];
+      for (uint32_t i = 0; i < dim; ++i) row[i] = normal(generator);
+      p.b[(size_t)l * K + k] = width(generator);
+    }
+  }
+  return p;
+}
+
+bool ReadPointsFile(const std::string& path, uint32_t dim, std::vector<std::string>* names,
+                    std::vector<Point>* points) {
+  std::ifstream fin(path.c_str());
+  if (!fin) return false;
+  std::string line;
+  while (std::getline(fin, line)) {
+    names->push_back(line);
+    std::getline(fin, line);
+    std::istringstream iss(line);
+    Point point;
+    point.data.assign(dim, 0.0);
+    for (uint32_t i = 0; i < dim; ++i) iss >> point.data[i];
+    points->push_back(point);
+  }
+  return true;
+}
+
+bool PointsToCodes(const std::vector<Point>& pts, uint32_t dim, std::vector<double>* table,
+                   std::vector<uint8_t>* codes, std::string* err) {
+  const uint32_t k = dim / 8;
+  table->clear();
+  codes->assign(pts.size() * (size_t)k, 0);
+  struct Row {
+    uint64_t w[8];
+    bool operator<(const Row& o) const { return memcmp(w, o.w, sizeof(w)) < 0; }
+  };
+  std::map<Row, uint8_t> rows;  // exact bit patterns: the GPU must hash the very same doubles
+  for (size_t i = 0; i < pts.size(); ++i) {
+    if (pts[i].data.size() != dim) {
+      if (err) *err = "DB point with the wrong dimension";
+      return false;
+    }
+    for (uint32_t p = 0; p < k; ++p) {
+      Row r;
+      memcpy(r.w, &pts[i].data[8 * p], 64);
+      std::map<Row, uint8_t>::iterator it = rows.find(r);
+      if (it == rows.end()) {
+        if (rows.size() >= 32) {
+          if (err)
+            *err = "DB points are not embeddings over an alphabet of <= 32 residues; the GPU index "
+                   "stores the DB as residue codes (arbitrary-point DBs are not supported)";
+          return false;
+        }
+        const uint8_t code = (uint8_t)rows.size();
+        it = rows.insert(std::make_pair(r, code)).first;
+        table->insert(table->end(), &pts[i].data[8 * p], &pts[i].data[8 * p] + 8);
+      }
+      (*codes)[i * k + p] = it->second;
+    }
+  }
+  if (table->empty()) table->assign(8, 0.0);
+  return true;
+}
+
+int Search(const std::vector<Point>& kmers, const std::vector<Point>& centers,
+           const std::vector<std::string>& kmer_names, const std::vector<std::string>& center_names,
+           const uint32_t& hash_K, const uint32_t& hash_L, const double& hash_W,
+           const double& hash_R, const std::string& output_file, const Planes& planes, int device,
+           std::string* err, std::vector<uint64_t>* table_sizes) {
+  const uint32_t dim = planes.dim;
+  if (dim == 0 || dim % 8 != 0 || planes.K != hash_K || planes.L != hash_L || planes.W != hash_W) {
+    if (err) *err = "planes do not match (dim, K, L, W)";
+    return HS_ERR_INVALID;
+  }
+  std::vector<double> table;
+  std::vector<uint8_t> codes;
+  if (!PointsToCodes(kmers, dim, &table, &codes, err)) return HS_ERR_INVALID;
+  std::vector<double> flat((size_t)centers.size() * dim);
+  for (size_t i = 0; i < centers.size(); ++i) {
+    if (centers[i].data.size() != dim) {
+      if (err) *err = "centre with the wrong dimension";
+      return HS_ERR_INVALID;
+    }
+    memcpy(&flat[i * dim], centers[i].data.data(), sizeof(double) * dim);
+  }
+  hs_params prm;
+  memset(&prm, 0, sizeof(prm));
+  prm.k = dim / 8;
+  prm.K = hash_K;
+  prm.L = hash_L;
+  prm.W = hash_W;
+  prm.device = device;
+  prm.alphabet = (uint32_t)(table.size() / 8);
+  hs_handle* h = nullptr;
+  hs_status st = hs_create(&prm, planes.a.data(), planes.b.data(), table.data(), &h);
+  struct Closer {
+    hs_handle* h;
+    ~Closer() { hs_destroy(h); }
+  };
+  if (st != HS_OK) {
+    if (err) *err = std::string("hs_create: ") + (h ? hs_last_error(h) : "no usable gfx950 device");
+    hs_destroy(h);
+    return st;
+  }
+  Closer closer = {h};
+  st = hs_index_build(h, codes.data(), kmers.size());
+  if (st != HS_OK) {
+    if (err) *err = std::string("hs_index_build: ") + hs_last_error(h);
+    return st;
+  }
+  if (table_sizes) {
+    hs_index_info info;
+    if (hs_index_info_get(h, &info) == HS_OK) table_sizes->assign(info.n_buckets, info.n_buckets + hash_L);
+  }
+  uint64_t cap = std::max<uint64_t>(1024, 16 * (uint64_t)centers.size()), n_hits = 0;
+  std::vector<uint32_t> hq, hid, ht;
+  std::vector<double> hd;
+  for (;;) {
+    hq.resize(cap);
+    hid.resize(cap);
+    ht.resize(cap);
+    hd.resize(cap);
+    st = hs_query(h, flat.data(), centers.size(), hash_R, hq.data(), hid.data(), ht.data(), hd.data(),
+                  cap, &n_hits, nullptr);
+    if (st == HS_ERR_CAPACITY) {
+      cap = n_hits;
+      continue;
+    }
+    break;
+  }
+  if (st != HS_OK) {
+    if (err) *err = std::string("hs_query: ") + hs_last_error(h);
+    return st;
+  }
+  std::ofstream fout(output_file.c_str());
+  for (uint64_t i = 0; i < n_hits; ++i)  // :240-241
+    fout << center_names[hq[i]] << " " << kmer_names[hid[i]] << " " << hd[i] << std::endl;
+  fout.close();
+  return HS_OK;
+}
+
+namespace {
+
+struct MotifRes {
+  std::string motif, protein;
+  double dis;
+};
+
+bool ResLess(const MotifRes& a, const MotifRes& b) {
+  if (a.motif == b.motif) return a.protein < b.protein;
+  return a.motif < b.motif;
+}
+
+int ResCompare(const MotifRes& a, const MotifRes& b) {
+  if (a.motif == b.motif) {
+    if (a.protein == b.protein) return 0;
+    return a.protein > b.protein ? 1 : -1;
+  }
+  return a.motif > b.motif ? 1 : -1;
+}
+
+// weight(): 1 below distance 24, then 1/(dis-24) clipped to [0,1]; inconsistent ground truth
+// (dis > R + 0.1) is reported through *bad instead of exit(0).
+double Weight(double dis, double R, bool* bad) {
+  if (dis > R + 0.1) {
+    *bad = true;
+    return 0;
+  }
+  if (dis < 0.0000001) return 1;
+  if (dis < 24) return 1;
+  double w = 1 / (dis - 24);
+  if (w > 1) return 1;
+  if (w < 0) return 1;
+  return w;
+}
+
+}  // namespace
+
+double Evaluate(const std::string& ground_truth, const std::string& output_file, const double& hash_R) {
+  std::vector<MotifRes> brute, found;
+  MotifRes r;
+  {
+    std::ifstream fin(ground_truth.c_str());
+    while (fin >> r.motif >> r.protein >> r.dis) brute.push_back(r);
+  }
+  {
+    std::ifstream fin(output_file.c_str());
+    while (fin >> r.motif >> r.protein >> r.dis) found.push_back(r);
+  }
+  std::sort(found.begin(), found.end(), ResLess);
+  size_t i = 0, j = 0;
+  double tp = 0.0, fn = 0.0;
+  bool bad = false;
+  std::unordered_map<int, int> tp_map, fn_map;  // distance decile histogram
+  while (i < brute.size() && j < found.size()) {
+    const int cmp = ResCompare(brute[i], found[j]);
+    if (cmp == 0) {
+      tp += Weight(brute[i].dis, hash_R, &bad);
+      tp_map[int(brute[i].dis * 100 / 10)]++;
+      ++i;
+      ++j;
+    } else if (cmp == 1) {
+      ++j;
+    } else {
+      fn += Weight(brute[i].dis, hash_R, &bad);
+      fn_map[int(brute[i].dis * 100 / 10)]++;
+      ++i;
+    }
+  }
+  while (i < brute.size()) {
+    fn += Weight(brute[i].dis, hash_R, &bad);
+    fn_map[int(brute[i].dis * 100 / 10)]++;
+    ++i;
+  }
+  std::ofstream fout((output_file + ".accuracy.txt").c_str());
+  for (int b = 0; b < 500; ++b) {
+    const bool has_fn = fn_map.find(b) != fn_map.end(), has_tp = tp_map.find(b) != tp_map.end();
+    if (has_fn && has_tp)
+      fout << b << " " << tp_map[b] / (fn_map[b] + (double)tp_map[b]) << " " << tp_map[b] << " "
+           << fn_map[b] << std::endl;
+    else if (has_fn)
+      fout << b << " " << 0 << " fn " << fn_map[b] << std::endl;
+    else if (has_tp)
+      fout << b << " " << 1 << " tp " << tp_map[b] << std::endl;
+  }
+  fout.close();
+  if (bad) return NAN;
+  return tp / (tp + fn);
+}
+
+}  // namespace hsearch

@@ -1,0 +1,68 @@
+// hs_host.hpp -- C++ host side above the C ABI (include/hsearch.h): the reference's operator
+// surface for the search path, with the same names, argument meaning and error behaviour, so a
+// caller of acgtun/hsearch's Search() can switch by changing an include and one extra argument
+// (the planes, which the reference draws from std::random_device and therefore cannot share).
+//
+//   reference                                         here
+//   struct Point {vector<double> data;}  (:18-23)     hsearch::Point
+//   LSH(dim, K, W) x L, random_device    (lsh.hpp)    hsearch::DrawPlanes(dim, K, L, W, seed)
+//   Search(kmers, centers, names..., K, L, W, R, out) hsearch::Search(... , planes, device)
+//   evaulate(ground_truth, out, R)       (:100-165)   hsearch::Evaluate
+//   points-file reader in main()         (:343-370)   hsearch::ReadPointsFile
+// (file:line = hclust/src/hclust/motif_both_points.cpp unless noted.)
+#ifndef HS_HOST_HPP
+#define HS_HOST_HPP
+
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+namespace hsearch {
+
+struct Point {
+  std::vector<double> data;
+};
+
+// L x K Gaussian normals a ~ N(0,1) (K*dim per table) and offsets b ~ U[0,W), drawn exactly as the
+// reference's LSH constructor does (lsh.hpp:10-31: default_random_engine, normal_distribution,
+// uniform_real_distribution, per function dim normals then one uniform, fresh distributions per
+// table) with the table-l engine seeded by seed + l instead of random_device.
+struct Planes {
+  uint32_t dim = 0, K = 0, L = 0;
+  double W = 0;
+  std::vector<double> a;  // [L][K][dim]
+  std::vector<double> b;  // [L][K]
+};
+Planes DrawPlanes(uint32_t dim, uint32_t K, uint32_t L, double W, uint32_t seed);
+
+// The reference's points file: per record one name line and one line of `dim` doubles (:343-354).
+bool ReadPointsFile(const std::string& path, uint32_t dim, std::vector<std::string>* names,
+                    std::vector<Point>* points);
+
+// DB points -> residue codes + the coordinate table they are embeddings of.  Every 8-tuple of every
+// DB point must be one of at most 32 distinct rows (true for anything KmerToCoordinates or
+// protein2datapoints produced, including the 6-significant-digit points files).  Returns false
+// with *err set when the points are not embeddings of such an alphabet.
+bool PointsToCodes(const std::vector<Point>& pts, uint32_t dim, std::vector<double>* table,
+                   std::vector<uint8_t>* codes, std::string* err);
+
+// Search() (:195-250).  Builds the L tables over `kmers`, probes them with every centre, verifies
+// candidates by squared Euclidean distance <= R*R and writes "<center> <kmer> <dist>" lines in the
+// reference's order (centre, table of first sight, ascending k-mer index).  Runs on `device`
+// through libhsearch_amd.so; returns 0, or an hs_status with *err set.  table_sizes (optional)
+// receives the number of distinct keys per table, which the reference prints (:217).
+int Search(const std::vector<Point>& kmers, const std::vector<Point>& centers,
+           const std::vector<std::string>& kmer_names, const std::vector<std::string>& center_names,
+           const uint32_t& hash_K, const uint32_t& hash_L, const double& hash_W,
+           const double& hash_R, const std::string& output_file, const Planes& planes, int device,
+           std::string* err, std::vector<uint64_t>* table_sizes = nullptr);
+
+// evaulate() (:100-165) with weight() (:67-87): weighted recall of a hits file against a ground
+// truth file sorted by (motif, protein); also writes <output_file>.accuracy.txt.  Returns NaN
+// where the reference would exit(0) on an inconsistent ground truth (:68-71).
+double Evaluate(const std::string& ground_truth, const std::string& output_file, const double& hash_R);
+
+}  // namespace hsearch
+
+#endif

@@ -1,0 +1,162 @@
+// hs_motif_search.cpp -- the `motif_both_points` program of the reference on the GPU path.
+//
+// Keeps the reference's command line (hclust/src/hclust/motif_both_points.cpp:302-320):
+//     -d <db.points> -c <centers.points> -l <k> -W <w> -T <R> -g <groundtruth> -o <out>
+// each also as -db/-center/-len/-window/-threshold/-groundtruth/-output (one or two dashes), and its
+// exit behaviour: a missing required option prints the help text and exits 0 (:332-335), a runtime
+// error prints to stderr and exits 1 (:387-393).  Additions: -K/-L (the reference parses them in
+// kmer_search.cpp:186-189 but hard-codes 4,4 here, :380-381 -- 4,4 stay the defaults), --seed
+// (planes are drawn like the reference's LSH constructor but from an explicit seed; default: from
+// std::random_device like the reference), --device, --planes-out (dump the planes), and -g becomes
+// optional (without it the evaluation step is skipped).
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "hs_host.hpp"
+
+namespace {
+
+struct Opt {
+  const char* long_name;
+  char short_name;
+  const char* descr;
+  bool required;
+};
+
+const Opt kOpts[] = {
+    {"db", 'd', "protein database file (points)", true},
+    {"center", 'c', "centers from Pfam database (points)", true},
+    {"len", 'l', "kmer length", true},
+    {"hash_K", 'K', "number of random lines [4]", false},
+    {"hash_L", 'L', "number of hash tables [4]", false},
+    {"window", 'W', "bucket width", true},
+    {"threshold", 'T', "kmer threshold", true},
+    {"groundtruth", 'g', "groundtruth (sorted brute-force hits); optional", false},
+    {"output", 'o', "output file name", true},
+    {"seed", 's', "seed of the LSH planes [random_device]", false},
+    {"device", 'G', "GPU ordinal [0]", false},
+    {"planes-out", 'P', "write the planes (binary doubles a[L][K][d] then b[L][K])", false},
+};
+
+void Help(const char* prog) {
+  fprintf(stderr, "Usage: %s [OPTIONS]\n\nOptions:\n", prog);
+  for (const Opt& o : kOpts)
+    fprintf(stderr, "  -%c, -%-12s %s%s\n", o.short_name, o.long_name, o.descr,
+            o.required ? " [REQUIRED]" : "");
+  fprintf(stderr, "\nHelp options:\n  -?, -help   print this help message\n\ncluster kmers to motifs\n");
+}
+
+}  // namespace
+
+int main(int argc, const char* argv[]) {
+  bool help = false;
+  std::map<std::string, std::string> val;
+  for (int i = 1; i < argc; ++i) {
+    std::string arg = argv[i];
+    if (arg == "-help" || arg == "--help" || arg == "-?" || arg == "-about") {
+      help = true;
+      continue;
+    }
+    if (arg.size() < 2 || arg[0] != '-') continue;  // leftover argument, ignored like the reference
+    std::string name = arg.substr(arg[1] == '-' ? 2 : 1);
+    const Opt* hit = nullptr;
+    for (const Opt& o : kOpts)
+      if (name == o.long_name || (name.size() == 1 && name[0] == o.short_name)) hit = &o;
+    if (!hit) {
+      fprintf(stderr, "unknown option %s\n", arg.c_str());
+      return EXIT_FAILURE;
+    }
+    if (i + 1 >= argc) {
+      fprintf(stderr, "option %s needs a value\n", arg.c_str());
+      return EXIT_FAILURE;
+    }
+    val[hit->long_name] = argv[++i];
+  }
+  if (argc > 1 && !help) {
+    fprintf(stdout, "[WELCOME TO HSEARCH v1.0 -- MI355X]\n[%s", argv[0]);
+    for (int i = 1; i < argc; ++i) fprintf(stdout, " %s", argv[i]);
+    fprintf(stdout, "]\n");
+  }
+  if (argc == 1 || help) {
+    Help(argv[0]);
+    return EXIT_SUCCESS;
+  }
+  for (const Opt& o : kOpts)
+    if (o.required && !val.count(o.long_name)) {
+      fprintf(stderr, "missing required option -%c\n", o.short_name);
+      Help(argv[0]);
+      return EXIT_SUCCESS;  // as the reference: option_missing() -> message, EXIT_SUCCESS
+    }
+  const uint32_t kmer_length = (uint32_t)strtoul(val["len"].c_str(), nullptr, 10);
+  const uint32_t hash_K = val.count("hash_K") ? (uint32_t)strtoul(val["hash_K"].c_str(), nullptr, 10) : 4;
+  const uint32_t hash_L = val.count("hash_L") ? (uint32_t)strtoul(val["hash_L"].c_str(), nullptr, 10) : 4;
+  const double hash_W = strtod(val["window"].c_str(), nullptr);
+  const double hash_R = strtod(val["threshold"].c_str(), nullptr);
+  const int device = val.count("device") ? atoi(val["device"].c_str()) : 0;
+  const uint32_t dim = 8 * kmer_length;
+  uint32_t seed;
+  if (val.count("seed")) {
+    seed = (uint32_t)strtoul(val["seed"].c_str(), nullptr, 10);
+  } else {
+    std::random_device rd;
+    seed = rd();
+  }
+  try {
+    std::vector<std::string> kmer_names, center_names;
+    std::vector<hsearch::Point> kmers, centers;
+    std::cout << "Read Kmers..." << std::endl;
+    if (!hsearch::ReadPointsFile(val["db"], dim, &kmer_names, &kmers)) {
+      fprintf(stderr, "cannot open %s\n", val["db"].c_str());
+      return EXIT_FAILURE;
+    }
+    std::cout << "Read Centers..." << std::endl;
+    if (!hsearch::ReadPointsFile(val["center"], dim, &center_names, &centers)) {
+      fprintf(stderr, "cannot open %s\n", val["center"].c_str());
+      return EXIT_FAILURE;
+    }
+    std::cout << "number of kmers " << kmers.size() << std::endl;
+    std::cout << "number of centers " << centers.size() << std::endl;
+    const hsearch::Planes planes = hsearch::DrawPlanes(dim, hash_K, hash_L, hash_W, seed);
+    if (val.count("planes-out")) {
+      std::ofstream pf(val["planes-out"].c_str(), std::ios::binary);
+      pf.write(reinterpret_cast<const char*>(planes.a.data()), planes.a.size() * sizeof(double));
+      pf.write(reinterpret_cast<const char*>(planes.b.data()), planes.b.size() * sizeof(double));
+    }
+    printf("hash_K = %u hash_L = %u seed = %u\n", hash_K, hash_L, seed);
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    std::string err;
+    std::vector<uint64_t> table_sizes;
+    const int st = hsearch::Search(kmers, centers, kmer_names, center_names, hash_K, hash_L, hash_W,
+                                   hash_R, val["output"], planes, device, &err, &table_sizes);
+    if (st != 0) {
+      fprintf(stderr, "ERROR: %s (status %d)\n", err.c_str(), st);
+      return EXIT_FAILURE;
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    for (uint64_t ts : table_sizes) std::cout << "table size " << ts << std::endl;
+    const double secs = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+    if (val.count("groundtruth")) {
+      std::cout << "evaulate ..." << std::endl;
+      printf("ACCURACY: %lf %lf\n", hsearch::Evaluate(val["groundtruth"], val["output"], hash_R), secs);
+    } else {
+      printf("SEARCH: %lf seconds\n", secs);
+    }
+  } catch (const std::bad_alloc&) {
+    fprintf(stderr, "ERROR: could not allocate memory\n");
+    return EXIT_FAILURE;
+  } catch (const std::exception& e) {
+    fprintf(stderr, "%s\n", e.what());
+    return EXIT_FAILURE;
+  }
+  return EXIT_SUCCESS;
+}

@@ -17,7 +17,7 @@
  *   - requires a gfx950 device: there is no CPU fallback, calls fail with HS_ERR_NO_DEVICE.
  *
  * Layouts (all row-major, densely packed)
- *   codes   [n][k]      uint8   rows of the amino-acid table (0..19), see hs_tables.h
+ *   codes   [n][k]      uint8   rows of the coordinate table (0..alphabet-1), see hs_tables.h
  *   points  [n][d]      double  d = 8*k
  *   planes  a[L][K][d], b[L][K] double  (LSH::a, LSH::b of table l -- lsh.hpp:65-66)
  *   buckets [n][L][K]   int32
@@ -54,7 +54,7 @@ typedef struct hs_params {
   uint32_t L;      /* hash tables (hash_L), 1..32 */
   double W;        /* bucket width (hash_W) */
   int32_t device;  /* HIP device ordinal */
-  uint32_t flags;  /* reserved, 0 */
+  uint32_t alphabet; /* rows of the coordinate table, 1..32; 0 means 20 (the amino acids) */
 } hs_params;
 
 typedef struct hs_handle hs_handle;
@@ -86,7 +86,10 @@ typedef struct hs_index_info {
 
 /* Replaces L constructions of LSH (lsh.hpp:10-31), except that the planes are an INPUT: the
  * reference draws them from std::random_device (lsh.hpp:19-20), which no caller can reproduce.
- * coords: [20][8] embedding table, or NULL for HS_AA_COORDS (util.hpp:21-42). */
+ * coords: [alphabet][8] embedding table, or NULL for HS_AA_COORDS (util.hpp:21-42).  A caller whose
+ * DB arrives as points (the reference's points files carry the table rounded to 6 significant
+ * digits, protein2datapoints.cpp:23-29) passes the distinct 8-tuples it found as the table and the
+ * row indices as codes, so both sides hash exactly the same doubles. */
 HS_API hs_status hs_create(const hs_params* params, const double* a, const double* b,
                            const double* coords, hs_handle** out);
 HS_API void hs_destroy(hs_handle* h);

@@ -72,3 +72,80 @@ def test_bruteforce_matches_oracle(oracle):
     got = eng.bruteforce(centers, R)
     _assert_hits_equal(got, want)
     eng.close()
+
+
+@pytest.mark.parametrize("n,nq,topk", [(6000, 50, 10), (60000, 40, 10), (50000, 20, 3)])
+def test_bruteforce_topk_matches_oracle(oracle, n, nq, topk):
+    k = 25
+    a, b = synth.make_planes(k, 4, 2, 100.0)
+    codes = synth.make_db(n, k, seed=3)
+    centers, _ = synth.make_queries(codes, nq, jitter=0.25, seed=4)
+    eng = Engine(k, 4, 2, 100.0, a, b)
+    eng.index_build(codes)
+    want_id, want_d2 = oracle.bruteforce_topk(oracle.embed_codes(codes), centers, topk)
+    got_id, got_d2 = eng.bruteforce_topk(centers, topk)
+    assert np.array_equal(got_id, want_id)
+    assert np.array_equal(got_d2, want_d2)
+    eng.close()
+
+
+def test_aliased_key_strings_share_a_bucket(oracle):
+    """Small W, K=2: distinct int tuples whose decimal concatenations coincide -- e.g. (1,23) and
+    (12,3) -- are ONE key in the reference (lsh.hpp:51-59).  The index must reproduce that."""
+    import hsearch_amd
+    k, K, L, W, R, n, nq = 25, 2, 2, 1.0, 45.0, 30000, 300
+    a, b = synth.make_planes(k, K, L, W, seed=99)
+    codes = synth.make_db(n, k, seed=8)
+    centers, _ = synth.make_queries(codes, nq, seed=9)
+    pts = oracle.embed_codes(codes)
+    ints = oracle.hash_all(a, b, W, pts)
+    aliased = 0
+    for l in range(L):
+        groups = {}
+        for t in map(tuple, ints[:, l]):
+            groups.setdefault(hsearch_amd.key_string(t), set()).add(t)
+        aliased += sum(1 for v in groups.values() if len(v) > 1)
+    assert aliased > 0, "workload does not exercise key aliasing"
+    eng = Engine(k, K, L, W, a, b)
+    info = eng.index_build(codes)
+    ix = oracle.Index(a, b, W, pts)
+    assert info["n_buckets"] == ix.table_sizes()
+    want = ix.query(centers, R)
+    got = eng.query(centers, R)
+    assert np.array_equal(got["cand"], want["cand"])
+    _assert_hits_equal(got, want)
+    eng.close()
+
+
+def test_edge_cases(oracle):
+    k, K, L, W, R = 25, 4, 3, 100.0, 40.0
+    a, b = synth.make_planes(k, K, L, W)
+    codes = synth.make_db(500, k)
+    centers, _ = synth.make_queries(codes, 20)
+    eng = Engine(k, K, L, W, a, b)
+    import hsearch_amd
+    with pytest.raises(hsearch_amd.HsError):           # query before build
+        eng.query(centers, R)
+    eng.index_build(codes[:0])                          # empty DB
+    assert len(eng.query(centers, R)["q"]) == 0
+    eng.index_build(codes)
+    assert len(eng.query(centers[:0], R)["q"]) == 0     # empty query batch
+    got = eng.query(centers, 0.0)                       # R = 0: exact duplicates only
+    want = oracle.search(a, b, W, 0.0, oracle.embed_codes(codes), centers)
+    _assert_hits_equal(got, want)
+    bad = codes.copy()
+    bad[3, 7] = 20
+    with pytest.raises(hsearch_amd.HsError):            # residue code outside the alphabet
+        eng.index_build(bad)
+    # capacity protocol: too small a buffer reports the required size, then succeeds
+    eng.index_build(codes)
+    full = eng.query(centers, R)
+    small = eng.query(centers, R, cap=1)
+    _assert_hits_equal(small, full)
+    # duplicates in the DB (same k-mer many times) and a single-point DB
+    dup = np.repeat(codes[:5], 40, axis=0)
+    eng.index_build(dup)
+    want = oracle.search(a, b, W, R, oracle.embed_codes(dup), oracle.embed_codes(codes[:5]))
+    _assert_hits_equal(eng.query(oracle.embed_codes(codes[:5]), R), want)
+    assert len(want["q"]) == 200
+    eng.close()

@@ -1,0 +1,121 @@
+"""C++ host layer (hsearch_amd/host): command-line contract of the reference's motif_both_points
+(motif_both_points.cpp:302-335, 387-393) and the plane generator.  CPU part needs no GPU; the GPU
+part runs the whole FASTA-less pipeline points-file in -> hits-file out."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "hsearch_amd", "bin", "hs_motif_both_points")
+
+
+def _bin():
+    if not os.path.exists(BIN):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "hsearch_amd", "host")], check=True,
+                       stdout=subprocess.DEVNULL)
+    return BIN
+
+
+def _write_points(path, pts, fmt="%.17g"):
+    with open(path, "w") as f:
+        for i, row in enumerate(pts):
+            f.write("p%d\n" % i)
+            f.write(" ".join(fmt % v for v in row) + "\n")
+
+
+def test_help_and_missing_option_exit_zero():
+    r = subprocess.run([_bin()], capture_output=True, text=True)
+    assert r.returncode == 0 and "Usage" in r.stderr
+    r = subprocess.run([_bin(), "-d", "x", "-c", "y"], capture_output=True, text=True)
+    assert r.returncode == 0 and "missing required option" in r.stderr   # :332-335
+    r = subprocess.run([_bin(), "-help"], capture_output=True, text=True)
+    assert r.returncode == 0
+
+
+def test_planes_match_reference_constructor(tmp_path, golden_dir):
+    """--seed s must reproduce what L reference LSH objects seeded s, s+1, ... draw (lsh.hpp:10-31);
+    the golden planes were dumped from the compiled reference."""
+    import torch
+    g = json.load(open(os.path.join(golden_dir, "search.json")))
+    for case in g["cases"][:3]:
+        z = np.load(os.path.join(golden_dir, case["file"]))
+        d = 8 * case["k"]
+        db, cen, out, planes = [str(tmp_path / n) for n in ("db", "cen", "out", "planes")]
+        _write_points(db, np.zeros((2, d)))
+        _write_points(cen, np.zeros((1, d)))
+        r = subprocess.run([_bin(), "-d", db, "-c", cen, "-l", str(case["k"]), "-K", str(case["K"]),
+                            "-L", str(case["L"]), "-W", repr(case["W"]), "-T", repr(case["R"]),
+                            "-o", out, "--seed", str(case["plane_seed"]), "--planes-out", planes],
+                           capture_output=True, text=True)
+        if not torch.cuda.is_available():
+            assert r.returncode == 1 and "gfx950" in r.stderr      # fails loudly, no CPU fallback
+        raw = np.fromfile(planes, dtype=np.float64)
+        na = case["L"] * case["K"] * d
+        assert np.array_equal(raw[:na].reshape(z["a"].shape), z["a"])
+        assert np.array_equal(raw[na:].reshape(z["b"].shape), z["b"])
+
+
+@pytest.mark.gpu
+def test_cli_hits_file_matches_reference_golden(tmp_path, golden_dir, oracle):
+    g = json.load(open(os.path.join(golden_dir, "search.json")))
+    for case in g["cases"]:
+        z = np.load(os.path.join(golden_dir, case["file"]))
+        db, cen, out = [str(tmp_path / n) for n in ("db", "cen", "out")]
+        _write_points(db, oracle.embed_codes(z["codes"]))
+        _write_points(cen, z["centers"])
+        r = subprocess.run([_bin(), "-d", db, "-c", cen, "-l", str(case["k"]), "-K", str(case["K"]),
+                            "-L", str(case["L"]), "-W", repr(case["W"]), "-T", repr(case["R"]),
+                            "-o", out, "--seed", str(case["plane_seed"])],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        lines = [ln.split() for ln in open(out)]
+        assert [ln[0] for ln in lines] == ["p%d" % q for q in z["hit_q"]]
+        assert [ln[1] for ln in lines] == ["p%d" % i for i in z["hit_id"]]
+        assert [ln[2] for ln in lines] == case["hit_dist_text"]
+
+
+@pytest.mark.gpu
+def test_cli_lossy_points_file_and_evaluate(tmp_path, oracle):
+    """DB written like protein2datapoints does (ostream default precision, 6 significant digits,
+    protein2datapoints.cpp:23-29): the host derives codes + the rounded table from the file, so both
+    sides hash the same doubles.  Checked against the oracle run on the parsed doubles."""
+    from hsearch_amd import synth
+    k, K, L, W, R, n, nq, seed = 25, 4, 4, 100.0, 40.0, 4000, 200, 77
+    codes = synth.make_db(n, k, seed=5)
+    centers, _ = synth.make_queries(codes, nq, seed=6, jitter=0.3)
+    db, cen, out, planes, gt = [str(tmp_path / x) for x in ("db", "cen", "out", "planes", "gt")]
+    _write_points(db, synth.embed(codes), fmt="%g")
+    _write_points(cen, centers, fmt="%g")
+    r = subprocess.run([_bin(), "-d", db, "-c", cen, "-l", str(k), "-K", str(K), "-L", str(L),
+                        "-W", repr(W), "-T", repr(R), "-o", out, "--seed", str(seed),
+                        "--planes-out", planes], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    raw = np.fromfile(planes, dtype=np.float64)
+    a = raw[:L * K * 8 * k].reshape(L, K, 8 * k)
+    b = raw[L * K * 8 * k:].reshape(L, K)
+    parse = lambda p: np.array([[float(v) for v in ln.split()] for ln in open(p).read().split("\n")[1::2] if ln])
+    dbp, cp = parse(db), parse(cen)
+    assert np.abs(dbp - synth.embed(codes)).max() > 0     # really lossy
+    want = oracle.search(a, b, W, R, dbp, cp)
+    want_path = str(tmp_path / "want")
+    oracle.write_hits(want_path, want["q"], want["id"], want["dist"])
+    got = [ln.split() for ln in open(out)]
+    exp = [ln.split() for ln in open(want_path)]
+    assert len(got) == len(exp) > 0
+    assert [(g_[0], g_[1], g_[2]) for g_ in got] == [("p" + e[0], "p" + e[1], e[2]) for e in exp]
+    # -g: evaluation against a sorted brute-force file (the reference's evaluate2 + evaulate flow)
+    bf = oracle.bruteforce(dbp, cp, R)
+    rows = sorted(("p%d" % q, "p%d" % i, d_) for q, i, d_ in zip(bf["q"], bf["id"], bf["dist"]))
+    with open(gt, "w") as f:
+        for q, i, d_ in rows:
+            f.write("%s %s %.6g\n" % (q, i, d_))
+    r = subprocess.run([_bin(), "-d", db, "-c", cen, "-l", str(k), "-K", str(K), "-L", str(L),
+                        "-W", repr(W), "-T", repr(R), "-o", out, "--seed", str(seed), "-g", gt],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    acc = float([ln for ln in r.stdout.splitlines() if ln.startswith("ACCURACY:")][0].split()[1])
+    assert acc == pytest.approx(oracle.evaluate(gt, out, R), abs=1e-6)
+    assert 0.5 < acc <= 1.0
