@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
 
 
 def parse():
@@ -42,6 +43,7 @@ def parse():
     ap.add_argument("--cpu-n", type=int, default=200_000, help="DB sample of the CPU baseline")
     ap.add_argument("--cpu-nq", type=int, default=200, help="query sample of the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify-mode", choices=["auto", "stream", "join"], default="auto")
     return ap.parse_args()
 
 
@@ -134,6 +136,7 @@ def main():
     centers, src = synth.make_queries(codes, args.nq, seed=synth.SEED_QUERIES + 1000 * rank)
 
     eng = Engine(k, K, L, W, a, b, device=local_rank)
+    eng.set_verify_mode(args.verify_mode)
     t0 = time.perf_counter()
     info = eng.index_build(codes)
     t_build = time.perf_counter() - t0
@@ -177,6 +180,9 @@ def main():
         step()
     verify_ms, cand, hits_local, hash_ms, probe_ms, fin_ms = 0.0, 0, 0, 0.0, 0.0, 0.0
     launches = 0
+    join_batches = 0
+    join_ms = 0.0
+    jstat = (0, 0, 0)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -187,6 +193,9 @@ def main():
         probe_ms += p["ms_probe"]
         fin_ms += p["ms_finalize"]
         launches += p["verify_launches"]
+        join_batches += p["join_batches"]
+        join_ms += p["ms_join"]
+        jstat = (p["join_items"], p["join_pairs"], p["join_pairs_issued"])
         cand = p["candidates"]
         hits_local = nh
     fence()
@@ -214,6 +223,30 @@ def main():
                 traffic = json.load(open(tpath)).get("verify_bytes_per_launch")
             except Exception:
                 traffic = None
+        if join_batches:
+            # dominant kernel = hs_join_kernel, an fp16 MFMA GEMM of depth 208 (25 positions x 8
+            # coordinates + 8 extras) per (bucket member, probing query) pair: 2*208 flop per pair.
+            j_ms = join_ms / steps
+            flop = jstat[1] * 2.0 * 208.0          # real (member, query) pairs routed to the join
+            tf = flop / (j_ms * 1e-3) / 1e12 if j_ms > 0 else 0.0
+            roofline = {"bound": "mfma", "kernel": "hs_join_kernel", "achieved": tf,
+                        "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": tf / MFMA_F16_PEAK_TFLOPS, "traffic": traffic,
+                        "flop_per_step": flop, "pairs_per_step": jstat[1],
+                        "pairs_issued_per_step": jstat[2], "work_items_per_step": jstat[0],
+                        "issued_tflops": (jstat[2] * 416.0 / (j_ms * 1e-3) / 1e12) if j_ms > 0 else 0.0,
+                        "kernel_ms_per_step": j_ms, "streaming_kernel_ms_per_step": v_ms - j_ms,
+                        "pairs_streamed_per_step": cand - jstat[1],
+                        "launches_per_step": launches / steps,
+                        "hbm_algorithmic_gbs": achieved,
+                        "hbm_algorithmic_frac_of_8TBs": achieved / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_step": algo_bytes}
+        else:
+            roofline = {"bound": "hbm", "kernel": "hs_verify_kernel", "achieved": achieved,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": traffic, "algorithmic_bytes_per_step": algo_bytes,
+                        "kernel_ms_per_step": v_ms, "launches_per_step": launches / steps,
+                        "packed_stream_bytes_per_step": cand * 16 * ((k + 24) // 25)}
         line = {
             "metric": "motif queries/sec (LSH probe + verify, index resident in HBM)",
             "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
@@ -223,14 +256,9 @@ def main():
                                    "index replicated per GPU" % (args.n, k, L, K, W, R, args.nq),
                        "db_kmers": args.n, "k": k, "L": L, "K": K, "W": W, "R": R,
                        "queries_per_gpu": args.nq, "parallelism": "query-sharded x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "hs_verify_kernel", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic,
-                         "algorithmic_bytes_per_step": algo_bytes,
-                         "kernel_ms_per_step": v_ms,
-                         "launches_per_step": launches / steps,
-                         "packed_stream_bytes_per_step": cand * 16 * ((k + 24) // 25)},
-            "phases_ms_per_step": {"hash_queries": hash_ms / steps, "probe_qtables": probe_ms / steps,
+            "roofline": roofline,
+            "verify_mode": args.verify_mode,
+            "phases_ms_per_step": {"hash_queries": hash_ms / steps, "probe_segments": probe_ms / steps,
                                    "verify": v_ms, "finalize_sort": fin_ms / steps},
             "candidates_per_query": cand / args.nq, "hits_per_step_rank0": hits_local,
             "hits_gathered": total_hits,

@@ -15,6 +15,7 @@ _STATUS = ["HS_OK", "HS_ERR_INVALID", "HS_ERR_NO_DEVICE", "HS_ERR_HIP", "HS_ERR_
 _ALPHABET = "ARNDCQEGHILKMFPSTWYV"
 
 EXPORTS = ["hs_create", "hs_destroy", "hs_last_error", "hs_get_profile", "hs_version",
+           "hs_set_verify_mode",
            "hs_embed_codes", "hs_hash_codes", "hs_hash_points", "hs_key_string", "hs_key_fingerprint",
            "hs_key_strings_equal", "hs_index_build",
            "hs_index_info_get", "hs_query", "hs_query_dev", "hs_bruteforce", "hs_bruteforce_topk"]
@@ -36,7 +37,9 @@ class _Profile(C.Structure):
     _fields_ = [("ms_hash", C.c_double), ("ms_sort", C.c_double), ("ms_gather", C.c_double),
                 ("ms_probe", C.c_double), ("ms_verify", C.c_double), ("ms_finalize", C.c_double),
                 ("ms_total", C.c_double), ("candidates", C.c_uint64), ("provisional", C.c_uint64),
-                ("hits", C.c_uint64), ("verify_launches", C.c_uint64)]
+                ("hits", C.c_uint64), ("verify_launches", C.c_uint64), ("join_batches", C.c_uint64),
+                ("ms_join", C.c_double), ("join_items", C.c_uint64), ("join_pairs", C.c_uint64),
+                ("join_pairs_issued", C.c_uint64)]
 
 
 class _IndexInfo(C.Structure):
@@ -149,6 +152,10 @@ class Engine:
     def _check(self, st):
         if st != HS_OK:
             raise HsError(st, self._lib.hs_last_error(self._h).decode())
+
+    def set_verify_mode(self, mode):
+        """'auto' | 'stream' | 'join' -- which filter kernel runs in front of the exact decision."""
+        self._check(self._lib.hs_set_verify_mode(self._h, {"auto": 0, "stream": 1, "join": 2}[mode]))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -44,7 +44,7 @@ struct DevBuf {
   T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-enum { EV_COUNT = 10 };
+enum { EV_COUNT = 12 };
 
 }  // namespace
 
@@ -68,6 +68,13 @@ struct hs_handle {
   // query workspace (grown on demand, reused across calls)
   DevBuf qints, qstart, qcount, nslices, slice_off, tq, prov, hit_key, hit_val, hit_key2, hit_val2,
       counters, temp, io_centers, io_q, io_id, io_table, io_dist, io_cand, io_codes, io_misc;
+  // bucket-join workspace
+  DevBuf c16s, item_desc;
+  uint32_t join_min_q = 3, join_min_m = 16;  // segment routing thresholds (HS_JOIN_MIN_Q / _M)
+  DevBuf jtab, c16, seg_keys, seg_keys_sorted, seg_vals, sorted_ql, seg_key, seg_cnt, seg_qoff,
+      seg_items, item_off, seg_n;
+  bool join_tables_ok = false;  // fp16 can carry the coordinate table
+  int verify_mode = 0;          // 0 auto, 1 streaming kernel, 2 bucket join
   std::string err;
   hs_profile prof;
 };
@@ -180,7 +187,28 @@ hs_status hs_create(const hs_params* params, const double* a, const double* b, c
   HS_HIP(h, hipMemcpyAsync(h->b.p, b, (size_t)h->LK * 8, hipMemcpyHostToDevice, h->stream));
   HS_HIP(h, hipMemcpyAsync(h->coords.p, coords ? coords : &HS_AA_COORDS[0][0],
                            (size_t)h->alphabet * 8 * 8, hipMemcpyHostToDevice, h->stream));
+  // fp16 coordinate table + row norms of the bucket-join filter
+  HS_HIP(h, h->jtab.reserve(512 + 128 + 64));
+  HS_HIP(h, hipMemsetAsync(h->jtab.p, 0, 512 + 128 + 64, h->stream));
+  HS_HIP(h, hs_launch_jtables(h->coords.as<double>(), h->alphabet, h->jtab.p,
+                              reinterpret_cast<float*>(h->jtab.as<char>() + 512),
+                              reinterpret_cast<uint32_t*>(h->jtab.as<char>() + 640), h->stream));
+  uint32_t unsafe = 1;
+  HS_HIP(h, hipMemcpyAsync(&unsafe, h->jtab.as<char>() + 640, 4, hipMemcpyDeviceToHost, h->stream));
   HS_HIP(h, hipStreamSynchronize(h->stream));
+  h->join_tables_ok = (unsafe == 0);
+  if (const char* m = getenv("HS_VERIFY_MODE")) {
+    if (!strcmp(m, "stream")) h->verify_mode = 1;
+    if (!strcmp(m, "join")) h->verify_mode = 2;
+  }
+  if (const char* m = getenv("HS_JOIN_MIN_Q")) h->join_min_q = (uint32_t)std::max(1, atoi(m));
+  if (const char* m = getenv("HS_JOIN_MIN_M")) h->join_min_m = (uint32_t)std::max(1, atoi(m));
+  return HS_OK;
+}
+
+hs_status hs_set_verify_mode(hs_handle* h, int mode) {
+  if (!h || mode < 0 || mode > 2) return HS_ERR_INVALID;
+  h->verify_mode = mode;
   return HS_OK;
 }
 
@@ -192,7 +220,9 @@ void hs_destroy(hs_handle* h) {
                     &h->qcount, &h->nslices, &h->slice_off, &h->tq, &h->prov, &h->hit_key,
                     &h->hit_val, &h->hit_key2, &h->hit_val2, &h->counters, &h->temp,
                     &h->io_centers, &h->io_q, &h->io_id, &h->io_table, &h->io_dist, &h->io_cand,
-                    &h->io_codes, &h->io_misc};
+                    &h->io_codes, &h->io_misc, &h->jtab, &h->c16, &h->seg_keys, &h->seg_keys_sorted,
+                    &h->seg_vals, &h->sorted_ql, &h->seg_key, &h->seg_cnt, &h->seg_qoff,
+                    &h->seg_items, &h->item_off, &h->seg_n, &h->c16s, &h->item_desc};
   for (DevBuf* bf : bufs) bf->release();
   for (int l = 0; l < HS_MAX_L; ++l) {
     h->t_dirkey[l].release();
@@ -427,7 +457,6 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   const float r2_hi = filter_bound(r2);
   const int n_blocks = h->n_cu * 8;
   uint32_t* d_cnt = h->counters.as<uint32_t>();
-  HS_HIP(h, h->tq.reserve((size_t)nq * k * HS_TROW * 4));
   HS_HIP(h, hipMemsetAsync(d_cnt, 0, 64, h->stream));
   HS_HIP(h, hipEventRecord(h->ev[0], h->stream));
   if (!brute) {
@@ -447,15 +476,95 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
                               h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
                               h->nslices.as<uint32_t>(), d_cand,
                               reinterpret_cast<unsigned long long*>(d_cnt + 2), h->stream));
+  }
+  // Bucket join (hs_join.hip) when fp16 can carry the data and a k-mer is one packed word; the
+  // streaming kernel otherwise (and for brute force).  With the join on, segments (bucket x its
+  // probing queries) with too few queries to fill MFMA columns still go to the streaming kernel:
+  // both kernels append survivors to the same list in front of the same exact decision.
+  bool use_join = !brute && h->verify_mode != 1 && h->join_tables_ok && k <= 25 && r2 < 30000.0;
+  uint32_t* d_unsafe = d_cnt + 8;
+  unsigned long long* d_jstats = reinterpret_cast<unsigned long long*>(d_cnt + 10);
+  uint32_t n_items = 0, n_slices = 1;
+  if (use_join) {
+    const size_t n1 = (size_t)nql + 1;
+    HS_HIP(h, h->c16.reserve((size_t)nq * 208 * 2));
+    HS_HIP(h, h->c16s.reserve(((size_t)nql + 64) * 208 * 2));
+    HS_HIP(h, h->seg_keys.reserve(n1 * 8));
+    HS_HIP(h, h->seg_keys_sorted.reserve(n1 * 8));
+    HS_HIP(h, h->seg_vals.reserve(n1 * 4));
+    HS_HIP(h, h->sorted_ql.reserve(n1 * 4));
+    HS_HIP(h, h->seg_key.reserve(n1 * 8));
+    HS_HIP(h, h->seg_cnt.reserve(n1 * 4));
+    HS_HIP(h, h->seg_qoff.reserve(n1 * 4));
+    HS_HIP(h, h->seg_items.reserve(n1 * 4));
+    HS_HIP(h, h->item_off.reserve(n1 * 4));
+    HS_HIP(h, h->seg_n.reserve(64));
+    HS_HIP(h, h->temp.reserve(std::max(std::max(hs_sort_pairs_u64_u32_temp(nql), hs_rle_u64_temp(nql)),
+                                       hs_scan_u32_temp(n1)) + 256));
+    HS_HIP(h, hs_launch_qprep(d_centers, nq, k, r2, h->c16.p, d_unsafe, h->stream));
+    HS_HIP(h, hs_launch_seg_keys(h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(), nql, L,
+                                 h->seg_keys.as<uint64_t>(), h->seg_vals.as<uint32_t>(), h->stream));
+    HS_HIP(h, hs_sort_pairs_u64_u32(h->temp.p, h->temp.cap, h->seg_keys.as<uint64_t>(),
+                                    h->seg_keys_sorted.as<uint64_t>(), h->seg_vals.as<uint32_t>(),
+                                    h->sorted_ql.as<uint32_t>(), nql, h->stream));
+    HS_HIP(h, hipMemsetAsync(h->seg_cnt.p, 0, n1 * 4, h->stream));
+    HS_HIP(h, hs_rle_u64(h->temp.p, h->temp.cap, h->seg_keys_sorted.as<uint64_t>(),
+                         h->seg_key.as<uint64_t>(), h->seg_cnt.as<uint32_t>(),
+                         h->seg_n.as<uint32_t>(), nql, h->stream));
+    HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, h->seg_cnt.as<uint32_t>(),
+                                    h->seg_qoff.as<uint32_t>(), n1, h->stream));
+    HS_HIP(h, hs_launch_seg_route(h->seg_key.as<uint64_t>(), h->seg_cnt.as<uint32_t>(),
+                                  h->seg_qoff.as<uint32_t>(), h->seg_n.as<uint32_t>(),
+                                  h->sorted_ql.as<uint32_t>(), h->qcount.as<uint32_t>(), nql,
+                                  h->join_min_q, h->join_min_m, h->seg_items.as<uint32_t>(), d_jstats,
+                                  h->nslices.as<uint32_t>(), h->stream));
+    HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, h->seg_items.as<uint32_t>(),
+                                    h->item_off.as<uint32_t>(), n1, h->stream));
+    HS_HIP(h, hs_launch_gather_c16(h->c16.p, h->sorted_ql.as<uint32_t>(), nql, L, h->c16s.p, h->stream));
+  }
+  if (!brute) {
     HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, h->nslices.as<uint32_t>(),
                                     h->slice_off.as<uint32_t>(), (size_t)nql + 1, h->stream));
+    // one host round trip: join legality, number of join items, number of streaming slices
+    uint32_t unsafe = 0;
+    if (use_join) {
+      HS_HIP(h, hipMemcpyAsync(&unsafe, d_unsafe, 4, hipMemcpyDeviceToHost, h->stream));
+      HS_HIP(h, hipMemcpyAsync(&n_items, h->item_off.as<uint32_t>() + nql, 4, hipMemcpyDeviceToHost,
+                               h->stream));
+    }
+    HS_HIP(h, hipMemcpyAsync(&n_slices, h->slice_off.as<uint32_t>() + nql, 4, hipMemcpyDeviceToHost,
+                             h->stream));
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    if (use_join && unsafe) {
+      // a query fp16 cannot carry: this batch streams entirely (re-derive the slice counts)
+      use_join = false;
+      n_items = 0;
+      HS_HIP(h, hipMemsetAsync(d_cnt + 2, 0, 8, h->stream));
+      HS_HIP(h, hs_launch_probe(h->tabs, h->qints.as<int32_t>(), nq, K, L, h->key_seed,
+                                h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
+                                h->nslices.as<uint32_t>(), d_cand,
+                                reinterpret_cast<unsigned long long*>(d_cnt + 2), h->stream));
+      HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, h->nslices.as<uint32_t>(),
+                                      h->slice_off.as<uint32_t>(), (size_t)nql + 1, h->stream));
+      n_slices = 1;
+    }
+    if (n_items) {
+      HS_HIP(h, h->item_desc.reserve((size_t)n_items * 32));
+      HS_HIP(h, hs_launch_item_desc(h->tabs, h->seg_key.as<uint64_t>(), h->seg_cnt.as<uint32_t>(),
+                                    h->seg_qoff.as<uint32_t>(), h->item_off.as<uint32_t>(), nql,
+                                    h->sorted_ql.as<uint32_t>(), h->qcount.as<uint32_t>(), n_items,
+                                    h->item_desc.as<uint4>(), h->stream));
+    }
   }
-  HS_HIP(h, hs_launch_qtables(d_centers, nq, k, h->coords.as<double>(), h->alphabet, h->tq.as<float>(),
-                              h->stream));
+  if (brute || n_slices) {
+    HS_HIP(h, h->tq.reserve((size_t)nq * k * HS_TROW * 4));
+    HS_HIP(h, hs_launch_qtables(d_centers, nq, k, h->coords.as<double>(), h->alphabet,
+                                h->tq.as<float>(), h->stream));
+  }
   HS_HIP(h, hipEventRecord(h->ev[2], h->stream));
   uint32_t prov_cap = (uint32_t)std::max<size_t>(h->prov.cap / 8, std::max<size_t>(1u << 20, 16ull * nq));
   uint32_t host_cnt[4] = {0, 0, 0, 0};
-  double ms_verify = 0, ms_final = 0;
+  double ms_verify = 0, ms_final = 0, ms_join = 0;
   uint32_t launches = 0;
   for (;;) {  // retried only when a workspace capacity was exceeded
     HS_HIP(h, h->prov.reserve((size_t)prov_cap * 8));
@@ -469,9 +578,16 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
                                      nq, k, r2_hi, d_cnt, prov_cap, h->prov.as<uint2>(), nullptr,
                                      nullptr, n_blocks, h->stream));
     } else {
-      HS_HIP(h, hs_launch_verify(h->tabs, h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
-                                 h->slice_off.as<uint32_t>(), nql, h->tq.as<float>(), k, L, r2_hi,
-                                 d_cnt, prov_cap, h->prov.as<uint2>(), n_blocks, h->stream));
+      if (n_items)
+        HS_HIP(h, hs_launch_join(h->item_desc.as<uint4>(), n_items, h->sorted_ql.as<uint32_t>(),
+                                 h->c16s.p, h->jtab.p,
+                                 reinterpret_cast<const float*>(h->jtab.as<char>() + 512), k, d_cnt,
+                                 prov_cap, h->prov.as<uint2>(), h->n_cu * 2, h->stream));
+      HS_HIP(h, hipEventRecord(h->ev[10], h->stream));
+      if (n_slices)
+        HS_HIP(h, hs_launch_verify(h->tabs, h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
+                                   h->slice_off.as<uint32_t>(), nql, h->tq.as<float>(), k, L, r2_hi,
+                                   d_cnt, prov_cap, h->prov.as<uint2>(), n_blocks, h->stream));
     }
     HS_HIP(h, hipEventRecord(h->ev[4], h->stream));
     if (brute) {
@@ -490,6 +606,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, hipMemcpyAsync(host_cnt, d_cnt, 16, hipMemcpyDeviceToHost, h->stream));
     HS_HIP(h, hipStreamSynchronize(h->stream));
     ms_verify += ev_ms(h, 3, 4);
+    if (!brute && n_items) ms_join += ev_ms(h, 3, 10);
     ms_final += ev_ms(h, 4, 5);
     ++launches;
     if (host_cnt[0] > prov_cap) {
@@ -507,6 +624,15 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   memcpy(&cand_total, host_cnt + 2, 8);
   h->prof.candidates += brute ? (uint64_t)nq * h->n : cand_total;
   h->prof.provisional += host_cnt[0];
+  h->prof.join_batches += n_items ? 1 : 0;
+  h->prof.ms_join += ms_join;
+  h->prof.join_items += n_items;
+  if (use_join) {
+    unsigned long long js[2] = {0, 0};
+    HS_HIP(h, hipMemcpy(js, d_jstats, 16, hipMemcpyDeviceToHost));
+    h->prof.join_pairs_issued += js[0];
+    h->prof.join_pairs += js[1];
+  }
   *n_batch_hits = host_cnt[1];
   return HS_OK;
 }

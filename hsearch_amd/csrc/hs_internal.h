@@ -179,6 +179,31 @@ hipError_t hs_launch_bruteforce(const uint4* d_packed_all, uint32_t n, const flo
                                 uint32_t nq, int k, float r2_hi, uint32_t* d_prov_count,
                                 uint32_t prov_cap, uint2* d_prov, const float* d_q_thr,
                                 float* d_slice_min, int n_blocks, hipStream_t s);
+// bucket join (hs_join.hip)
+hipError_t hs_launch_jtables(const double* d_coords, int alphabet, void* d_tab16, float* d_rownorm,
+                             uint32_t* d_unsafe, hipStream_t s);
+hipError_t hs_launch_qprep(const double* d_centers, uint32_t nq, int k, double r2, void* d_c16,
+                           uint32_t* d_unsafe, hipStream_t s);
+hipError_t hs_launch_seg_keys(const uint32_t* d_qstart, const uint32_t* d_qcount, uint32_t nql, int L,
+                              uint64_t* d_keys, uint32_t* d_vals, hipStream_t s);
+// items[j] for joined segments (>= min_q probing queries and >= min_m members), 0 otherwise, and
+// nslices[ql] = 0 for the probes of joined segments; stats[0] += MFMA pairs issued, [1] += real pairs
+hipError_t hs_launch_seg_route(const uint64_t* d_seg_key, const uint32_t* d_seg_cnt,
+                               const uint32_t* d_seg_qoff, const uint32_t* d_n_seg,
+                               const uint32_t* d_sorted_ql, const uint32_t* d_qcount, uint32_t n_max,
+                               uint32_t min_q, uint32_t min_m, uint32_t* d_items,
+                               unsigned long long* d_stats, uint32_t* d_nslices, hipStream_t s);
+hipError_t hs_launch_item_desc(const hs_tables_dev& tabs, const uint64_t* d_seg_key,
+                               const uint32_t* d_seg_cnt,
+                               const uint32_t* d_seg_qoff, const uint32_t* d_item_off, uint32_t n_max,
+                               const uint32_t* d_sorted_ql, const uint32_t* d_qcount, uint32_t n_items,
+                               uint4* d_desc, hipStream_t s);
+hipError_t hs_launch_gather_c16(const void* d_c16, const uint32_t* d_sorted_ql, uint32_t nql, int L,
+                                void* d_out, hipStream_t s);
+hipError_t hs_launch_join(const uint4* d_desc, uint32_t n_items,
+                          const uint32_t* d_sorted_ql, const void* d_c16s, const void* d_tab16,
+                          const float* d_rownorm, int k, uint32_t* d_prov_count, uint32_t prov_cap,
+                          uint2* d_prov, int n_blocks, hipStream_t s);
 hipError_t hs_launch_kth_min(const float* d_slice_min, uint32_t nq, uint32_t per_q, uint32_t topk,
                              float* d_thr, hipStream_t s);
 hipError_t hs_launch_topk_exact(const uint8_t* d_codes, const double* d_centers,

@@ -1,0 +1,447 @@
+// hs_join.hip -- bucket-join form of candidate verification (rows a8/a9), gfx950 MFMA.
+//
+// The reference verifies, for every query q and table l, every member of q's bucket
+// (motif_both_points.cpp:232-242).  Many queries probe the SAME bucket (the largest buckets hold
+// several per cent of the DB and are probed by thousands of queries), so the work
+//     sum over (table, bucket B) of |members(B)| x |queries probing B|
+// is a block-sparse product.  Here a workgroup takes a tile of 256 members of one bucket, keeps
+// their embedded coordinates as fp16 MFMA A-fragments in registers, and streams the probing
+// queries past them in chunks of 32 through LDS: members are read from HBM once per tile instead
+// of once per (query, member) pair.
+//
+// What the MFMA computes is a FILTER, never a result: with x = member, c = query,
+//     G = |x|^2 + |c|^2 - 2 x^.c^ - R^2 - slack - e_c |x|^          (x^, c^ = fp16 roundings)
+// folded into one K = 208 GEMM (25 positions x 8 coordinates + 8 "extras" that carry the norms,
+// the threshold and the error term), and a pair survives iff G <= 0.  The error term is a rigorous
+// bound: |2 x^.c^ - 2 x.c| <= 2 (2^-10 + 2^-22) |x||c|  (fp16 round-to-nearest, Cauchy-Schwarz),
+// fp32 accumulation and hi/lo splitting of the norms are covered by slack = 1.  Hence every pair
+// with exact d2 <= R^2 survives; survivors (rare) are re-evaluated in the reference's fp64 order
+// and decided by its own test in hs_finalize_kernel, exactly as for the streaming kernel.
+#include <algorithm>
+
+#include "hs_internal.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int JK = 208;     // GEMM depth = 26 groups of 8 halves
+constexpr int JG = 26;      // groups: 25 positions + extras
+constexpr int JROW = 216;   // LDS row stride in halves: 432 B = 27 x 16 B -> conflict-free b128
+constexpr int JQ = 32;      // queries per chunk (MFMA N)
+constexpr int JM = 256;     // members per workgroup tile (4 waves x 2 x 32 rows)
+constexpr int JQG = 512;    // queries per work item (<= 16 chunks)
+constexpr float JSLACK = 1.0f;
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// ---------------------------------------------------------------------------------- query prep
+// c16[q] = { -2 fp16(c_i) for i < 8k, zeros up to 200, extras }:
+//   extras = { 1, 1, hi(v), lo(v), -e_c, 0, 0, 0 },  v = |c|^2 - R^2 - slack,  e_c >= 2^-9 1.0003 |c|.
+// One wavefront per query.  unsafe |= 1 when fp16 cannot carry the query (then the caller uses the
+// streaming kernel instead).
+__global__ __launch_bounds__(256) void hs_qprep_kernel(const double* __restrict__ centers, uint32_t nq,
+                                                       int k, double r2, _Float16* __restrict__ c16,
+                                                       uint32_t* __restrict__ unsafe) {
+  const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= nq) return;
+  const int lane = lane_id();
+  const int d = 8 * k;
+  const double* c = centers + (uint64_t)q * d;
+  _Float16* out = c16 + (uint64_t)q * JK;
+  double nc = 0.0;
+  bool bad = false;
+  for (int i = lane; i < 200; i += 64) {
+    _Float16 h = (_Float16)0.f;
+    if (i < d) {
+      const double v = c[i];
+      nc += v * v;
+      bad = bad || !(fabs(v) < 16000.0);
+      h = (_Float16)(float)v;
+      h = (_Float16)(-2.0f * (float)h);  // exact: scaling by 2
+    }
+    out[i] = h;
+  }
+  for (int off = 32; off; off >>= 1) nc += __shfl_xor(nc, off);
+  bad = bad || !(nc < 30000.0) || !(r2 < 30000.0);
+  if (__ballot(bad) && lane == 0) atomicOr(unsafe, 1u);
+  if (lane == 0) {
+    const float v = (float)(nc - r2 - (double)JSLACK);
+    const _Float16 vhi = (_Float16)v;
+    const _Float16 vlo = (_Float16)(v - (float)vhi);
+    const float ec = (float)(sqrt(nc) * (1.01 / 512.0));
+    out[200] = (_Float16)1.f;
+    out[201] = (_Float16)1.f;
+    out[202] = vhi;
+    out[203] = vlo;
+    out[204] = (_Float16)(-ec);
+    out[205] = (_Float16)0.f;
+    out[206] = (_Float16)0.f;
+    out[207] = (_Float16)0.f;
+  }
+}
+
+// fp16 coordinate table [32][8] and fp32 squared row norms [32] of the handle's alphabet
+__global__ void hs_jtables_kernel(const double* __restrict__ coords, int alphabet,
+                                  _Float16* __restrict__ tab16, float* __restrict__ rownorm,
+                                  uint32_t* __restrict__ unsafe) {
+  const int aa = threadIdx.x;
+  if (aa >= 32) return;
+  double n = 0.0;
+  bool bad = false;
+  for (int j = 0; j < 8; ++j) {
+    const double v = aa < alphabet ? coords[aa * 8 + j] : 0.0;
+    n += v * v;
+    bad = bad || !(fabs(v) < 16000.0);
+    tab16[aa * 8 + j] = (_Float16)(float)v;
+  }
+  rownorm[aa] = (float)n;
+  if (bad) atomicOr(unsafe, 1u);
+}
+
+// ---------------------------------------------------------------------------- segments / items
+// key = (table << 32 | first sorted position of the bucket) for probes that found a bucket.
+__global__ __launch_bounds__(256) void hs_seg_keys_kernel(const uint32_t* __restrict__ qstart,
+                                                          const uint32_t* __restrict__ qcount,
+                                                          uint32_t nql, int L,
+                                                          uint64_t* __restrict__ keys,
+                                                          uint32_t* __restrict__ vals) {
+  const uint32_t ql = blockIdx.x * 256 + threadIdx.x;
+  if (ql >= nql) return;
+  const uint32_t l = ql % (uint32_t)L;
+  keys[ql] = qcount[ql] ? (((uint64_t)l << 32) | qstart[ql]) : ~0ull;
+  vals[ql] = ql;
+}
+
+// Routing: a segment (bucket x its probing queries) goes to the MFMA join when enough queries share
+// it, otherwise its queries stay with the streaming kernel (one wavefront per query and slice).
+// items[j] = member tiles x query groups for joined segments, 0 otherwise / past the end.
+__global__ __launch_bounds__(256) void hs_seg_route_kernel(const uint64_t* __restrict__ seg_key,
+                                                           const uint32_t* __restrict__ seg_cnt,
+                                                           const uint32_t* __restrict__ seg_qoff,
+                                                           const uint32_t* __restrict__ n_seg,
+                                                           const uint32_t* __restrict__ sorted_ql,
+                                                           const uint32_t* __restrict__ qcount,
+                                                           uint32_t n_max, uint32_t min_q,
+                                                           uint32_t min_m, uint32_t* __restrict__ items,
+                                                           unsigned long long* __restrict__ stats) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j > n_max) return;
+  uint32_t it = 0;
+  if (j < *n_seg && seg_key[j] != ~0ull) {
+    const uint32_t m = qcount[sorted_ql[seg_qoff[j]]];
+    const uint32_t nq = seg_cnt[j];
+    if (nq >= min_q && m >= min_m) {
+      it = ((m + JM - 1) / JM) * ((nq + JQG - 1) / JQG);
+      // MFMA pairs actually issued (64-row waves x 32-column chunks) vs real pairs
+      atomicAdd(stats + 0, (unsigned long long)((m + 63) / 64 * 64) * ((nq + JQ - 1) / JQ * JQ));
+      atomicAdd(stats + 1, (unsigned long long)m * nq);
+    }
+  }
+  items[j] = it;
+}
+
+// nslices[ql] = 0 for probes whose segment was routed to the join (they keep their slice count,
+// written by the probe kernel, otherwise).  One thread per sorted probe; segment by binary search.
+__global__ __launch_bounds__(256) void hs_seg_unslice_kernel(const uint32_t* __restrict__ seg_qoff,
+                                                             const uint32_t* __restrict__ n_seg,
+                                                             const uint32_t* __restrict__ items,
+                                                             const uint32_t* __restrict__ sorted_ql,
+                                                             uint32_t nql, uint32_t* __restrict__ nslices) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= nql) return;
+  uint32_t lo = 0, hi = *n_seg;  // largest j with seg_qoff[j] <= p
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (seg_qoff[mid] <= p) lo = mid; else hi = mid;
+  }
+  if (items[lo]) nslices[sorted_ql[p]] = 0;
+}
+
+// One descriptor (2 x uint4) per work item:
+//   { pointer to the bucket's first packed member (lo, hi), M, member tile },
+//   { qoff, q_begin, q_end, first sorted position of the bucket }
+__global__ __launch_bounds__(256) void hs_item_desc_kernel(hs_tables_dev tabs,
+                                                           const uint64_t* __restrict__ seg_key,
+                                                           const uint32_t* __restrict__ seg_cnt,
+                                                           const uint32_t* __restrict__ seg_qoff,
+                                                           const uint32_t* __restrict__ item_off,
+                                                           uint32_t n_max,
+                                                           const uint32_t* __restrict__ sorted_ql,
+                                                           const uint32_t* __restrict__ qcount,
+                                                           uint32_t n_items, uint4* __restrict__ desc) {
+  const uint32_t item = blockIdx.x * 256 + threadIdx.x;
+  if (item >= n_items) return;
+  uint32_t lo = 0, hi = n_max;  // largest j with item_off[j] <= item (zero-item segments share
+  while (hi - lo > 1) {         // their successor's offset, so the last such j owns the item)
+    const uint32_t mid = (lo + hi) >> 1;
+    if (item_off[mid] <= item) lo = mid; else hi = mid;
+  }
+  const uint32_t seg = lo;
+  const uint64_t key = seg_key[seg];
+  const uint32_t nQ = seg_cnt[seg], qoff = seg_qoff[seg];
+  const uint32_t M = qcount[sorted_ql[qoff]];
+  const uint32_t tiles_m = (M + JM - 1) / JM;
+  const uint32_t local = item - item_off[seg];
+  const uint32_t mt = local % tiles_m, qg = local / tiles_m;
+  const uint32_t q_begin = qg * JQG;
+  const uint32_t mstart = (uint32_t)key;
+  const uint64_t ptr = reinterpret_cast<uint64_t>(tabs.t[(uint32_t)(key >> 32)].packed + mstart);
+  desc[2 * (uint64_t)item] = make_uint4((uint32_t)ptr, (uint32_t)(ptr >> 32), M, mt);
+  desc[2 * (uint64_t)item + 1] = make_uint4(qoff, q_begin, min(nQ, q_begin + JQG), mstart);
+}
+
+// c16 rows in SEGMENT order, so that a chunk of 32 probing queries is one contiguous 13 KB block
+__global__ __launch_bounds__(256) void hs_gather_c16_kernel(const _Float16* __restrict__ c16,
+                                                            const uint32_t* __restrict__ sorted_ql,
+                                                            uint32_t nql, int L,
+                                                            _Float16* __restrict__ out) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (uint64_t)nql * JG) return;
+  const uint32_t p = (uint32_t)(t / JG);
+  const int g = (int)(t - (uint64_t)p * JG);
+  const uint32_t q = sorted_ql[p] / (uint32_t)L;
+  *reinterpret_cast<uint4*>(out + (uint64_t)p * JK + g * 8) =
+      *reinterpret_cast<const uint4*>(c16 + (uint64_t)q * JK + g * 8);
+}
+
+// ------------------------------------------------------------------------------------------ join
+template <int R>
+__device__ __forceinline__ uint32_t even_residue(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
+  // residue at bit 10*R of the (already half-shifted) 128-bit word, R = 0..12
+  constexpr int bit = 10 * R, wi = bit >> 5, sh = bit & 31;
+  const uint32_t lo = wi == 0 ? x : wi == 1 ? y : wi == 2 ? z : w;
+  if constexpr (sh > 27) {
+    const uint32_t hi = wi == 0 ? y : wi == 1 ? z : w;
+    return __funnelshift_r(lo, hi, sh) & 31u;
+  } else {
+    return (lo >> sh) & 31u;
+  }
+}
+
+constexpr int JPIECES = JQ * JG;  // 16-byte pieces of one query chunk: 832
+
+__device__ __forceinline__ half8 lds_b(const _Float16* tile, int off) {
+  return *reinterpret_cast<const half8*>(tile + off);
+}
+
+// One work item = (member tile of <= 256 bucket entries, group of <= 512 probing queries).
+// Waves: 4 x (2 x 32 members); A fragments (whole K) live in registers for the item; query chunks
+// of 32 stream through a double-buffered LDS tile, prefetched into registers one chunk ahead; the
+// B fragments of a chunk are read from LDS four k-steps ahead of the MFMAs that consume them.
+__global__ __launch_bounds__(256, 2) void hs_join_kernel(
+    const uint4* __restrict__ desc, uint32_t n_items, const uint32_t* __restrict__ sorted_ql,
+    const _Float16* __restrict__ c16s, const _Float16* __restrict__ tab16,
+    const float* __restrict__ rownorm, int k, uint32_t* __restrict__ prov_count, uint32_t prov_cap,
+    uint2* __restrict__ prov) {
+  __shared__ __attribute__((aligned(16))) _Float16 sB[2][JQ * JROW];
+  __shared__ __attribute__((aligned(16))) _Float16 sTab[32 * 8];
+  __shared__ float sNorm[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  sTab[tid] = tab16[tid];
+  if (tid < 32) sNorm[tid] = rownorm[tid];
+  __syncthreads();
+  // This thread's 4 pieces of a chunk (the last 192 threads repeat piece 831: same bytes to the
+  // same LDS address, which keeps every load and store unconditional).
+  int src_piece[4], dst[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = min(tid + 256 * j, JPIECES - 1);
+    const int row = i / JG, g = i - row * JG;
+    src_piece[j] = i;
+    dst[j] = row * JROW + g * 8;
+  }
+  const int boff = r * JROW + h * 8;  // B fragment of k-step s: boff + 16 s (halves)
+  int buf = 0;
+  for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const uint4 d0 = desc[2 * (uint64_t)item], d1 = desc[2 * (uint64_t)item + 1];
+    const uint4* __restrict__ packed =
+        reinterpret_cast<const uint4*>(((uint64_t)d0.y << 32) | (uint64_t)d0.x);
+    const uint32_t M = d0.z, mt = d0.w;
+    const uint32_t qoff = d1.x, q_begin = d1.y, q_end = d1.z, mstart = d1.w;
+    const uint32_t wbase = mt * JM + wave * 64;
+    const bool wave_on = wbase < M;  // wave-uniform: this wave owns at least one real member
+    // prefetch the first query chunk while the A fragments are being built
+    uint4 pre0, pre1, pre2, pre3;
+    {
+      const uint4* src = reinterpret_cast<const uint4*>(c16s + (uint64_t)(qoff + q_begin) * JK);
+      pre0 = src[src_piece[0]];
+      pre1 = src[src_piece[1]];
+      pre2 = src[src_piece[2]];
+      pre3 = src[src_piece[3]];
+    }
+    half8 A[2][13];
+    if (wave_on) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const uint32_t idx = wbase + t * 32 + r;
+        const uint4 pk = packed[min(idx, M - 1)];
+        // lanes of the upper half take the odd positions: shift the 125-bit word down by 5
+        const uint32_t sh5 = 5u * (uint32_t)h;
+        const uint32_t x = __funnelshift_r(pk.x, pk.y, sh5), y = __funnelshift_r(pk.y, pk.z, sh5),
+                       z = __funnelshift_r(pk.z, pk.w, sh5), w = pk.w >> sh5;
+        float nx = 0.f;
+#define HS_AFRAG(S)                                                        \
+  {                                                                        \
+    const uint32_t aa = even_residue<S>(x, y, z, w);                       \
+    A[t][S] = *reinterpret_cast<const half8*>(&sTab[aa * 8]);             \
+    nx += (2 * S + h < k) ? sNorm[aa] : 0.f;                               \
+  }
+        HS_AFRAG(0) HS_AFRAG(1) HS_AFRAG(2) HS_AFRAG(3) HS_AFRAG(4) HS_AFRAG(5)
+        HS_AFRAG(6) HS_AFRAG(7) HS_AFRAG(8) HS_AFRAG(9) HS_AFRAG(10) HS_AFRAG(11)
+#undef HS_AFRAG
+        {
+          // group 24 (position 24) for the lower half, group 25 (extras) for the upper half
+          const uint32_t aa = even_residue<12>(x, y, z, w);
+          const half8 pos24 = *reinterpret_cast<const half8*>(&sTab[aa * 8]);
+          if (h == 0) nx += (24 < k) ? sNorm[aa] : 0.f;
+          nx += __shfl_xor(nx, 32);  // |x|^2 = even positions + odd positions
+          const _Float16 nhi = (_Float16)nx;
+          const _Float16 nlo = (_Float16)(nx - (float)nhi);
+          const _Float16 xn = (_Float16)(sqrtf(nx) * 1.002f);
+          half8 ex;
+          ex[0] = nhi; ex[1] = nlo; ex[2] = (_Float16)1.f; ex[3] = (_Float16)1.f;
+          ex[4] = xn; ex[5] = (_Float16)0.f; ex[6] = (_Float16)0.f; ex[7] = (_Float16)0.f;
+          A[t][12] = h ? ex : pos24;
+        }
+      }
+    }
+    for (uint32_t qc = q_begin; qc < q_end; qc += JQ) {
+      _Float16* tile = sB[buf];
+      *reinterpret_cast<uint4*>(&tile[dst[0]]) = pre0;
+      *reinterpret_cast<uint4*>(&tile[dst[1]]) = pre1;
+      *reinterpret_cast<uint4*>(&tile[dst[2]]) = pre2;
+      *reinterpret_cast<uint4*>(&tile[dst[3]]) = pre3;
+      __syncthreads();  // tile complete; also: every wave is past its reads of the other buffer
+      if (qc + JQ < q_end) {  // uniform
+        const uint4* src = reinterpret_cast<const uint4*>(c16s + (uint64_t)(qoff + qc + JQ) * JK);
+        pre0 = src[src_piece[0]];
+        pre1 = src[src_piece[1]];
+        pre2 = src[src_piece[2]];
+        pre3 = src[src_piece[3]];
+      }
+      buf ^= 1;
+      if (!wave_on) continue;
+      floatx16 acc0, acc1;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        acc0[i] = 0.f;
+        acc1[i] = 0.f;
+      }
+      half8 b0 = lds_b(tile, boff), b1 = lds_b(tile, boff + 16), b2 = lds_b(tile, boff + 32),
+            b3 = lds_b(tile, boff + 48);
+#define HS_STEP(S, B)                                                                  \
+  acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][S], B, acc0, 0, 0, 0);           \
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][S], B, acc1, 0, 0, 0);           \
+  if (S + 4 < 13) B = lds_b(tile, boff + 16 * (S + 4));
+      HS_STEP(0, b0) HS_STEP(1, b1) HS_STEP(2, b2) HS_STEP(3, b3)
+      HS_STEP(4, b0) HS_STEP(5, b1) HS_STEP(6, b2) HS_STEP(7, b3)
+      HS_STEP(8, b0) HS_STEP(9, b1) HS_STEP(10, b2) HS_STEP(11, b3)
+      HS_STEP(12, b0)
+#undef HS_STEP
+      // ---- survivors: G <= 0 (rare).  D layout: col = lane & 31, row = (i&3) + 8 (i>>2) + 4 h.
+      uint32_t mask = 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        mask |= (acc0[i] <= 0.f ? 1u : 0u) << i;
+        mask |= (acc1[i] <= 0.f ? 1u : 0u) << (16 + i);
+      }
+      if (__ballot(mask != 0)) {
+        const bool col_ok = qc + (uint32_t)r < q_end;
+        const uint32_t ql = col_ok ? sorted_ql[qoff + qc + r] : 0u;
+        if (!col_ok) mask = 0;
+        while (true) {
+          uint32_t idx = 0;
+          bool pass = false;
+          if (mask) {
+            const int bit = __ffs((int)mask) - 1;
+            mask &= mask - 1;
+            const int t = bit >> 4, i = bit & 15;
+            idx = wbase + (uint32_t)(t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h);
+            pass = idx < M;
+          }
+          const unsigned long long m = __ballot(pass);
+          if (m) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(prov_count, (uint32_t)__popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (pass) {
+              const uint32_t o = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+              if (o < prov_cap) prov[o] = make_uint2(ql, mstart + idx);
+            }
+          }
+          if (!__ballot(mask != 0)) break;
+        }
+      }
+    }
+  }
+}
+
+inline unsigned blocks_for(uint64_t n, unsigned per = 256) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+hipError_t hs_launch_jtables(const double* d_coords, int alphabet, void* d_tab16, float* d_rownorm,
+                             uint32_t* d_unsafe, hipStream_t s) {
+  hs_jtables_kernel<<<1, 32, 0, s>>>(d_coords, alphabet, (_Float16*)d_tab16, d_rownorm, d_unsafe);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_qprep(const double* d_centers, uint32_t nq, int k, double r2, void* d_c16,
+                           uint32_t* d_unsafe, hipStream_t s) {
+  if (!nq) return hipSuccess;
+  hs_qprep_kernel<<<blocks_for(nq, 4), 256, 0, s>>>(d_centers, nq, k, r2, (_Float16*)d_c16, d_unsafe);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_seg_keys(const uint32_t* d_qstart, const uint32_t* d_qcount, uint32_t nql, int L,
+                              uint64_t* d_keys, uint32_t* d_vals, hipStream_t s) {
+  if (!nql) return hipSuccess;
+  hs_seg_keys_kernel<<<blocks_for(nql), 256, 0, s>>>(d_qstart, d_qcount, nql, L, d_keys, d_vals);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_seg_route(const uint64_t* d_seg_key, const uint32_t* d_seg_cnt,
+                               const uint32_t* d_seg_qoff, const uint32_t* d_n_seg,
+                               const uint32_t* d_sorted_ql, const uint32_t* d_qcount, uint32_t n_max,
+                               uint32_t min_q, uint32_t min_m, uint32_t* d_items,
+                               unsigned long long* d_stats, uint32_t* d_nslices, hipStream_t s) {
+  hs_seg_route_kernel<<<blocks_for((uint64_t)n_max + 1), 256, 0, s>>>(
+      d_seg_key, d_seg_cnt, d_seg_qoff, d_n_seg, d_sorted_ql, d_qcount, n_max, min_q, min_m, d_items,
+      d_stats);
+  hs_seg_unslice_kernel<<<blocks_for(n_max), 256, 0, s>>>(d_seg_qoff, d_n_seg, d_items, d_sorted_ql,
+                                                         n_max, d_nslices);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_item_desc(const hs_tables_dev& tabs, const uint64_t* d_seg_key,
+                               const uint32_t* d_seg_cnt,
+                               const uint32_t* d_seg_qoff, const uint32_t* d_item_off, uint32_t n_max,
+                               const uint32_t* d_sorted_ql, const uint32_t* d_qcount, uint32_t n_items,
+                               uint4* d_desc, hipStream_t s) {
+  if (!n_items) return hipSuccess;
+  hs_item_desc_kernel<<<blocks_for(n_items), 256, 0, s>>>(tabs, d_seg_key, d_seg_cnt, d_seg_qoff, d_item_off,
+                                                          n_max, d_sorted_ql, d_qcount, n_items, d_desc);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_gather_c16(const void* d_c16, const uint32_t* d_sorted_ql, uint32_t nql, int L,
+                                void* d_out, hipStream_t s) {
+  if (!nql) return hipSuccess;
+  hs_gather_c16_kernel<<<blocks_for((uint64_t)nql * JG), 256, 0, s>>>(
+      (const _Float16*)d_c16, d_sorted_ql, nql, L, (_Float16*)d_out);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_join(const uint4* d_desc, uint32_t n_items,
+                          const uint32_t* d_sorted_ql, const void* d_c16s, const void* d_tab16,
+                          const float* d_rownorm, int k, uint32_t* d_prov_count, uint32_t prov_cap,
+                          uint2* d_prov, int n_blocks, hipStream_t s) {
+  if (!n_items) return hipSuccess;
+  hs_join_kernel<<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_sorted_ql, (const _Float16*)d_c16s,
+                                          (const _Float16*)d_tab16, d_rownorm, k, d_prov_count,
+                                          prov_cap, d_prov);
+  return hipGetLastError();
+}

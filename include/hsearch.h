@@ -72,6 +72,11 @@ typedef struct hs_profile {
   uint64_t provisional;  /* candidates that passed the fp32 filter */
   uint64_t hits;
   uint64_t verify_launches;
+  uint64_t join_batches;   /* query batches in which the MFMA bucket join ran */
+  double ms_join;          /* of ms_verify: the hs_join_kernel part (rest = streaming kernel) */
+  uint64_t join_items;     /* (member tile, query group) work items of the join */
+  uint64_t join_pairs;     /* (member, query) pairs routed to the join */
+  uint64_t join_pairs_issued; /* MFMA rows x columns actually issued for them (padding included) */
 } hs_profile;
 
 typedef struct hs_index_info {
@@ -95,6 +100,11 @@ HS_API hs_status hs_create(const hs_params* params, const double* a, const doubl
 HS_API void hs_destroy(hs_handle* h);
 HS_API const char* hs_last_error(const hs_handle* h);
 HS_API hs_status hs_get_profile(const hs_handle* h, hs_profile* out);
+/* Candidate-verification kernel: 0 = auto (bucket join when legal, else streaming), 1 = streaming
+ * scan (hs_verify_kernel), 2 = MFMA bucket join (hs_join_kernel) wherever it is legal.  Both are
+ * filters in front of the same exact fp64 decision, so results are identical; the environment
+ * variable HS_VERIFY_MODE=stream|join sets the default of new handles. */
+HS_API hs_status hs_set_verify_mode(hs_handle* h, int mode);
 HS_API const char* hs_version(void);
 
 /* ---- embedding + hashing (rows a2, a4, a5, a6) ----------------------------------------------- */

@@ -54,10 +54,63 @@ def test_search_hits_match_oracle(oracle, k, K, L, W, R, n, nq):
     ix = oracle.Index(a, b, W, oracle.embed_codes(codes))
     assert info["n_buckets"] == ix.table_sizes()
     want = ix.query(centers, R)
-    got = eng.query(centers, R)
-    assert np.array_equal(got["cand"], want["cand"])
-    _assert_hits_equal(got, want)
     assert len(want["q"]) > 0
+    # both filter kernels sit in front of the same exact decision: identical results
+    for mode in ("stream", "join", "auto"):
+        eng.set_verify_mode(mode)
+        got = eng.query(centers, R)
+        assert np.array_equal(got["cand"], want["cand"]), mode
+        _assert_hits_equal(got, want)
+        prof = eng.profile()
+        assert prof["candidates"] == int(want["cand"].sum())
+        if mode == "stream" or k > 25:
+            assert prof["join_batches"] == 0
+        elif W >= 50.0:
+            assert prof["join_batches"] > 0      # the MFMA bucket join really ran
+            assert 0 < prof["join_pairs"] <= prof["candidates"]
+    eng.close()
+
+
+def test_join_with_many_queries_per_bucket(oracle):
+    """Coarse keys (K=2, large W): a handful of huge buckets, each probed by hundreds of queries --
+    multi-chunk, multi-tile work items of the bucket join, plus ragged tile/chunk remainders."""
+    k, K, L, W, R, n, nq = 25, 2, 3, 400.0, 42.0, 30011, 1531
+    a, b = synth.make_planes(k, K, L, W, seed=5)
+    codes = synth.make_db(n, k, seed=6)
+    centers, _ = synth.make_queries(codes, nq, seed=7, jitter=0.2)
+    eng = Engine(k, K, L, W, a, b)
+    info = eng.index_build(codes)
+    assert max(info["max_bucket"]) > 4000
+    want = oracle.search(a, b, W, R, oracle.embed_codes(codes), centers)
+    for mode in ("join", "stream"):
+        eng.set_verify_mode(mode)
+        got = eng.query(centers, R)
+        assert np.array_equal(got["cand"], want["cand"])
+        _assert_hits_equal(got, want)
+    # far-away and huge-magnitude queries: fp16 cannot carry them, the batch must fall back
+    far = centers[:64].copy()
+    far[:8] *= 40.0
+    far[8:16] += 3.0e4
+    eng.set_verify_mode("join")
+    got = eng.query(far, R)
+    _assert_hits_equal(got, oracle.search(a, b, W, R, oracle.embed_codes(codes), far))
+    assert eng.profile()["join_batches"] == 0
+    eng.close()
+    # every segment through the join (no routing of thin segments to the streaming kernel)
+    import os
+    os.environ["HS_JOIN_MIN_Q"] = "1"
+    os.environ["HS_JOIN_MIN_M"] = "1"
+    try:
+        eng = Engine(k, K, L, W, a, b)
+    finally:
+        del os.environ["HS_JOIN_MIN_Q"], os.environ["HS_JOIN_MIN_M"]
+    eng.index_build(codes)
+    eng.set_verify_mode("join")
+    got = eng.query(centers, R)
+    _assert_hits_equal(got, want)
+    prof = eng.profile()
+    assert prof["join_pairs"] == prof["candidates"] == int(want["cand"].sum())
+    assert prof["join_pairs_issued"] >= prof["join_pairs"]
     eng.close()
 
 
