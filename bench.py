@@ -32,8 +32,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=10_000_000, help="DB k-mers")
-    ap.add_argument("--nq", type=int, default=100_000, help="queries per GPU")
+    ap.add_argument("--db-size", dest="n", type=int, default=10_000_000, help="DB k-mers")
+    ap.add_argument("--queries", dest="nq", type=int, default=100_000, help="queries per GPU")
     ap.add_argument("--k", type=int, default=25)
     ap.add_argument("--K", type=int, default=16)
     ap.add_argument("--L", type=int, default=8)
@@ -124,10 +124,17 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # HS_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share
+    # devices, collectives go through host memory); the driver's runs use RCCL ("nccl").
+    backend = os.environ.get("HS_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     k, K, L, W, R = args.k, args.K, args.L, args.W, args.R
     d = 8 * k
@@ -135,7 +142,7 @@ def main():
     codes = synth.make_db(args.n, k)
     centers, src = synth.make_queries(codes, args.nq, seed=synth.SEED_QUERIES + 1000 * rank)
 
-    eng = Engine(k, K, L, W, a, b, device=local_rank)
+    eng = Engine(k, K, L, W, a, b, device=dev_index)
     eng.set_verify_mode(args.verify_mode)
     t0 = time.perf_counter()
     info = eng.index_build(codes)
@@ -201,7 +208,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     total_hits = int(gathered[0].numel())

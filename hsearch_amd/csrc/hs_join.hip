@@ -31,7 +31,7 @@ constexpr int JG = 26;      // groups: 25 positions + extras
 constexpr int JROW = 216;   // LDS row stride in halves: 432 B = 27 x 16 B -> conflict-free b128
 constexpr int JQ = 32;      // queries per chunk (MFMA N)
 constexpr int JM = 256;     // members per workgroup tile (4 waves x 2 x 32 rows)
-constexpr int JQG = 512;    // queries per work item (<= 16 chunks)
+constexpr int JQG = 2048;   // queries per work item (<= 64 chunks)
 constexpr float JSLACK = 1.0f;
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
@@ -255,29 +255,41 @@ __global__ __launch_bounds__(256, 2) void hs_join_kernel(
   }
   const int boff = r * JROW + h * 8;  // B fragment of k-step s: boff + 16 s (halves)
   int buf = 0;
-  for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const uint4 d0 = desc[2 * (uint64_t)item], d1 = desc[2 * (uint64_t)item + 1];
-    const uint4* __restrict__ packed =
-        reinterpret_cast<const uint4*>(((uint64_t)d0.y << 32) | (uint64_t)d0.x);
+  uint32_t item = blockIdx.x;
+  if (item >= n_items) return;
+  // Software pipeline ACROSS items: the descriptor, the packed members and the first query chunk
+  // of the next item are fetched while the current item computes, so an item's prologue is only
+  // the A-fragment build (LDS table reads), not three dependent global-memory latencies.
+  uint4 d0 = desc[2 * (uint64_t)item], d1 = desc[2 * (uint64_t)item + 1];
+  uint4 pkA, pkB, pre0, pre1, pre2, pre3;
+  {
+    const uint4* packed = reinterpret_cast<const uint4*>(((uint64_t)d0.y << 32) | (uint64_t)d0.x);
+    const uint32_t idx = d0.w * JM + wave * 64 + r;
+    pkA = packed[min(idx, d0.z - 1)];
+    pkB = packed[min(idx + 32, d0.z - 1)];
+    const uint4* src = reinterpret_cast<const uint4*>(c16s + (uint64_t)(d1.x + d1.y) * JK);
+    pre0 = src[src_piece[0]];
+    pre1 = src[src_piece[1]];
+    pre2 = src[src_piece[2]];
+    pre3 = src[src_piece[3]];
+  }
+  while (true) {
     const uint32_t M = d0.z, mt = d0.w;
     const uint32_t qoff = d1.x, q_begin = d1.y, q_end = d1.z, mstart = d1.w;
     const uint32_t wbase = mt * JM + wave * 64;
     const bool wave_on = wbase < M;  // wave-uniform: this wave owns at least one real member
-    // prefetch the first query chunk while the A fragments are being built
-    uint4 pre0, pre1, pre2, pre3;
-    {
-      const uint4* src = reinterpret_cast<const uint4*>(c16s + (uint64_t)(qoff + q_begin) * JK);
-      pre0 = src[src_piece[0]];
-      pre1 = src[src_piece[1]];
-      pre2 = src[src_piece[2]];
-      pre3 = src[src_piece[3]];
+    const uint32_t next_item = item + gridDim.x;
+    const bool has_next = next_item < n_items;
+    uint4 nd0 = d0, nd1 = d1;
+    if (has_next) {
+      nd0 = desc[2 * (uint64_t)next_item];
+      nd1 = desc[2 * (uint64_t)next_item + 1];
     }
     half8 A[2][13];
     if (wave_on) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const uint32_t idx = wbase + t * 32 + r;
-        const uint4 pk = packed[min(idx, M - 1)];
+        const uint4 pk = t ? pkB : pkA;
         // lanes of the upper half take the odd positions: shift the 125-bit word down by 5
         const uint32_t sh5 = 5u * (uint32_t)h;
         const uint32_t x = __funnelshift_r(pk.x, pk.y, sh5), y = __funnelshift_r(pk.y, pk.z, sh5),
@@ -315,12 +327,21 @@ __global__ __launch_bounds__(256, 2) void hs_join_kernel(
       *reinterpret_cast<uint4*>(&tile[dst[2]]) = pre2;
       *reinterpret_cast<uint4*>(&tile[dst[3]]) = pre3;
       __syncthreads();  // tile complete; also: every wave is past its reads of the other buffer
-      if (qc + JQ < q_end) {  // uniform
-        const uint4* src = reinterpret_cast<const uint4*>(c16s + (uint64_t)(qoff + qc + JQ) * JK);
+      {
+        // next chunk of this item, or the first chunk of the next item (all uniform)
+        const bool more = qc + JQ < q_end;
+        const uint64_t row = more ? (uint64_t)(qoff + qc + JQ) : (uint64_t)(nd1.x + nd1.y);
+        const uint4* src = reinterpret_cast<const uint4*>(c16s + row * JK);
         pre0 = src[src_piece[0]];
         pre1 = src[src_piece[1]];
         pre2 = src[src_piece[2]];
         pre3 = src[src_piece[3]];
+      }
+      if (qc == q_begin) {  // the A fragments are built: the packed words can be replaced
+        const uint4* packed = reinterpret_cast<const uint4*>(((uint64_t)nd0.y << 32) | (uint64_t)nd0.x);
+        const uint32_t idx = nd0.w * JM + wave * 64 + r;
+        pkA = packed[min(idx, nd0.z - 1)];
+        pkB = packed[min(idx + 32, nd0.z - 1)];
       }
       buf ^= 1;
       if (!wave_on) continue;
@@ -342,13 +363,16 @@ __global__ __launch_bounds__(256, 2) void hs_join_kernel(
       HS_STEP(12, b0)
 #undef HS_STEP
       // ---- survivors: G <= 0 (rare).  D layout: col = lane & 31, row = (i&3) + 8 (i>>2) + 4 h.
-      uint32_t mask = 0;
+      float gmin = fminf(acc0[0], acc1[0]);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        mask |= (acc0[i] <= 0.f ? 1u : 0u) << i;
-        mask |= (acc1[i] <= 0.f ? 1u : 0u) << (16 + i);
-      }
-      if (__ballot(mask != 0)) {
+      for (int i = 1; i < 16; ++i) gmin = fminf(gmin, fminf(acc0[i], acc1[i]));
+      if (__ballot(gmin <= 0.f)) {
+        uint32_t mask = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          mask |= (acc0[i] <= 0.f ? 1u : 0u) << i;
+          mask |= (acc1[i] <= 0.f ? 1u : 0u) << (16 + i);
+        }
         const bool col_ok = qc + (uint32_t)r < q_end;
         const uint32_t ql = col_ok ? sorted_ql[qoff + qc + r] : 0u;
         if (!col_ok) mask = 0;
@@ -376,6 +400,10 @@ __global__ __launch_bounds__(256, 2) void hs_join_kernel(
         }
       }
     }
+    if (!has_next) break;
+    item = next_item;
+    d0 = nd0;
+    d1 = nd1;
   }
 }
 

@@ -28,6 +28,9 @@ def allgather_hits(q, ids, table, distance, n_hits, q_offset=0, group=None):
     reference's global output order when shards are contiguous blocks.
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world > 1 and q.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal mode (ranks sharing GPUs): gloo moves host memory
+        q, ids, table, distance = q.cpu(), ids.cpu(), table.cpu(), distance.cpu()
     dev = q.device
     q = q[:n_hits].to(torch.int64) + int(q_offset)
     ids = ids[:n_hits].to(torch.int64)
