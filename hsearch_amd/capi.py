@@ -15,7 +15,7 @@ _STATUS = ["HS_OK", "HS_ERR_INVALID", "HS_ERR_NO_DEVICE", "HS_ERR_HIP", "HS_ERR_
 _ALPHABET = "ARNDCQEGHILKMFPSTWYV"
 
 EXPORTS = ["hs_create", "hs_destroy", "hs_last_error", "hs_get_profile", "hs_version",
-           "hs_set_verify_mode",
+           "hs_set_verify_mode", "hs_self_join", "hs_clustering",
            "hs_embed_codes", "hs_hash_codes", "hs_hash_points", "hs_key_string", "hs_key_fingerprint",
            "hs_key_strings_equal", "hs_index_build",
            "hs_index_info_get", "hs_query", "hs_query_dev", "hs_bruteforce", "hs_bruteforce_topk"]
@@ -279,3 +279,64 @@ class Engine:
         self._check(self._lib.hs_bruteforce_topk(self._h, _vp(centers), C.c_uint64(nq),
                                                  C.c_uint32(topk), _vp(nn), _vp(d2)))
         return nn, d2
+
+    # -- a12
+    def self_join(self, R, sqrt_test=True, cap=None):
+        """All ordered within-bucket pairs (i, j), i != j, within R: dict(i, j, table, dist)."""
+        cap = int(cap) if cap is not None else 1 << 16
+        while True:
+            ei = np.empty(cap, dtype=np.uint32)
+            ej = np.empty(cap, dtype=np.uint32)
+            et = np.empty(cap, dtype=np.uint32)
+            ed = np.empty(cap, dtype=np.float64)
+            n = C.c_uint64(0)
+            st = self._lib.hs_self_join(self._h, C.c_double(R), C.c_int(1 if sqrt_test else 0),
+                                        _vp(ei), _vp(ej), _vp(et), _vp(ed), C.c_uint64(cap), C.byref(n))
+            if st == HS_ERR_CAPACITY:
+                cap = int(n.value)
+                continue
+            self._check(st)
+            n = int(n.value)
+            return dict(i=ei[:n], j=ej[:n], table=et[:n], dist=ed[:n])
+
+
+def clustering(k, K, L, W, a, b, codes, R, device=0, coords=None):
+    """Clustering() of hclust2.cpp:86-151 on the GPU path: (merged, owner, absorbed_table)."""
+    lib = load()
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    n = codes.shape[0]
+    assert a.shape == (L, K, 8 * k) and b.shape == (L, K) and codes.shape == (n, k)
+    cptr, alpha = None, 0
+    if coords is not None:
+        coords = np.ascontiguousarray(coords, dtype=np.float64)
+        cptr, alpha = _vp(coords), coords.shape[0]
+    params = _Params(int(k), int(K), int(L), float(W), int(device), alpha)
+    merged = np.empty(n, dtype=np.uint8)
+    owner = np.empty(n, dtype=np.uint32)
+    table = np.empty(n, dtype=np.uint32)
+    err = C.create_string_buffer(512)
+    st = lib.hs_clustering(C.byref(params), _vp(a), _vp(b), cptr, _vp(codes), C.c_uint64(n),
+                           C.c_double(R), _vp(merged), _vp(owner), _vp(table), err, C.c_uint32(512))
+    if st != HS_OK:
+        raise HsError(st, err.value.decode())
+    return merged, owner, table
+
+
+def clusters_file_text(merged, owner, table, names=None):
+    """The reference's clusters file (hclust2.cpp:137-150) from hs_clustering's outputs."""
+    n = len(merged)
+    members = {}
+    order = np.lexsort((np.arange(n), table.astype(np.int64)))
+    for i in order:
+        if merged[i] == 2:
+            members.setdefault(int(owner[i]), []).append(int(i))
+    out, cid = [], 0
+    for i in range(n):
+        if merged[i] in (0, 1):
+            ids = [i] + members.get(i, [])
+            out.append("#clusterid:%d:size%d" % (cid, len(ids)))
+            out.extend(str(j) if names is None else names[j] for j in ids)
+            cid += 1
+    return "\n".join(out) + "\n"

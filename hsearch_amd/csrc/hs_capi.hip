@@ -73,6 +73,7 @@ struct hs_handle {
   uint32_t join_min_q = 3, join_min_m = 16;  // segment routing thresholds (HS_JOIN_MIN_Q / _M)
   DevBuf jtab, c16, seg_keys, seg_keys_sorted, seg_vals, sorted_ql, seg_key, seg_cnt, seg_qoff,
       seg_items, item_off, seg_n;
+  bool sqrt_test = false;       // hit test sqrt(d2) <= R (hclust2.cpp:119-120) instead of d2 <= R*R
   bool join_tables_ok = false;  // fp16 can carry the coordinate table
   int verify_mode = 0;          // 0 auto, 1 streaming kernel, 2 bucket join
   std::string err;
@@ -598,7 +599,8 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     } else {
       HS_HIP(h, hs_launch_finalize(h->tabs, h->codes.as<uint8_t>(), d_centers, h->coords.as<double>(),
                                    h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
-                                   h->prov.as<uint2>(), d_cnt, prov_cap, k, L, r2, q_base, d_cnt + 1,
+                                   h->prov.as<uint2>(), d_cnt, prov_cap, k, L, r2,
+                                   h->sqrt_test ? R : (double)NAN, q_base, d_cnt + 1,
                                    hit_cap, h->hit_key.as<uint64_t>(), h->hit_val.as<uint64_t>(),
                                    h->stream));
     }
@@ -742,6 +744,81 @@ hs_status hs_query(hs_handle* h, const double* centers, uint64_t nq, double R, u
 hs_status hs_bruteforce(hs_handle* h, const double* centers, uint64_t nq, double R, uint32_t* hit_q,
                         uint32_t* hit_id, double* hit_dist, uint64_t cap, uint64_t* n_hits) {
   return host_query(h, centers, nq, R, true, hit_q, hit_id, nullptr, hit_dist, cap, n_hits, nullptr);
+}
+
+hs_status hs_self_join(hs_handle* h, double R, int sqrt_test, uint32_t* edge_i, uint32_t* edge_j,
+                       uint32_t* edge_table, double* edge_dist, uint64_t cap, uint64_t* n_edges) {
+  if (!h || !n_edges) return HS_ERR_INVALID;
+  *n_edges = 0;
+  if (!h->built) return fail(h, HS_ERR_STATE, "hs_index_build has not been called");
+  if (cap && (!edge_i || !edge_j || !edge_dist)) return HS_ERR_INVALID;
+  hs_status st = ensure_device(h);
+  if (st) return st;
+  const uint64_t n = h->n;
+  const uint32_t CH = 1u << 18;  // queries embedded per chunk (8k doubles each)
+  uint64_t total = 0;
+  std::vector<uint32_t> hq, hid, ht;
+  std::vector<double> hd;
+  hs_profile acc;
+  memset(&acc, 0, sizeof(acc));
+  DevBuf centers, dq, did, dt, dd;
+  struct Guard {
+    DevBuf* b[5];
+    ~Guard() { for (DevBuf* x : b) x->release(); }
+  } guard = {{&centers, &dq, &did, &dt, &dd}};
+  for (uint64_t q0 = 0; q0 < n; q0 += CH) {
+    const uint64_t nq = std::min<uint64_t>(CH, n - q0);
+    HS_HIP(h, centers.reserve((size_t)nq * h->d * 8));
+    HS_HIP(h, hs_launch_embed(h->codes.as<uint8_t>() + q0 * h->p.k, nq, (int)h->p.k,
+                              h->coords.as<double>(), centers.as<double>(), h->stream));
+    uint64_t hcap = std::max<uint64_t>(dq.cap / 4, 4 * nq + 1024), nh = 0;
+    for (;;) {
+      HS_HIP(h, dq.reserve(hcap * 4));
+      HS_HIP(h, did.reserve(hcap * 4));
+      HS_HIP(h, dt.reserve(hcap * 4));
+      HS_HIP(h, dd.reserve(hcap * 8));
+      h->sqrt_test = sqrt_test != 0;
+      st = run_query(h, centers.as<double>(), nq, R, false, dq.as<uint32_t>(), did.as<uint32_t>(),
+                     dt.as<uint32_t>(), dd.as<double>(), hcap, &nh, nullptr);
+      h->sqrt_test = false;
+      if (st == HS_ERR_CAPACITY) {
+        hcap = nh + nh / 8 + 1024;
+        continue;
+      }
+      break;
+    }
+    if (st != HS_OK) return st;
+    acc.ms_hash += h->prof.ms_hash; acc.ms_probe += h->prof.ms_probe; acc.ms_verify += h->prof.ms_verify;
+    acc.ms_join += h->prof.ms_join; acc.ms_finalize += h->prof.ms_finalize; acc.ms_total += h->prof.ms_total;
+    acc.candidates += h->prof.candidates; acc.provisional += h->prof.provisional;
+    acc.join_pairs += h->prof.join_pairs; acc.join_pairs_issued += h->prof.join_pairs_issued;
+    acc.join_items += h->prof.join_items; acc.join_batches += h->prof.join_batches;
+    acc.verify_launches += h->prof.verify_launches;
+    hq.resize(nh); hid.resize(nh); ht.resize(nh); hd.resize(nh);
+    if (nh) {
+      HS_HIP(h, hipMemcpyAsync(hq.data(), dq.p, nh * 4, hipMemcpyDeviceToHost, h->stream));
+      HS_HIP(h, hipMemcpyAsync(hid.data(), did.p, nh * 4, hipMemcpyDeviceToHost, h->stream));
+      HS_HIP(h, hipMemcpyAsync(ht.data(), dt.p, nh * 4, hipMemcpyDeviceToHost, h->stream));
+      HS_HIP(h, hipMemcpyAsync(hd.data(), dd.p, nh * 8, hipMemcpyDeviceToHost, h->stream));
+      HS_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    for (uint64_t e = 0; e < nh; ++e) {
+      const uint64_t i = q0 + hq[e];
+      if (i == hid[e]) continue;  // a k-mer is in its own bucket at distance 0
+      if (total < cap) {
+        edge_i[total] = (uint32_t)i;
+        edge_j[total] = hid[e];
+        if (edge_table) edge_table[total] = ht[e];
+        edge_dist[total] = hd[e];
+      }
+      ++total;
+    }
+  }
+  h->prof = acc;
+  h->prof.hits = total;
+  *n_edges = total;
+  if (total > cap) return fail(h, HS_ERR_CAPACITY, "edge buffers too small; see *n_edges");
+  return HS_OK;
 }
 
 hs_status hs_bruteforce_topk(hs_handle* h, const double* centers, uint64_t nq, uint32_t topk,

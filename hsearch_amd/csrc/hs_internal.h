@@ -168,9 +168,9 @@ hipError_t hs_launch_finalize(const hs_tables_dev& tabs, const uint8_t* d_codes,
                               const double* d_centers, const double* d_coords,
                               const uint32_t* d_qstart, const uint32_t* d_qcount,
                               const uint2* d_prov, const uint32_t* d_prov_count, uint32_t prov_cap,
-                              int k, int L, double r2, uint32_t q_base, uint32_t* d_hit_count,
-                              uint32_t hit_cap, uint64_t* d_hit_key, uint64_t* d_hit_val,
-                              hipStream_t s);
+                              int k, int L, double r2, double r_sqrt, uint32_t q_base,
+                              uint32_t* d_hit_count, uint32_t hit_cap, uint64_t* d_hit_key,
+                              uint64_t* d_hit_val, hipStream_t s);
 hipError_t hs_launch_unpack_hits(const uint64_t* d_key, const uint64_t* d_val, uint32_t n,
                                  uint32_t* d_q, uint32_t* d_id, uint32_t* d_table, double* d_dist,
                                  hipStream_t s);

@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
                                                           const uint2* __restrict__ prov,
                                                           const uint32_t* __restrict__ prov_count,
                                                           uint32_t prov_cap, int k, int L, double r2,
-                                                          uint32_t q_base,
+                                                          double r_sqrt, uint32_t q_base,
                                                           uint32_t* __restrict__ hit_count,
                                                           uint32_t hit_cap,
                                                           uint64_t* __restrict__ hit_key,
@@ -498,7 +498,10 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
     }
     if (seen) continue;
     const double d2 = exact_dist2(codes + (uint64_t)id * k, centers + (uint64_t)q * 8 * k, coords, k);
-    if (d2 <= r2) {
+    // Search(): d2 <= R*R (motif_both_points.cpp:239); Clustering(): sqrt(d2) <= R
+    // (hclust2.cpp:64-71,119-120), selected by a non-NaN r_sqrt.
+    const bool hit = (r_sqrt == r_sqrt) ? (__dsqrt_rn(d2) <= r_sqrt) : (d2 <= r2);
+    if (hit) {
       const uint32_t idx = atomicAdd(hit_count, 1u);
       if (idx < hit_cap) {
         hit_key[idx] = ((uint64_t)(q_base + q) << 37) | ((uint64_t)l << 32) | id;
@@ -708,11 +711,11 @@ hipError_t hs_launch_finalize(const hs_tables_dev& tabs, const uint8_t* d_codes,
                               const double* d_centers, const double* d_coords,
                               const uint32_t* d_qstart, const uint32_t* d_qcount,
                               const uint2* d_prov, const uint32_t* d_prov_count, uint32_t prov_cap,
-                              int k, int L, double r2, uint32_t q_base, uint32_t* d_hit_count,
-                              uint32_t hit_cap, uint64_t* d_hit_key, uint64_t* d_hit_val,
-                              hipStream_t s) {
+                              int k, int L, double r2, double r_sqrt, uint32_t q_base,
+                              uint32_t* d_hit_count, uint32_t hit_cap, uint64_t* d_hit_key,
+                              uint64_t* d_hit_val, hipStream_t s) {
   hs_finalize_kernel<<<1024, 256, 0, s>>>(tabs, d_codes, d_centers, d_coords, d_qstart, d_qcount,
-                                          d_prov, d_prov_count, prov_cap, k, L, r2, q_base,
+                                          d_prov, d_prov_count, prov_cap, k, L, r2, r_sqrt, q_base,
                                           d_hit_count, hit_cap, d_hit_key, d_hit_val);
   return hipGetLastError();
 }

@@ -12,6 +12,7 @@
 #include <sstream>
 #include <unordered_map>
 
+#include "../../include/hs_tables.h"
 #include "../../include/hsearch.h"
 
 namespace hsearch {
@@ -166,6 +167,83 @@ int Search(const std::vector<Point>& kmers, const std::vector<Point>& centers,
   for (uint64_t i = 0; i < n_hits; ++i)  // :240-241
     fout << center_names[hq[i]] << " " << kmer_names[hid[i]] << " " << hd[i] << std::endl;
   fout.close();
+  return HS_OK;
+}
+
+bool ReadKmerFasta(const std::string& path, std::vector<Kmer>* kmers) {
+  std::ifstream fin(path.c_str());
+  if (!fin) return false;
+  std::string tok;
+  while (fin >> tok) {
+    if (tok[0] == '>') {
+      Kmer km;
+      km.name = tok.substr(1);
+      fin >> km.seq;
+      kmers->push_back(km);
+    }
+  }
+  return true;
+}
+
+int Clustering(const std::vector<Kmer>& kmers, const uint32_t& hash_K, const uint32_t& hash_L,
+               const double& hash_W, const double& hash_R, const std::string& output_file,
+               const Planes& planes, int device, uint32_t unknown_seed, std::string* err,
+               uint64_t* n_clusters) {
+  const uint32_t dim = planes.dim, k = dim / 8;
+  if (dim == 0 || dim % 8 != 0 || planes.K != hash_K || planes.L != hash_L || planes.W != hash_W) {
+    if (err) *err = "planes do not match (dim, K, L, W)";
+    return HS_ERR_INVALID;
+  }
+  const size_t n = kmers.size();
+  std::vector<uint8_t> codes(n * (size_t)k);
+  std::minstd_rand unknown(unknown_seed);
+  for (size_t i = 0; i < n; ++i) {
+    if (kmers[i].seq.size() != k) {
+      if (err) *err = "k-mer '" + kmers[i].name + "' does not have length " + std::to_string(k);
+      return HS_ERR_INVALID;
+    }
+    for (uint32_t p = 0; p < k; ++p) {
+      const int c = kmers[i].seq[p] - 'A';
+      int code = (c >= 0 && c < 26) ? HS_LETTER_TO_CODE[c] : -1;  // base[], util.hpp:92
+      if (code < 0) code = (int)(unknown() % 20);
+      codes[i * k + p] = (uint8_t)code;
+    }
+  }
+  hs_params prm;
+  memset(&prm, 0, sizeof(prm));
+  prm.k = k;
+  prm.K = hash_K;
+  prm.L = hash_L;
+  prm.W = hash_W;
+  prm.device = device;
+  std::vector<uint8_t> merged(n);
+  std::vector<uint32_t> owner(n), table(n);
+  char msg[512] = {0};
+  const hs_status st = hs_clustering(&prm, planes.a.data(), planes.b.data(), nullptr, codes.data(), n,
+                                     hash_R, merged.data(), owner.data(), table.data(), msg, sizeof(msg));
+  if (st != HS_OK) {
+    if (err) *err = msg;
+    return st;
+  }
+  // members of a cluster in absorption order: table by table, ascending id inside a table
+  std::vector<std::vector<uint32_t> > members(n);
+  std::vector<uint32_t> order;
+  for (size_t i = 0; i < n; ++i)
+    if (merged[i] == 2) order.push_back((uint32_t)i);
+  std::stable_sort(order.begin(), order.end(),
+                   [&](uint32_t x, uint32_t y) { return table[x] < table[y]; });
+  for (uint32_t i : order) members[owner[i]].push_back(i);
+  std::ofstream fout(output_file.c_str());
+  uint32_t cluster_id = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (merged[i] == 1 || merged[i] == 0) {
+      fout << "#clusterid:" << cluster_id++ << ":size" << members[i].size() + 1 << std::endl;
+      fout << kmers[i].name << std::endl;
+      for (uint32_t j : members[i]) fout << kmers[j].name << std::endl;
+    }
+  }
+  fout.close();
+  if (n_clusters) *n_clusters = cluster_id;
   return HS_OK;
 }
 

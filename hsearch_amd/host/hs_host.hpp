@@ -58,6 +58,20 @@ int Search(const std::vector<Point>& kmers, const std::vector<Point>& centers,
            const double& hash_R, const std::string& output_file, const Planes& planes, int device,
            std::string* err, std::vector<uint64_t>* table_sizes = nullptr);
 
+// Clustering() of hclust2.cpp:86-151.  kmers: name + sequence (letters of the 20-letter alphabet; a
+// letter outside it is replaced by a residue drawn from a generator seeded with `unknown_seed`,
+// where the reference uses rand()%20, hclust2.cpp:54-56).  Writes the reference's clusters file
+// ("#clusterid:<i>:size<m>" + member names, :137-150).  Returns 0 or an hs_status with *err set.
+struct Kmer {
+  std::string name, seq;
+};
+// hclust2's reader (:231-241): whitespace tokens, ">name" then the sequence token.
+bool ReadKmerFasta(const std::string& path, std::vector<Kmer>* kmers);
+int Clustering(const std::vector<Kmer>& kmers, const uint32_t& hash_K, const uint32_t& hash_L,
+               const double& hash_W, const double& hash_R, const std::string& output_file,
+               const Planes& planes, int device, uint32_t unknown_seed, std::string* err,
+               uint64_t* n_clusters = nullptr);
+
 // evaulate() (:100-165) with weight() (:67-87): weighted recall of a hits file against a ground
 // truth file sorted by (motif, protein); also writes <output_file>.accuracy.txt.  Returns NaN
 // where the reference would exit(0) on an inconsistent ground truth (:68-71).

@@ -162,6 +162,29 @@ HS_API hs_status hs_bruteforce(hs_handle* h, const double* centers, uint64_t nq,
 HS_API hs_status hs_bruteforce_topk(hs_handle* h, const double* centers, uint64_t nq,
                                     uint32_t topk, uint32_t* nn_id, double* nn_dist2);
 
+/* ---- all-vs-all near-neighbour graph + greedy clustering (row a12) ------------------------------- */
+
+/* Every ordered pair (i, j), i != j, of indexed k-mers that share a bucket in some table and lie
+ * within R of each other; edge_table = the first table in which they share a bucket.  Sorted by
+ * (i, table, j).  sqrt_test != 0 selects hclust2's test sqrt(d2) <= R (hclust2.cpp:64-71,119-120)
+ * instead of Search()'s d2 <= R*R.  This is the bucket-local member x center distance work of
+ * Clustering() (hclust2.cpp:107-132) done as one join per table. */
+HS_API hs_status hs_self_join(hs_handle* h, double R, int sqrt_test, uint32_t* edge_i,
+                              uint32_t* edge_j, uint32_t* edge_table, double* edge_dist,
+                              uint64_t cap, uint64_t* n_edges);
+
+/* Replaces Clustering() (hclust2.cpp:86-151) with explicit planes a[L][K][d], b[L][K]: table by
+ * table, an LSH table over the not-yet-absorbed k-mers, then greedy leader clustering inside every
+ * bucket in ascending id order.  The distance work runs on the GPU (hs_self_join per table), the
+ * order-dependent greedy pass on the host.  Outputs: merged[n] in {0 unprocessed, 1 center,
+ * 2 absorbed} (hclust2.cpp:93-96), owner[n] = absorbing center (itself if not absorbed),
+ * absorbed_table[n] = table in which it was absorbed (0xffffffff if not): members of a cluster in
+ * the reference's file order are its center followed by its members sorted by (absorbed_table, id). */
+HS_API hs_status hs_clustering(const hs_params* params, const double* a, const double* b,
+                               const double* coords, const uint8_t* codes, uint64_t n, double R,
+                               uint8_t* merged, uint32_t* owner, uint32_t* absorbed_table,
+                               char* err, uint32_t err_cap);
+
 #ifdef __cplusplus
 }
 #endif

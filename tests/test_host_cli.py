@@ -119,3 +119,28 @@ def test_cli_lossy_points_file_and_evaluate(tmp_path, oracle):
     acc = float([ln for ln in r.stdout.splitlines() if ln.startswith("ACCURACY:")][0].split()[1])
     assert acc == pytest.approx(oracle.evaluate(gt, out, R), abs=1e-6)
     assert 0.5 < acc <= 1.0
+
+
+@pytest.mark.gpu
+def test_hclust2_cli_matches_reference_golden(tmp_path, golden_dir):
+    """hs_hclust2 -k kmers.fa -l k -K -L -W -T -o out --seed s  ==  the compiled reference's hclust2
+    Clustering() with its LSH objects seeded s, s+1, ... (byte-identical clusters file)."""
+    binary = os.path.join(ROOT, "hsearch_amd", "bin", "hs_hclust2")
+    if not os.path.exists(binary):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "hsearch_amd", "host")], check=True,
+                       stdout=subprocess.DEVNULL)
+    letters = "ARNDCQEGHILKMFPSTWYV"
+    g = json.load(open(os.path.join(golden_dir, "clustering.json")))
+    for case in g["cases"]:
+        z = np.load(os.path.join(golden_dir, case["file"]))
+        fa, out = str(tmp_path / "kmers.fa"), str(tmp_path / "clusters.txt")
+        with open(fa, "w") as f:
+            for i, row in enumerate(z["codes"]):
+                f.write(">%d\n%s\n" % (i, "".join(letters[c] for c in row)))
+        r = subprocess.run([binary, "-k", fa, "-l", str(case["k"]), "-K", str(case["K"]), "-L",
+                            str(case["L"]), "-W", repr(case["W"]), "-T", repr(case["R"]), "-o", out,
+                            "--seed", str(case["plane_seed"])], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert open(out).read() == case["clusters_file"]
+    r = subprocess.run([binary, "-k", "x"], capture_output=True, text=True)
+    assert r.returncode == 0 and "missing required option" in r.stderr    # hclust2.cpp:223-226
