@@ -1,0 +1,126 @@
+"""BASELINE.json's full sizes, where the CPU oracle cannot run: size-independent properties.
+
+  configs[1]  10 M 25-mers, L=8, K=16, 100 k queries      (search)
+  configs[3]  1 M 25-mers all-vs-all + hclust             (clustering)
+  configs[4]  mixed k in {15, 25, 39}                      (three indexes, one launch sequence)
+"""
+import numpy as np
+import pytest
+
+import hsearch_amd
+from hsearch_amd import Engine, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _exact_d2(codes_rows, centers_rows):
+    """Left-to-right fp64 sum of squared differences (motif_both_points.cpp:176-183), vectorised
+    over pairs: the accumulation order over i is the reference's."""
+    x = synth.embed(codes_rows)
+    acc = np.zeros(len(x))
+    for i in range(x.shape[1]):
+        r = x[:, i] - centers_rows[:, i]
+        acc = acc + r * r
+    return acc
+
+
+def test_config2_search_properties():
+    k, K, L, W, R, n, nq = 25, 16, 8, 200.0, 40.0, 10_000_000, 100_000
+    a, b = synth.make_planes(k, K, L, W)
+    codes = synth.make_db(n, k)
+    centers, src = synth.make_queries(codes, nq)
+    eng = Engine(k, K, L, W, a, b)
+    info = eng.index_build(codes)
+    assert info["n"] == n and sum(info["n_buckets"]) > 0
+    res = {}
+    for mode in ("join", "stream"):
+        eng.set_verify_mode(mode)
+        res[mode] = eng.query(centers, R)
+    j, s = res["join"], res["stream"]
+    # the two filter kernels are interchangeable: identical candidates, hits, order, distances
+    assert np.array_equal(j["cand"], s["cand"])
+    for f in ("q", "id", "table", "dist"):
+        assert np.array_equal(j[f], s[f]), f
+    q, ids, tab, dist = j["q"].astype(np.int64), j["id"].astype(np.int64), j["table"].astype(np.int64), j["dist"]
+    # reference output order: query, then table of first sight, then ascending id; no duplicates
+    key = (q << 40) | (tab << 32) | ids
+    assert np.all(np.diff(key) > 0)
+    assert len(np.unique((q << 32) | ids)) == len(q)
+    # every reported distance is the exact fp64 value and within R
+    sel = np.random.default_rng(0).choice(len(q), size=min(20000, len(q)), replace=False)
+    d2 = _exact_d2(codes[ids[sel]], centers[q[sel]])
+    assert np.array_equal(np.sqrt(d2), dist[sel])
+    assert np.all(d2 <= R * R)
+    # a query that is an exact copy of a DB k-mer shares every bucket with it: found in table 0
+    exact = np.nonzero((synth.embed(codes[src[:5000]]) == centers[:5000]).all(axis=1))[0]
+    assert len(exact) > 500
+    hit = set(zip(q.tolist(), ids.tolist()))
+    first_table = {(qq, ii): tt for qq, ii, tt in zip(q.tolist(), ids.tolist(), tab.tolist())}
+    for qi in exact:
+        assert (int(qi), int(src[qi])) in hit
+        assert first_table[(int(qi), int(src[qi]))] == 0
+    # candidate counts are bucket populations: bounded by the largest bucket of each table
+    assert np.all(j["cand"].max(axis=0) <= np.array(info["max_bucket"]))
+    # radius recall against the exhaustive scan on a query subsample, and exact top-10 sanity
+    sub = centers[:128]
+    bf = eng.bruteforce(sub, R)
+    truth = set(zip(bf["q"].tolist(), bf["id"].tolist()))
+    found = {(a_, b_) for a_, b_ in hit if a_ < 128}
+    assert found <= truth                      # LSH never reports a pair the exhaustive scan lacks
+    assert len(found) / len(truth) > 0.75
+    nn, nd2 = eng.bruteforce_topk(sub[:32], 10)
+    assert np.all(np.diff(nd2, axis=1) >= 0)
+    for qi in range(32):
+        mine = sorted((d_, i_) for (q_, i_), d_ in zip(zip(bf["q"].tolist(), bf["id"].tolist()), bf["dist"].tolist()) if q_ == qi)
+        kk = min(len(mine), 10)
+        assert [i_ for _, i_ in mine[:kk]] == nn[qi, :kk].tolist()
+    eng.close()
+
+
+def test_config4_clustering_properties():
+    k, K, L, W, R, n = 25, 16, 8, 200.0, 40.0, 1_000_000
+    rng = np.random.default_rng(3)
+    fam = rng.integers(0, 20, size=(2000, k), dtype=np.uint8)          # 2000 planted families x 50
+    rows = np.repeat(fam, 50, axis=0)
+    m = rng.integers(0, 5, size=len(rows))
+    for s in range(4):
+        sel = np.nonzero(m > s)[0]
+        rows[sel, rng.integers(0, k, size=len(sel))] = rng.integers(0, 20, size=len(sel), dtype=np.uint8)
+    codes = np.concatenate([rows, synth.make_db(n - len(rows), k, seed=9)])
+    rng.shuffle(codes)
+    a, b = synth.make_planes(k, K, L, W, seed=77)
+    merged, owner, table = hsearch_amd.clustering(k, K, L, W, a, b, codes, R)
+    m2, o2, t2 = hsearch_amd.clustering(k, K, L, W, a, b, codes, R)       # deterministic
+    assert np.array_equal(merged, m2) and np.array_equal(owner, o2) and np.array_equal(table, t2)
+    absorbed = np.nonzero(merged == 2)[0]
+    assert len(absorbed) > 50_000
+    assert np.all(merged[owner[absorbed]] == 1)                 # absorbed only by real centers
+    assert np.all(owner[merged != 2] == np.nonzero(merged != 2)[0])
+    assert np.all((table != 0xffffffff) == (merged == 2))
+    assert set(np.unique(merged)) <= {0, 1, 2}
+    assert np.all(np.isin(np.nonzero(merged == 1)[0], owner[absorbed]))   # every center owns someone
+    # every absorbed k-mer lies within R of its center (hclust2.cpp:119-120: sqrt form, exact fp64)
+    sel = rng.choice(absorbed, size=20000, replace=False)
+    d2 = _exact_d2(codes[sel], synth.embed(codes[owner[sel]]))
+    assert np.all(np.sqrt(d2) <= R)
+    # the clusters file accounts for every k-mer exactly once (num_of_kmers, hclust2.cpp:139,149)
+    sizes = np.bincount(owner, minlength=n)[merged != 2]
+    assert sizes.sum() == n
+
+
+def test_config5_mixed_lengths(oracle):
+    R, W, K, L = 40.0, 150.0, 8, 4
+    for k in (15, 25, 39):
+        a, b = synth.make_planes(k, K, L, W, seed=100 + k)
+        codes = synth.make_db(200_000, k, seed=k)
+        centers, _ = synth.make_queries(codes, 2000, seed=k + 1, jitter=0.1)
+        eng = Engine(k, K, L, W, a, b)
+        eng.index_build(codes)
+        got = eng.query(centers, R)
+        ix = oracle.Index(a, b, W, oracle.embed_codes(codes))
+        want = ix.query(centers, R)
+        for f in ("q", "id", "table", "dist"):
+            assert np.array_equal(got[f], want[f]), (k, f)
+        assert np.array_equal(got["cand"], want["cand"])
+        assert len(want["q"]) > 100
+        eng.close()
