@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+JOIN_K = 112.0  # GEMM depth of hs_join_kernel
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
 
 
@@ -231,17 +232,18 @@ def main():
             except Exception:
                 traffic = None
         if join_batches:
-            # dominant kernel = hs_join_kernel, an fp16 MFMA GEMM of depth 208 (25 positions x 8
-            # coordinates + 8 extras) per (bucket member, probing query) pair: 2*208 flop per pair.
+            # dominant kernel = hs_join_kernel, an fp16 MFMA GEMM of depth JOIN_K = 112 (25 positions
+            # x 4 coordinates + 8 extras + 4 pad) per (bucket member, probing query) pair:
+            # 2*112 flop per pair (hsearch_amd/csrc/hs_join.hip).
             j_ms = join_ms / steps
-            flop = jstat[1] * 2.0 * 208.0          # real (member, query) pairs routed to the join
+            flop = jstat[1] * 2.0 * JOIN_K          # real (member, query) pairs routed to the join
             tf = flop / (j_ms * 1e-3) / 1e12 if j_ms > 0 else 0.0
             roofline = {"bound": "mfma", "kernel": "hs_join_kernel", "achieved": tf,
                         "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": tf / MFMA_F16_PEAK_TFLOPS, "traffic": traffic,
                         "flop_per_step": flop, "pairs_per_step": jstat[1],
                         "pairs_issued_per_step": jstat[2], "work_items_per_step": jstat[0],
-                        "issued_tflops": (jstat[2] * 416.0 / (j_ms * 1e-3) / 1e12) if j_ms > 0 else 0.0,
+                        "issued_tflops": (jstat[2] * 2.0 * JOIN_K / (j_ms * 1e-3) / 1e12) if j_ms > 0 else 0.0,
                         "kernel_ms_per_step": j_ms, "streaming_kernel_ms_per_step": v_ms - j_ms,
                         "pairs_streamed_per_step": cand - jstat[1],
                         "launches_per_step": launches / steps,

@@ -656,7 +656,7 @@ static hs_status run_query(hs_handle* h, const double* d_centers, uint64_t nq, d
   HS_HIP(h, hipEventRecord(h->ev[8], h->stream));
   uint64_t total = 0;
   if (nq && h->n && !(brute && R < 0)) {
-    const uint32_t QB = 1u << 16;  // queries per batch: bounds the workspace
+    const uint32_t QB = 1u << 17;  // queries per batch: bounds the workspace
     for (uint64_t q0 = 0; q0 < nq; q0 += QB) {
       const uint32_t nqb = (uint32_t)std::min<uint64_t>(QB, nq - q0);
       uint32_t nh = 0;

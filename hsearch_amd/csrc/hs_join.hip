@@ -4,58 +4,67 @@
 // (motif_both_points.cpp:232-242).  Many queries probe the SAME bucket (the largest buckets hold
 // several per cent of the DB and are probed by thousands of queries), so the work
 //     sum over (table, bucket B) of |members(B)| x |queries probing B|
-// is a block-sparse product.  Here a workgroup takes a tile of 256 members of one bucket, keeps
+// is a block-sparse product.  Here a workgroup takes a tile of 512 members of one bucket, keeps
 // their embedded coordinates as fp16 MFMA A-fragments in registers, and streams the probing
 // queries past them in chunks of 32 through LDS: members are read from HBM once per tile instead
 // of once per (query, member) pair.
 //
-// What the MFMA computes is a FILTER, never a result: with x = member, c = query,
-//     G = |x|^2 + |c|^2 - 2 x^.c^ - R^2 - slack - e_c |x|^          (x^, c^ = fp16 roundings)
-// folded into one K = 208 GEMM (25 positions x 8 coordinates + 8 "extras" that carry the norms,
-// the threshold and the error term), and a pair survives iff G <= 0.  The error term is a rigorous
-// bound: |2 x^.c^ - 2 x.c| <= 2 (2^-10 + 2^-22) |x||c|  (fp16 round-to-nearest, Cauchy-Schwarz),
-// fp32 accumulation and hi/lo splitting of the norms are covered by slack = 1.  Hence every pair
-// with exact d2 <= R^2 survives; survivors (rare) are re-evaluated in the reference's fp64 order
-// and decided by its own test in hs_finalize_kernel, exactly as for the streaming kernel.
+// What the MFMA computes is a FILTER, never a result.  Let x1, c1 be member and query restricted
+// to the first 4 of the 8 MDS coordinates of every residue position (the table's columns are
+// ordered by spread: 4 columns carry 76 % of the mean squared residue distance).  Then
+// |x1 - c1|^2 <= |x - c|^2, so with
+//     G = |x1|^2 + |c1|^2 - 2 x1^.c1^ - R^2 - slack - e_c |x1|^      (x1^, c1^ = fp16 roundings)
+// a pair with exact d2 <= R^2 always has G <= 0:  |2 x1^.c1^ - 2 x1.c1| <= 2 (2^-10 + 2^-22)
+// |x1||c1| (fp16 round-to-nearest + Cauchy-Schwarz) is covered by e_c |x1|^ with
+// e_c = 1.01 * 2^-9 |c1|, and fp32 accumulation plus the hi/lo splitting of the norms by
+// slack = 1.  G is ONE K = 112 GEMM: 100 coordinates + 8 "extras" columns that carry the norms,
+// the threshold and the error term (+ 4 pad).  Survivors (G <= 0; a few per million pairs) are
+// re-evaluated in the reference's fp64 order and decided by its own test in hs_finalize_kernel,
+// exactly as for the streaming kernel.
 #include <algorithm>
 
 #include "hs_internal.h"
 
 namespace {
 
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int JK = 208;     // GEMM depth = 26 groups of 8 halves
-constexpr int JG = 26;      // groups: 25 positions + extras
-constexpr int JROW = 216;   // LDS row stride in halves: 432 B = 27 x 16 B -> conflict-free b128
+constexpr int JD = 4;       // MDS coordinates per residue used by the filter
+constexpr int JG = 14;      // groups of 8 halves: 12 position pairs, position 24 (+pad), extras
+constexpr int JK = 8 * JG;  // GEMM depth 112 = 7 k-steps of 16
+constexpr int JS = 7;       // k-steps
+constexpr int JROW = 120;   // LDS row stride in halves: 240 B = 15 x 16 B -> conflict-free b128
 constexpr int JQ = 32;      // queries per chunk (MFMA N)
-constexpr int JM = 256;     // members per workgroup tile (4 waves x 2 x 32 rows)
+constexpr int JT = 4;       // 32-member MFMA row tiles per wave
+constexpr int JM = 4 * JT * 32;  // members per workgroup tile: 512
 constexpr int JQG = 2048;   // queries per work item (<= 64 chunks)
 constexpr float JSLACK = 1.0f;
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 // ---------------------------------------------------------------------------------- query prep
-// c16[q] = { -2 fp16(c_i) for i < 8k, zeros up to 200, extras }:
-//   extras = { 1, 1, hi(v), lo(v), -e_c, 0, 0, 0 },  v = |c|^2 - R^2 - slack,  e_c >= 2^-9 1.0003 |c|.
-// One wavefront per query.  unsafe |= 1 when fp16 cannot carry the query (then the caller uses the
-// streaming kernel instead).
+// c16[q] (JK halves): group g < 12 = { -2 c[pos 2g][0..3], -2 c[pos 2g+1][0..3] }, group 12 =
+// { -2 c[pos 24][0..3], 0 x4 }, group 13 = extras { 1, 1, hi(v), lo(v), -e_c, 0, 0, 0 } with
+// v = |c1|^2 - R^2 - slack and e_c >= 2^-9 * 1.0003 |c1|.  Positions >= k are zero.  One
+// wavefront per query.  unsafe |= 1 when fp16 cannot carry the query (the caller then uses the
+// streaming kernel for the batch).
 __global__ __launch_bounds__(256) void hs_qprep_kernel(const double* __restrict__ centers, uint32_t nq,
                                                        int k, double r2, _Float16* __restrict__ c16,
                                                        uint32_t* __restrict__ unsafe) {
   const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= nq) return;
   const int lane = lane_id();
-  const int d = 8 * k;
-  const double* c = centers + (uint64_t)q * d;
+  const double* c = centers + (uint64_t)q * 8 * k;
   _Float16* out = c16 + (uint64_t)q * JK;
   double nc = 0.0;
   bool bad = false;
-  for (int i = lane; i < 200; i += 64) {
+  for (int i = lane; i < JK - 8; i += 64) {  // 104 coordinate slots (the last 4 are pad)
+    const int pos = i >> 2, j = i & 3;
     _Float16 h = (_Float16)0.f;
-    if (i < d) {
-      const double v = c[i];
+    if (pos < k && pos < 25) {
+      const double v = c[8 * pos + j];
       nc += v * v;
       bad = bad || !(fabs(v) < 16000.0);
       h = (_Float16)(float)v;
@@ -63,6 +72,8 @@ __global__ __launch_bounds__(256) void hs_qprep_kernel(const double* __restrict_
     }
     out[i] = h;
   }
+  // coordinates 4..7 only matter for the legality check
+  for (int i = lane; i < 8 * k; i += 64) bad = bad || !(fabs(c[i]) < 16000.0);
   for (int off = 32; off; off >>= 1) nc += __shfl_xor(nc, off);
   bad = bad || !(nc < 30000.0) || !(r2 < 30000.0);
   if (__ballot(bad) && lane == 0) atomicOr(unsafe, 1u);
@@ -71,18 +82,19 @@ __global__ __launch_bounds__(256) void hs_qprep_kernel(const double* __restrict_
     const _Float16 vhi = (_Float16)v;
     const _Float16 vlo = (_Float16)(v - (float)vhi);
     const float ec = (float)(sqrt(nc) * (1.01 / 512.0));
-    out[200] = (_Float16)1.f;
-    out[201] = (_Float16)1.f;
-    out[202] = vhi;
-    out[203] = vlo;
-    out[204] = (_Float16)(-ec);
-    out[205] = (_Float16)0.f;
-    out[206] = (_Float16)0.f;
-    out[207] = (_Float16)0.f;
+    _Float16* ex = out + 8 * 13;
+    ex[0] = (_Float16)1.f;
+    ex[1] = (_Float16)1.f;
+    ex[2] = vhi;
+    ex[3] = vlo;
+    ex[4] = (_Float16)(-ec);
+    ex[5] = (_Float16)0.f;
+    ex[6] = (_Float16)0.f;
+    ex[7] = (_Float16)0.f;
   }
 }
 
-// fp16 coordinate table [32][8] and fp32 squared row norms [32] of the handle's alphabet
+// fp16 table [32][4] of the first JD coordinates and fp32 squared norms [32] of those coordinates
 __global__ void hs_jtables_kernel(const double* __restrict__ coords, int alphabet,
                                   _Float16* __restrict__ tab16, float* __restrict__ rownorm,
                                   uint32_t* __restrict__ unsafe) {
@@ -92,9 +104,11 @@ __global__ void hs_jtables_kernel(const double* __restrict__ coords, int alphabe
   bool bad = false;
   for (int j = 0; j < 8; ++j) {
     const double v = aa < alphabet ? coords[aa * 8 + j] : 0.0;
-    n += v * v;
     bad = bad || !(fabs(v) < 16000.0);
-    tab16[aa * 8 + j] = (_Float16)(float)v;
+    if (j < JD) {
+      n += v * v;
+      tab16[aa * JD + j] = (_Float16)(float)v;
+    }
   }
   rownorm[aa] = (float)n;
   if (bad) atomicOr(unsafe, 1u);
@@ -134,8 +148,9 @@ __global__ __launch_bounds__(256) void hs_seg_route_kernel(const uint64_t* __res
     const uint32_t nq = seg_cnt[j];
     if (nq >= min_q && m >= min_m) {
       it = ((m + JM - 1) / JM) * ((nq + JQG - 1) / JQG);
-      // MFMA pairs actually issued (64-row waves x 32-column chunks) vs real pairs
-      atomicAdd(stats + 0, (unsigned long long)((m + 63) / 64 * 64) * ((nq + JQ - 1) / JQ * JQ));
+      // MFMA pairs actually issued (128-row waves x 32-column chunks) vs real pairs
+      atomicAdd(stats + 0, (unsigned long long)((m + 32 * JT - 1) / (32 * JT) * (32 * JT)) *
+                               ((nq + JQ - 1) / JQ * JQ));
       atomicAdd(stats + 1, (unsigned long long)m * nq);
     }
   }
@@ -192,7 +207,7 @@ __global__ __launch_bounds__(256) void hs_item_desc_kernel(hs_tables_dev tabs,
   desc[2 * (uint64_t)item + 1] = make_uint4(qoff, q_begin, min(nQ, q_begin + JQG), mstart);
 }
 
-// c16 rows in SEGMENT order, so that a chunk of 32 probing queries is one contiguous 13 KB block
+// c16 rows in SEGMENT order, so that a chunk of 32 probing queries is one contiguous 7 KB block
 __global__ __launch_bounds__(256) void hs_gather_c16_kernel(const _Float16* __restrict__ c16,
                                                             const uint32_t* __restrict__ sorted_ql,
                                                             uint32_t nql, int L,
@@ -207,10 +222,10 @@ __global__ __launch_bounds__(256) void hs_gather_c16_kernel(const _Float16* __re
 }
 
 // ------------------------------------------------------------------------------------------ join
-template <int R>
-__device__ __forceinline__ uint32_t even_residue(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
-  // residue at bit 10*R of the (already half-shifted) 128-bit word, R = 0..12
-  constexpr int bit = 10 * R, wi = bit >> 5, sh = bit & 31;
+// residue at bit BIT of a 128-bit packed word (x = bits 0..31, ...), BIT + 5 <= 128
+template <int BIT>
+__device__ __forceinline__ uint32_t residue_at(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
+  constexpr int wi = BIT >> 5, sh = BIT & 31;
   const uint32_t lo = wi == 0 ? x : wi == 1 ? y : wi == 2 ? z : w;
   if constexpr (sh > 27) {
     const uint32_t hi = wi == 0 ? y : wi == 1 ? z : w;
@@ -220,34 +235,70 @@ __device__ __forceinline__ uint32_t even_residue(uint32_t x, uint32_t y, uint32_
   }
 }
 
-constexpr int JPIECES = JQ * JG;  // 16-byte pieces of one query chunk: 832
+constexpr int JPIECES = JQ * JG;  // 16-byte pieces of one query chunk: 448
 
 __device__ __forceinline__ half8 lds_b(const _Float16* tile, int off) {
   return *reinterpret_cast<const half8*>(tile + off);
 }
 
-// One work item = (member tile of <= 256 bucket entries, group of <= 512 probing queries).
-// Waves: 4 x (2 x 32 members); A fragments (whole K) live in registers for the item; query chunks
+// A fragments (whole K) of one 32-member row tile for lane (r, h): k-step s < 6 carries positions
+// 4s + 2h and 4s + 2h + 1; k-step 6 carries position 24 (lower half) / the extras (upper half).
+__device__ __forceinline__ void build_afrags(const uint4 pk, int h, int k, const _Float16* sTab,
+                                             const float* sNorm, half8 (&A)[JS]) {
+  // lanes of the upper half take positions 2,3, 6,7, ...: shift the 125-bit word down by 10
+  const uint32_t sh = 10u * (uint32_t)h;
+  const uint32_t x = __funnelshift_r(pk.x, pk.y, sh), y = __funnelshift_r(pk.y, pk.z, sh),
+                 z = __funnelshift_r(pk.z, pk.w, sh), w = pk.w >> sh;
+  float nx = 0.f;
+#define HS_AFRAG(S)                                                                 \
+  {                                                                                 \
+    const uint32_t a0 = residue_at<20 * S>(x, y, z, w), a1 = residue_at<20 * S + 5>(x, y, z, w); \
+    const half4 lo = *reinterpret_cast<const half4*>(&sTab[a0 * JD]);               \
+    const half4 hi = *reinterpret_cast<const half4*>(&sTab[a1 * JD]);               \
+    A[S] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);                 \
+    nx += (4 * S + 2 * h < k) ? sNorm[a0] : 0.f;                                    \
+    nx += (4 * S + 2 * h + 1 < k) ? sNorm[a1] : 0.f;                                \
+  }
+  HS_AFRAG(0) HS_AFRAG(1) HS_AFRAG(2) HS_AFRAG(3) HS_AFRAG(4) HS_AFRAG(5)
+#undef HS_AFRAG
+  // position 24 sits at bit 120 of the UNSHIFTED word
+  const uint32_t a24 = (pk.w >> 24) & 31u;
+  if (h == 0) nx += (24 < k) ? sNorm[a24] : 0.f;
+  nx += __shfl_xor(nx, 32);  // |x1|^2 = this half's positions + the other half's
+  const half4 p24 = *reinterpret_cast<const half4*>(&sTab[a24 * JD]);
+  const half4 zero4 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+  const _Float16 nhi = (_Float16)nx;
+  const _Float16 nlo = (_Float16)(nx - (float)nhi);
+  const _Float16 xn = (_Float16)(sqrtf(nx) * 1.002f);
+  half8 ex;
+  ex[0] = nhi; ex[1] = nlo; ex[2] = (_Float16)1.f; ex[3] = (_Float16)1.f;
+  ex[4] = xn; ex[5] = (_Float16)0.f; ex[6] = (_Float16)0.f; ex[7] = (_Float16)0.f;
+  A[6] = h ? ex : __builtin_shufflevector(p24, zero4, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// One work item = (member tile of <= 512 bucket entries, group of <= 2048 probing queries).
+// Waves: 4 x (4 x 32 members); A fragments (whole K) live in registers for the item; query chunks
 // of 32 stream through a double-buffered LDS tile, prefetched into registers one chunk ahead; the
-// B fragments of a chunk are read from LDS four k-steps ahead of the MFMAs that consume them.
+// descriptor, packed members and first query chunk of the NEXT item are fetched while the current
+// item computes, so an item's prologue is only the A-fragment build (LDS table reads).
 __global__ __launch_bounds__(256, 2) void hs_join_kernel(
     const uint4* __restrict__ desc, uint32_t n_items, const uint32_t* __restrict__ sorted_ql,
     const _Float16* __restrict__ c16s, const _Float16* __restrict__ tab16,
     const float* __restrict__ rownorm, int k, uint32_t* __restrict__ prov_count, uint32_t prov_cap,
     uint2* __restrict__ prov) {
   __shared__ __attribute__((aligned(16))) _Float16 sB[2][JQ * JROW];
-  __shared__ __attribute__((aligned(16))) _Float16 sTab[32 * 8];
+  __shared__ __attribute__((aligned(16))) _Float16 sTab[32 * JD];
   __shared__ float sNorm[32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  sTab[tid] = tab16[tid];
+  if (tid < 32 * JD) sTab[tid] = tab16[tid];
   if (tid < 32) sNorm[tid] = rownorm[tid];
   __syncthreads();
-  // This thread's 4 pieces of a chunk (the last 192 threads repeat piece 831: same bytes to the
+  // This thread's 2 pieces of a chunk (the last 64 threads repeat piece 447: same bytes to the
   // same LDS address, which keeps every load and store unconditional).
-  int src_piece[4], dst[4];
+  int src_piece[2], dst[2];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < 2; ++j) {
     const int i = min(tid + 256 * j, JPIECES - 1);
     const int row = i / JG, g = i - row * JG;
     src_piece[j] = i;
@@ -257,26 +308,21 @@ __global__ __launch_bounds__(256, 2) void hs_join_kernel(
   int buf = 0;
   uint32_t item = blockIdx.x;
   if (item >= n_items) return;
-  // Software pipeline ACROSS items: the descriptor, the packed members and the first query chunk
-  // of the next item are fetched while the current item computes, so an item's prologue is only
-  // the A-fragment build (LDS table reads), not three dependent global-memory latencies.
   uint4 d0 = desc[2 * (uint64_t)item], d1 = desc[2 * (uint64_t)item + 1];
-  uint4 pkA, pkB, pre0, pre1, pre2, pre3;
+  uint4 pk[JT], pre0, pre1;
   {
     const uint4* packed = reinterpret_cast<const uint4*>(((uint64_t)d0.y << 32) | (uint64_t)d0.x);
-    const uint32_t idx = d0.w * JM + wave * 64 + r;
-    pkA = packed[min(idx, d0.z - 1)];
-    pkB = packed[min(idx + 32, d0.z - 1)];
+    const uint32_t idx = d0.w * JM + wave * (32 * JT) + r;
+#pragma unroll
+    for (int t = 0; t < JT; ++t) pk[t] = packed[min(idx + 32 * t, d0.z - 1)];
     const uint4* src = reinterpret_cast<const uint4*>(c16s + (uint64_t)(d1.x + d1.y) * JK);
     pre0 = src[src_piece[0]];
     pre1 = src[src_piece[1]];
-    pre2 = src[src_piece[2]];
-    pre3 = src[src_piece[3]];
   }
   while (true) {
     const uint32_t M = d0.z, mt = d0.w;
     const uint32_t qoff = d1.x, q_begin = d1.y, q_end = d1.z, mstart = d1.w;
-    const uint32_t wbase = mt * JM + wave * 64;
+    const uint32_t wbase = mt * JM + wave * (32 * JT);
     const bool wave_on = wbase < M;  // wave-uniform: this wave owns at least one real member
     const uint32_t next_item = item + gridDim.x;
     const bool has_next = next_item < n_items;
@@ -285,47 +331,15 @@ __global__ __launch_bounds__(256, 2) void hs_join_kernel(
       nd0 = desc[2 * (uint64_t)next_item];
       nd1 = desc[2 * (uint64_t)next_item + 1];
     }
-    half8 A[2][13];
+    half8 A[JT][JS];
     if (wave_on) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const uint4 pk = t ? pkB : pkA;
-        // lanes of the upper half take the odd positions: shift the 125-bit word down by 5
-        const uint32_t sh5 = 5u * (uint32_t)h;
-        const uint32_t x = __funnelshift_r(pk.x, pk.y, sh5), y = __funnelshift_r(pk.y, pk.z, sh5),
-                       z = __funnelshift_r(pk.z, pk.w, sh5), w = pk.w >> sh5;
-        float nx = 0.f;
-#define HS_AFRAG(S)                                                        \
-  {                                                                        \
-    const uint32_t aa = even_residue<S>(x, y, z, w);                       \
-    A[t][S] = *reinterpret_cast<const half8*>(&sTab[aa * 8]);             \
-    nx += (2 * S + h < k) ? sNorm[aa] : 0.f;                               \
-  }
-        HS_AFRAG(0) HS_AFRAG(1) HS_AFRAG(2) HS_AFRAG(3) HS_AFRAG(4) HS_AFRAG(5)
-        HS_AFRAG(6) HS_AFRAG(7) HS_AFRAG(8) HS_AFRAG(9) HS_AFRAG(10) HS_AFRAG(11)
-#undef HS_AFRAG
-        {
-          // group 24 (position 24) for the lower half, group 25 (extras) for the upper half
-          const uint32_t aa = even_residue<12>(x, y, z, w);
-          const half8 pos24 = *reinterpret_cast<const half8*>(&sTab[aa * 8]);
-          if (h == 0) nx += (24 < k) ? sNorm[aa] : 0.f;
-          nx += __shfl_xor(nx, 32);  // |x|^2 = even positions + odd positions
-          const _Float16 nhi = (_Float16)nx;
-          const _Float16 nlo = (_Float16)(nx - (float)nhi);
-          const _Float16 xn = (_Float16)(sqrtf(nx) * 1.002f);
-          half8 ex;
-          ex[0] = nhi; ex[1] = nlo; ex[2] = (_Float16)1.f; ex[3] = (_Float16)1.f;
-          ex[4] = xn; ex[5] = (_Float16)0.f; ex[6] = (_Float16)0.f; ex[7] = (_Float16)0.f;
-          A[t][12] = h ? ex : pos24;
-        }
-      }
+      for (int t = 0; t < JT; ++t) build_afrags(pk[t], h, k, sTab, sNorm, A[t]);
     }
     for (uint32_t qc = q_begin; qc < q_end; qc += JQ) {
       _Float16* tile = sB[buf];
       *reinterpret_cast<uint4*>(&tile[dst[0]]) = pre0;
       *reinterpret_cast<uint4*>(&tile[dst[1]]) = pre1;
-      *reinterpret_cast<uint4*>(&tile[dst[2]]) = pre2;
-      *reinterpret_cast<uint4*>(&tile[dst[3]]) = pre3;
       __syncthreads();  // tile complete; also: every wave is past its reads of the other buffer
       {
         // next chunk of this item, or the first chunk of the next item (all uniform)
@@ -334,69 +348,64 @@ __global__ __launch_bounds__(256, 2) void hs_join_kernel(
         const uint4* src = reinterpret_cast<const uint4*>(c16s + row * JK);
         pre0 = src[src_piece[0]];
         pre1 = src[src_piece[1]];
-        pre2 = src[src_piece[2]];
-        pre3 = src[src_piece[3]];
       }
       if (qc == q_begin) {  // the A fragments are built: the packed words can be replaced
         const uint4* packed = reinterpret_cast<const uint4*>(((uint64_t)nd0.y << 32) | (uint64_t)nd0.x);
-        const uint32_t idx = nd0.w * JM + wave * 64 + r;
-        pkA = packed[min(idx, nd0.z - 1)];
-        pkB = packed[min(idx + 32, nd0.z - 1)];
+        const uint32_t idx = nd0.w * JM + wave * (32 * JT) + r;
+#pragma unroll
+        for (int t = 0; t < JT; ++t) pk[t] = packed[min(idx + 32 * t, nd0.z - 1)];
       }
       buf ^= 1;
       if (!wave_on) continue;
-      floatx16 acc0, acc1;
+      floatx16 acc[JT];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        acc0[i] = 0.f;
-        acc1[i] = 0.f;
-      }
-      half8 b0 = lds_b(tile, boff), b1 = lds_b(tile, boff + 16), b2 = lds_b(tile, boff + 32),
-            b3 = lds_b(tile, boff + 48);
-#define HS_STEP(S, B)                                                                  \
-  acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][S], B, acc0, 0, 0, 0);           \
-  acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][S], B, acc1, 0, 0, 0);           \
-  if (S + 4 < 13) B = lds_b(tile, boff + 16 * (S + 4));
-      HS_STEP(0, b0) HS_STEP(1, b1) HS_STEP(2, b2) HS_STEP(3, b3)
-      HS_STEP(4, b0) HS_STEP(5, b1) HS_STEP(6, b2) HS_STEP(7, b3)
-      HS_STEP(8, b0) HS_STEP(9, b1) HS_STEP(10, b2) HS_STEP(11, b3)
-      HS_STEP(12, b0)
+      for (int t = 0; t < JT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+      half8 b0 = lds_b(tile, boff), b1 = lds_b(tile, boff + 16), b2 = lds_b(tile, boff + 32);
+#define HS_STEP(S, B)                                                                        \
+  _Pragma("unroll") for (int t = 0; t < JT; ++t)                                             \
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][S], B, acc[t], 0, 0, 0);          \
+  if (S + 3 < JS) B = lds_b(tile, boff + 16 * (S + 3));
+      HS_STEP(0, b0) HS_STEP(1, b1) HS_STEP(2, b2) HS_STEP(3, b0) HS_STEP(4, b1) HS_STEP(5, b2)
+      HS_STEP(6, b0)
 #undef HS_STEP
-      // ---- survivors: G <= 0 (rare).  D layout: col = lane & 31, row = (i&3) + 8 (i>>2) + 4 h.
-      float gmin = fminf(acc0[0], acc1[0]);
+      // ---- survivors: G <= 0 (a few per million).  D layout: col = lane & 31,
+      //      row = (i & 3) + 8 (i >> 2) + 4 h.
+      float gmin = acc[0][0];
 #pragma unroll
-      for (int i = 1; i < 16; ++i) gmin = fminf(gmin, fminf(acc0[i], acc1[i]));
+      for (int t = 0; t < JT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gmin = fminf(gmin, acc[t][i]);
       if (__ballot(gmin <= 0.f)) {
-        uint32_t mask = 0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          mask |= (acc0[i] <= 0.f ? 1u : 0u) << i;
-          mask |= (acc1[i] <= 0.f ? 1u : 0u) << (16 + i);
-        }
         const bool col_ok = qc + (uint32_t)r < q_end;
         const uint32_t ql = col_ok ? sorted_ql[qoff + qc + r] : 0u;
-        if (!col_ok) mask = 0;
-        while (true) {
-          uint32_t idx = 0;
-          bool pass = false;
-          if (mask) {
-            const int bit = __ffs((int)mask) - 1;
-            mask &= mask - 1;
-            const int t = bit >> 4, i = bit & 15;
-            idx = wbase + (uint32_t)(t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h);
-            pass = idx < M;
-          }
-          const unsigned long long m = __ballot(pass);
-          if (m) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(prov_count, (uint32_t)__popcll(m));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (pass) {
-              const uint32_t o = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-              if (o < prov_cap) prov[o] = make_uint2(ql, mstart + idx);
+#pragma unroll
+        for (int t = 0; t < JT; ++t) {
+          uint32_t mask = 0;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) mask |= (acc[t][i] <= 0.f ? 1u : 0u) << i;
+          if (!col_ok) mask = 0;
+          while (__ballot(mask != 0)) {
+            uint32_t idx = 0;
+            bool pass = false;
+            if (mask) {
+              const int i = __ffs((int)mask) - 1;
+              mask &= mask - 1;
+              idx = wbase + (uint32_t)(t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h);
+              pass = idx < M;
+            }
+            const unsigned long long m = __ballot(pass);
+            if (m) {
+              uint32_t base = 0;
+              if (lane == 0) base = atomicAdd(prov_count, (uint32_t)__popcll(m));
+              base = __builtin_amdgcn_readfirstlane(base);
+              if (pass) {
+                const uint32_t o = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (o < prov_cap) prov[o] = make_uint2(ql, mstart + idx);
+              }
             }
           }
-          if (!__ballot(mask != 0)) break;
         }
       }
     }

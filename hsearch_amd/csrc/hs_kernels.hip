@@ -67,7 +67,9 @@ __global__ __launch_bounds__(256) void hs_hash_kernel(const uint8_t* __restrict_
     __syncthreads();
   }
   const double* xrow = FROM_CODES ? nullptr : pts + (valid ? i : 0) * (uint64_t)d;
-  for (int fc = 0; fc < F; fc += KC) {
+  // gridDim.y > 1 (few points, e.g. a query batch): each block row takes every gridDim.y-th chunk
+  // of KC functions, so the launch fills the chip instead of running one block per CU.
+  for (int fc = (int)blockIdx.y * KC; fc < F; fc += KC * (int)gridDim.y) {
     double acc[KC];
 #pragma unroll
     for (int f = 0; f < KC; ++f) acc[f] = 0.0;
@@ -484,8 +486,12 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
     const uint32_t q = ql / (uint32_t)L;
     const int l = (int)(ql % (uint32_t)L);
     const uint32_t id = tabs.t[l].ids[pos];
-    bool seen = false;
-    for (int l2 = 0; l2 < l && !seen; ++l2) {
+    // exact decision first: most survivors of a coarse filter fail it, and it needs no searching
+    const double d2 = exact_dist2(codes + (uint64_t)id * k, centers + (uint64_t)q * 8 * k, coords, k);
+    // Search(): d2 <= R*R (motif_both_points.cpp:239); Clustering(): sqrt(d2) <= R
+    // (hclust2.cpp:64-71,119-120), selected by a non-NaN r_sqrt.
+    bool hit = (r_sqrt == r_sqrt) ? (__dsqrt_rn(d2) <= r_sqrt) : (d2 <= r2);
+    for (int l2 = 0; l2 < l && hit; ++l2) {  // first-seen dedupe (label[], :233)
       const uint32_t c2 = qcount[q * L + l2];
       if (!c2) continue;
       const uint32_t* ids2 = tabs.t[l2].ids + qstart[q * L + l2];
@@ -494,13 +500,8 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
         const uint32_t mid = (lo + hi) >> 1;
         if (ids2[mid] < id) lo = mid + 1; else hi = mid;
       }
-      seen = lo < c2 && ids2[lo] == id;
+      if (lo < c2 && ids2[lo] == id) hit = false;
     }
-    if (seen) continue;
-    const double d2 = exact_dist2(codes + (uint64_t)id * k, centers + (uint64_t)q * 8 * k, coords, k);
-    // Search(): d2 <= R*R (motif_both_points.cpp:239); Clustering(): sqrt(d2) <= R
-    // (hclust2.cpp:64-71,119-120), selected by a non-NaN r_sqrt.
-    const bool hit = (r_sqrt == r_sqrt) ? (__dsqrt_rn(d2) <= r_sqrt) : (d2 <= r2);
     if (hit) {
       const uint32_t idx = atomicAdd(hit_count, 1u);
       if (idx < hit_cap) {
@@ -574,9 +575,14 @@ static hipError_t launch_hash(const uint8_t* d_codes, const double* d_pts, uint6
   if (!n || !F) return hipSuccess;
   const unsigned blocks = blocks_for(n);
   const size_t lds = FROM_CODES ? 256u * (size_t)k : 0;
-#define HS_HASH(KC)                                                                              \
-  hs_hash_kernel<KC, FROM_CODES><<<blocks, 256, lds, s>>>(d_codes, d_pts, n, k, d_a, d_b, F, W, \
-                                                          d_coords, d_out, out_stride)
+  const int kc = F % 16 == 0 ? 16 : F % 8 == 0 ? 8 : F % 5 == 0 ? 5 : F % 4 == 0 ? 4 : F % 2 == 0 ? 2 : 1;
+  const unsigned chunks = (unsigned)(F / kc);
+  // enough block rows to reach ~8 blocks per CU when the point count alone does not
+  const unsigned gy = std::max(1u, std::min(chunks, 2048u / std::max(blocks, 1u)));
+  const dim3 grid(blocks, gy);
+#define HS_HASH(KC)                                                                            \
+  hs_hash_kernel<KC, FROM_CODES><<<grid, 256, lds, s>>>(d_codes, d_pts, n, k, d_a, d_b, F, W, \
+                                                        d_coords, d_out, out_stride)
   if (F % 16 == 0) HS_HASH(16);
   else if (F % 8 == 0) HS_HASH(8);
   else if (F % 5 == 0) HS_HASH(5);
