@@ -71,6 +71,7 @@ struct hs_handle {
   // bucket-join workspace
   DevBuf c16s, item_desc;
   uint32_t join_min_q = 3, join_min_m = 16;  // segment routing thresholds (HS_JOIN_MIN_Q / _M)
+  int join_blocks_per_cu = 2;                // resident workgroups of hs_join_kernel per CU
   DevBuf jtab, c16, seg_keys, seg_keys_sorted, seg_vals, sorted_ql, seg_key, seg_cnt, seg_qoff,
       seg_items, item_off, seg_n;
   bool sqrt_test = false;       // hit test sqrt(d2) <= R (hclust2.cpp:119-120) instead of d2 <= R*R
@@ -204,6 +205,7 @@ hs_status hs_create(const hs_params* params, const double* a, const double* b, c
   }
   if (const char* m = getenv("HS_JOIN_MIN_Q")) h->join_min_q = (uint32_t)std::max(1, atoi(m));
   if (const char* m = getenv("HS_JOIN_MIN_M")) h->join_min_m = (uint32_t)std::max(1, atoi(m));
+  if (const char* m = getenv("HS_JOIN_BLOCKS_PER_CU")) h->join_blocks_per_cu = std::max(1, atoi(m));
   return HS_OK;
 }
 
@@ -580,10 +582,11 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
                                      nullptr, n_blocks, h->stream));
     } else {
       if (n_items)
-        HS_HIP(h, hs_launch_join(h->item_desc.as<uint4>(), n_items, h->sorted_ql.as<uint32_t>(),
+        HS_HIP(h, hs_launch_join(h->item_desc.as<uint4>(), n_items, h->tabs.t[0].packed,
+                                 h->sorted_ql.as<uint32_t>(),
                                  h->c16s.p, h->jtab.p,
                                  reinterpret_cast<const float*>(h->jtab.as<char>() + 512), k, d_cnt,
-                                 prov_cap, h->prov.as<uint2>(), h->n_cu * 2, h->stream));
+                                 prov_cap, h->prov.as<uint2>(), h->n_cu * h->join_blocks_per_cu, h->stream));
       HS_HIP(h, hipEventRecord(h->ev[10], h->stream));
       if (n_slices)
         HS_HIP(h, hs_launch_verify(h->tabs, h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),

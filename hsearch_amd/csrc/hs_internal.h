@@ -200,7 +200,7 @@ hipError_t hs_launch_item_desc(const hs_tables_dev& tabs, const uint64_t* d_seg_
                                uint4* d_desc, hipStream_t s);
 hipError_t hs_launch_gather_c16(const void* d_c16, const uint32_t* d_sorted_ql, uint32_t nql, int L,
                                 void* d_out, hipStream_t s);
-hipError_t hs_launch_join(const uint4* d_desc, uint32_t n_items,
+hipError_t hs_launch_join(const uint4* d_desc, uint32_t n_items, const uint4* d_packed_base,
                           const uint32_t* d_sorted_ql, const void* d_c16s, const void* d_tab16,
                           const float* d_rownorm, int k, uint32_t* d_prov_count, uint32_t prov_cap,
                           uint2* d_prov, int n_blocks, hipStream_t s);

@@ -17,7 +17,7 @@
 // a pair with exact d2 <= R^2 always has G <= 0:  |2 x1^.c1^ - 2 x1.c1| <= 2 (2^-10 + 2^-22)
 // |x1||c1| (fp16 round-to-nearest + Cauchy-Schwarz) is covered by e_c |x1|^ with
 // e_c = 1.01 * 2^-9 |c1|, and fp32 accumulation plus the hi/lo splitting of the norms by
-// slack = 1.  G is ONE K = 112 GEMM: 100 coordinates + 8 "extras" columns that carry the norms,
+// slack (1, plus 0.5 because the kernel tests the sign bit, G < 0).  G is ONE K = 112 GEMM: 100 coordinates + 8 "extras" columns that carry the norms,
 // the threshold and the error term (+ 4 pad).  Survivors (G <= 0; a few per million pairs) are
 // re-evaluated in the reference's fp64 order and decided by its own test in hs_finalize_kernel,
 // exactly as for the streaming kernel.
@@ -40,7 +40,8 @@ constexpr int JQ = 32;      // queries per chunk (MFMA N)
 constexpr int JT = 4;       // 32-member MFMA row tiles per wave
 constexpr int JM = 4 * JT * 32;  // members per workgroup tile: 512
 constexpr int JQG = 2048;   // queries per work item (<= 64 chunks)
-constexpr float JSLACK = 1.0f;
+constexpr uint32_t JRES = 64;  // survivor slots a wave reserves per atomic
+constexpr float JSLACK = 1.5f;  // 1 for the rounding analysis + 0.5 so that "G < 0" covers "G <= 0"
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void hs_seg_unslice_kernel(const uint32_t* __r
 }
 
 // One descriptor (2 x uint4) per work item:
-//   { pointer to the bucket's first packed member (lo, hi), M, member tile },
+//   { offset of the bucket's first packed member from table 0's packed array (lo, hi), M, tile },
 //   { qoff, q_begin, q_end, first sorted position of the bucket }
 __global__ __launch_bounds__(256) void hs_item_desc_kernel(hs_tables_dev tabs,
                                                            const uint64_t* __restrict__ seg_key,
@@ -202,8 +203,12 @@ __global__ __launch_bounds__(256) void hs_item_desc_kernel(hs_tables_dev tabs,
   const uint32_t mt = local % tiles_m, qg = local / tiles_m;
   const uint32_t q_begin = qg * JQG;
   const uint32_t mstart = (uint32_t)key;
-  const uint64_t ptr = reinterpret_cast<uint64_t>(tabs.t[(uint32_t)(key >> 32)].packed + mstart);
-  desc[2 * (uint64_t)item] = make_uint4((uint32_t)ptr, (uint32_t)(ptr >> 32), M, mt);
+  // offset (in 16-byte words) from table 0's packed array: base + offset keeps the member loads
+  // in the global address space (a pointer rebuilt from integers compiles to flat loads, whose
+  // lgkmcnt accounting stalls the LDS waits of the MFMA loop)
+  const int64_t off = (reinterpret_cast<intptr_t>(tabs.t[(uint32_t)(key >> 32)].packed) -
+                       reinterpret_cast<intptr_t>(tabs.t[0].packed)) / 16 + (int64_t)mstart;
+  desc[2 * (uint64_t)item] = make_uint4((uint32_t)(uint64_t)off, (uint32_t)((uint64_t)off >> 32), M, mt);
   desc[2 * (uint64_t)item + 1] = make_uint4(qoff, q_begin, min(nQ, q_begin + JQG), mstart);
 }
 
@@ -282,10 +287,10 @@ __device__ __forceinline__ void build_afrags(const uint4 pk, int h, int k, const
 // descriptor, packed members and first query chunk of the NEXT item are fetched while the current
 // item computes, so an item's prologue is only the A-fragment build (LDS table reads).
 __global__ __launch_bounds__(256, 2) void hs_join_kernel(
-    const uint4* __restrict__ desc, uint32_t n_items, const uint32_t* __restrict__ sorted_ql,
-    const _Float16* __restrict__ c16s, const _Float16* __restrict__ tab16,
-    const float* __restrict__ rownorm, int k, uint32_t* __restrict__ prov_count, uint32_t prov_cap,
-    uint2* __restrict__ prov) {
+    const uint4* __restrict__ desc, uint32_t n_items, const uint4* __restrict__ packed_base,
+    const uint32_t* __restrict__ sorted_ql, const _Float16* __restrict__ c16s,
+    const _Float16* __restrict__ tab16, const float* __restrict__ rownorm, int k,
+    uint32_t* __restrict__ prov_count, uint32_t prov_cap, uint2* __restrict__ prov) {
   __shared__ __attribute__((aligned(16))) _Float16 sB[2][JQ * JROW];
   __shared__ __attribute__((aligned(16))) _Float16 sTab[32 * JD];
   __shared__ float sNorm[32];
@@ -308,10 +313,14 @@ __global__ __launch_bounds__(256, 2) void hs_join_kernel(
   int buf = 0;
   uint32_t item = blockIdx.x;
   if (item >= n_items) return;
+  uint32_t res_base = 0, res_used = JRES;  // no survivor block reserved yet
+  // the two workgroups of a CU run the same loop: start the second half a chunk later so that one
+  // group's MFMA phase tends to face the other's load/LDS/barrier phase
+  if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_sleep(8);
   uint4 d0 = desc[2 * (uint64_t)item], d1 = desc[2 * (uint64_t)item + 1];
   uint4 pk[JT], pre0, pre1;
   {
-    const uint4* packed = reinterpret_cast<const uint4*>(((uint64_t)d0.y << 32) | (uint64_t)d0.x);
+    const uint4* packed = packed_base + (int64_t)(((uint64_t)d0.y << 32) | (uint64_t)d0.x);
     const uint32_t idx = d0.w * JM + wave * (32 * JT) + r;
 #pragma unroll
     for (int t = 0; t < JT; ++t) pk[t] = packed[min(idx + 32 * t, d0.z - 1)];
@@ -350,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void hs_join_kernel(
         pre1 = src[src_piece[1]];
       }
       if (qc == q_begin) {  // the A fragments are built: the packed words can be replaced
-        const uint4* packed = reinterpret_cast<const uint4*>(((uint64_t)nd0.y << 32) | (uint64_t)nd0.x);
+        const uint4* packed = packed_base + (int64_t)(((uint64_t)nd0.y << 32) | (uint64_t)nd0.x);
         const uint32_t idx = nd0.w * JM + wave * (32 * JT) + r;
 #pragma unroll
         for (int t = 0; t < JT; ++t) pk[t] = packed[min(idx + 32 * t, nd0.z - 1)];
@@ -362,29 +371,50 @@ __global__ __launch_bounds__(256, 2) void hs_join_kernel(
       for (int t = 0; t < JT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-      half8 b0 = lds_b(tile, boff), b1 = lds_b(tile, boff + 16), b2 = lds_b(tile, boff + 32);
+      // B fragments ping-pong between two register sets; the read for k-step s+2 is issued right
+      // behind the 4 MFMAs of k-step s, so its LDS latency runs under the MFMAs of k-step s+1.
+      half8 b0 = lds_b(tile, boff), b1 = lds_b(tile, boff + 16);
 #define HS_STEP(S, B)                                                                        \
   _Pragma("unroll") for (int t = 0; t < JT; ++t)                                             \
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][S], B, acc[t], 0, 0, 0);          \
-  if (S + 3 < JS) B = lds_b(tile, boff + 16 * (S + 3));
-      HS_STEP(0, b0) HS_STEP(1, b1) HS_STEP(2, b2) HS_STEP(3, b0) HS_STEP(4, b1) HS_STEP(5, b2)
+  if (S + 2 < JS) B = lds_b(tile, boff + 16 * (S + 2));
+      HS_STEP(0, b0) HS_STEP(1, b1) HS_STEP(2, b0) HS_STEP(3, b1) HS_STEP(4, b0) HS_STEP(5, b1)
       HS_STEP(6, b0)
 #undef HS_STEP
+      // pin that order: 2 reads, 5 x (4 MFMA, 1 read), 8 MFMA  (0x100 = DS read, 0x008 = MFMA)
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+      for (int s = 0; s < JS - 2; ++s) {
+        __builtin_amdgcn_sched_group_barrier(0x008, JT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * JT, 0);
       // ---- survivors: G <= 0 (a few per million).  D layout: col = lane & 31,
       //      row = (i & 3) + 8 (i >> 2) + 4 h.
-      float gmin = acc[0][0];
+      // "some G < 0" = sign bit of the OR of all 64 accumulators: a log-depth tree of v_or3
+      // instead of a 64-deep chain of dependent v_min (which cost 17 % of the kernel).  The test
+      // is G < 0 (sign bit) rather than G <= 0; JSLACK carries the half unit that makes up for it.
+      uint32_t sg[JT];
 #pragma unroll
-      for (int t = 0; t < JT; ++t)
+      for (int t = 0; t < JT; ++t) {
+        uint32_t o[4];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) gmin = fminf(gmin, acc[t][i]);
-      if (__ballot(gmin <= 0.f)) {
+        for (int j = 0; j < 4; ++j)
+          o[j] = __float_as_uint(acc[t][4 * j]) | __float_as_uint(acc[t][4 * j + 1]) |
+                 __float_as_uint(acc[t][4 * j + 2]) | __float_as_uint(acc[t][4 * j + 3]);
+        sg[t] = (o[0] | o[1]) | (o[2] | o[3]);
+      }
+      uint32_t sany = sg[0];
+#pragma unroll
+      for (int t = 1; t < JT; ++t) sany |= sg[t];
+      if (__ballot((int)sany < 0)) {
         const bool col_ok = qc + (uint32_t)r < q_end;
         const uint32_t ql = col_ok ? sorted_ql[qoff + qc + r] : 0u;
 #pragma unroll
         for (int t = 0; t < JT; ++t) {
           uint32_t mask = 0;
 #pragma unroll
-          for (int i = 0; i < 16; ++i) mask |= (acc[t][i] <= 0.f ? 1u : 0u) << i;
+          for (int i = 0; i < 16; ++i) mask |= (__float_as_uint(acc[t][i]) >> 31) << i;
           if (!col_ok) mask = 0;
           while (__ballot(mask != 0)) {
             uint32_t idx = 0;
@@ -397,13 +427,22 @@ __global__ __launch_bounds__(256, 2) void hs_join_kernel(
             }
             const unsigned long long m = __ballot(pass);
             if (m) {
-              uint32_t base = 0;
-              if (lane == 0) base = atomicAdd(prov_count, (uint32_t)__popcll(m));
-              base = __builtin_amdgcn_readfirstlane(base);
+              // survivor slots are reserved 64 at a time per wave: one atomic per ~64 survivors
+              // instead of one per ballot (a single counter saturates near 88 atomics/us)
+              const uint32_t cnt = (uint32_t)__popcll(m);
+              if (res_used + cnt > JRES) {
+                if (res_used < JRES && lane >= (int)res_used && res_base + lane < prov_cap)
+                  prov[res_base + lane] = make_uint2(0xffffffffu, 0u);  // unused tail: skipped later
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(prov_count, (uint32_t)JRES);
+                res_base = __builtin_amdgcn_readfirstlane(base);
+                res_used = 0;
+              }
               if (pass) {
-                const uint32_t o = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                const uint32_t o = res_base + res_used + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                 if (o < prov_cap) prov[o] = make_uint2(ql, mstart + idx);
               }
+              res_used += cnt;
             }
           }
         }
@@ -414,6 +453,8 @@ __global__ __launch_bounds__(256, 2) void hs_join_kernel(
     d0 = nd0;
     d1 = nd1;
   }
+  if (res_used < JRES && lane >= (int)res_used && res_base + lane < prov_cap)
+    prov[res_base + lane] = make_uint2(0xffffffffu, 0u);
 }
 
 inline unsigned blocks_for(uint64_t n, unsigned per = 256) { return (unsigned)((n + per - 1) / per); }
@@ -472,12 +513,12 @@ hipError_t hs_launch_gather_c16(const void* d_c16, const uint32_t* d_sorted_ql, 
   return hipGetLastError();
 }
 
-hipError_t hs_launch_join(const uint4* d_desc, uint32_t n_items,
+hipError_t hs_launch_join(const uint4* d_desc, uint32_t n_items, const uint4* d_packed_base,
                           const uint32_t* d_sorted_ql, const void* d_c16s, const void* d_tab16,
                           const float* d_rownorm, int k, uint32_t* d_prov_count, uint32_t prov_cap,
                           uint2* d_prov, int n_blocks, hipStream_t s) {
   if (!n_items) return hipSuccess;
-  hs_join_kernel<<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_sorted_ql, (const _Float16*)d_c16s,
+  hs_join_kernel<<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_sorted_ql, (const _Float16*)d_c16s,
                                           (const _Float16*)d_tab16, d_rownorm, k, d_prov_count,
                                           prov_cap, d_prov);
   return hipGetLastError();

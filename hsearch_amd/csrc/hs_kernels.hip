@@ -483,6 +483,7 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
   const uint32_t n = min(*prov_count, prov_cap);
   for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
     const uint32_t ql = prov[e].x, pos = prov[e].y;
+    if (ql == 0xffffffffu) continue;  // unused slot of a wave's reserved block (hs_join_kernel)
     const uint32_t q = ql / (uint32_t)L;
     const int l = (int)(ql % (uint32_t)L);
     const uint32_t id = tabs.t[l].ids[pos];
