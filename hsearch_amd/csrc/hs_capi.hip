@@ -69,7 +69,7 @@ struct hs_handle {
   DevBuf qints, qstart, qcount, nslices, slice_off, tq, prov, hit_key, hit_val, hit_key2, hit_val2,
       counters, temp, io_centers, io_q, io_id, io_table, io_dist, io_cand, io_codes, io_misc;
   // bucket-join workspace
-  DevBuf c16s, item_desc;
+  DevBuf c16s, item_desc, probe_slow;
   uint32_t join_min_q = 3, join_min_m = 16;  // segment routing thresholds (HS_JOIN_MIN_Q / _M)
   int join_blocks_per_cu = 2;                // resident workgroups of hs_join_kernel per CU
   DevBuf jtab, c16, seg_keys, seg_keys_sorted, seg_vals, sorted_ql, seg_key, seg_cnt, seg_qoff,
@@ -225,7 +225,8 @@ void hs_destroy(hs_handle* h) {
                     &h->io_centers, &h->io_q, &h->io_id, &h->io_table, &h->io_dist, &h->io_cand,
                     &h->io_codes, &h->io_misc, &h->jtab, &h->c16, &h->seg_keys, &h->seg_keys_sorted,
                     &h->seg_vals, &h->sorted_ql, &h->seg_key, &h->seg_cnt, &h->seg_qoff,
-                    &h->seg_items, &h->item_off, &h->seg_n, &h->c16s, &h->item_desc};
+                    &h->seg_items, &h->item_off, &h->seg_n, &h->c16s, &h->item_desc,
+                    &h->probe_slow};
   for (DevBuf* bf : bufs) bf->release();
   for (int l = 0; l < HS_MAX_L; ++l) {
     h->t_dirkey[l].release();
@@ -309,11 +310,11 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
   const int K = (int)h->p.K, L = (int)h->p.L, k = (int)h->p.k, d = h->d, PW = h->PW;
   *collided = false;
   // scratch shared by all tables
-  DevBuf ints, keys, keys_sorted, iota, rle_unique, rle_counts, small, sort_temp;
+  DevBuf ints, keys, keys_sorted, iota, rle_unique, rle_counts, small, sort_temp, slow_q;
   struct Guard {
-    DevBuf* b[8];
+    DevBuf* b[9];
     ~Guard() { for (DevBuf* x : b) x->release(); }
-  } guard = {{&ints, &keys, &keys_sorted, &iota, &rle_unique, &rle_counts, &small, &sort_temp}};
+  } guard = {{&ints, &keys, &keys_sorted, &iota, &rle_unique, &rle_counts, &small, &sort_temp, &slow_q}};
   HS_HIP(h, ints.reserve(std::max<size_t>(16, (size_t)n * K * 4)));
   HS_HIP(h, keys.reserve(std::max<size_t>(16, (size_t)n * 8)));
   HS_HIP(h, keys_sorted.reserve(std::max<size_t>(16, (size_t)n * 8)));
@@ -342,8 +343,11 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
       HS_HIP(h, hs_sort_pairs_u64_u32(sort_temp.p, sort_temp.cap, keys.as<uint64_t>(),
                                       keys_sorted.as<uint64_t>(), iota.as<uint32_t>(),
                                       h->t_ids[l].as<uint32_t>(), n, h->stream));
+      const uint32_t slow_cap = 1u << 16;
+      HS_HIP(h, slow_q.reserve(((size_t)slow_cap + 1) * 4));
       HS_HIP(h, hs_launch_check_runs(keys_sorted.as<uint64_t>(), h->t_ids[l].as<uint32_t>(),
-                                     ints.as<int32_t>(), n, K, d_small + 1, h->stream));
+                                     ints.as<int32_t>(), n, K, d_small + 1, slow_q.as<uint32_t>(),
+                                     slow_cap, false, h->stream));
       HS_HIP(h, hs_rle_u64(sort_temp.p, sort_temp.cap, keys_sorted.as<uint64_t>(),
                            rle_unique.as<uint64_t>(), rle_counts.as<uint32_t>(), d_small, n,
                            h->stream));
@@ -352,8 +356,16 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
       HS_HIP(h, hipStreamSynchronize(h->stream));
       nb = host_small[0];
       flag = host_small[1];
+      if (flag & 2u) {  // very many aliased neighbours (tiny W): compare every pair as strings
+        HS_HIP(h, hipMemsetAsync(d_small + 1, 0, 4, h->stream));
+        HS_HIP(h, hs_launch_check_runs(keys_sorted.as<uint64_t>(), h->t_ids[l].as<uint32_t>(),
+                                       ints.as<int32_t>(), n, K, d_small + 1, slow_q.as<uint32_t>(),
+                                       slow_cap, true, h->stream));
+        HS_HIP(h, hipMemcpyAsync(&flag, d_small + 1, 4, hipMemcpyDeviceToHost, h->stream));
+        HS_HIP(h, hipStreamSynchronize(h->stream));
+      }
     }
-    if (flag) {
+    if (flag & 1u) {
       *collided = true;
       return HS_OK;
     }
@@ -467,6 +479,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, h->qstart.reserve((size_t)nql * 4));
     HS_HIP(h, h->qcount.reserve((size_t)nql * 4));
     HS_HIP(h, h->nslices.reserve(((size_t)nql + 1) * 4));
+    HS_HIP(h, h->probe_slow.reserve(((size_t)nql + 1) * 4));
     HS_HIP(h, h->slice_off.reserve(((size_t)nql + 1) * 4));
     HS_HIP(h, h->temp.reserve(hs_scan_u32_temp((size_t)nql + 1) + 256));
     HS_HIP(h, hs_launch_hash_points(d_centers, nq, k, h->a.as<double>(), h->b.as<double>(), h->LK,
@@ -478,7 +491,8 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, hs_launch_probe(h->tabs, h->qints.as<int32_t>(), nq, K, L, h->key_seed,
                               h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
                               h->nslices.as<uint32_t>(), d_cand,
-                              reinterpret_cast<unsigned long long*>(d_cnt + 2), h->stream));
+                              reinterpret_cast<unsigned long long*>(d_cnt + 2),
+                              h->probe_slow.as<uint32_t>(), h->stream));
   }
   // Bucket join (hs_join.hip) when fp16 can carry the data and a k-mer is one packed word; the
   // streaming kernel otherwise (and for brute force).  With the join on, segments (bucket x its
@@ -546,7 +560,8 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
       HS_HIP(h, hs_launch_probe(h->tabs, h->qints.as<int32_t>(), nq, K, L, h->key_seed,
                                 h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
                                 h->nslices.as<uint32_t>(), d_cand,
-                                reinterpret_cast<unsigned long long*>(d_cnt + 2), h->stream));
+                                reinterpret_cast<unsigned long long*>(d_cnt + 2),
+                              h->probe_slow.as<uint32_t>(), h->stream));
       HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, h->nslices.as<uint32_t>(),
                                       h->slice_off.as<uint32_t>(), (size_t)nql + 1, h->stream));
       n_slices = 1;

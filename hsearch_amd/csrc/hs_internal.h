@@ -140,9 +140,12 @@ hipError_t hs_launch_hash_points(const double* d_pts, uint64_t n, int k, const d
 // keys[i] = fingerprint(ints[i*stride .. +K)); ids[i] = i (if ids != null)
 hipError_t hs_launch_keys(const int32_t* d_ints, uint64_t n, int stride, int K, uint32_t seed,
                           uint64_t* d_keys, uint32_t* d_ids, hipStream_t s);
-// flag |= 1 if two sorted neighbours share a fingerprint but not a key string
+// flag |= 1 if two sorted neighbours share a fingerprint but not a key string; flag |= 2 if the
+// queue of non-identical neighbour tuples (d_slow: count + slow_cap positions) overflowed, in which
+// case the caller repeats the call with exhaustive = true (every neighbour pair compared as strings)
 hipError_t hs_launch_check_runs(const uint64_t* d_keys_sorted, const uint32_t* d_ids_sorted,
                                 const int32_t* d_ints, uint64_t n, int K, uint32_t* d_flag,
+                                uint32_t* d_slow, uint32_t slow_cap, bool exhaustive,
                                 hipStream_t s);
 hipError_t hs_launch_dir_tuples(const uint32_t* d_dir_start, const uint32_t* d_ids_sorted,
                                 const int32_t* d_ints, uint32_t nb, int K, int32_t* d_dir_tuple,
@@ -157,7 +160,7 @@ hipError_t hs_launch_max_u32(const uint32_t* d_in, uint32_t n, uint32_t* d_out, 
 hipError_t hs_launch_probe(const hs_tables_dev& tabs, const int32_t* d_qints, uint32_t nq, int K,
                            int L, uint32_t seed, uint32_t* d_qstart, uint32_t* d_qcount,
                            uint32_t* d_nslices, uint64_t* d_cand_out, unsigned long long* d_cand_total,
-                           hipStream_t s);
+                           uint32_t* d_slow /* [nq*L + 1] */, hipStream_t s);
 hipError_t hs_launch_qtables(const double* d_centers, uint32_t nq, int k, const double* d_coords,
                              int alphabet, float* d_tq, hipStream_t s);
 hipError_t hs_launch_verify(const hs_tables_dev& tabs, const uint32_t* d_qstart,

@@ -112,25 +112,54 @@ __global__ __launch_bounds__(256) void hs_keys_kernel(const int32_t* __restrict_
   if (ids) ids[i] = (uint32_t)i;
 }
 
+// Sorted neighbours with equal fingerprints must have equal key STRINGS.  Identical tuples (the
+// common case) are settled here without any scratch; neighbours whose tuples differ (aliased
+// strings or a fingerprint collision) are queued for hs_check_runs_slow_kernel.
+// slow[0] = queued count, slow[1..] = positions p.
 __global__ __launch_bounds__(256) void hs_check_runs_kernel(const uint64_t* __restrict__ keys,
                                                             const uint32_t* __restrict__ ids,
                                                             const int32_t* __restrict__ ints,
                                                             uint64_t n, int K,
-                                                            uint32_t* __restrict__ flag) {
+                                                            uint32_t* __restrict__ slow,
+                                                            uint32_t slow_cap) {
   const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x + 1;
   if (p >= n) return;
   if (keys[p] != keys[p - 1]) return;
-  int32_t x[HS_MAX_K], y[HS_MAX_K];
   const int32_t* px = ints + (uint64_t)ids[p] * K;
   const int32_t* py = ints + (uint64_t)ids[p - 1] * K;
   bool same = true;
-  for (int j = 0; j < K; ++j) {
-    x[j] = px[j];
-    y[j] = py[j];
-    same = same && (x[j] == y[j]);
-  }
+  for (int j = 0; j < K; ++j) same = same && (px[j] == py[j]);
   if (same) return;
-  if (!hs_key_equal(x, y, K)) atomicOr(flag, 1u);
+  const uint32_t at = atomicAdd(slow, 1u);
+  if (at < slow_cap) slow[1 + at] = (uint32_t)p;
+}
+
+// flag |= 1: a fingerprint collision (equal fingerprints, different key strings);
+// flag |= 2: more queued pairs than the queue holds (the caller then checks every pair).
+__global__ __launch_bounds__(256) void hs_check_runs_slow_kernel(const uint32_t* __restrict__ ids,
+                                                                 const int32_t* __restrict__ ints,
+                                                                 int K, const uint32_t* __restrict__ slow,
+                                                                 uint32_t slow_cap, uint64_t n_all,
+                                                                 const uint64_t* __restrict__ keys,
+                                                                 uint32_t* __restrict__ flag) {
+  // n_all != 0: exhaustive mode over every neighbour pair (queue overflow)
+  const uint64_t total = n_all ? n_all - 1 : min(slow[0], slow_cap);
+  if (!n_all && slow[0] > slow_cap) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(flag, 2u);
+    return;
+  }
+  for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (uint64_t)gridDim.x * 256) {
+    const uint64_t p = n_all ? t + 1 : slow[1 + t];
+    if (n_all && keys[p] != keys[p - 1]) continue;
+    int32_t x[HS_MAX_K], y[HS_MAX_K];
+    const int32_t* px = ints + (uint64_t)ids[p] * K;
+    const int32_t* py = ints + (uint64_t)ids[p - 1] * K;
+    for (int j = 0; j < K; ++j) {
+      x[j] = px[j];
+      y[j] = py[j];
+    }
+    if (!hs_key_equal(x, y, K)) atomicOr(flag, 1u);
+  }
 }
 
 __global__ __launch_bounds__(256) void hs_dir_tuples_kernel(const uint32_t* __restrict__ dir_start,
@@ -210,6 +239,9 @@ __device__ __forceinline__ int residue_x4(const uint4& p) {
 }
 
 // ------------------------------------------------------------------------------------------ probe
+// Fast path: fingerprint found and the bucket's stored tuple IDENTICAL to the query's (no scratch).
+// A found fingerprint with a different tuple (aliased key strings, or a fingerprint collision
+// between a query and a DB key) is queued: slow[0] = count, slow[1..] = ql.
 __global__ __launch_bounds__(256) void hs_probe_kernel(hs_tables_dev tabs,
                                                        const int32_t* __restrict__ qints,
                                                        uint32_t nq, int K, int L, uint32_t seed,
@@ -217,14 +249,16 @@ __global__ __launch_bounds__(256) void hs_probe_kernel(hs_tables_dev tabs,
                                                        uint32_t* __restrict__ qcount,
                                                        uint32_t* __restrict__ nslices,
                                                        uint64_t* __restrict__ cand_out,
-                                                       unsigned long long* __restrict__ cand_total) {
+                                                       unsigned long long* __restrict__ cand_total,
+                                                       uint32_t* __restrict__ slow) {
   const uint32_t ql = blockIdx.x * 256 + threadIdx.x;
   uint32_t count = 0, start = 0;
   if (ql < nq * (uint32_t)L) {
     const int l = (int)(ql % (uint32_t)L);
-    int32_t t[HS_MAX_K];
-    for (int j = 0; j < K; ++j) t[j] = qints[(uint64_t)ql * K + j];
-    const uint64_t key = hs_key_of(t, K, seed);
+    const int32_t* t = qints + (uint64_t)ql * K;
+    uint64_t hk = hs_key_init(seed);
+    for (int j = 0; j < K; ++j) hk = hs_key_put_int(hk, t[j]);
+    const uint64_t key = hs_key_fin(hk);
     const hs_table_dev& tb = tabs.t[l];
     uint32_t lo = 0, hi = tb.nb;
     while (lo < hi) {
@@ -232,11 +266,14 @@ __global__ __launch_bounds__(256) void hs_probe_kernel(hs_tables_dev tabs,
       if (tb.dir_key[mid] < key) lo = mid + 1; else hi = mid;
     }
     if (lo < tb.nb && tb.dir_key[lo] == key) {
-      int32_t u[HS_MAX_K];
-      for (int j = 0; j < K; ++j) u[j] = tb.dir_tuple[(uint64_t)lo * K + j];
-      if (hs_key_equal(t, u, K)) {  // HashKey string equality, lsh.hpp:51-59
+      const int32_t* u = tb.dir_tuple + (uint64_t)lo * K;
+      bool same = true;
+      for (int j = 0; j < K; ++j) same = same && (t[j] == u[j]);
+      if (same) {
         start = tb.dir_start[lo];
         count = tb.dir_start[lo + 1] - start;
+      } else {
+        slow[1 + atomicAdd(slow, 1u)] = ql;
       }
     }
     qstart[ql] = start;
@@ -249,6 +286,44 @@ __global__ __launch_bounds__(256) void hs_probe_kernel(hs_tables_dev tabs,
   if (lane_id() == 0 && c) atomicAdd(cand_total, c);
 }
 
+// Rare path: HashKey STRING equality (lsh.hpp:51-59) between the query's tuple and the tuple of
+// the bucket with the same fingerprint.
+__global__ __launch_bounds__(256) void hs_probe_slow_kernel(hs_tables_dev tabs,
+                                                            const int32_t* __restrict__ qints,
+                                                            int K, int L, uint32_t seed,
+                                                            uint32_t* __restrict__ qstart,
+                                                            uint32_t* __restrict__ qcount,
+                                                            uint32_t* __restrict__ nslices,
+                                                            uint64_t* __restrict__ cand_out,
+                                                            unsigned long long* __restrict__ cand_total,
+                                                            const uint32_t* __restrict__ slow) {
+  const uint32_t total = slow[0];
+  for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const uint32_t ql = slow[1 + e];
+    const int l = (int)(ql % (uint32_t)L);
+    int32_t t[HS_MAX_K], u[HS_MAX_K];
+    for (int j = 0; j < K; ++j) t[j] = qints[(uint64_t)ql * K + j];
+    const uint64_t key = hs_key_of(t, K, seed);
+    const hs_table_dev& tb = tabs.t[l];
+    uint32_t lo = 0, hi = tb.nb;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (tb.dir_key[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    if (lo < tb.nb && tb.dir_key[lo] == key) {
+      for (int j = 0; j < K; ++j) u[j] = tb.dir_tuple[(uint64_t)lo * K + j];
+      if (hs_key_equal(t, u, K)) {
+        const uint32_t start = tb.dir_start[lo], count = tb.dir_start[lo + 1] - start;
+        qstart[ql] = start;
+        qcount[ql] = count;
+        nslices[ql] = (count + HS_SLICE - 1) / HS_SLICE;
+        if (cand_out) cand_out[ql] = count;
+        atomicAdd(cand_total, (unsigned long long)count);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------- qtables
 // T[q][pos][aa] = sum_j (coord[aa][j] - c[q][8 pos + j])^2, fp64 then rounded to fp32.
 // Rows are HS_TROW floats so a wave reads one with a single coalesced 128-byte load.
@@ -256,22 +331,25 @@ __global__ __launch_bounds__(256) void hs_qtables_kernel(const double* __restric
                                                          uint32_t nq, int k,
                                                          const double* __restrict__ coords,
                                                          int alphabet, float* __restrict__ tq) {
-  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (uint64_t)nq * k * HS_TROW) return;
-  const int aa = (int)(t % HS_TROW);
-  const uint64_t qp = t / HS_TROW;  // q*k + pos
-  float v = 0.f;
-  if (aa < alphabet) {
-    const double* c = centers + qp * 8;
+  // lane aa keeps its residue's 8 coordinates in registers; each group of 32 lanes walks rows
+  // (q, pos) grid-stride: 8 broadcast loads of the centre's coordinates, one coalesced 128-B store
+  const int aa = threadIdx.x & (HS_TROW - 1);
+  double xc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) xc[j] = aa < alphabet ? coords[aa * 8 + j] : 0.0;
+  const uint64_t rows = (uint64_t)nq * k;
+  const uint64_t groups = (uint64_t)gridDim.x * (256 / HS_TROW);
+  for (uint64_t row = (uint64_t)blockIdx.x * (256 / HS_TROW) + (threadIdx.x / HS_TROW); row < rows;
+       row += groups) {
+    const double* c = centers + row * 8;
     double s = 0.0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const double r = coords[aa * 8 + j] - c[j];
+      const double r = xc[j] - c[j];
       s += r * r;
     }
-    v = (float)s;
+    tq[row * HS_TROW + aa] = aa < alphabet ? (float)s : 0.f;
   }
-  tq[t] = v;
 }
 
 // ----------------------------------------------------------------------------------------- verify
@@ -614,10 +692,20 @@ hipError_t hs_launch_keys(const int32_t* d_ints, uint64_t n, int stride, int K, 
 
 hipError_t hs_launch_check_runs(const uint64_t* d_keys_sorted, const uint32_t* d_ids_sorted,
                                 const int32_t* d_ints, uint64_t n, int K, uint32_t* d_flag,
+                                uint32_t* d_slow, uint32_t slow_cap, bool exhaustive,
                                 hipStream_t s) {
   if (n < 2) return hipSuccess;
+  if (exhaustive) {
+    hs_check_runs_slow_kernel<<<2048, 256, 0, s>>>(d_ids_sorted, d_ints, K, d_slow, slow_cap, n,
+                                                   d_keys_sorted, d_flag);
+    return hipGetLastError();
+  }
+  hipError_t e = hipMemsetAsync(d_slow, 0, 4, s);
+  if (e != hipSuccess) return e;
   hs_check_runs_kernel<<<blocks_for(n - 1), 256, 0, s>>>(d_keys_sorted, d_ids_sorted, d_ints, n, K,
-                                                         d_flag);
+                                                         d_slow, slow_cap);
+  hs_check_runs_slow_kernel<<<64, 256, 0, s>>>(d_ids_sorted, d_ints, K, d_slow, slow_cap, 0,
+                                               d_keys_sorted, d_flag);
   return hipGetLastError();
 }
 
@@ -661,19 +749,23 @@ hipError_t hs_launch_gather_packed(const uint4* d_packed_all, const uint32_t* d_
 hipError_t hs_launch_probe(const hs_tables_dev& tabs, const int32_t* d_qints, uint32_t nq, int K,
                            int L, uint32_t seed, uint32_t* d_qstart, uint32_t* d_qcount,
                            uint32_t* d_nslices, uint64_t* d_cand_out,
-                           unsigned long long* d_cand_total, hipStream_t s) {
+                           unsigned long long* d_cand_total, uint32_t* d_slow, hipStream_t s) {
   if (!nq) return hipSuccess;
+  hipError_t e = hipMemsetAsync(d_slow, 0, 4, s);
+  if (e != hipSuccess) return e;
   hs_probe_kernel<<<blocks_for((uint64_t)nq * L), 256, 0, s>>>(tabs, d_qints, nq, K, L, seed,
                                                                d_qstart, d_qcount, d_nslices,
-                                                               d_cand_out, d_cand_total);
+                                                               d_cand_out, d_cand_total, d_slow);
+  hs_probe_slow_kernel<<<64, 256, 0, s>>>(tabs, d_qints, K, L, seed, d_qstart, d_qcount, d_nslices,
+                                          d_cand_out, d_cand_total, d_slow);
   return hipGetLastError();
 }
 
 hipError_t hs_launch_qtables(const double* d_centers, uint32_t nq, int k, const double* d_coords,
                              int alphabet, float* d_tq, hipStream_t s) {
   if (!nq) return hipSuccess;
-  hs_qtables_kernel<<<blocks_for((uint64_t)nq * k * HS_TROW), 256, 0, s>>>(d_centers, nq, k,
-                                                                           d_coords, alphabet, d_tq);
+  const unsigned blocks = (unsigned)std::min<uint64_t>(blocks_for((uint64_t)nq * k * HS_TROW), 256u * 16u);
+  hs_qtables_kernel<<<blocks, 256, 0, s>>>(d_centers, nq, k, d_coords, alphabet, d_tq);
   return hipGetLastError();
 }
 
