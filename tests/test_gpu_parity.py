@@ -202,3 +202,29 @@ def test_edge_cases(oracle):
     _assert_hits_equal(eng.query(oracle.embed_codes(codes[:5]), R), want)
     assert len(want["q"]) == 200
     eng.close()
+
+
+def test_multi_batch_queries_and_rebuild(oracle):
+    """More queries than one internal batch (131072): batches must concatenate in the reference's
+    global order; and a handle can be re-indexed with another DB."""
+    k, K, L, W, R = 25, 4, 3, 120.0, 40.0
+    a, b = synth.make_planes(k, K, L, W, seed=12)
+    codes = synth.make_db(3000, k, seed=13)
+    nq = 140_000
+    centers, _ = synth.make_queries(codes, nq, seed=14)
+    eng = Engine(k, K, L, W, a, b)
+    eng.index_build(codes)
+    got = eng.query(centers, R)
+    ix = oracle.Index(a, b, W, oracle.embed_codes(codes))
+    want = ix.query(centers, R)
+    assert np.array_equal(got["cand"], want["cand"])
+    _assert_hits_equal(got, want)
+    assert len(want["q"]) > nq // 2 and want["q"].max() > 131072
+    # rebuild with a different, larger DB on the same handle
+    codes2 = synth.make_db(9000, k, seed=15)
+    info = eng.index_build(codes2)
+    assert info["n"] == 9000
+    c2, _ = synth.make_queries(codes2, 500, seed=16, jitter=0.2)
+    want2 = oracle.search(a, b, W, R, oracle.embed_codes(codes2), c2)
+    _assert_hits_equal(eng.query(c2, R), want2)
+    eng.close()
