@@ -24,7 +24,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-JOIN_K = 112.0  # GEMM depth of hs_join_kernel
+JOIN_K = 112.0     # GEMM depth of hs_join_kernel (fp16)
+JOIN_K_I8 = 128.0  # GEMM depth of hs_join8_kernel (int8)
+MFMA_I8_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md: I8 MFMA = 2x the BF16 rate per clock
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
 
 
@@ -44,7 +46,7 @@ def parse():
     ap.add_argument("--cpu-n", type=int, default=200_000, help="DB sample of the CPU baseline")
     ap.add_argument("--cpu-nq", type=int, default=200, help="query sample of the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--verify-mode", choices=["auto", "stream", "join"], default="auto")
+    ap.add_argument("--verify-mode", choices=["auto", "stream", "join", "join16"], default="auto")
     return ap.parse_args()
 
 
@@ -190,6 +192,7 @@ def main():
     launches = 0
     join_batches = 0
     join_ms = 0.0
+    join_i8 = 0
     jstat = (0, 0, 0)
     fence()
     t0 = time.perf_counter()
@@ -204,6 +207,7 @@ def main():
         join_batches += p["join_batches"]
         join_ms += p["ms_join"]
         jstat = (p["join_items"], p["join_pairs"], p["join_pairs_issued"])
+        join_i8 += p["join_i8_batches"]
         cand = p["candidates"]
         hits_local = nh
     fence()
@@ -236,14 +240,18 @@ def main():
             # x 4 coordinates + 8 extras + 4 pad) per (bucket member, probing query) pair:
             # 2*112 flop per pair (hsearch_amd/csrc/hs_join.hip).
             j_ms = join_ms / steps
-            flop = jstat[1] * 2.0 * JOIN_K          # real (member, query) pairs routed to the join
+            i8 = join_i8 > 0
+            jk = JOIN_K_I8 if i8 else JOIN_K
+            peak = MFMA_I8_PEAK_TOPS if i8 else MFMA_F16_PEAK_TFLOPS
+            flop = jstat[1] * 2.0 * jk          # real (member, query) pairs routed to the join
             tf = flop / (j_ms * 1e-3) / 1e12 if j_ms > 0 else 0.0
-            roofline = {"bound": "mfma", "kernel": "hs_join_kernel", "achieved": tf,
-                        "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": tf / MFMA_F16_PEAK_TFLOPS, "traffic": traffic,
+            roofline = {"bound": "mfma", "kernel": "hs_join8_kernel" if i8 else "hs_join_kernel",
+                        "mfma_dtype": "i8" if i8 else "f16", "gemm_depth": jk, "achieved": tf,
+                        "peak": peak, "unit": "TOP/s" if i8 else "TFLOP/s",
+                        "frac": tf / peak, "traffic": traffic,
                         "flop_per_step": flop, "pairs_per_step": jstat[1],
                         "pairs_issued_per_step": jstat[2], "work_items_per_step": jstat[0],
-                        "issued_tflops": (jstat[2] * 2.0 * JOIN_K / (j_ms * 1e-3) / 1e12) if j_ms > 0 else 0.0,
+                        "issued_tops": (jstat[2] * 2.0 * jk / (j_ms * 1e-3) / 1e12) if j_ms > 0 else 0.0,
                         "kernel_ms_per_step": j_ms, "streaming_kernel_ms_per_step": v_ms - j_ms,
                         "pairs_streamed_per_step": cand - jstat[1],
                         "launches_per_step": launches / steps,

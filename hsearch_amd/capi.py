@@ -39,7 +39,7 @@ class _Profile(C.Structure):
                 ("ms_total", C.c_double), ("candidates", C.c_uint64), ("provisional", C.c_uint64),
                 ("hits", C.c_uint64), ("verify_launches", C.c_uint64), ("join_batches", C.c_uint64),
                 ("ms_join", C.c_double), ("join_items", C.c_uint64), ("join_pairs", C.c_uint64),
-                ("join_pairs_issued", C.c_uint64)]
+                ("join_pairs_issued", C.c_uint64), ("join_i8_batches", C.c_uint64)]
 
 
 class _IndexInfo(C.Structure):
@@ -155,7 +155,7 @@ class Engine:
 
     def set_verify_mode(self, mode):
         """'auto' | 'stream' | 'join' -- which filter kernel runs in front of the exact decision."""
-        self._check(self._lib.hs_set_verify_mode(self._h, {"auto": 0, "stream": 1, "join": 2}[mode]))
+        self._check(self._lib.hs_set_verify_mode(self._h, {"auto": 0, "stream": 1, "join": 2, "join16": 3}[mode]))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -69,7 +69,8 @@ struct hs_handle {
   DevBuf qints, qstart, qcount, nslices, slice_off, tq, prov, hit_key, hit_val, hit_key2, hit_val2,
       counters, temp, io_centers, io_q, io_id, io_table, io_dist, io_cand, io_codes, io_misc;
   // bucket-join workspace
-  DevBuf c16s, item_desc, probe_slow;
+  DevBuf c16s, item_desc, probe_slow, jtab8;
+  bool join8_tables_ok = false;  // int8 can carry the coordinate table
   uint32_t join_min_q = 3, join_min_m = 16;  // segment routing thresholds (HS_JOIN_MIN_Q / _M)
   int join_blocks_per_cu = 2;                // resident workgroups of hs_join_kernel per CU
   DevBuf jtab, c16, seg_keys, seg_keys_sorted, seg_vals, sorted_ql, seg_key, seg_cnt, seg_qoff,
@@ -199,9 +200,19 @@ hs_status hs_create(const hs_params* params, const double* a, const double* b, c
   HS_HIP(h, hipMemcpyAsync(&unsafe, h->jtab.as<char>() + 640, 4, hipMemcpyDeviceToHost, h->stream));
   HS_HIP(h, hipStreamSynchronize(h->stream));
   h->join_tables_ok = (unsafe == 0);
+  // int8 table {x^ packed, |x1|^2, L1(x^)} x 32 at bytes 0..511, scale {s, s^2/2} at 512, flag at 640
+  HS_HIP(h, h->jtab8.reserve(1024));
+  HS_HIP(h, hipMemsetAsync(h->jtab8.p, 0, 1024, h->stream));
+  HS_HIP(h, hs_launch_jtables8(h->coords.as<double>(), h->alphabet, h->jtab8.p, h->jtab8.as<float>() + 128,
+                               reinterpret_cast<uint32_t*>(h->jtab8.as<char>() + 640), h->stream));
+  uint32_t unsafe8 = 1;
+  HS_HIP(h, hipMemcpyAsync(&unsafe8, h->jtab8.as<char>() + 640, 4, hipMemcpyDeviceToHost, h->stream));
+  HS_HIP(h, hipStreamSynchronize(h->stream));
+  h->join8_tables_ok = (unsafe8 == 0);
   if (const char* m = getenv("HS_VERIFY_MODE")) {
     if (!strcmp(m, "stream")) h->verify_mode = 1;
     if (!strcmp(m, "join")) h->verify_mode = 2;
+    if (!strcmp(m, "join16")) h->verify_mode = 3;
   }
   if (const char* m = getenv("HS_JOIN_MIN_Q")) h->join_min_q = (uint32_t)std::max(1, atoi(m));
   if (const char* m = getenv("HS_JOIN_MIN_M")) h->join_min_m = (uint32_t)std::max(1, atoi(m));
@@ -210,7 +221,7 @@ hs_status hs_create(const hs_params* params, const double* a, const double* b, c
 }
 
 hs_status hs_set_verify_mode(hs_handle* h, int mode) {
-  if (!h || mode < 0 || mode > 2) return HS_ERR_INVALID;
+  if (!h || mode < 0 || mode > 3) return HS_ERR_INVALID;
   h->verify_mode = mode;
   return HS_OK;
 }
@@ -226,7 +237,7 @@ void hs_destroy(hs_handle* h) {
                     &h->io_codes, &h->io_misc, &h->jtab, &h->c16, &h->seg_keys, &h->seg_keys_sorted,
                     &h->seg_vals, &h->sorted_ql, &h->seg_key, &h->seg_cnt, &h->seg_qoff,
                     &h->seg_items, &h->item_off, &h->seg_n, &h->c16s, &h->item_desc,
-                    &h->probe_slow};
+                    &h->probe_slow, &h->jtab8};
   for (DevBuf* bf : bufs) bf->release();
   for (int l = 0; l < HS_MAX_L; ++l) {
     h->t_dirkey[l].release();
@@ -499,6 +510,8 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   // probing queries) with too few queries to fill MFMA columns still go to the streaming kernel:
   // both kernels append survivors to the same list in front of the same exact decision.
   bool use_join = !brute && h->verify_mode != 1 && h->join_tables_ok && k <= 25 && r2 < 30000.0;
+  // int8 form of the join filter (hs_join8.hip) unless forced to fp16 (mode 3) or not representable
+  bool use_i8 = use_join && h->join8_tables_ok && h->verify_mode != 3;
   uint32_t* d_unsafe = d_cnt + 8;
   unsigned long long* d_jstats = reinterpret_cast<unsigned long long*>(d_cnt + 10);
   uint32_t n_items = 0, n_slices = 1;
@@ -518,7 +531,11 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, h->seg_n.reserve(64));
     HS_HIP(h, h->temp.reserve(std::max(std::max(hs_sort_pairs_u64_u32_temp(nql), hs_rle_u64_temp(nql)),
                                        hs_scan_u32_temp(n1)) + 256));
-    HS_HIP(h, hs_launch_qprep(d_centers, nq, k, r2, h->c16.p, d_unsafe, h->stream));
+    if (use_i8)
+      HS_HIP(h, hs_launch_qprep8(d_centers, nq, k, r2, h->jtab8.as<float>() + 128, h->c16.p, d_unsafe,
+                                 h->stream));
+    else
+      HS_HIP(h, hs_launch_qprep(d_centers, nq, k, r2, h->c16.p, d_unsafe, h->stream));
     HS_HIP(h, hs_launch_seg_keys(h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(), nql, L,
                                  h->seg_keys.as<uint64_t>(), h->seg_vals.as<uint32_t>(), h->stream));
     HS_HIP(h, hs_sort_pairs_u64_u32(h->temp.p, h->temp.cap, h->seg_keys.as<uint64_t>(),
@@ -537,7 +554,10 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
                                   h->nslices.as<uint32_t>(), h->stream));
     HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, h->seg_items.as<uint32_t>(),
                                     h->item_off.as<uint32_t>(), n1, h->stream));
-    HS_HIP(h, hs_launch_gather_c16(h->c16.p, h->sorted_ql.as<uint32_t>(), nql, L, h->c16s.p, h->stream));
+    if (use_i8)
+      HS_HIP(h, hs_launch_gather_c8(h->c16.p, h->sorted_ql.as<uint32_t>(), nql, L, h->c16s.p, h->stream));
+    else
+      HS_HIP(h, hs_launch_gather_c16(h->c16.p, h->sorted_ql.as<uint32_t>(), nql, L, h->c16s.p, h->stream));
   }
   if (!brute) {
     HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, h->nslices.as<uint32_t>(),
@@ -552,6 +572,15 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, hipMemcpyAsync(&n_slices, h->slice_off.as<uint32_t>() + nql, 4, hipMemcpyDeviceToHost,
                              h->stream));
     HS_HIP(h, hipStreamSynchronize(h->stream));
+    if (use_i8 && unsafe) {
+      // a query int8 cannot carry: redo the query rows in fp16 (segments and items are shared)
+      use_i8 = false;
+      HS_HIP(h, hipMemsetAsync(d_unsafe, 0, 4, h->stream));
+      HS_HIP(h, hs_launch_qprep(d_centers, nq, k, r2, h->c16.p, d_unsafe, h->stream));
+      HS_HIP(h, hs_launch_gather_c16(h->c16.p, h->sorted_ql.as<uint32_t>(), nql, L, h->c16s.p, h->stream));
+      HS_HIP(h, hipMemcpyAsync(&unsafe, d_unsafe, 4, hipMemcpyDeviceToHost, h->stream));
+      HS_HIP(h, hipStreamSynchronize(h->stream));
+    }
     if (use_join && unsafe) {
       // a query fp16 cannot carry: this batch streams entirely (re-derive the slice counts)
       use_join = false;
@@ -596,7 +625,12 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
                                      nq, k, r2_hi, d_cnt, prov_cap, h->prov.as<uint2>(), nullptr,
                                      nullptr, n_blocks, h->stream));
     } else {
-      if (n_items)
+      if (n_items && use_i8)
+        HS_HIP(h, hs_launch_join8(h->item_desc.as<uint4>(), n_items, h->tabs.t[0].packed,
+                                  h->sorted_ql.as<uint32_t>(), h->c16s.p, h->jtab8.p,
+                                  h->jtab8.as<float>() + 128, k, d_cnt, prov_cap, h->prov.as<uint2>(),
+                                  h->n_cu * h->join_blocks_per_cu, h->stream));
+      else if (n_items)
         HS_HIP(h, hs_launch_join(h->item_desc.as<uint4>(), n_items, h->tabs.t[0].packed,
                                  h->sorted_ql.as<uint32_t>(),
                                  h->c16s.p, h->jtab.p,
@@ -645,6 +679,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   h->prof.candidates += brute ? (uint64_t)nq * h->n : cand_total;
   h->prof.provisional += host_cnt[0];
   h->prof.join_batches += n_items ? 1 : 0;
+  h->prof.join_i8_batches += (n_items && use_i8) ? 1 : 0;
   h->prof.ms_join += ms_join;
   h->prof.join_items += n_items;
   if (use_join) {

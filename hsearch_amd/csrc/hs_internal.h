@@ -207,6 +207,17 @@ hipError_t hs_launch_join(const uint4* d_desc, uint32_t n_items, const uint4* d_
                           const uint32_t* d_sorted_ql, const void* d_c16s, const void* d_tab16,
                           const float* d_rownorm, int k, uint32_t* d_prov_count, uint32_t prov_cap,
                           uint2* d_prov, int n_blocks, hipStream_t s);
+// int8 form of the join filter (hs_join8.hip)
+hipError_t hs_launch_jtables8(const double* d_coords, int alphabet, void* d_tab8, float* d_scale,
+                              uint32_t* d_unsafe, hipStream_t s);
+hipError_t hs_launch_qprep8(const double* d_centers, uint32_t nq, int k, double r2,
+                            const float* d_scale, void* d_c8, uint32_t* d_unsafe, hipStream_t s);
+hipError_t hs_launch_gather_c8(const void* d_c8, const uint32_t* d_sorted_ql, uint32_t nql, int L,
+                               void* d_out, hipStream_t s);
+hipError_t hs_launch_join8(const uint4* d_desc, uint32_t n_items, const uint4* d_packed_base,
+                           const uint32_t* d_sorted_ql, const void* d_c8s, const void* d_tab8,
+                           const float* d_scale, int k, uint32_t* d_prov_count, uint32_t prov_cap,
+                           uint2* d_prov, int n_blocks, hipStream_t s);
 hipError_t hs_launch_kth_min(const float* d_slice_min, uint32_t nq, uint32_t per_q, uint32_t topk,
                              float* d_thr, hipStream_t s);
 hipError_t hs_launch_topk_exact(const uint8_t* d_codes, const double* d_centers,

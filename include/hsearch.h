@@ -77,6 +77,7 @@ typedef struct hs_profile {
   uint64_t join_items;     /* (member tile, query group) work items of the join */
   uint64_t join_pairs;     /* (member, query) pairs routed to the join */
   uint64_t join_pairs_issued; /* MFMA rows x columns actually issued for them (padding included) */
+  uint64_t join_i8_batches;   /* of join_batches: those run by the int8 form (hs_join8_kernel) */
 } hs_profile;
 
 typedef struct hs_index_info {
@@ -101,9 +102,10 @@ HS_API void hs_destroy(hs_handle* h);
 HS_API const char* hs_last_error(const hs_handle* h);
 HS_API hs_status hs_get_profile(const hs_handle* h, hs_profile* out);
 /* Candidate-verification kernel: 0 = auto (bucket join when legal, else streaming), 1 = streaming
- * scan (hs_verify_kernel), 2 = MFMA bucket join (hs_join_kernel) wherever it is legal.  Both are
- * filters in front of the same exact fp64 decision, so results are identical; the environment
- * variable HS_VERIFY_MODE=stream|join sets the default of new handles. */
+ * scan (hs_verify_kernel), 2 = MFMA bucket join wherever it is legal (int8 hs_join8_kernel, else
+ * fp16 hs_join_kernel), 3 = the fp16 join only.  All are filters in front of the same exact fp64
+ * decision, so results are identical; the environment variable HS_VERIFY_MODE=stream|join|join16
+ * sets the default of new handles. */
 HS_API hs_status hs_set_verify_mode(hs_handle* h, int mode);
 HS_API const char* hs_version(void);
 

@@ -33,10 +33,13 @@ def test_config2_search_properties():
     info = eng.index_build(codes)
     assert info["n"] == n and sum(info["n_buckets"]) > 0
     res = {}
-    for mode in ("join", "stream"):
+    for mode in ("join", "join16", "stream"):
         eng.set_verify_mode(mode)
         res[mode] = eng.query(centers, R)
+        assert (eng.profile()["join_i8_batches"] > 0) == (mode == "join")
     j, s = res["join"], res["stream"]
+    for f in ("q", "id", "table", "dist"):
+        assert np.array_equal(res["join16"][f], s[f]), f
     # the two filter kernels are interchangeable: identical candidates, hits, order, distances
     assert np.array_equal(j["cand"], s["cand"])
     for f in ("q", "id", "table", "dist"):

@@ -56,7 +56,7 @@ def test_search_hits_match_oracle(oracle, k, K, L, W, R, n, nq):
     want = ix.query(centers, R)
     assert len(want["q"]) > 0
     # both filter kernels sit in front of the same exact decision: identical results
-    for mode in ("stream", "join", "auto"):
+    for mode in ("stream", "join", "join16", "auto"):
         eng.set_verify_mode(mode)
         got = eng.query(centers, R)
         assert np.array_equal(got["cand"], want["cand"]), mode
@@ -68,6 +68,8 @@ def test_search_hits_match_oracle(oracle, k, K, L, W, R, n, nq):
         elif W >= 50.0:
             assert prof["join_batches"] > 0      # the MFMA bucket join really ran
             assert 0 < prof["join_pairs"] <= prof["candidates"]
+            # "join"/"auto" = the int8 kernel, "join16" = the fp16 kernel
+            assert (prof["join_i8_batches"] > 0) == (mode != "join16")
     eng.close()
 
 
@@ -82,16 +84,23 @@ def test_join_with_many_queries_per_bucket(oracle):
     info = eng.index_build(codes)
     assert max(info["max_bucket"]) > 4000
     want = oracle.search(a, b, W, R, oracle.embed_codes(codes), centers)
-    for mode in ("join", "stream"):
+    for mode in ("join", "join16", "stream"):
         eng.set_verify_mode(mode)
         got = eng.query(centers, R)
         assert np.array_equal(got["cand"], want["cand"])
         _assert_hits_equal(got, want)
-    # far-away and huge-magnitude queries: fp16 cannot carry them, the batch must fall back
+    # queries slightly outside the table's range: int8 cannot carry them, fp16 can
+    wide = centers[:64].copy()
+    wide[:8, ::8] += 9.0
+    eng.set_verify_mode("join")
+    got = eng.query(wide, R)
+    _assert_hits_equal(got, oracle.search(a, b, W, R, oracle.embed_codes(codes), wide))
+    prof = eng.profile()
+    assert prof["join_batches"] > 0 and prof["join_i8_batches"] == 0
+    # far-away and huge-magnitude queries: fp16 cannot carry them either, the batch must stream
     far = centers[:64].copy()
     far[:8] *= 40.0
     far[8:16] += 3.0e4
-    eng.set_verify_mode("join")
     got = eng.query(far, R)
     _assert_hits_equal(got, oracle.search(a, b, W, R, oracle.embed_codes(codes), far))
     assert eng.profile()["join_batches"] == 0
