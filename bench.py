@@ -133,7 +133,9 @@ def main():
     dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # HS_BENCH_FORCE_DIST=1: run the collective path even with one rank (RCCL rehearsal on one GPU)
+    use_dist = world > 1 or bool(os.environ.get("HS_BENCH_FORCE_DIST"))
+    if use_dist:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -178,11 +180,12 @@ def main():
                     raise
                 state["cap"] = int(e.needed * 1.25) + 1024
                 state["out"] = alloc(state["cap"])
-        gathered = hdist.allgather_hits(o["q"], o["id"], o["table"], o["dist"], nh, q_offset=q_lo)
+        gathered = hdist.allgather_hits(o["q"], o["id"], o["table"], o["dist"], nh, q_offset=q_lo,
+                                        force=use_dist)
         return nh, gathered
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -212,7 +215,7 @@ def main():
         hits_local = nh
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -300,7 +303,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args, a, b, codes, centers)
         print(json.dumps(line))
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

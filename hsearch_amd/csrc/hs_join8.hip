@@ -35,7 +35,8 @@ constexpr int QD = 4;        // table columns used
 constexpr int QROW = 128;    // bytes of a quantised query row (global)
 constexpr int QPIECES = 8;   // 16-byte pieces per row
 constexpr int QLROW = 144;   // LDS row stride in bytes (9 x 16: conflict-free b128)
-constexpr int JQ = 32;       // queries per chunk
+constexpr int JQ = 32;       // queries per MFMA column tile
+constexpr int JC = 64;       // queries per LDS chunk (one barrier): two column tiles
 constexpr int JT = 4;        // 32-member row tiles per wave
 constexpr int JM = 4 * JT * 32;  // must equal hs_join.hip's JM (work items are shared)
 constexpr uint32_t JRES = 64;
@@ -249,14 +250,14 @@ __global__ __launch_bounds__(256, 2) void hs_join8_kernel(
     const uint32_t* __restrict__ sorted_ql, const int8_t* __restrict__ c8s,
     const uint4* __restrict__ tab8, const float* __restrict__ scale, int k,
     uint32_t* __restrict__ prov_count, uint32_t prov_cap, uint2* __restrict__ prov) {
-  __shared__ __attribute__((aligned(16))) int8_t sB[2][JQ * QLROW];
+  __shared__ __attribute__((aligned(16))) int8_t sB[2][JC * QLROW];
   __shared__ uint4 sTab8[32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   if (tid < 32) sTab8[tid] = tab8[tid];
   const float s2half = scale[1];
   __syncthreads();
-  // one 16-byte piece of a chunk per thread: row = tid / 8, piece = tid % 8
+  // two 16-byte pieces of a chunk per thread: rows tid / 8 and 32 + tid / 8, piece tid % 8
   const int dst = (tid >> 3) * QLROW + (tid & 7) * 16;
   const int boff = r * QLROW + h * 16;  // B operand of k-step s: boff + 32 s (bytes)
   int buf = 0;
@@ -265,13 +266,15 @@ __global__ __launch_bounds__(256, 2) void hs_join8_kernel(
   uint32_t res_base = 0, res_used = JRES;
   if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_sleep(8);
   uint4 d0 = desc[2 * (uint64_t)item], d1 = desc[2 * (uint64_t)item + 1];
-  uint4 pk[JT], pre;
+  uint4 pk[JT], pre, pre2;
   {
     const uint4* packed = packed_base + (int64_t)(((uint64_t)d0.y << 32) | (uint64_t)d0.x);
     const uint32_t idx = d0.w * JM + wave * (32 * JT) + r;
 #pragma unroll
     for (int t = 0; t < JT; ++t) pk[t] = packed[min(idx + 32 * t, d0.z - 1)];
-    pre = reinterpret_cast<const uint4*>(c8s + (uint64_t)(d1.x + d1.y) * QROW)[tid];
+    const uint4* src = reinterpret_cast<const uint4*>(c8s + (uint64_t)(d1.x + d1.y) * QROW);
+    pre = src[tid];
+    pre2 = src[tid + 256];
   }
   while (true) {
     const uint32_t M = d0.z, mt = d0.w;
@@ -290,16 +293,19 @@ __global__ __launch_bounds__(256, 2) void hs_join8_kernel(
 #pragma unroll
       for (int t = 0; t < JT; ++t) build_afrags8(pk[t], h, k, sTab8, s2half, A[t]);
     }
-    for (uint32_t qc = q_begin; qc < q_end; qc += JQ) {
-      int8_t* tile = sB[buf];
-      *reinterpret_cast<uint4*>(&tile[dst]) = pre;
+    for (uint32_t qc0 = q_begin; qc0 < q_end; qc0 += JC) {
+      int8_t* tile0 = sB[buf];
+      *reinterpret_cast<uint4*>(&tile0[dst]) = pre;
+      *reinterpret_cast<uint4*>(&tile0[dst + JQ * QLROW]) = pre2;
       __syncthreads();
       {
-        const bool more = qc + JQ < q_end;
-        const uint64_t row = more ? (uint64_t)(qoff + qc + JQ) : (uint64_t)(nd1.x + nd1.y);
-        pre = reinterpret_cast<const uint4*>(c8s + row * QROW)[tid];
+        const bool more = qc0 + JC < q_end;
+        const uint64_t row = more ? (uint64_t)(qoff + qc0 + JC) : (uint64_t)(nd1.x + nd1.y);
+        const uint4* src = reinterpret_cast<const uint4*>(c8s + row * QROW);
+        pre = src[tid];
+        pre2 = src[tid + 256];
       }
-      if (qc == q_begin) {
+      if (qc0 == q_begin) {
         const uint4* packed = packed_base + (int64_t)(((uint64_t)nd0.y << 32) | (uint64_t)nd0.x);
         const uint32_t idx = nd0.w * JM + wave * (32 * JT) + r;
 #pragma unroll
@@ -307,6 +313,11 @@ __global__ __launch_bounds__(256, 2) void hs_join8_kernel(
       }
       buf ^= 1;
       if (!wave_on) continue;
+#pragma unroll 1
+      for (int half = 0; half < JC / JQ; ++half) {
+      const uint32_t qc = qc0 + (uint32_t)(half * JQ);
+      if (qc >= q_end) break;  // uniform: the second column tile of a ragged last chunk
+      const int8_t* tile = tile0 + half * JQ * QLROW;
       intx16 acc[JT];
 #pragma unroll
       for (int t = 0; t < JT; ++t)
@@ -376,6 +387,7 @@ __global__ __launch_bounds__(256, 2) void hs_join8_kernel(
             }
           }
         }
+      }
       }
     }
     if (!has_next) break;

@@ -18,7 +18,7 @@ def shard_bounds(n_total, rank, world):
     return lo, hi
 
 
-def allgather_hits(q, ids, table, distance, n_hits, q_offset=0, group=None):
+def allgather_hits(q, ids, table, distance, n_hits, q_offset=0, group=None, force=False):
     """All-gather hit tuples of every rank.
 
     q, ids, table: int32/uint32-like 1-D tensors (same device), distance: float64, only the first
@@ -36,7 +36,7 @@ def allgather_hits(q, ids, table, distance, n_hits, q_offset=0, group=None):
     ids = ids[:n_hits].to(torch.int64)
     table = table[:n_hits].to(torch.int64)
     distance = distance[:n_hits]
-    if world == 1:
+    if world == 1 and not (force and dist.is_initialized()):
         return q, ids, table, distance
     counts = torch.zeros(world, dtype=torch.int64, device=dev)
     mine = torch.tensor([n_hits], dtype=torch.int64, device=dev)
