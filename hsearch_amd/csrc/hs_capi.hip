@@ -61,8 +61,10 @@ struct hs_handle {
   uint64_t n = 0;
   uint32_t key_seed = 0;
   DevBuf codes, packed_all;
-  DevBuf t_dirkey[HS_MAX_L], t_dirstart[HS_MAX_L], t_dirtuple[HS_MAX_L], t_packed[HS_MAX_L],
-      t_ids[HS_MAX_L];
+  DevBuf t_dirkey[HS_MAX_L], t_dirstart[HS_MAX_L], t_dirtuple[HS_MAX_L], t_ids[HS_MAX_L];
+  // bucket-ordered packed copies of all tables in ONE allocation ([L][n][PW]), and the int8 join's
+  // per-entry records ([L][n], k <= 25 only) at the same entry offsets
+  DevBuf t_packed, t_rec8;
   hs_tables_dev tabs;
   hs_index_info info;
   // query workspace (grown on demand, reused across calls)
@@ -71,6 +73,7 @@ struct hs_handle {
   // bucket-join workspace
   DevBuf c16s, item_desc, probe_slow, jtab8;
   bool join8_tables_ok = false;  // int8 can carry the coordinate table
+  bool join8_wave = true;        // wave-independent int8 join (HS_JOIN8_VARIANT=lds selects the staged one)
   uint32_t join_min_q = 3, join_min_m = 16;  // segment routing thresholds (HS_JOIN_MIN_Q / _M)
   int join_blocks_per_cu = 2;                // resident workgroups of hs_join_kernel per CU
   DevBuf jtab, c16, seg_keys, seg_keys_sorted, seg_vals, sorted_ql, seg_key, seg_cnt, seg_qoff,
@@ -209,6 +212,7 @@ hs_status hs_create(const hs_params* params, const double* a, const double* b, c
   HS_HIP(h, hipMemcpyAsync(&unsafe8, h->jtab8.as<char>() + 640, 4, hipMemcpyDeviceToHost, h->stream));
   HS_HIP(h, hipStreamSynchronize(h->stream));
   h->join8_tables_ok = (unsafe8 == 0);
+  if (const char* m = getenv("HS_JOIN8_VARIANT")) h->join8_wave = strcmp(m, "lds") != 0;
   if (const char* m = getenv("HS_VERIFY_MODE")) {
     if (!strcmp(m, "stream")) h->verify_mode = 1;
     if (!strcmp(m, "join")) h->verify_mode = 2;
@@ -237,13 +241,12 @@ void hs_destroy(hs_handle* h) {
                     &h->io_codes, &h->io_misc, &h->jtab, &h->c16, &h->seg_keys, &h->seg_keys_sorted,
                     &h->seg_vals, &h->sorted_ql, &h->seg_key, &h->seg_cnt, &h->seg_qoff,
                     &h->seg_items, &h->item_off, &h->seg_n, &h->c16s, &h->item_desc,
-                    &h->probe_slow, &h->jtab8};
+                    &h->probe_slow, &h->jtab8, &h->t_packed, &h->t_rec8};
   for (DevBuf* bf : bufs) bf->release();
   for (int l = 0; l < HS_MAX_L; ++l) {
     h->t_dirkey[l].release();
     h->t_dirstart[l].release();
     h->t_dirtuple[l].release();
-    h->t_packed[l].release();
     h->t_ids[l].release();
   }
   if (h->ev_ok)
@@ -338,9 +341,12 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
   HS_HIP(h, sort_temp.reserve(temp_bytes));
   uint32_t* d_small = small.as<uint32_t>();
   double ms_hash = 0, ms_sort = 0, ms_gather = 0;
+  const bool with_rec8 = h->join8_tables_ok && PW == 1;
+  HS_HIP(h, h->t_packed.reserve(std::max<size_t>(16, (size_t)L * n * PW * 16)));
+  if (with_rec8) HS_HIP(h, h->t_rec8.reserve(std::max<size_t>(16, (size_t)L * n * 16)));
   for (int l = 0; l < L; ++l) {
+    uint4* const tab_packed = h->t_packed.as<uint4>() + (size_t)l * n * PW;
     HS_HIP(h, h->t_ids[l].reserve(std::max<size_t>(16, (size_t)n * 4)));
-    HS_HIP(h, h->t_packed[l].reserve(std::max<size_t>(16, (size_t)n * PW * 16)));
     HS_HIP(h, hipMemsetAsync(d_small, 0, 64, h->stream));
     HS_HIP(h, hipEventRecord(h->ev[0], h->stream));
     HS_HIP(h, hs_launch_hash_codes(h->codes.as<uint8_t>(), n, k, h->a.as<double>() + (size_t)l * K * d,
@@ -395,8 +401,13 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
                                    ints.as<int32_t>(), nb, K, h->t_dirtuple[l].as<int32_t>(),
                                    h->stream));
     HS_HIP(h, hipEventRecord(h->ev[2], h->stream));
-    HS_HIP(h, hs_launch_gather_packed(h->packed_all.as<uint4>(), h->t_ids[l].as<uint32_t>(), n, PW,
-                                      h->t_packed[l].as<uint4>(), h->stream));
+    if (with_rec8)
+      HS_HIP(h, hs_launch_gather_rec8(h->packed_all.as<uint4>(), h->t_ids[l].as<uint32_t>(), (uint32_t)n,
+                                      k, h->jtab8.p, h->jtab8.as<float>() + 128, tab_packed,
+                                      h->t_rec8.as<uint4>() + (size_t)l * n, h->stream));
+    else
+      HS_HIP(h, hs_launch_gather_packed(h->packed_all.as<uint4>(), h->t_ids[l].as<uint32_t>(), n, PW,
+                                        tab_packed, h->stream));
     HS_HIP(h, hipEventRecord(h->ev[3], h->stream));
     HS_HIP(h, hipMemcpyAsync(&max_count, d_small + 2, 4, hipMemcpyDeviceToHost, h->stream));
     HS_HIP(h, hipStreamSynchronize(h->stream));
@@ -407,7 +418,7 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
     tb.dir_key = h->t_dirkey[l].as<uint64_t>();
     tb.dir_start = h->t_dirstart[l].as<uint32_t>();
     tb.dir_tuple = h->t_dirtuple[l].as<int32_t>();
-    tb.packed = h->t_packed[l].as<uint4>();
+    tb.packed = tab_packed;
     tb.ids = h->t_ids[l].as<uint32_t>();
     tb.nb = nb;
     h->info.n_buckets[l] = nb;
@@ -457,10 +468,9 @@ hs_status hs_index_build(hs_handle* h, const uint8_t* codes, uint64_t n) {
   h->prof.ms_total = ev_ms(h, 8, 9);
   h->info.n = n;
   h->info.key_seed = seed;
-  uint64_t bytes = h->codes.cap + h->packed_all.cap;
+  uint64_t bytes = h->codes.cap + h->packed_all.cap + h->t_packed.cap + h->t_rec8.cap;
   for (uint32_t l = 0; l < h->p.L; ++l)
-    bytes += h->t_dirkey[l].cap + h->t_dirstart[l].cap + h->t_dirtuple[l].cap + h->t_packed[l].cap +
-             h->t_ids[l].cap;
+    bytes += h->t_dirkey[l].cap + h->t_dirstart[l].cap + h->t_dirtuple[l].cap + h->t_ids[l].cap;
   h->info.device_bytes = bytes;
   h->built = true;
   return HS_OK;
@@ -514,7 +524,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   bool use_i8 = use_join && h->join8_tables_ok && h->verify_mode != 3;
   uint32_t* d_unsafe = d_cnt + 8;
   unsigned long long* d_jstats = reinterpret_cast<unsigned long long*>(d_cnt + 10);
-  uint32_t n_items = 0, n_slices = 1;
+  uint32_t n_items = 0, n_slices = 1, jm = HS_JM_BLOCK;
   if (use_join) {
     const size_t n1 = (size_t)nql + 1;
     HS_HIP(h, h->c16.reserve((size_t)nq * 208 * 2));
@@ -547,15 +557,21 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
                          h->seg_n.as<uint32_t>(), nql, h->stream));
     HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, h->seg_cnt.as<uint32_t>(),
                                     h->seg_qoff.as<uint32_t>(), n1, h->stream));
+    // work items: one wave's 128 members for the wave-independent int8 join, 512 otherwise
+    jm = (use_i8 && h->join8_wave) ? HS_JM_WAVE : HS_JM_BLOCK;
     HS_HIP(h, hs_launch_seg_route(h->seg_key.as<uint64_t>(), h->seg_cnt.as<uint32_t>(),
                                   h->seg_qoff.as<uint32_t>(), h->seg_n.as<uint32_t>(),
                                   h->sorted_ql.as<uint32_t>(), h->qcount.as<uint32_t>(), nql,
-                                  h->join_min_q, h->join_min_m, h->seg_items.as<uint32_t>(), d_jstats,
-                                  h->nslices.as<uint32_t>(), h->stream));
+                                  h->join_min_q, h->join_min_m, jm, h->seg_items.as<uint32_t>(),
+                                  d_jstats, h->nslices.as<uint32_t>(), h->stream));
     HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, h->seg_items.as<uint32_t>(),
                                     h->item_off.as<uint32_t>(), n1, h->stream));
     if (use_i8)
-      HS_HIP(h, hs_launch_gather_c8(h->c16.p, h->sorted_ql.as<uint32_t>(), nql, L, h->c16s.p, h->stream));
+      HS_HIP(h, (h->join8_wave ? hs_launch_gather_c8t(h->c16.p, h->sorted_ql.as<uint32_t>(),
+                                                     h->seg_qoff.as<uint32_t>(), nql, L, h->c16s.p,
+                                                     h->stream)
+                               : hs_launch_gather_c8(h->c16.p, h->sorted_ql.as<uint32_t>(), nql, L,
+                                                     h->c16s.p, h->stream)));
     else
       HS_HIP(h, hs_launch_gather_c16(h->c16.p, h->sorted_ql.as<uint32_t>(), nql, L, h->c16s.p, h->stream));
   }
@@ -579,6 +595,19 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
       HS_HIP(h, hs_launch_qprep(d_centers, nq, k, r2, h->c16.p, d_unsafe, h->stream));
       HS_HIP(h, hs_launch_gather_c16(h->c16.p, h->sorted_ql.as<uint32_t>(), nql, L, h->c16s.p, h->stream));
       HS_HIP(h, hipMemcpyAsync(&unsafe, d_unsafe, 4, hipMemcpyDeviceToHost, h->stream));
+      if (jm != HS_JM_BLOCK) {  // the fp16 kernel works on 512-member items: cut the segments again
+        jm = HS_JM_BLOCK;
+        HS_HIP(h, hipMemsetAsync(d_jstats, 0, 16, h->stream));
+        HS_HIP(h, hs_launch_seg_route(h->seg_key.as<uint64_t>(), h->seg_cnt.as<uint32_t>(),
+                                      h->seg_qoff.as<uint32_t>(), h->seg_n.as<uint32_t>(),
+                                      h->sorted_ql.as<uint32_t>(), h->qcount.as<uint32_t>(), nql,
+                                      h->join_min_q, h->join_min_m, jm, h->seg_items.as<uint32_t>(),
+                                      d_jstats, h->nslices.as<uint32_t>(), h->stream));
+        HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, h->seg_items.as<uint32_t>(),
+                                        h->item_off.as<uint32_t>(), (size_t)nql + 1, h->stream));
+        HS_HIP(h, hipMemcpyAsync(&n_items, h->item_off.as<uint32_t>() + nql, 4, hipMemcpyDeviceToHost,
+                                 h->stream));
+      }
       HS_HIP(h, hipStreamSynchronize(h->stream));
     }
     if (use_join && unsafe) {
@@ -599,7 +628,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
       HS_HIP(h, h->item_desc.reserve((size_t)n_items * 32));
       HS_HIP(h, hs_launch_item_desc(h->tabs, h->seg_key.as<uint64_t>(), h->seg_cnt.as<uint32_t>(),
                                     h->seg_qoff.as<uint32_t>(), h->item_off.as<uint32_t>(), nql,
-                                    h->sorted_ql.as<uint32_t>(), h->qcount.as<uint32_t>(), n_items,
+                                    h->sorted_ql.as<uint32_t>(), h->qcount.as<uint32_t>(), n_items, jm,
                                     h->item_desc.as<uint4>(), h->stream));
     }
   }
@@ -625,10 +654,15 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
                                      nq, k, r2_hi, d_cnt, prov_cap, h->prov.as<uint2>(), nullptr,
                                      nullptr, n_blocks, h->stream));
     } else {
-      if (n_items && use_i8)
+      if (n_items && use_i8 && h->join8_wave)
+        HS_HIP(h, hs_launch_join8w(h->item_desc.as<uint4>(), n_items, h->tabs.t[0].packed,
+                                   h->t_rec8.as<uint4>(), h->c16s.p, h->jtab8.p, d_cnt, prov_cap,
+                                   h->prov.as<uint2>(), d_cnt + 32, h->n_cu * h->join_blocks_per_cu,
+                                   h->stream));
+      else if (n_items && use_i8)
         HS_HIP(h, hs_launch_join8(h->item_desc.as<uint4>(), n_items, h->tabs.t[0].packed,
-                                  h->sorted_ql.as<uint32_t>(), h->c16s.p, h->jtab8.p,
-                                  h->jtab8.as<float>() + 128, k, d_cnt, prov_cap, h->prov.as<uint2>(),
+                                  h->t_rec8.as<uint4>(), h->sorted_ql.as<uint32_t>(), h->c16s.p,
+                                  h->jtab8.p, d_cnt, prov_cap, h->prov.as<uint2>(),
                                   h->n_cu * h->join_blocks_per_cu, h->stream));
       else if (n_items)
         HS_HIP(h, hs_launch_join(h->item_desc.as<uint4>(), n_items, h->tabs.t[0].packed,
@@ -651,8 +685,8 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     } else {
       HS_HIP(h, hs_launch_finalize(h->tabs, h->codes.as<uint8_t>(), d_centers, h->coords.as<double>(),
                                    h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
-                                   h->prov.as<uint2>(), d_cnt, prov_cap, k, L, r2,
-                                   h->sqrt_test ? R : (double)NAN, q_base, d_cnt + 1,
+                                   h->prov.as<uint2>(), d_cnt, prov_cap, h->sorted_ql.as<uint32_t>(),
+                                   k, L, r2, h->sqrt_test ? R : (double)NAN, q_base, d_cnt + 1,
                                    hit_cap, h->hit_key.as<uint64_t>(), h->hit_val.as<uint64_t>(),
                                    h->stream));
     }

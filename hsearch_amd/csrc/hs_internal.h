@@ -12,6 +12,9 @@
 #define HS_MAX_K 32
 #define HS_ALPHABET_PAD 32  // table rows addressable by a 5-bit residue code
 #define HS_TROW 32          // floats per row of a per-query distance table (20 used)
+// survivor entries {probe, entry position}: probe = q_local * L + table, or -- from the join
+// kernels -- HS_PROV_INDIRECT | position of the probe in segment order (index into sorted_ql)
+#define HS_PROV_INDIRECT 0x80000000u
 #define HS_SLICE 4096u      // candidates one wavefront scans per work item
 #define HS_KEY_CHARS (11 * HS_MAX_K + 1)
 
@@ -171,9 +174,9 @@ hipError_t hs_launch_finalize(const hs_tables_dev& tabs, const uint8_t* d_codes,
                               const double* d_centers, const double* d_coords,
                               const uint32_t* d_qstart, const uint32_t* d_qcount,
                               const uint2* d_prov, const uint32_t* d_prov_count, uint32_t prov_cap,
-                              int k, int L, double r2, double r_sqrt, uint32_t q_base,
-                              uint32_t* d_hit_count, uint32_t hit_cap, uint64_t* d_hit_key,
-                              uint64_t* d_hit_val, hipStream_t s);
+                              const uint32_t* d_sorted_ql, int k, int L, double r2, double r_sqrt,
+                              uint32_t q_base, uint32_t* d_hit_count, uint32_t hit_cap,
+                              uint64_t* d_hit_key, uint64_t* d_hit_val, hipStream_t s);
 hipError_t hs_launch_unpack_hits(const uint64_t* d_key, const uint64_t* d_val, uint32_t n,
                                  uint32_t* d_q, uint32_t* d_id, uint32_t* d_table, double* d_dist,
                                  hipStream_t s);
@@ -194,13 +197,17 @@ hipError_t hs_launch_seg_keys(const uint32_t* d_qstart, const uint32_t* d_qcount
 hipError_t hs_launch_seg_route(const uint64_t* d_seg_key, const uint32_t* d_seg_cnt,
                                const uint32_t* d_seg_qoff, const uint32_t* d_n_seg,
                                const uint32_t* d_sorted_ql, const uint32_t* d_qcount, uint32_t n_max,
-                               uint32_t min_q, uint32_t min_m, uint32_t* d_items,
+                               uint32_t min_q, uint32_t min_m, uint32_t jm, uint32_t* d_items,
                                unsigned long long* d_stats, uint32_t* d_nslices, hipStream_t s);
 hipError_t hs_launch_item_desc(const hs_tables_dev& tabs, const uint64_t* d_seg_key,
                                const uint32_t* d_seg_cnt,
                                const uint32_t* d_seg_qoff, const uint32_t* d_item_off, uint32_t n_max,
                                const uint32_t* d_sorted_ql, const uint32_t* d_qcount, uint32_t n_items,
-                               uint4* d_desc, hipStream_t s);
+                               uint32_t jm, uint4* d_desc, hipStream_t s);
+// members per work item: 512 (one workgroup tile) for the staged kernels, 128 (one wave) for the
+// wave-independent int8 join
+#define HS_JM_BLOCK 512u
+#define HS_JM_WAVE 128u
 hipError_t hs_launch_gather_c16(const void* d_c16, const uint32_t* d_sorted_ql, uint32_t nql, int L,
                                 void* d_out, hipStream_t s);
 hipError_t hs_launch_join(const uint4* d_desc, uint32_t n_items, const uint4* d_packed_base,
@@ -214,10 +221,21 @@ hipError_t hs_launch_qprep8(const double* d_centers, uint32_t nq, int k, double 
                             const float* d_scale, void* d_c8, uint32_t* d_unsafe, hipStream_t s);
 hipError_t hs_launch_gather_c8(const void* d_c8, const uint32_t* d_sorted_ql, uint32_t nql, int L,
                                void* d_out, hipStream_t s);
+hipError_t hs_launch_gather_c8t(const void* d_c8, const uint32_t* d_sorted_ql, const uint32_t* d_seg_qoff,
+                                uint32_t nql, int L, void* d_out, hipStream_t s);
+hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* d_packed_base,
+                            const uint4* d_rec_base, const void* d_c8t, const void* d_tab8,
+                            uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov,
+                            uint32_t* d_item_counter, int n_blocks, hipStream_t s);
 hipError_t hs_launch_join8(const uint4* d_desc, uint32_t n_items, const uint4* d_packed_base,
-                           const uint32_t* d_sorted_ql, const void* d_c8s, const void* d_tab8,
-                           const float* d_scale, int k, uint32_t* d_prov_count, uint32_t prov_cap,
+                           const uint4* d_rec_base, const uint32_t* d_sorted_ql, const void* d_c8s,
+                           const void* d_tab8, uint32_t* d_prov_count, uint32_t prov_cap,
                            uint2* d_prov, int n_blocks, hipStream_t s);
+// bucket-ordered packed copy of one table (k <= 25) + the per-entry 16-byte A-row tails of the
+// int8 join (d_out_rec[i] belongs to d_out_packed[i])
+hipError_t hs_launch_gather_rec8(const uint4* d_packed_all, const uint32_t* d_ids_sorted, uint32_t n,
+                                 int k, const void* d_tab8, const float* d_scale, uint4* d_out_packed,
+                                 uint4* d_out_rec, hipStream_t s);
 hipError_t hs_launch_kth_min(const float* d_slice_min, uint32_t nq, uint32_t per_q, uint32_t topk,
                              float* d_thr, hipStream_t s);
 hipError_t hs_launch_topk_exact(const uint8_t* d_codes, const double* d_centers,

@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256) void hs_seg_route_kernel(const uint64_t* __res
                                                            const uint32_t* __restrict__ sorted_ql,
                                                            const uint32_t* __restrict__ qcount,
                                                            uint32_t n_max, uint32_t min_q,
-                                                           uint32_t min_m, uint32_t* __restrict__ items,
+                                                           uint32_t min_m, uint32_t jm,
+                                                           uint32_t* __restrict__ items,
                                                            unsigned long long* __restrict__ stats) {
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
   if (j > n_max) return;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void hs_seg_route_kernel(const uint64_t* __res
     const uint32_t m = qcount[sorted_ql[seg_qoff[j]]];
     const uint32_t nq = seg_cnt[j];
     if (nq >= min_q && m >= min_m) {
-      it = ((m + JM - 1) / JM) * ((nq + JQG - 1) / JQG);
+      it = ((m + jm - 1) / jm) * ((nq + JQG - 1) / JQG);
       // MFMA pairs actually issued (128-row waves x 32-column chunks) vs real pairs
       atomicAdd(stats + 0, (unsigned long long)((m + 32 * JT - 1) / (32 * JT) * (32 * JT)) *
                                ((nq + JQ - 1) / JQ * JQ));
@@ -186,7 +187,8 @@ __global__ __launch_bounds__(256) void hs_item_desc_kernel(hs_tables_dev tabs,
                                                            uint32_t n_max,
                                                            const uint32_t* __restrict__ sorted_ql,
                                                            const uint32_t* __restrict__ qcount,
-                                                           uint32_t n_items, uint4* __restrict__ desc) {
+                                                           uint32_t n_items, uint32_t jm,
+                                                           uint4* __restrict__ desc) {
   const uint32_t item = blockIdx.x * 256 + threadIdx.x;
   if (item >= n_items) return;
   uint32_t lo = 0, hi = n_max;  // largest j with item_off[j] <= item (zero-item segments share
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256) void hs_item_desc_kernel(hs_tables_dev tabs,
   const uint64_t key = seg_key[seg];
   const uint32_t nQ = seg_cnt[seg], qoff = seg_qoff[seg];
   const uint32_t M = qcount[sorted_ql[qoff]];
-  const uint32_t tiles_m = (M + JM - 1) / JM;
+  const uint32_t tiles_m = (M + jm - 1) / jm;
   const uint32_t local = item - item_off[seg];
   const uint32_t mt = local % tiles_m, qg = local / tiles_m;
   const uint32_t q_begin = qg * JQG;
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void hs_join_kernel(
       for (int t = 1; t < JT; ++t) sany |= sg[t];
       if (__ballot((int)sany < 0)) {
         const bool col_ok = qc + (uint32_t)r < q_end;
-        const uint32_t ql = col_ok ? sorted_ql[qoff + qc + r] : 0u;
+        const uint32_t ql = HS_PROV_INDIRECT | (qoff + qc + (uint32_t)r);
 #pragma unroll
         for (int t = 0; t < JT; ++t) {
           uint32_t mask = 0;
@@ -484,11 +486,11 @@ hipError_t hs_launch_seg_keys(const uint32_t* d_qstart, const uint32_t* d_qcount
 hipError_t hs_launch_seg_route(const uint64_t* d_seg_key, const uint32_t* d_seg_cnt,
                                const uint32_t* d_seg_qoff, const uint32_t* d_n_seg,
                                const uint32_t* d_sorted_ql, const uint32_t* d_qcount, uint32_t n_max,
-                               uint32_t min_q, uint32_t min_m, uint32_t* d_items,
+                               uint32_t min_q, uint32_t min_m, uint32_t jm, uint32_t* d_items,
                                unsigned long long* d_stats, uint32_t* d_nslices, hipStream_t s) {
   hs_seg_route_kernel<<<blocks_for((uint64_t)n_max + 1), 256, 0, s>>>(
-      d_seg_key, d_seg_cnt, d_seg_qoff, d_n_seg, d_sorted_ql, d_qcount, n_max, min_q, min_m, d_items,
-      d_stats);
+      d_seg_key, d_seg_cnt, d_seg_qoff, d_n_seg, d_sorted_ql, d_qcount, n_max, min_q, min_m, jm,
+      d_items, d_stats);
   hs_seg_unslice_kernel<<<blocks_for(n_max), 256, 0, s>>>(d_seg_qoff, d_n_seg, d_items, d_sorted_ql,
                                                          n_max, d_nslices);
   return hipGetLastError();
@@ -498,10 +500,10 @@ hipError_t hs_launch_item_desc(const hs_tables_dev& tabs, const uint64_t* d_seg_
                                const uint32_t* d_seg_cnt,
                                const uint32_t* d_seg_qoff, const uint32_t* d_item_off, uint32_t n_max,
                                const uint32_t* d_sorted_ql, const uint32_t* d_qcount, uint32_t n_items,
-                               uint4* d_desc, hipStream_t s) {
+                               uint32_t jm, uint4* d_desc, hipStream_t s) {
   if (!n_items) return hipSuccess;
   hs_item_desc_kernel<<<blocks_for(n_items), 256, 0, s>>>(tabs, d_seg_key, d_seg_cnt, d_seg_qoff, d_item_off,
-                                                          n_max, d_sorted_ql, d_qcount, n_items, d_desc);
+                                                          n_max, d_sorted_ql, d_qcount, n_items, jm, d_desc);
   return hipGetLastError();
 }
 

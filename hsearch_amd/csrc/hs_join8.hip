@@ -17,10 +17,18 @@
 //
 // K layout (128 = 4 k-steps x 2 lane halves x 16 bytes): byte 4p + j = coordinate j of position p
 // for p < 25; the 28 bytes of positions 25..31 are spare and carry -rho and -gamma as products of
-// base-127 digits: slots 0..13: A = digits of rho, B = (-127 x13, -1); slots 14..27: A = (127 x13,
-// 1), B = digits of -gamma.  A value too large for 13 digits is clamped in the permissive direction
-// (the filter may only pass MORE); a gamma too negative to represent marks the batch unsafe.
+// base-127 digits: bytes 100..111: A = digits of rho (11 + remainder), B = (-127 x11, -1); bytes
+// 112..113 unused; bytes 114..127: A = (127 x13, 1), B = digits of -gamma.  A value too large for
+// its digits is clamped in the permissive direction (the filter may only pass MORE); a gamma too
+// negative to represent marks the batch unsafe.
+//
+// rho depends on the member only, so it is evaluated ONCE, at index build: hs_gather_rec8_kernel
+// writes, next to the bucket-ordered packed copy, a 16-byte record per entry = bytes 96..111 of the
+// member's A row (x^ of position 24, then the 12 rho slots).  The join kernel then builds a member's
+// A operand with 12 dword table lookups per lane and nothing else.
+#include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 
@@ -40,14 +48,16 @@ constexpr int JC = 64;       // queries per LDS chunk (one barrier): two column 
 constexpr int JT = 4;        // 32-member row tiles per wave
 constexpr int JM = 4 * JT * 32;  // must equal hs_join.hip's JM (work items are shared)
 constexpr uint32_t JRES = 64;
-constexpr int DIG = 13;      // base-127 digits (+1 remainder slot) per threshold term
-constexpr int DIGMAX = 127 * DIG;
+constexpr int DIG = 13;      // base-127 digits (+1 remainder slot) of -gamma
+constexpr int RDIG = 11;     // base-127 digits (+1 remainder slot) of rho
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
-// 14 signed int8 slots d[0..13] with 127 * (d0 + ... + d12) + d13 == v, or the closest value on
+// ND + 1 signed int8 slots with 127 * (d[0] + ... + d[ND-1]) + d[ND] == v, or the closest value on
 // the `permissive` side when v does not fit (lower for rho: the filter only gets more permissive).
-__device__ __forceinline__ void digits127(int v, int (&d)[DIG + 1], bool* overflow_high) {
+template <int ND>
+__device__ __forceinline__ void digits127(int v, int (&d)[ND + 1], bool* overflow_high) {
+  constexpr int DIGMAX = 127 * ND;
   // floor division by 127 for either sign
   int q = v / 127;
   int rem = v - q * 127;
@@ -65,12 +75,12 @@ __device__ __forceinline__ void digits127(int v, int (&d)[DIG + 1], bool* overfl
     rem = 0;
   }
 #pragma unroll
-  for (int j = 0; j < DIG; ++j) {
+  for (int j = 0; j < ND; ++j) {
     const int take = max(-127, min(127, q));
     d[j] = take;
     q -= take;
   }
-  d[DIG] = rem;
+  d[ND] = rem;
 }
 
 // ---------------------------------------------------------------------------------- tables
@@ -112,7 +122,8 @@ __global__ void hs_jtables8_kernel(const double* __restrict__ coords, int alphab
 
 // ---------------------------------------------------------------------------------- query prep
 // c8[q] (128 bytes): byte 4p + j = c^ of coordinate j (< 4) of position p (< min(k, 25)), zeros
-// up to byte 99; spare slots at bytes 100..127: (-127 x13, -1) then the digits of -gamma.
+// up to byte 99; spare slots: bytes 100..111 = (-127 x11, -1), 112..113 = 0, 114..127 = the digits
+// of -gamma.
 __global__ __launch_bounds__(256) void hs_qprep8_kernel(const double* __restrict__ centers, uint32_t nq,
                                                         int k, double r2, const float* __restrict__ scale,
                                                         int8_t* __restrict__ c8,
@@ -155,14 +166,15 @@ __global__ __launch_bounds__(256) void hs_qprep8_kernel(const double* __restrict
   const int v = bad ? 0 : -(int)g;
   // -gamma too LARGE for the digits would have to be clamped in the non-permissive direction
   bool too_high = false;
-  digits127(v, d, &too_high);
+  digits127<DIG>(v, d, &too_high);
   bad = bad || too_high;
   if (__ballot(bad) && lane == 0) atomicOr(unsafe, 1u);
   if (lane < 28) {
     int8_t b;
-    if (lane < DIG) b = (int8_t)-127;
-    else if (lane == DIG) b = (int8_t)-1;
-    else b = (int8_t)d[lane - (DIG + 1)];
+    if (lane < RDIG) b = (int8_t)-127;
+    else if (lane == RDIG) b = (int8_t)-1;
+    else if (lane < 14) b = 0;
+    else b = (int8_t)d[lane - 14];
     out[100 + lane] = b;
   }
 }
@@ -200,62 +212,96 @@ __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
 }
 
 // A operands (4 k-steps) of one 32-member row tile for lane (r, h): k-step s < 3 carries positions
-// 8s + 4h + {0,1,2,3}; k-step 3 carries position 24 and the spare slots.
-__device__ __forceinline__ void build_afrags8(const uint4 pk, int h, int k, const uint4* sTab8,
-                                              float s2half, intx4 (&A)[4]) {
+// 8s + 4h + {0,1,2,3} (positions >= k meet zero query bytes, so their rows need no masking);
+// k-step 3 = the entry's prebuilt record (h = 0) or the constant factors of the gamma slots (h = 1).
+__device__ __forceinline__ void build_afrags8(const uint4 pk, const uint4 rec, int h,
+                                              const uint32_t* sTab8, intx4 (&A)[4]) {
   // lanes of the upper half take positions 4..7, 12..15, ...: shift the word down by 20 bits
   const uint32_t sh = 20u * (uint32_t)h;
   const uint32_t x = __funnelshift_r(pk.x, pk.y, sh), y = __funnelshift_r(pk.y, pk.z, sh),
                  z = __funnelshift_r(pk.z, pk.w, sh), w = pk.w >> sh;
-  float nx = 0.f;
-  int l1 = 0;
-#define HS_A8(S, M)                                                                  \
-  {                                                                                  \
-    const uint4 row = sTab8[residue_at<40 * S + 5 * M>(x, y, z, w)];                 \
-    A[S][M] = (int)row.x;                                                            \
-    const bool real = 8 * S + 4 * h + M < k;                                         \
-    nx += real ? __uint_as_float(row.y) : 0.f;                                       \
-    l1 += real ? (int)row.z : 0;                                                     \
-  }
+#define HS_A8(S, M) A[S][M] = (int)sTab8[residue_at<40 * S + 5 * M>(x, y, z, w)];
   HS_A8(0, 0) HS_A8(0, 1) HS_A8(0, 2) HS_A8(0, 3)
   HS_A8(1, 0) HS_A8(1, 1) HS_A8(1, 2) HS_A8(1, 3)
   HS_A8(2, 0) HS_A8(2, 1) HS_A8(2, 2) HS_A8(2, 3)
 #undef HS_A8
-  const uint4 row24 = sTab8[(pk.w >> 24) & 31u];  // position 24 sits at bit 120 of the unshifted word
-  if (h == 0 && 24 < k) {
-    nx += __uint_as_float(row24.y);
-    l1 += (int)row24.z;
-  }
-  nx += __shfl_xor(nx, 32);
-  l1 += __shfl_xor(l1, 32);
-  const int dims = QD * min(k, 25);
-  const int rho = (int)floorf(s2half * nx - 0.5f * (float)l1 - 0.25f * (float)dims - 2.0f);
-  int d[DIG + 1];
-  digits127(rho, d, nullptr);  // too large -> clamped down: more permissive, never less
-  if (h == 0) {
-    A[3][0] = 24 < k ? (int)row24.x : 0;
-    A[3][1] = (int)pack4(d[0], d[1], d[2], d[3]);
-    A[3][2] = (int)pack4(d[4], d[5], d[6], d[7]);
-    A[3][3] = (int)pack4(d[8], d[9], d[10], d[11]);
-  } else {
-    A[3][0] = (int)pack4(d[12], d[13], 127, 127);
-    A[3][1] = (int)pack4(127, 127, 127, 127);
-    A[3][2] = (int)pack4(127, 127, 127, 127);
-    A[3][3] = (int)pack4(127, 127, 127, 1);
-  }
+  constexpr uint32_t C127 = 0x7f7f7f7fu;
+  A[3][0] = h ? 0x7f7f0000 : (int)rec.x;          // bytes 112, 113 unused; 114.. = 127
+  A[3][1] = h ? (int)C127 : (int)rec.y;
+  A[3][2] = h ? (int)C127 : (int)rec.z;
+  A[3][3] = h ? 0x017f7f7f : (int)rec.w;          // byte 127 = 1 (remainder slot of -gamma)
 }
+
+// index build: bucket-ordered packed copy of one table + the 16-byte A-row tail of every entry
+__global__ __launch_bounds__(256) void hs_gather_rec8_kernel(const uint4* __restrict__ packed_all,
+                                                             const uint32_t* __restrict__ ids,
+                                                             uint32_t n, int k,
+                                                             const uint4* __restrict__ tab8,
+                                                             const float* __restrict__ scale,
+                                                             uint4* __restrict__ out_packed,
+                                                             uint4* __restrict__ out_rec) {
+  __shared__ uint4 sTab[32];
+  if (threadIdx.x < 32) sTab[threadIdx.x] = tab8[threadIdx.x];
+  __syncthreads();
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  const uint4 pk = packed_all[ids[t]];
+  out_packed[t] = pk;
+  const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
+  const int kk = min(k, 25);
+  double nx = 0.0;
+  int l1 = 0;
+  uint32_t x24 = 0;
+#pragma unroll
+  for (int p = 0; p < 25; ++p) {
+    const int bit = 5 * p, wi = bit >> 5, sh = bit & 31;
+    uint32_t c = w[wi] >> sh;
+    if (sh > 27) c |= w[wi + 1] << (32 - sh);
+    const uint4 row = sTab[c & 31u];
+    if (p < kk) {
+      nx += (double)__uint_as_float(row.y);
+      l1 += (int)row.z;
+      if (p == 24) x24 = row.x;
+    }
+  }
+  // rho = floor(s^2 |x1|^2 / 2 - L1(x^)/2 - dims/4 - 2); the 2 absorbs the fp32 roundings of
+  // scale[1] and of the table's squared norms
+  const double rho = floor((double)scale[1] * nx - 0.5 * (double)l1 - 0.25 * (double)(QD * kk) - 2.0);
+  int d[RDIG + 1];
+  digits127<RDIG>((int)rho, d, nullptr);  // too large -> clamped down: more permissive, never less
+  out_rec[t] = make_uint4(x24, pack4(d[0], d[1], d[2], d[3]), pack4(d[4], d[5], d[6], d[7]),
+                          pack4(d[8], d[9], d[10], d[11]));
+}
+
+#ifdef HS_JOIN_TIMING
+// s_memtime ordered after the value `dep` exists (a scalar), so an interval really ends when the
+// work producing dep has completed
+__device__ __forceinline__ uint64_t memtime_after(uint32_t dep) {
+  uint64_t t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "s"(dep) : "memory");
+  return t;
+}
+#define HS_TD(i, dep) { const uint64_t now_ = memtime_after((uint32_t)(dep)); tacc[i] += now_ - tlast; tlast = now_; }
+#define HS_T(i) HS_TD(i, 0)
+__device__ unsigned long long g_join8_timing[8];
+#else
+#define HS_T(i)
+#define HS_TD(i, dep)
+#endif
 
 __global__ __launch_bounds__(256, 2) void hs_join8_kernel(
     const uint4* __restrict__ desc, uint32_t n_items, const uint4* __restrict__ packed_base,
-    const uint32_t* __restrict__ sorted_ql, const int8_t* __restrict__ c8s,
-    const uint4* __restrict__ tab8, const float* __restrict__ scale, int k,
-    uint32_t* __restrict__ prov_count, uint32_t prov_cap, uint2* __restrict__ prov) {
+    const uint4* __restrict__ rec_base, const uint32_t* __restrict__ sorted_ql,
+    const int8_t* __restrict__ c8s, const uint4* __restrict__ tab8,
+    uint32_t* __restrict__ prov_count, uint32_t prov_cap, uint2* __restrict__ prov, int ablate) {
   __shared__ __attribute__((aligned(16))) int8_t sB[2][JC * QLROW];
-  __shared__ uint4 sTab8[32];
+  __shared__ uint32_t sTab8[32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  if (tid < 32) sTab8[tid] = tab8[tid];
-  const float s2half = scale[1];
+#ifdef HS_JOIN_TIMING
+  uint64_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
+  if (tid < 32) sTab8[tid] = tab8[tid].x;
   __syncthreads();
   // two 16-byte pieces of a chunk per thread: rows tid / 8 and 32 + tid / 8, piece tid % 8
   const int dst = (tid >> 3) * QLROW + (tid & 7) * 16;
@@ -266,12 +312,18 @@ __global__ __launch_bounds__(256, 2) void hs_join8_kernel(
   uint32_t res_base = 0, res_used = JRES;
   if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_sleep(8);
   uint4 d0 = desc[2 * (uint64_t)item], d1 = desc[2 * (uint64_t)item + 1];
-  uint4 pk[JT], pre, pre2;
+  uint4 pk[JT], rk[JT], pre, pre2;
   {
-    const uint4* packed = packed_base + (int64_t)(((uint64_t)d0.y << 32) | (uint64_t)d0.x);
+    const int64_t off = (int64_t)(((uint64_t)d0.y << 32) | (uint64_t)d0.x);
+    const uint4* packed = packed_base + off;
+    const uint4* recs = rec_base + off;
     const uint32_t idx = d0.w * JM + wave * (32 * JT) + r;
 #pragma unroll
-    for (int t = 0; t < JT; ++t) pk[t] = packed[min(idx + 32 * t, d0.z - 1)];
+    for (int t = 0; t < JT; ++t) {
+      const uint32_t m = min(idx + 32 * t, d0.z - 1);
+      pk[t] = packed[m];
+      rk[t] = recs[m];
+    }
     const uint4* src = reinterpret_cast<const uint4*>(c8s + (uint64_t)(d1.x + d1.y) * QROW);
     pre = src[tid];
     pre2 = src[tid + 256];
@@ -291,13 +343,16 @@ __global__ __launch_bounds__(256, 2) void hs_join8_kernel(
     intx4 A[JT][4];
     if (wave_on) {
 #pragma unroll
-      for (int t = 0; t < JT; ++t) build_afrags8(pk[t], h, k, sTab8, s2half, A[t]);
+      for (int t = 0; t < JT; ++t) build_afrags8(pk[t], rk[t], h, sTab8, A[t]);
     }
+    HS_TD(0, __builtin_amdgcn_readfirstlane(A[0][0][0] ^ A[JT - 1][3][3] ^ A[JT - 1][2][0]))
     for (uint32_t qc0 = q_begin; qc0 < q_end; qc0 += JC) {
       int8_t* tile0 = sB[buf];
       *reinterpret_cast<uint4*>(&tile0[dst]) = pre;
       *reinterpret_cast<uint4*>(&tile0[dst + JQ * QLROW]) = pre2;
+      HS_TD(1, __builtin_amdgcn_readfirstlane(pre.x ^ pre2.x))
       __syncthreads();
+      HS_T(2)
       {
         const bool more = qc0 + JC < q_end;
         const uint64_t row = more ? (uint64_t)(qoff + qc0 + JC) : (uint64_t)(nd1.x + nd1.y);
@@ -306,12 +361,19 @@ __global__ __launch_bounds__(256, 2) void hs_join8_kernel(
         pre2 = src[tid + 256];
       }
       if (qc0 == q_begin) {
-        const uint4* packed = packed_base + (int64_t)(((uint64_t)nd0.y << 32) | (uint64_t)nd0.x);
+        const int64_t off = (int64_t)(((uint64_t)nd0.y << 32) | (uint64_t)nd0.x);
+        const uint4* packed = packed_base + off;
+        const uint4* recs = rec_base + off;
         const uint32_t idx = nd0.w * JM + wave * (32 * JT) + r;
 #pragma unroll
-        for (int t = 0; t < JT; ++t) pk[t] = packed[min(idx + 32 * t, nd0.z - 1)];
+        for (int t = 0; t < JT; ++t) {
+          const uint32_t m = min(idx + 32 * t, nd0.z - 1);
+          pk[t] = packed[m];
+          rk[t] = recs[m];
+        }
       }
       buf ^= 1;
+      HS_T(3)
       if (!wave_on) continue;
 #pragma unroll 1
       for (int half = 0; half < JC / JQ; ++half) {
@@ -350,9 +412,11 @@ __global__ __launch_bounds__(256, 2) void hs_join8_kernel(
                  (uint32_t)acc[t][4 * j + 3];
         sall &= (o[0] & o[1]) & (o[2] & o[3]);
       }
-      if (__ballot((int)sall >= 0)) {
+      const unsigned long long any_pass = __ballot((int)sall >= 0);
+      HS_TD(4, (uint32_t)any_pass ^ (uint32_t)(any_pass >> 32))
+      if (any_pass && !(ablate & 1)) {
         const bool col_ok = qc + (uint32_t)r < q_end;
-        const uint32_t ql = col_ok ? sorted_ql[qoff + qc + r] : 0u;
+        const uint32_t ql = HS_PROV_INDIRECT | (qoff + qc + (uint32_t)r);
 #pragma unroll
         for (int t = 0; t < JT; ++t) {
           uint32_t mask = 0;
@@ -388,6 +452,7 @@ __global__ __launch_bounds__(256, 2) void hs_join8_kernel(
           }
         }
       }
+      HS_T(5)
       }
     }
     if (!has_next) break;
@@ -395,6 +460,297 @@ __global__ __launch_bounds__(256, 2) void hs_join8_kernel(
     d0 = nd0;
     d1 = nd1;
   }
+  if (res_used < JRES && lane >= (int)res_used && res_base + lane < prov_cap)
+    prov[res_base + lane] = make_uint2(0xffffffffu, 0u);
+#ifdef HS_JOIN_TIMING
+  HS_T(6)
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_join8_timing[i], (unsigned long long)tacc[i]);
+#endif
+}
+
+
+// ------------------------------------------------------------------ wave-independent variant
+// Query rows in TILE-FRAGMENT order: the 32-query tile starting at segment-order row p0 (a multiple
+// of 32 inside its segment), nr = rows of the tile (32, less at the segment's ragged end), keeps
+// 16-byte piece g = 2 s + h of its row j at uint4 index p0 * 8 + g * nr + j: the B operand of
+// k-step s is then ONE fully coalesced 16-byte-per-lane load, straight into registers.
+__global__ __launch_bounds__(256) void hs_gather_c8t_kernel(const int8_t* __restrict__ c8,
+                                                            const uint32_t* __restrict__ sorted_ql,
+                                                            const uint32_t* __restrict__ seg_qoff,
+                                                            uint32_t nql, int L,
+                                                            uint4* __restrict__ out) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= nql) return;
+  uint32_t lo = 0, hi = nql + 1;  // largest j with seg_qoff[j] <= p (seg_qoff[nql] == nql > p)
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (seg_qoff[mid] <= p) lo = mid; else hi = mid;
+  }
+  const uint32_t qoff = seg_qoff[lo], nQ = seg_qoff[lo + 1] - qoff;
+  const uint32_t local = p - qoff, tile = local >> 5, j = local & 31u;
+  const uint32_t nr = min(32u, nQ - (tile << 5));
+  const uint32_t q = sorted_ql[p] / (uint32_t)L;
+  const uint4* src = reinterpret_cast<const uint4*>(c8 + (uint64_t)q * QROW);
+  uint4* dst = out + (uint64_t)(qoff + (tile << 5)) * QPIECES + j;
+#pragma unroll
+  for (int g = 0; g < QPIECES; ++g) dst[(uint32_t)g * nr] = src[g];
+}
+
+// No LDS staging and no workgroup barrier: a work item is 128 bucket members x <= 2048 probing
+// queries and belongs to ONE wave, which holds the members' A operands in registers and streams the
+// B tiles from L2 straight into registers (double-buffered, one tile ahead, across item
+// boundaries).  Waves take their first item by position and every further one from a global
+// counter (two items ahead, so the descriptor and the packed members are there in time): a stall
+// -- survivor bookkeeping, a late load -- costs that wave only, and no wave idles at the end.
+__device__ __forceinline__ void load_btile(intx4 (&B)[4], const uint4* __restrict__ c8t, uint32_t row0,
+                                           uint32_t nr, int lane) {
+  const uint4* base = c8t + (uint64_t)row0 * QPIECES;
+  if (nr == 32u) {  // full tile: piece (s, h) of row r sits at 64 s + lane
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const uint4 v = base[64 * s + lane];
+      B[s] = intx4{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+    }
+  } else {  // ragged last tile of a segment: nr rows, piece g of row j at g * nr + j
+    const uint32_t r = (uint32_t)lane & 31u, h = (uint32_t)lane >> 5;
+    const uint32_t j = min(r, nr - 1u) + h * nr;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const uint4 v = base[(uint32_t)(2 * s) * nr + j];
+      B[s] = intx4{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+    }
+  }
+}
+
+// Survivors of one accumulator group (GT row tiles of 32 members, first one T0) against the 32
+// queries of the tile at segment-relative offset qc: rows (i & 3) + 8 (i >> 2) + 4 h of tile t with
+// acc >= 0.  Rare path; slots of the survivor list are reserved 64 at a time per wave.
+template <int GT>
+__device__ __forceinline__ void emit_survivors(const intx16 (&acc)[GT], int T0, uint32_t qc,
+                                               uint32_t qoff, uint32_t q_end, uint32_t wbase,
+                                               uint32_t M, uint32_t mstart, int lane,
+                                               uint32_t& res_base, uint32_t& res_used,
+                                               uint32_t* __restrict__ prov_count, uint32_t prov_cap,
+                                               uint2* __restrict__ prov) {
+  const int r = lane & 31, h = lane >> 5;
+  const bool col_ok = qc + (uint32_t)r < q_end;
+  const uint32_t ql = HS_PROV_INDIRECT | (qoff + qc + (uint32_t)r);
+#pragma unroll
+  for (int t = 0; t < GT; ++t) {
+    uint32_t any = 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) any &= (uint32_t)acc[t][i];
+    if (!__ballot((int)any >= 0)) continue;  // no survivor in this row tile
+    uint32_t mask = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mask |= ((~(uint32_t)acc[t][i]) >> 31) << i;
+    if (!col_ok) mask = 0;
+    while (__ballot(mask != 0)) {
+      uint32_t idx = 0;
+      bool pass = false;
+      if (mask) {
+        const int i = __ffs((int)mask) - 1;
+        mask &= mask - 1;
+        idx = wbase + (uint32_t)((T0 + t) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h);
+        pass = idx < M;
+      }
+      const unsigned long long m = __ballot(pass);
+      if (m) {
+        const uint32_t cnt = (uint32_t)__popcll(m);
+        if (res_used + cnt > JRES) {
+          if (res_used < JRES && lane >= (int)res_used && res_base + lane < prov_cap)
+            prov[res_base + lane] = make_uint2(0xffffffffu, 0u);
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(prov_count, (uint32_t)JRES);
+          res_base = __builtin_amdgcn_readfirstlane(base);
+          res_used = 0;
+        }
+        if (pass) {
+          const uint32_t o = res_base + res_used + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          if (o < prov_cap) prov[o] = make_uint2(ql, mstart + idx);
+        }
+        res_used += cnt;
+      }
+    }
+  }
+}
+
+// sign bit of the result = AND of the sign bits of the 32 accumulators of a 2-tile group
+__device__ __forceinline__ uint32_t and_tree2(const intx16 (&acc)[2]) {
+  uint32_t a = 0xffffffffu;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) a = a & (uint32_t)acc[t][i] & (uint32_t)acc[t][i + 1];
+  return a;
+}
+
+// The wave's 4 row tiles form two accumulator groups X (tiles 0, 1) and Y (tiles 2, 3).  Per
+// query tile: 8 MFMAs into X while the sign test of Y (previous query tile) issues in their gaps,
+// then 8 MFMAs into Y beside the sign test of X -- the vector instructions of the epilogue never
+// stand between two MFMAs of the same wave.
+__global__ __launch_bounds__(256, 2) void hs_join8w_kernel(
+    const uint4* __restrict__ desc, uint32_t n_items, const uint4* __restrict__ packed_base,
+    const uint4* __restrict__ rec_base, const uint4* __restrict__ c8t,
+    const uint4* __restrict__ tab8, uint32_t* __restrict__ prov_count, uint32_t prov_cap,
+    uint2* __restrict__ prov, uint32_t* __restrict__ item_counter, uint32_t G) {
+  static_assert(JT == 4, "two accumulator groups of two row tiles");
+  __shared__ uint32_t sTab8[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  if (tid < 32) sTab8[tid] = tab8[tid].x;
+  __syncthreads();  // the only one: the table is read-only from here on
+  // Items come in chunks of G consecutive ones (same-address atomics are slow: one per chunk): the
+  // first chunk by position, every further one from the counter, requested a whole chunk ahead.
+  const uint32_t first_dynamic = gridDim.x * 4u * G;
+  uint32_t item = (blockIdx.x * 4u + (uint32_t)wave) * G;
+  if (item >= n_items) return;
+  uint32_t chunk_end = item + G;
+  uint32_t res_base = 0, res_used = JRES;
+  uint32_t next_chunk_v = 0;
+  if (lane == 0) next_chunk_v = atomicAdd(item_counter, G);
+  uint4 d0 = desc[2 * (uint64_t)item], d1 = desc[2 * (uint64_t)item + 1];
+  uint4 pk[JT], rk[JT];
+  intx4 Ba[4], Bb[4];
+#define HS_LOAD_MEMBERS(D0)                                                              \
+  {                                                                                      \
+    const int64_t off_ = (int64_t)(((uint64_t)(D0).y << 32) | (uint64_t)(D0).x);         \
+    const uint4* packed_ = packed_base + off_;                                           \
+    const uint4* recs_ = rec_base + off_;                                                \
+    const uint32_t idx_ = (D0).w * (32 * JT) + r;                                        \
+    _Pragma("unroll") for (int t = 0; t < JT; ++t) {                                     \
+      const uint32_t m_ = min(idx_ + 32 * t, (D0).z - 1);                                \
+      pk[t] = packed_[m_];                                                               \
+      rk[t] = recs_[m_];                                                                 \
+    }                                                                                    \
+  }
+  // Waves start an item's query tiles at a wave-dependent pair and wrap around: resident waves
+  // work on neighbouring items of the same (bucket, query group); walking the tiles in lock step
+  // would make every tile a simultaneous first touch.
+  const uint32_t skew = (blockIdx.x * 4u + (uint32_t)wave) * 7u;
+#define HS_FIRST_Q(D1) ((D1).y + 64u * (skew % (((D1).z - (D1).y + 63u) >> 6)))
+  // Every B prefetch below is UNCONDITIONAL (a tile that does not exist is replaced by a harmless
+  // valid one): the vector-memory counter is waited on by count, in issue order, so the number of
+  // loads in flight at each wait must not depend on the path taken.
+#define HS_LOAD_PAIR(ROW, Q0, QEND)                                                              \
+  {                                                                                              \
+    load_btile(Ba, c8t, (ROW) + (Q0), min(32u, (QEND) - (Q0)), lane);                            \
+    const uint32_t q1_ = (Q0) + 32u < (QEND) ? (Q0) + 32u : (Q0);                                \
+    load_btile(Bb, c8t, (ROW) + q1_, min(32u, (QEND) - q1_), lane);                              \
+  }
+  HS_LOAD_MEMBERS(d0)
+  {
+    const uint32_t q0 = HS_FIRST_Q(d1);
+    HS_LOAD_PAIR(d1.x, q0, d1.z)
+  }
+  while (true) {
+    const uint32_t M = d0.z, mt = d0.w;
+    const uint32_t qoff = d1.x, q_begin = d1.y, q_end = d1.z, mstart = d1.w;
+    const uint32_t wbase = mt * (32 * JT);
+    uint32_t next_item = item + 1;
+    if (next_item == chunk_end) {
+      next_item = first_dynamic + __builtin_amdgcn_readfirstlane(next_chunk_v);
+      chunk_end = next_item + G;
+      if (lane == 0 && next_item < n_items) next_chunk_v = atomicAdd(item_counter, G);
+    }
+    const bool has_next = next_item < n_items;
+    uint4 nd0 = d0, nd1 = d1;
+    if (has_next) {
+      nd0 = desc[2 * (uint64_t)next_item];
+      nd1 = desc[2 * (uint64_t)next_item + 1];
+    }
+    intx4 A[JT][4];
+#pragma unroll
+    for (int t = 0; t < JT; ++t) build_afrags8(pk[t], rk[t], h, sTab8, A[t]);
+    HS_LOAD_MEMBERS(nd0)
+    intx16 accX[2], accY[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) accY[t][i] = -1;  // "no survivor" for the first tile's Y test
+    uint32_t prev_qc = q_begin;
+    const uint32_t n_pairs = (q_end - q_begin + 63u) >> 6;
+    uint32_t qc0 = HS_FIRST_Q(d1);
+    // one pair of query tiles (the second may not exist); the first pair of an item is a copy of
+    // its own, outside the loop, because the member loads just issued change the load counts
+    auto do_pair = [&](uint32_t pi) {
+      // the pair after this one: of this item (wrapping around), or the next item's first
+      uint32_t nrow = qoff, nq0 = qc0 + 64u, nqend = q_end;
+      if (nq0 >= q_end) nq0 = q_begin;
+      if (pi + 1 == n_pairs) {
+        nrow = nd1.x;
+        nq0 = HS_FIRST_Q(nd1);
+        nqend = nd1.z;
+      }
+      const uint32_t nq1 = nq0 + 32u < nqend ? nq0 + 32u : nq0;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const uint32_t qc = qc0 + 32u * (uint32_t)half;
+        intx4 (&B)[4] = half ? Bb : Ba;
+        if (half == 0 || qc < q_end) {
+          // ---- phase 1: X <- A[0..1] x B, beside the sign test of Y (previous query tile)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) accX[t][i] = 0;
+          const uint32_t sY = and_tree2(accY);
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+              accX[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[t][s], B[s], accX[t], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 8; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          }
+          if (__ballot((int)sY >= 0))
+            emit_survivors<2>(accY, 2, prev_qc, qoff, q_end, wbase, M, mstart, lane, res_base,
+                              res_used, prov_count, prov_cap, prov);
+          // ---- phase 2: Y <- A[2..3] x B, beside the sign test of X
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) accY[t][i] = 0;
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+              accY[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[2 + t][s], B[s], accY[t], 0, 0, 0);
+          const uint32_t sX = and_tree2(accX);
+#pragma unroll
+          for (int g = 0; g < 8; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          }
+          if (__ballot((int)sX >= 0))
+            emit_survivors<2>(accX, 0, qc, qoff, q_end, wbase, M, mstart, lane, res_base, res_used,
+                              prov_count, prov_cap, prov);
+          prev_qc = qc;
+        }
+        // the same-numbered tile of the next pair into the registers just consumed
+        const uint32_t nb = half ? nq1 : nq0;
+        load_btile(B, c8t, nrow + nb, min(32u, nqend - nb), lane);
+      }
+      qc0 = nq0;
+    };
+    do_pair(0);
+    for (uint32_t pi = 1; pi < n_pairs; ++pi) do_pair(pi);
+    {  // the item's last Y group
+      const uint32_t sY = and_tree2(accY);
+      if (__ballot((int)sY >= 0))
+        emit_survivors<2>(accY, 2, prev_qc, qoff, q_end, wbase, M, mstart, lane, res_base, res_used,
+                          prov_count, prov_cap, prov);
+    }
+    if (!has_next) break;
+    item = next_item;
+    d0 = nd0;
+    d1 = nd1;
+  }
+#undef HS_LOAD_PAIR
+#undef HS_LOAD_MEMBERS
+#undef HS_FIRST_Q
   if (res_used < JRES && lane >= (int)res_used && res_base + lane < prov_cap)
     prov[res_base + lane] = make_uint2(0xffffffffu, 0u);
 }
@@ -425,13 +781,59 @@ hipError_t hs_launch_gather_c8(const void* d_c8, const uint32_t* d_sorted_ql, ui
   return hipGetLastError();
 }
 
+hipError_t hs_launch_gather_c8t(const void* d_c8, const uint32_t* d_sorted_ql, const uint32_t* d_seg_qoff,
+                                uint32_t nql, int L, void* d_out, hipStream_t s) {
+  if (!nql) return hipSuccess;
+  hs_gather_c8t_kernel<<<blocks_for(nql), 256, 0, s>>>((const int8_t*)d_c8, d_sorted_ql, d_seg_qoff, nql,
+                                                       L, (uint4*)d_out);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* d_packed_base,
+                            const uint4* d_rec_base, const void* d_c8t, const void* d_tab8,
+                            uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov,
+                            uint32_t* d_item_counter, int n_blocks, hipStream_t s) {
+  if (!n_items) return hipSuccess;
+  hipError_t e = hipMemsetAsync(d_item_counter, 0, 4, s);
+  if (e != hipSuccess) return e;
+  // chunk size: 8 items per counter access when there is plenty of work, fewer for small launches
+  const uint32_t n_waves = (uint32_t)n_blocks * 4u;
+  const uint32_t G = std::max(1u, std::min(8u, n_items / (n_waves * 8u)));
+  hs_join8w_kernel<<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_rec_base,
+                                            (const uint4*)d_c8t, (const uint4*)d_tab8, d_prov_count,
+                                            prov_cap, d_prov, d_item_counter, G);
+  return hipGetLastError();
+}
+
 hipError_t hs_launch_join8(const uint4* d_desc, uint32_t n_items, const uint4* d_packed_base,
-                           const uint32_t* d_sorted_ql, const void* d_c8s, const void* d_tab8,
-                           const float* d_scale, int k, uint32_t* d_prov_count, uint32_t prov_cap,
+                           const uint4* d_rec_base, const uint32_t* d_sorted_ql, const void* d_c8s,
+                           const void* d_tab8, uint32_t* d_prov_count, uint32_t prov_cap,
                            uint2* d_prov, int n_blocks, hipStream_t s) {
   if (!n_items) return hipSuccess;
-  hs_join8_kernel<<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_sorted_ql,
-                                           (const int8_t*)d_c8s, (const uint4*)d_tab8, d_scale, k,
-                                           d_prov_count, prov_cap, d_prov);
+  hs_join8_kernel<<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_rec_base, d_sorted_ql,
+                                           (const int8_t*)d_c8s, (const uint4*)d_tab8,
+                                           d_prov_count, prov_cap, d_prov,
+                                           getenv("HS_ABLATE") ? atoi(getenv("HS_ABLATE")) : 0);
+#ifdef HS_JOIN_TIMING
+  {
+    unsigned long long t[8];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_join8_timing), sizeof(t));
+    fprintf(stderr, "join8 timing (wave-cycles): build %llu stage %llu barrier %llu prefetch %llu mfma %llu surv %llu tail %llu\n",
+            t[0], t[1], t[2], t[3], t[4], t[5], t[6]);
+    memset(t, 0, sizeof(t));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_join8_timing), t, sizeof(t));
+  }
+#endif
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_gather_rec8(const uint4* d_packed_all, const uint32_t* d_ids_sorted, uint32_t n,
+                                 int k, const void* d_tab8, const float* d_scale, uint4* d_out_packed,
+                                 uint4* d_out_rec, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hs_gather_rec8_kernel<<<blocks_for(n), 256, 0, s>>>(d_packed_all, d_ids_sorted, n, k,
+                                                      (const uint4*)d_tab8, d_scale, d_out_packed,
+                                                      d_out_rec);
   return hipGetLastError();
 }

@@ -552,7 +552,9 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
                                                           const uint32_t* __restrict__ qcount,
                                                           const uint2* __restrict__ prov,
                                                           const uint32_t* __restrict__ prov_count,
-                                                          uint32_t prov_cap, int k, int L, double r2,
+                                                          uint32_t prov_cap,
+                                                          const uint32_t* __restrict__ sorted_ql,
+                                                          int k, int L, double r2,
                                                           double r_sqrt, uint32_t q_base,
                                                           uint32_t* __restrict__ hit_count,
                                                           uint32_t hit_cap,
@@ -560,8 +562,11 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
                                                           uint64_t* __restrict__ hit_val) {
   const uint32_t n = min(*prov_count, prov_cap);
   for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
-    const uint32_t ql = prov[e].x, pos = prov[e].y;
+    uint32_t ql = prov[e].x;
+    const uint32_t pos = prov[e].y;
     if (ql == 0xffffffffu) continue;  // unused slot of a wave's reserved block (hs_join_kernel)
+    // the join kernels name the probe by its position in segment order (no load in their hot loop)
+    if (ql & HS_PROV_INDIRECT) ql = sorted_ql[ql & ~HS_PROV_INDIRECT];
     const uint32_t q = ql / (uint32_t)L;
     const int l = (int)(ql % (uint32_t)L);
     const uint32_t id = tabs.t[l].ids[pos];
@@ -810,11 +815,12 @@ hipError_t hs_launch_finalize(const hs_tables_dev& tabs, const uint8_t* d_codes,
                               const double* d_centers, const double* d_coords,
                               const uint32_t* d_qstart, const uint32_t* d_qcount,
                               const uint2* d_prov, const uint32_t* d_prov_count, uint32_t prov_cap,
-                              int k, int L, double r2, double r_sqrt, uint32_t q_base,
-                              uint32_t* d_hit_count, uint32_t hit_cap, uint64_t* d_hit_key,
-                              uint64_t* d_hit_val, hipStream_t s) {
+                              const uint32_t* d_sorted_ql, int k, int L, double r2, double r_sqrt,
+                              uint32_t q_base, uint32_t* d_hit_count, uint32_t hit_cap,
+                              uint64_t* d_hit_key, uint64_t* d_hit_val, hipStream_t s) {
   hs_finalize_kernel<<<1024, 256, 0, s>>>(tabs, d_codes, d_centers, d_coords, d_qstart, d_qcount,
-                                          d_prov, d_prov_count, prov_cap, k, L, r2, r_sqrt, q_base,
+                                          d_prov, d_prov_count, prov_cap, d_sorted_ql, k, L, r2,
+                                          r_sqrt, q_base,
                                           d_hit_count, hit_cap, d_hit_key, d_hit_val);
   return hipGetLastError();
 }
