@@ -99,6 +99,11 @@ hs_status fail(hs_handle* h, hs_status st, const std::string& msg) {
       return fail(h, e_ == hipErrorOutOfMemory ? HS_ERR_NOMEM : HS_ERR_HIP,                  \
                   std::string(#expr) + ": " + hipGetErrorString(e_));                        \
   } while (0)
+#define HS_CHECK(expr)                \
+  do {                                \
+    hs_status st_ = (expr);           \
+    if (st_ != HS_OK) return st_;     \
+  } while (0)
 
 float ev_ms(hs_handle* h, int i0, int i1) {
   float ms = 0.f;
@@ -315,6 +320,32 @@ hs_status hs_hash_points(hs_handle* h, const double* points, uint64_t n, int32_t
   HS_HIP(h, hipStreamSynchronize(h->stream));
   memset(&h->prof, 0, sizeof(h->prof));
   h->prof.ms_hash = h->prof.ms_total = ev_ms(h, 0, 1);
+  return HS_OK;
+}
+
+// Segments -> work items of jm members x <= 2048 queries: routing (join or streaming), the item
+// numbering order (many-query segments first), item offsets.  Workspace reuse: seg_keys = flags and
+// their scan, seg_vals = order, seg_keys_sorted = item counts in that order (all free by now).
+static hs_status cut_items(hs_handle* h, uint32_t nql, uint32_t jm, unsigned long long* d_jstats) {
+  const size_t n1 = (size_t)nql + 1;
+  uint32_t* big = h->seg_keys.as<uint32_t>();
+  uint32_t* big_pos = big + n1;
+  uint32_t* order = h->seg_vals.as<uint32_t>();
+  uint32_t* items_ord = h->seg_keys_sorted.as<uint32_t>();
+  HS_HIP(h, hs_launch_seg_route(h->seg_key.as<uint64_t>(), h->seg_cnt.as<uint32_t>(),
+                                h->seg_qoff.as<uint32_t>(), h->seg_n.as<uint32_t>(),
+                                h->sorted_ql.as<uint32_t>(), h->qcount.as<uint32_t>(), nql,
+                                h->join_min_q, h->join_min_m, jm, h->seg_items.as<uint32_t>(),
+                                d_jstats, h->nslices.as<uint32_t>(), h->stream));
+  HS_HIP(h, hipMemsetAsync(big + nql, 0, 4, h->stream));
+  HS_HIP(h, hipMemsetAsync(items_ord + nql, 0, 4, h->stream));
+  HS_HIP(h, hs_launch_seg_big(h->seg_cnt.as<uint32_t>(), h->seg_items.as<uint32_t>(), nql, 512u, big,
+                              h->stream));
+  HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, big, big_pos, n1, h->stream));
+  HS_HIP(h, hs_launch_seg_order(big_pos, h->seg_items.as<uint32_t>(), nql, order, items_ord,
+                                h->stream));
+  HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, items_ord, h->item_off.as<uint32_t>(), n1,
+                                  h->stream));
   return HS_OK;
 }
 
@@ -559,13 +590,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
                                     h->seg_qoff.as<uint32_t>(), n1, h->stream));
     // work items: one wave's 128 members for the wave-independent int8 join, 512 otherwise
     jm = (use_i8 && h->join8_wave) ? HS_JM_WAVE : HS_JM_BLOCK;
-    HS_HIP(h, hs_launch_seg_route(h->seg_key.as<uint64_t>(), h->seg_cnt.as<uint32_t>(),
-                                  h->seg_qoff.as<uint32_t>(), h->seg_n.as<uint32_t>(),
-                                  h->sorted_ql.as<uint32_t>(), h->qcount.as<uint32_t>(), nql,
-                                  h->join_min_q, h->join_min_m, jm, h->seg_items.as<uint32_t>(),
-                                  d_jstats, h->nslices.as<uint32_t>(), h->stream));
-    HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, h->seg_items.as<uint32_t>(),
-                                    h->item_off.as<uint32_t>(), n1, h->stream));
+    HS_CHECK(cut_items(h, nql, jm, d_jstats));
     if (use_i8)
       HS_HIP(h, (h->join8_wave ? hs_launch_gather_c8t(h->c16.p, h->sorted_ql.as<uint32_t>(),
                                                      h->seg_qoff.as<uint32_t>(), nql, L, h->c16s.p,
@@ -598,13 +623,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
       if (jm != HS_JM_BLOCK) {  // the fp16 kernel works on 512-member items: cut the segments again
         jm = HS_JM_BLOCK;
         HS_HIP(h, hipMemsetAsync(d_jstats, 0, 16, h->stream));
-        HS_HIP(h, hs_launch_seg_route(h->seg_key.as<uint64_t>(), h->seg_cnt.as<uint32_t>(),
-                                      h->seg_qoff.as<uint32_t>(), h->seg_n.as<uint32_t>(),
-                                      h->sorted_ql.as<uint32_t>(), h->qcount.as<uint32_t>(), nql,
-                                      h->join_min_q, h->join_min_m, jm, h->seg_items.as<uint32_t>(),
-                                      d_jstats, h->nslices.as<uint32_t>(), h->stream));
-        HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, h->seg_items.as<uint32_t>(),
-                                        h->item_off.as<uint32_t>(), (size_t)nql + 1, h->stream));
+        HS_CHECK(cut_items(h, nql, jm, d_jstats));
         HS_HIP(h, hipMemcpyAsync(&n_items, h->item_off.as<uint32_t>() + nql, 4, hipMemcpyDeviceToHost,
                                  h->stream));
       }
@@ -629,7 +648,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
       HS_HIP(h, hs_launch_item_desc(h->tabs, h->seg_key.as<uint64_t>(), h->seg_cnt.as<uint32_t>(),
                                     h->seg_qoff.as<uint32_t>(), h->item_off.as<uint32_t>(), nql,
                                     h->sorted_ql.as<uint32_t>(), h->qcount.as<uint32_t>(), n_items, jm,
-                                    h->item_desc.as<uint4>(), h->stream));
+                                    h->seg_vals.as<uint32_t>(), h->item_desc.as<uint4>(), h->stream));
     }
   }
   if (brute || n_slices) {

@@ -203,7 +203,13 @@ hipError_t hs_launch_item_desc(const hs_tables_dev& tabs, const uint64_t* d_seg_
                                const uint32_t* d_seg_cnt,
                                const uint32_t* d_seg_qoff, const uint32_t* d_item_off, uint32_t n_max,
                                const uint32_t* d_sorted_ql, const uint32_t* d_qcount, uint32_t n_items,
-                               uint32_t jm, uint4* d_desc, hipStream_t s);
+                               uint32_t jm, const uint32_t* d_order, uint4* d_desc, hipStream_t s);
+// item numbering order of the segments: many-query segments first (stable two-class partition):
+// d_big[n + 1] flags (last = 0) -> exclusive scan -> d_order[n], d_items_ordered[n]
+hipError_t hs_launch_seg_big(const uint32_t* d_seg_cnt, const uint32_t* d_items, uint32_t n,
+                             uint32_t min_q, uint32_t* d_big, hipStream_t s);
+hipError_t hs_launch_seg_order(const uint32_t* d_big_pos, const uint32_t* d_items, uint32_t n,
+                               uint32_t* d_order, uint32_t* d_items_ordered, hipStream_t s);
 // members per work item: 512 (one workgroup tile) for the staged kernels, 128 (one wave) for the
 // wave-independent int8 join
 #define HS_JM_BLOCK 512u

@@ -176,6 +176,29 @@ __global__ __launch_bounds__(256) void hs_seg_unslice_kernel(const uint32_t* __r
   if (items[lo]) nslices[sorted_ql[p]] = 0;
 }
 
+// Item numbering order of the segments: those with many probing queries first (a stable
+// two-class partition).  The join hands items out from a counter, so the last ones handed out
+// should be small.  big[j] -> exclusive scan -> order[] and the item counts in that order.
+__global__ __launch_bounds__(256) void hs_seg_big_kernel(const uint32_t* __restrict__ seg_cnt,
+                                                         const uint32_t* __restrict__ items,
+                                                         uint32_t n, uint32_t min_q,
+                                                         uint32_t* __restrict__ big) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j < n) big[j] = (items[j] && seg_cnt[j] >= min_q) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void hs_seg_order_kernel(const uint32_t* __restrict__ big_pos,
+                                                           const uint32_t* __restrict__ items,
+                                                           uint32_t n, uint32_t* __restrict__ order,
+                                                           uint32_t* __restrict__ items_ordered) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  // big_pos has n + 1 entries: [n] = number of big segments
+  const bool big = big_pos[j + 1] != big_pos[j];
+  const uint32_t pos = big ? big_pos[j] : big_pos[n] + (j - big_pos[j]);
+  order[pos] = j;
+  items_ordered[pos] = items[j];
+}
+
 // One descriptor (2 x uint4) per work item:
 //   { offset of the bucket's first packed member from table 0's packed array (lo, hi), M, tile },
 //   { qoff, q_begin, q_end, first sorted position of the bucket }
@@ -188,6 +211,7 @@ __global__ __launch_bounds__(256) void hs_item_desc_kernel(hs_tables_dev tabs,
                                                            const uint32_t* __restrict__ sorted_ql,
                                                            const uint32_t* __restrict__ qcount,
                                                            uint32_t n_items, uint32_t jm,
+                                                           const uint32_t* __restrict__ order,
                                                            uint4* __restrict__ desc) {
   const uint32_t item = blockIdx.x * 256 + threadIdx.x;
   if (item >= n_items) return;
@@ -196,12 +220,12 @@ __global__ __launch_bounds__(256) void hs_item_desc_kernel(hs_tables_dev tabs,
     const uint32_t mid = (lo + hi) >> 1;
     if (item_off[mid] <= item) lo = mid; else hi = mid;
   }
-  const uint32_t seg = lo;
+  const uint32_t seg = order[lo];  // item_off runs over the segments in `order`
   const uint64_t key = seg_key[seg];
   const uint32_t nQ = seg_cnt[seg], qoff = seg_qoff[seg];
   const uint32_t M = qcount[sorted_ql[qoff]];
   const uint32_t tiles_m = (M + jm - 1) / jm;
-  const uint32_t local = item - item_off[seg];
+  const uint32_t local = item - item_off[lo];
   const uint32_t mt = local % tiles_m, qg = local / tiles_m;
   const uint32_t q_begin = qg * JQG;
   const uint32_t mstart = (uint32_t)key;
@@ -496,14 +520,26 @@ hipError_t hs_launch_seg_route(const uint64_t* d_seg_key, const uint32_t* d_seg_
   return hipGetLastError();
 }
 
+hipError_t hs_launch_seg_big(const uint32_t* d_seg_cnt, const uint32_t* d_items, uint32_t n,
+                             uint32_t min_q, uint32_t* d_big, hipStream_t s) {
+  hs_seg_big_kernel<<<blocks_for(n), 256, 0, s>>>(d_seg_cnt, d_items, n, min_q, d_big);
+  return hipGetLastError();
+}
+hipError_t hs_launch_seg_order(const uint32_t* d_big_pos, const uint32_t* d_items, uint32_t n,
+                               uint32_t* d_order, uint32_t* d_items_ordered, hipStream_t s) {
+  hs_seg_order_kernel<<<blocks_for(n), 256, 0, s>>>(d_big_pos, d_items, n, d_order, d_items_ordered);
+  return hipGetLastError();
+}
+
 hipError_t hs_launch_item_desc(const hs_tables_dev& tabs, const uint64_t* d_seg_key,
                                const uint32_t* d_seg_cnt,
                                const uint32_t* d_seg_qoff, const uint32_t* d_item_off, uint32_t n_max,
                                const uint32_t* d_sorted_ql, const uint32_t* d_qcount, uint32_t n_items,
-                               uint32_t jm, uint4* d_desc, hipStream_t s) {
+                               uint32_t jm, const uint32_t* d_order, uint4* d_desc, hipStream_t s) {
   if (!n_items) return hipSuccess;
   hs_item_desc_kernel<<<blocks_for(n_items), 256, 0, s>>>(tabs, d_seg_key, d_seg_cnt, d_seg_qoff, d_item_off,
-                                                          n_max, d_sorted_ql, d_qcount, n_items, jm, d_desc);
+                                                          n_max, d_sorted_ql, d_qcount, n_items, jm, d_order,
+                                                          d_desc);
   return hipGetLastError();
 }
 

@@ -542,10 +542,10 @@ __device__ __forceinline__ void emit_survivors(const intx16 (&acc)[GT], int T0, 
 #pragma unroll
     for (int i = 0; i < 16; ++i) any &= (uint32_t)acc[t][i];
     if (!__ballot((int)any >= 0)) continue;  // no survivor in this row tile
-    uint32_t mask = 0;
+    uint32_t neg = 0;  // bit i = sign of acc[t][i]: shift the sign bits in, last element first
 #pragma unroll
-    for (int i = 0; i < 16; ++i) mask |= ((~(uint32_t)acc[t][i]) >> 31) << i;
-    if (!col_ok) mask = 0;
+    for (int i = 15; i >= 0; --i) neg = __builtin_amdgcn_alignbit(neg, (uint32_t)acc[t][i], 31);
+    uint32_t mask = col_ok ? (~neg & 0xffffu) : 0u;
     while (__ballot(mask != 0)) {
       uint32_t idx = 0;
       bool pass = false;
@@ -586,6 +586,12 @@ __device__ __forceinline__ uint32_t and_tree2(const intx16 (&acc)[2]) {
   return a;
 }
 
+// wave-uniform copy of a descriptor word (keeps it, and everything derived from it, in SGPRs)
+__device__ __forceinline__ uint4 uniform4(const uint4 v) {
+  return make_uint4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y),
+                    __builtin_amdgcn_readfirstlane(v.z), __builtin_amdgcn_readfirstlane(v.w));
+}
+
 // The wave's 4 row tiles form two accumulator groups X (tiles 0, 1) and Y (tiles 2, 3).  Per
 // query tile: 8 MFMAs into X while the sign test of Y (previous query tile) issues in their gaps,
 // then 8 MFMAs into Y beside the sign test of X -- the vector instructions of the epilogue never
@@ -597,98 +603,132 @@ __global__ __launch_bounds__(256, 2) void hs_join8w_kernel(
     uint2* __restrict__ prov, uint32_t* __restrict__ item_counter, uint32_t G) {
   static_assert(JT == 4, "two accumulator groups of two row tiles");
   __shared__ uint32_t sTab8[32];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // wave-uniform by construction: say so, or every per-item quantity derived from it (descriptor
+  // addresses, loop bounds) is computed per lane and the descriptor loads become vector loads
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
+#ifdef HS_JOIN_TIMING
+  uint64_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+  const uint64_t tstart = tlast;
+#endif
   if (tid < 32) sTab8[tid] = tab8[tid].x;
   __syncthreads();  // the only one: the table is read-only from here on
   // Items come in chunks of G consecutive ones (same-address atomics are slow: one per chunk): the
   // first chunk by position, every further one from the counter, requested a whole chunk ahead.
+  // Descriptors are fetched TWO items ahead (scalar loads), so the next item's is in registers
+  // when its member loads are issued.
   const uint32_t first_dynamic = gridDim.x * 4u * G;
   uint32_t item = (blockIdx.x * 4u + (uint32_t)wave) * G;
   if (item >= n_items) return;
-  uint32_t chunk_end = item + G;
   uint32_t res_base = 0, res_used = JRES;
   uint32_t next_chunk_v = 0;
   if (lane == 0) next_chunk_v = atomicAdd(item_counter, G);
-  uint4 d0 = desc[2 * (uint64_t)item], d1 = desc[2 * (uint64_t)item + 1];
-  uint4 pk[JT], rk[JT];
-  intx4 Ba[4], Bb[4];
+  // the item two ahead of the current one, and the end of the chunk it belongs to
+  uint32_t pf_item = item, pf_chunk_end = item + G;
+#define HS_ADVANCE_PF()                                                                  \
+  {                                                                                      \
+    ++pf_item;                                                                           \
+    if (pf_item == pf_chunk_end) {                                                       \
+      pf_item = first_dynamic + __builtin_amdgcn_readfirstlane(next_chunk_v);            \
+      pf_chunk_end = pf_item + G;                                                        \
+      if (lane == 0 && pf_item < n_items) next_chunk_v = atomicAdd(item_counter, G);     \
+    }                                                                                    \
+  }
+  uint4 d0 = uniform4(desc[2 * (uint64_t)item]), d1 = uniform4(desc[2 * (uint64_t)item + 1]);
+  HS_ADVANCE_PF()
+  uint32_t next_item = pf_item;
+  uint4 nd0 = d0, nd1 = d1;
+  if (next_item < n_items) {
+    nd0 = uniform4(desc[2 * (uint64_t)next_item]);
+    nd1 = uniform4(desc[2 * (uint64_t)next_item + 1]);
+  }
+  uint4 mk[JT];                  // lanes of the lower half: packed member, upper half: its record
+  constexpr int NB = 3;          // B tiles in flight per wave: the one in use + two prefetched
+  constexpr uint32_t GQ = 32 * NB;  // queries per group of NB tiles
+  intx4 Bq[NB][4];
+  // one 16-byte load per lane and row tile: the lower half-wave fetches the packed members, the
+  // upper half their records; the halves trade them at build time (v_permlane32_swap)
 #define HS_LOAD_MEMBERS(D0)                                                              \
   {                                                                                      \
     const int64_t off_ = (int64_t)(((uint64_t)(D0).y << 32) | (uint64_t)(D0).x);         \
-    const uint4* packed_ = packed_base + off_;                                           \
-    const uint4* recs_ = rec_base + off_;                                                \
+    const uint4* src_ = (h ? rec_base : packed_base) + off_;                             \
     const uint32_t idx_ = (D0).w * (32 * JT) + r;                                        \
-    _Pragma("unroll") for (int t = 0; t < JT; ++t) {                                     \
-      const uint32_t m_ = min(idx_ + 32 * t, (D0).z - 1);                                \
-      pk[t] = packed_[m_];                                                               \
-      rk[t] = recs_[m_];                                                                 \
-    }                                                                                    \
+    _Pragma("unroll") for (int t = 0; t < JT; ++t)                                       \
+      mk[t] = src_[min(idx_ + 32 * t, (D0).z - 1)];                                      \
   }
   // Waves start an item's query tiles at a wave-dependent pair and wrap around: resident waves
   // work on neighbouring items of the same (bucket, query group); walking the tiles in lock step
   // would make every tile a simultaneous first touch.
-  const uint32_t skew = (blockIdx.x * 4u + (uint32_t)wave) * 7u;
-#define HS_FIRST_Q(D1) ((D1).y + 64u * (skew % (((D1).z - (D1).y + 63u) >> 6)))
+  const uint32_t skew = ((blockIdx.x * 4u + (uint32_t)wave) * 40503u) & 0xffffu;
+#define HS_N_GROUPS(D1) (((D1).z - (D1).y + GQ - 1u) / GQ)
+#define HS_FIRST_Q(D1) ((D1).y + GQ * ((skew * HS_N_GROUPS(D1)) >> 16))
   // Every B prefetch below is UNCONDITIONAL (a tile that does not exist is replaced by a harmless
   // valid one): the vector-memory counter is waited on by count, in issue order, so the number of
   // loads in flight at each wait must not depend on the path taken.
-#define HS_LOAD_PAIR(ROW, Q0, QEND)                                                              \
-  {                                                                                              \
-    load_btile(Ba, c8t, (ROW) + (Q0), min(32u, (QEND) - (Q0)), lane);                            \
-    const uint32_t q1_ = (Q0) + 32u < (QEND) ? (Q0) + 32u : (Q0);                                \
-    load_btile(Bb, c8t, (ROW) + q1_, min(32u, (QEND) - q1_), lane);                              \
+#define HS_LOAD_GROUP(ROW, Q0, QEND)                                                             \
+  _Pragma("unroll") for (int u = 0; u < NB; ++u) {                                               \
+    const uint32_t qu_ = (Q0) + 32u * u < (QEND) ? (Q0) + 32u * u : (Q0);                        \
+    load_btile(Bq[u], c8t, (ROW) + qu_, min(32u, (QEND) - qu_), lane);                           \
   }
   HS_LOAD_MEMBERS(d0)
   {
     const uint32_t q0 = HS_FIRST_Q(d1);
-    HS_LOAD_PAIR(d1.x, q0, d1.z)
+    HS_LOAD_GROUP(d1.x, q0, d1.z)
   }
   while (true) {
     const uint32_t M = d0.z, mt = d0.w;
     const uint32_t qoff = d1.x, q_begin = d1.y, q_end = d1.z, mstart = d1.w;
     const uint32_t wbase = mt * (32 * JT);
-    uint32_t next_item = item + 1;
-    if (next_item == chunk_end) {
-      next_item = first_dynamic + __builtin_amdgcn_readfirstlane(next_chunk_v);
-      chunk_end = next_item + G;
-      if (lane == 0 && next_item < n_items) next_chunk_v = atomicAdd(item_counter, G);
-    }
     const bool has_next = next_item < n_items;
-    uint4 nd0 = d0, nd1 = d1;
-    if (has_next) {
-      nd0 = desc[2 * (uint64_t)next_item];
-      nd1 = desc[2 * (uint64_t)next_item + 1];
+    HS_ADVANCE_PF()  // pf_item = the item after next
+    HS_T(0)          // chunk bookkeeping
+    uint4 nnd0 = nd0, nnd1 = nd1;
+    if (pf_item < n_items) {
+      nnd0 = uniform4(desc[2 * (uint64_t)pf_item]);
+      nnd1 = uniform4(desc[2 * (uint64_t)pf_item + 1]);
     }
     intx4 A[JT][4];
 #pragma unroll
-    for (int t = 0; t < JT; ++t) build_afrags8(pk[t], rk[t], h, sTab8, A[t]);
+    for (int t = 0; t < JT; ++t) {
+      uint4 pk, rk;  // after the swap: pk = the lower half's value, rk = the upper half's, in all lanes
+#define HS_SWAP(C)                                                                        \
+  {                                                                                       \
+    const auto sw_ = __builtin_amdgcn_permlane32_swap(mk[t].C, mk[t].C, false, false);    \
+    pk.C = sw_[0];                                                                        \
+    rk.C = sw_[1];                                                                        \
+  }
+      HS_SWAP(x) HS_SWAP(y) HS_SWAP(z) HS_SWAP(w)
+#undef HS_SWAP
+      build_afrags8(pk, rk, h, sTab8, A[t]);
+    }
+    HS_TD(1, __builtin_amdgcn_readfirstlane(A[0][0][0] ^ A[JT - 1][3][3] ^ A[JT - 1][2][0] ^ A[1][1][1] ^ A[2][2][2]))
     HS_LOAD_MEMBERS(nd0)
+    HS_T(2)  // descriptor of the next item + issue of its member loads
     intx16 accX[2], accY[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) accY[t][i] = -1;  // "no survivor" for the first tile's Y test
     uint32_t prev_qc = q_begin;
-    const uint32_t n_pairs = (q_end - q_begin + 63u) >> 6;
+    const uint32_t n_groups = HS_N_GROUPS(d1);
     uint32_t qc0 = HS_FIRST_Q(d1);
-    // one pair of query tiles (the second may not exist); the first pair of an item is a copy of
-    // its own, outside the loop, because the member loads just issued change the load counts
-    auto do_pair = [&](uint32_t pi) {
-      // the pair after this one: of this item (wrapping around), or the next item's first
-      uint32_t nrow = qoff, nq0 = qc0 + 64u, nqend = q_end;
+    // one group of NB query tiles (the later ones may not exist); the first group of an item is a
+    // copy of its own, outside the loop, because the member loads just issued change the counts
+    auto do_group = [&](uint32_t gi) {
+      // the group after this one: of this item (wrapping around), or the next item's first
+      uint32_t nrow = qoff, nq0 = qc0 + GQ, nqend = q_end;
       if (nq0 >= q_end) nq0 = q_begin;
-      if (pi + 1 == n_pairs) {
+      if (gi + 1 == n_groups) {
         nrow = nd1.x;
         nq0 = HS_FIRST_Q(nd1);
         nqend = nd1.z;
       }
-      const uint32_t nq1 = nq0 + 32u < nqend ? nq0 + 32u : nq0;
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const uint32_t qc = qc0 + 32u * (uint32_t)half;
-        intx4 (&B)[4] = half ? Bb : Ba;
-        if (half == 0 || qc < q_end) {
+      for (int u = 0; u < NB; ++u) {
+        const uint32_t qc = qc0 + 32u * (uint32_t)u;
+        intx4 (&B)[4] = Bq[u];
+        if (u == 0 || qc < q_end) {
           // ---- phase 1: X <- A[0..1] x B, beside the sign test of Y (previous query tile)
 #pragma unroll
           for (int t = 0; t < 2; ++t)
@@ -729,30 +769,45 @@ __global__ __launch_bounds__(256, 2) void hs_join8w_kernel(
                               prov_count, prov_cap, prov);
           prev_qc = qc;
         }
-        // the same-numbered tile of the next pair into the registers just consumed
-        const uint32_t nb = half ? nq1 : nq0;
+        // the same-numbered tile of the next group into the registers just consumed
+        const uint32_t nb = nq0 + 32u * (uint32_t)u < nqend ? nq0 + 32u * (uint32_t)u : nq0;
         load_btile(B, c8t, nrow + nb, min(32u, nqend - nb), lane);
       }
       qc0 = nq0;
     };
-    do_pair(0);
-    for (uint32_t pi = 1; pi < n_pairs; ++pi) do_pair(pi);
+    do_group(0);
+    HS_T(3)
+    for (uint32_t gi = 1; gi < n_groups; ++gi) do_group(gi);
+    HS_T(4)
     {  // the item's last Y group
       const uint32_t sY = and_tree2(accY);
       if (__ballot((int)sY >= 0))
         emit_survivors<2>(accY, 2, prev_qc, qoff, q_end, wbase, M, mstart, lane, res_base, res_used,
                           prov_count, prov_cap, prov);
     }
+    HS_T(5)
     if (!has_next) break;
     item = next_item;
+    next_item = pf_item;
     d0 = nd0;
     d1 = nd1;
+    nd0 = nnd0;
+    nd1 = nnd1;
   }
-#undef HS_LOAD_PAIR
+#undef HS_ADVANCE_PF
+#undef HS_LOAD_GROUP
+#undef HS_N_GROUPS
 #undef HS_LOAD_MEMBERS
 #undef HS_FIRST_Q
   if (res_used < JRES && lane >= (int)res_used && res_base + lane < prov_cap)
     prov[res_base + lane] = make_uint2(0xffffffffu, 0u);
+#ifdef HS_JOIN_TIMING
+  HS_T(6)
+  if (lane == 0) {
+    for (int i = 0; i < 7; ++i) atomicAdd(&g_join8_timing[i], (unsigned long long)tacc[i]);
+    atomicMax(&g_join8_timing[7], (unsigned long long)(tlast - tstart));
+  }
+#endif
 }
 
 inline unsigned blocks_for(uint64_t n, unsigned per = 256) { return (unsigned)((n + per - 1) / per); }
@@ -798,10 +853,23 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
   if (e != hipSuccess) return e;
   // chunk size: 8 items per counter access when there is plenty of work, fewer for small launches
   const uint32_t n_waves = (uint32_t)n_blocks * 4u;
-  const uint32_t G = std::max(1u, std::min(8u, n_items / (n_waves * 8u)));
+  static const uint32_t g_max = getenv("HS_JOIN_CHUNK") ? (uint32_t)atoi(getenv("HS_JOIN_CHUNK")) : 8u;
+  const uint32_t G = std::max(2u, std::min(g_max, n_items / (n_waves * 8u)));
   hs_join8w_kernel<<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_rec_base,
                                             (const uint4*)d_c8t, (const uint4*)d_tab8, d_prov_count,
                                             prov_cap, d_prov, d_item_counter, G);
+#ifdef HS_JOIN_TIMING
+  {
+    unsigned long long t[8];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_join8_timing), sizeof(t));
+    fprintf(stderr, "join8w timing (wave-cycles): chunk %llu build(+member wait) %llu next-desc+issue %llu first group %llu other groups %llu flush %llu tail %llu | longest wave %llu, mean wave %llu\n",
+            t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7],
+            (t[0] + t[1] + t[2] + t[3] + t[4] + t[5] + t[6]) / (unsigned long long)(n_blocks * 4));
+    memset(t, 0, sizeof(t));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_join8_timing), t, sizeof(t));
+  }
+#endif
   return hipGetLastError();
 }
 

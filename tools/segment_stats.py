@@ -24,3 +24,11 @@ print("segments", len(segs), "pairs %.3e" % pairs.sum(), "wave A-builds %.3e" % 
 for lo, hi in [(1, 2), (3, 7), (8, 31), (32, 127), (128, 511), (512, 2047), (2048, 10**9)]:
     m = (Q >= lo) & (Q <= hi)
     print("nQ %5d..%-9d segs %7d  pairs %5.1f%%  builds %5.1f%%  mean M %8.0f" % (lo, hi, m.sum(), 100 * pairs[m].sum() / pairs.sum(), 100 * builds[m].sum() / builds.sum(), M[m].mean() if m.any() else 0))
+# wave-item view (128 members x <= 2048 queries per item): items and 32-query tiles per class
+j = (Q >= 3) & (M >= 16)
+items = np.ceil(M / 128) * np.ceil(Q / 2048)
+tiles = np.ceil(M / 128) * np.ceil(Q / 32)
+print("joined: items %.3e tiles %.3e" % (items[j].sum(), tiles[j].sum()))
+for lo, hi in [(3, 32), (33, 96), (97, 256), (257, 512), (513, 2048), (2049, 10**9)]:
+    m = j & (Q >= lo) & (Q <= hi)
+    print("nQ %5d..%-9d items %5.1f%%  tiles %5.1f%%  tiles/item %6.1f" % (lo, hi, 100 * items[m].sum() / items[j].sum(), 100 * tiles[m].sum() / tiles[j].sum(), tiles[m].sum() / max(1, items[m].sum())))
