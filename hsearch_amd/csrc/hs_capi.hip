@@ -45,6 +45,7 @@ struct DevBuf {
 };
 
 enum { EV_COUNT = 12 };
+enum { EV_FORK = 0, EV_JOIN = 1, EVX_COUNT = 2 };
 
 }  // namespace
 
@@ -55,6 +56,10 @@ struct hs_handle {
   hipStream_t stream = nullptr;
   hipEvent_t ev[EV_COUNT];
   bool ev_ok = false;
+  // side stream: the streaming filter (and its per-query tables) runs beside the bucket join
+  hipStream_t stream2 = nullptr;
+  hipEvent_t evx[EVX_COUNT];
+  bool evx_ok = false;
   DevBuf a, b, coords;
   // index
   bool built = false;
@@ -189,6 +194,10 @@ hs_status hs_create(const hs_params* params, const double* a, const double* b, c
   HS_HIP(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   for (int i = 0; i < EV_COUNT; ++i) HS_HIP(h, hipEventCreate(&h->ev[i]));
   h->ev_ok = true;
+  HS_HIP(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+  for (int i = 0; i < EVX_COUNT; ++i)
+    HS_HIP(h, hipEventCreateWithFlags(&h->evx[i], hipEventDisableTiming));
+  h->evx_ok = true;
   const size_t na = (size_t)h->LK * h->d;
   HS_HIP(h, h->a.reserve(na * 8));
   HS_HIP(h, h->b.reserve((size_t)h->LK * 8));
@@ -256,6 +265,9 @@ void hs_destroy(hs_handle* h) {
   }
   if (h->ev_ok)
     for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(h->ev[i]);
+  if (h->evx_ok)
+    for (int i = 0; i < EVX_COUNT; ++i) (void)hipEventDestroy(h->evx[i]);
+  if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -323,6 +335,19 @@ hs_status hs_hash_points(hs_handle* h, const double* points, uint64_t n, int32_t
   return HS_OK;
 }
 
+static inline int bit_width_u32(uint32_t v) {
+  int b = 0;
+  while (v) {
+    ++b;
+    v >>= 1;
+  }
+  return b;
+}
+// bits of a sorted position inside one table (segment keys: hs_launch_seg_keys)
+static inline int seg_shift_of(const hs_handle* h) {
+  return std::max(1, bit_width_u32((uint32_t)std::min<uint64_t>(h->n, 0xffffffffull)));
+}
+
 // Segments -> work items of jm members x <= 2048 queries: routing (join or streaming), the item
 // numbering order (many-query segments first), item offsets.  Workspace reuse: seg_keys = flags and
 // their scan, seg_vals = order, seg_keys_sorted = item counts in that order (all free by now).
@@ -335,8 +360,9 @@ static hs_status cut_items(hs_handle* h, uint32_t nql, uint32_t jm, unsigned lon
   HS_HIP(h, hs_launch_seg_route(h->seg_key.as<uint64_t>(), h->seg_cnt.as<uint32_t>(),
                                 h->seg_qoff.as<uint32_t>(), h->seg_n.as<uint32_t>(),
                                 h->sorted_ql.as<uint32_t>(), h->qcount.as<uint32_t>(), nql,
-                                h->join_min_q, h->join_min_m, jm, h->seg_items.as<uint32_t>(),
-                                d_jstats, h->nslices.as<uint32_t>(), h->stream));
+                                h->join_min_q, h->join_min_m, jm, (int)h->p.L, seg_shift_of(h),
+                                h->seg_items.as<uint32_t>(), d_jstats, h->nslices.as<uint32_t>(),
+                                h->stream));
   HS_HIP(h, hipMemsetAsync(big + nql, 0, 4, h->stream));
   HS_HIP(h, hipMemsetAsync(items_ord + nql, 0, 4, h->stream));
   HS_HIP(h, hs_launch_seg_big(h->seg_cnt.as<uint32_t>(), h->seg_items.as<uint32_t>(), nql, 512u, big,
@@ -390,7 +416,7 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
     if (n) {
       HS_HIP(h, hs_sort_pairs_u64_u32(sort_temp.p, sort_temp.cap, keys.as<uint64_t>(),
                                       keys_sorted.as<uint64_t>(), iota.as<uint32_t>(),
-                                      h->t_ids[l].as<uint32_t>(), n, h->stream));
+                                      h->t_ids[l].as<uint32_t>(), n, 64, h->stream));
       const uint32_t slow_cap = 1u << 16;
       HS_HIP(h, slow_q.reserve(((size_t)slow_cap + 1) * 4));
       HS_HIP(h, hs_launch_check_runs(keys_sorted.as<uint64_t>(), h->t_ids[l].as<uint32_t>(),
@@ -556,6 +582,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   uint32_t* d_unsafe = d_cnt + 8;
   unsigned long long* d_jstats = reinterpret_cast<unsigned long long*>(d_cnt + 10);
   uint32_t n_items = 0, n_slices = 1, jm = HS_JM_BLOCK;
+  const int seg_shift = seg_shift_of(h);
   if (use_join) {
     const size_t n1 = (size_t)nql + 1;
     HS_HIP(h, h->c16.reserve((size_t)nq * 208 * 2));
@@ -577,11 +604,12 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
                                  h->stream));
     else
       HS_HIP(h, hs_launch_qprep(d_centers, nq, k, r2, h->c16.p, d_unsafe, h->stream));
-    HS_HIP(h, hs_launch_seg_keys(h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(), nql, L,
+    HS_HIP(h, hs_launch_seg_keys(h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(), nql, L, seg_shift,
                                  h->seg_keys.as<uint64_t>(), h->seg_vals.as<uint32_t>(), h->stream));
     HS_HIP(h, hs_sort_pairs_u64_u32(h->temp.p, h->temp.cap, h->seg_keys.as<uint64_t>(),
                                     h->seg_keys_sorted.as<uint64_t>(), h->seg_vals.as<uint32_t>(),
-                                    h->sorted_ql.as<uint32_t>(), nql, h->stream));
+                                    h->sorted_ql.as<uint32_t>(), nql, seg_shift + bit_width_u32((uint32_t)L),
+                                    h->stream));
     HS_HIP(h, hipMemsetAsync(h->seg_cnt.p, 0, n1 * 4, h->stream));
     HS_HIP(h, hs_rle_u64(h->temp.p, h->temp.cap, h->seg_keys_sorted.as<uint64_t>(),
                          h->seg_key.as<uint64_t>(), h->seg_cnt.as<uint32_t>(),
@@ -648,15 +676,21 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
       HS_HIP(h, hs_launch_item_desc(h->tabs, h->seg_key.as<uint64_t>(), h->seg_cnt.as<uint32_t>(),
                                     h->seg_qoff.as<uint32_t>(), h->item_off.as<uint32_t>(), nql,
                                     h->sorted_ql.as<uint32_t>(), h->qcount.as<uint32_t>(), n_items, jm,
-                                    h->seg_vals.as<uint32_t>(), h->item_desc.as<uint4>(), h->stream));
+                                    seg_shift, h->seg_vals.as<uint32_t>(), h->item_desc.as<uint4>(),
+                                    h->stream));
     }
   }
+  // with a join in the batch, the streaming filter's tables and the filter itself go to the side
+  // stream and run beside the join kernel (both only append to the survivor list)
+  const bool side = !brute && n_items && n_slices;
   if (brute || n_slices) {
     HS_HIP(h, h->tq.reserve((size_t)nq * k * HS_TROW * 4));
-    HS_HIP(h, hs_launch_qtables(d_centers, nq, k, h->coords.as<double>(), h->alphabet,
-                                h->tq.as<float>(), h->stream));
+    if (!side)
+      HS_HIP(h, hs_launch_qtables(d_centers, nq, k, h->coords.as<double>(), h->alphabet,
+                                  h->tq.as<float>(), h->stream));
   }
   HS_HIP(h, hipEventRecord(h->ev[2], h->stream));
+  bool tables_done = !side;
   uint32_t prov_cap = (uint32_t)std::max<size_t>(h->prov.cap / 8, std::max<size_t>(1u << 20, 16ull * nq));
   uint32_t host_cnt[4] = {0, 0, 0, 0};
   double ms_verify = 0, ms_final = 0, ms_join = 0;
@@ -668,6 +702,18 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, h->hit_val.reserve((size_t)hit_cap * 8));
     HS_HIP(h, hipMemsetAsync(d_cnt, 0, 8, h->stream));
     HS_HIP(h, hipEventRecord(h->ev[3], h->stream));
+    if (side) {
+      HS_HIP(h, hipEventRecord(h->evx[EV_FORK], h->stream));
+      HS_HIP(h, hipStreamWaitEvent(h->stream2, h->evx[EV_FORK], 0));
+      if (!tables_done)
+        HS_HIP(h, hs_launch_qtables(d_centers, nq, k, h->coords.as<double>(), h->alphabet,
+                                    h->tq.as<float>(), h->stream2));
+      tables_done = true;
+      HS_HIP(h, hs_launch_verify(h->tabs, h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
+                                 h->slice_off.as<uint32_t>(), nql, h->tq.as<float>(), k, L, r2_hi,
+                                 d_cnt, prov_cap, h->prov.as<uint2>(), n_blocks, h->stream2));
+      HS_HIP(h, hipEventRecord(h->evx[EV_JOIN], h->stream2));
+    }
     if (brute) {
       HS_HIP(h, hs_launch_bruteforce(h->packed_all.as<uint4>(), (uint32_t)h->n, h->tq.as<float>(),
                                      nq, k, r2_hi, d_cnt, prov_cap, h->prov.as<uint2>(), nullptr,
@@ -690,7 +736,9 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
                                  reinterpret_cast<const float*>(h->jtab.as<char>() + 512), k, d_cnt,
                                  prov_cap, h->prov.as<uint2>(), h->n_cu * h->join_blocks_per_cu, h->stream));
       HS_HIP(h, hipEventRecord(h->ev[10], h->stream));
-      if (n_slices)
+      if (side)
+        HS_HIP(h, hipStreamWaitEvent(h->stream, h->evx[EV_JOIN], 0));
+      else if (n_slices)
         HS_HIP(h, hs_launch_verify(h->tabs, h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
                                    h->slice_off.as<uint32_t>(), nql, h->tq.as<float>(), k, L, r2_hi,
                                    d_cnt, prov_cap, h->prov.as<uint2>(), n_blocks, h->stream));

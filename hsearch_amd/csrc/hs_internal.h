@@ -116,8 +116,10 @@ static inline int hs_packed_words(int k) { return (k + 24) / 25; }
 
 // ---- primitive wrappers (hs_prims.hip, rocPRIM behind them) --------------------------------------
 size_t hs_sort_pairs_u64_u32_temp(size_t n);
+// keys ordered by their bits [0, end_bit) only
 hipError_t hs_sort_pairs_u64_u32(void* temp, size_t temp_bytes, const uint64_t* kin, uint64_t* kout,
-                                 const uint32_t* vin, uint32_t* vout, size_t n, hipStream_t s);
+                                 const uint32_t* vin, uint32_t* vout, size_t n, int end_bit,
+                                 hipStream_t s);
 size_t hs_sort_pairs_u64_u64_temp(size_t n);
 hipError_t hs_sort_pairs_u64_u64(void* temp, size_t temp_bytes, const uint64_t* kin, uint64_t* kout,
                                  const uint64_t* vin, uint64_t* vout, size_t n, int end_bit,
@@ -190,20 +192,24 @@ hipError_t hs_launch_jtables(const double* d_coords, int alphabet, void* d_tab16
                              uint32_t* d_unsafe, hipStream_t s);
 hipError_t hs_launch_qprep(const double* d_centers, uint32_t nq, int k, double r2, void* d_c16,
                            uint32_t* d_unsafe, hipStream_t s);
+// segment key of a probe = (table << shift) | first sorted position of its bucket; table = L for a
+// probe that found no bucket.  shift = bits of the largest position.
 hipError_t hs_launch_seg_keys(const uint32_t* d_qstart, const uint32_t* d_qcount, uint32_t nql, int L,
-                              uint64_t* d_keys, uint32_t* d_vals, hipStream_t s);
+                              int shift, uint64_t* d_keys, uint32_t* d_vals, hipStream_t s);
 // items[j] for joined segments (>= min_q probing queries and >= min_m members), 0 otherwise, and
 // nslices[ql] = 0 for the probes of joined segments; stats[0] += MFMA pairs issued, [1] += real pairs
 hipError_t hs_launch_seg_route(const uint64_t* d_seg_key, const uint32_t* d_seg_cnt,
                                const uint32_t* d_seg_qoff, const uint32_t* d_n_seg,
                                const uint32_t* d_sorted_ql, const uint32_t* d_qcount, uint32_t n_max,
-                               uint32_t min_q, uint32_t min_m, uint32_t jm, uint32_t* d_items,
-                               unsigned long long* d_stats, uint32_t* d_nslices, hipStream_t s);
+                               uint32_t min_q, uint32_t min_m, uint32_t jm, int L, int shift,
+                               uint32_t* d_items, unsigned long long* d_stats, uint32_t* d_nslices,
+                               hipStream_t s);
 hipError_t hs_launch_item_desc(const hs_tables_dev& tabs, const uint64_t* d_seg_key,
                                const uint32_t* d_seg_cnt,
                                const uint32_t* d_seg_qoff, const uint32_t* d_item_off, uint32_t n_max,
                                const uint32_t* d_sorted_ql, const uint32_t* d_qcount, uint32_t n_items,
-                               uint32_t jm, const uint32_t* d_order, uint4* d_desc, hipStream_t s);
+                               uint32_t jm, int shift, const uint32_t* d_order, uint4* d_desc,
+                               hipStream_t s);
 // item numbering order of the segments: many-query segments first (stable two-class partition):
 // d_big[n + 1] flags (last = 0) -> exclusive scan -> d_order[n], d_items_ordered[n]
 hipError_t hs_launch_seg_big(const uint32_t* d_seg_cnt, const uint32_t* d_items, uint32_t n,

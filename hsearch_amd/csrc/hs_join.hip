@@ -119,13 +119,15 @@ __global__ void hs_jtables_kernel(const double* __restrict__ coords, int alphabe
 // key = (table << 32 | first sorted position of the bucket) for probes that found a bucket.
 __global__ __launch_bounds__(256) void hs_seg_keys_kernel(const uint32_t* __restrict__ qstart,
                                                           const uint32_t* __restrict__ qcount,
-                                                          uint32_t nql, int L,
+                                                          uint32_t nql, int L, int shift,
                                                           uint64_t* __restrict__ keys,
                                                           uint32_t* __restrict__ vals) {
   const uint32_t ql = blockIdx.x * 256 + threadIdx.x;
   if (ql >= nql) return;
   const uint32_t l = ql % (uint32_t)L;
-  keys[ql] = qcount[ql] ? (((uint64_t)l << 32) | qstart[ql]) : ~0ull;
+  // (table, first sorted position of the bucket) in as few bits as they need -- the radix sort
+  // that groups the probes runs over those bits only; a probe of no bucket sorts last (table L)
+  keys[ql] = ((uint64_t)(qcount[ql] ? l : (uint32_t)L) << shift) | (qcount[ql] ? qstart[ql] : 0u);
   vals[ql] = ql;
 }
 
@@ -139,13 +141,13 @@ __global__ __launch_bounds__(256) void hs_seg_route_kernel(const uint64_t* __res
                                                            const uint32_t* __restrict__ sorted_ql,
                                                            const uint32_t* __restrict__ qcount,
                                                            uint32_t n_max, uint32_t min_q,
-                                                           uint32_t min_m, uint32_t jm,
+                                                           uint32_t min_m, uint32_t jm, int L, int shift,
                                                            uint32_t* __restrict__ items,
                                                            unsigned long long* __restrict__ stats) {
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
   if (j > n_max) return;
   uint32_t it = 0;
-  if (j < *n_seg && seg_key[j] != ~0ull) {
+  if (j < *n_seg && (seg_key[j] >> shift) < (uint64_t)L) {
     const uint32_t m = qcount[sorted_ql[seg_qoff[j]]];
     const uint32_t nq = seg_cnt[j];
     if (nq >= min_q && m >= min_m) {
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256) void hs_item_desc_kernel(hs_tables_dev tabs,
                                                            uint32_t n_max,
                                                            const uint32_t* __restrict__ sorted_ql,
                                                            const uint32_t* __restrict__ qcount,
-                                                           uint32_t n_items, uint32_t jm,
+                                                           uint32_t n_items, uint32_t jm, int shift,
                                                            const uint32_t* __restrict__ order,
                                                            uint4* __restrict__ desc) {
   const uint32_t item = blockIdx.x * 256 + threadIdx.x;
@@ -228,11 +230,11 @@ __global__ __launch_bounds__(256) void hs_item_desc_kernel(hs_tables_dev tabs,
   const uint32_t local = item - item_off[lo];
   const uint32_t mt = local % tiles_m, qg = local / tiles_m;
   const uint32_t q_begin = qg * JQG;
-  const uint32_t mstart = (uint32_t)key;
+  const uint32_t mstart = (uint32_t)(key & ((1ull << shift) - 1ull));
   // offset (in 16-byte words) from table 0's packed array: base + offset keeps the member loads
   // in the global address space (a pointer rebuilt from integers compiles to flat loads, whose
   // lgkmcnt accounting stalls the LDS waits of the MFMA loop)
-  const int64_t off = (reinterpret_cast<intptr_t>(tabs.t[(uint32_t)(key >> 32)].packed) -
+  const int64_t off = (reinterpret_cast<intptr_t>(tabs.t[(uint32_t)(key >> shift)].packed) -
                        reinterpret_cast<intptr_t>(tabs.t[0].packed)) / 16 + (int64_t)mstart;
   desc[2 * (uint64_t)item] = make_uint4((uint32_t)(uint64_t)off, (uint32_t)((uint64_t)off >> 32), M, mt);
   desc[2 * (uint64_t)item + 1] = make_uint4(qoff, q_begin, min(nQ, q_begin + JQG), mstart);
@@ -501,20 +503,21 @@ hipError_t hs_launch_qprep(const double* d_centers, uint32_t nq, int k, double r
 }
 
 hipError_t hs_launch_seg_keys(const uint32_t* d_qstart, const uint32_t* d_qcount, uint32_t nql, int L,
-                              uint64_t* d_keys, uint32_t* d_vals, hipStream_t s) {
+                              int shift, uint64_t* d_keys, uint32_t* d_vals, hipStream_t s) {
   if (!nql) return hipSuccess;
-  hs_seg_keys_kernel<<<blocks_for(nql), 256, 0, s>>>(d_qstart, d_qcount, nql, L, d_keys, d_vals);
+  hs_seg_keys_kernel<<<blocks_for(nql), 256, 0, s>>>(d_qstart, d_qcount, nql, L, shift, d_keys, d_vals);
   return hipGetLastError();
 }
 
 hipError_t hs_launch_seg_route(const uint64_t* d_seg_key, const uint32_t* d_seg_cnt,
                                const uint32_t* d_seg_qoff, const uint32_t* d_n_seg,
                                const uint32_t* d_sorted_ql, const uint32_t* d_qcount, uint32_t n_max,
-                               uint32_t min_q, uint32_t min_m, uint32_t jm, uint32_t* d_items,
-                               unsigned long long* d_stats, uint32_t* d_nslices, hipStream_t s) {
+                               uint32_t min_q, uint32_t min_m, uint32_t jm, int L, int shift,
+                               uint32_t* d_items, unsigned long long* d_stats, uint32_t* d_nslices,
+                               hipStream_t s) {
   hs_seg_route_kernel<<<blocks_for((uint64_t)n_max + 1), 256, 0, s>>>(
-      d_seg_key, d_seg_cnt, d_seg_qoff, d_n_seg, d_sorted_ql, d_qcount, n_max, min_q, min_m, jm,
-      d_items, d_stats);
+      d_seg_key, d_seg_cnt, d_seg_qoff, d_n_seg, d_sorted_ql, d_qcount, n_max, min_q, min_m, jm, L,
+      shift, d_items, d_stats);
   hs_seg_unslice_kernel<<<blocks_for(n_max), 256, 0, s>>>(d_seg_qoff, d_n_seg, d_items, d_sorted_ql,
                                                          n_max, d_nslices);
   return hipGetLastError();
@@ -535,11 +538,12 @@ hipError_t hs_launch_item_desc(const hs_tables_dev& tabs, const uint64_t* d_seg_
                                const uint32_t* d_seg_cnt,
                                const uint32_t* d_seg_qoff, const uint32_t* d_item_off, uint32_t n_max,
                                const uint32_t* d_sorted_ql, const uint32_t* d_qcount, uint32_t n_items,
-                               uint32_t jm, const uint32_t* d_order, uint4* d_desc, hipStream_t s) {
+                               uint32_t jm, int shift, const uint32_t* d_order, uint4* d_desc,
+                               hipStream_t s) {
   if (!n_items) return hipSuccess;
   hs_item_desc_kernel<<<blocks_for(n_items), 256, 0, s>>>(tabs, d_seg_key, d_seg_cnt, d_seg_qoff, d_item_off,
-                                                          n_max, d_sorted_ql, d_qcount, n_items, jm, d_order,
-                                                          d_desc);
+                                                          n_max, d_sorted_ql, d_qcount, n_items, jm, shift,
+                                                          d_order, d_desc);
   return hipGetLastError();
 }
 

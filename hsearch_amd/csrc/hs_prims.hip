@@ -17,8 +17,9 @@ size_t hs_sort_pairs_u64_u32_temp(size_t n) {
   return bytes;
 }
 hipError_t hs_sort_pairs_u64_u32(void* temp, size_t temp_bytes, const uint64_t* kin, uint64_t* kout,
-                                 const uint32_t* vin, uint32_t* vout, size_t n, hipStream_t s) {
-  return rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, n, 0, 64, s);
+                                 const uint32_t* vin, uint32_t* vout, size_t n, int end_bit,
+                                 hipStream_t s) {
+  return rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, n, 0, end_bit, s);
 }
 
 size_t hs_sort_pairs_u64_u64_temp(size_t n) {
