@@ -70,6 +70,7 @@ struct hs_handle {
   // bucket-ordered packed copies of all tables in ONE allocation ([L][n][PW]), and the int8 join's
   // per-entry records ([L][n], k <= 25 only) at the same entry offsets
   DevBuf t_packed, t_rec8;
+  DevBuf t_pos;  // [L][n] sorted position of every DB id in every table (first-seen dedupe)
   hs_tables_dev tabs;
   hs_index_info info;
   // query workspace (grown on demand, reused across calls)
@@ -255,7 +256,7 @@ void hs_destroy(hs_handle* h) {
                     &h->io_codes, &h->io_misc, &h->jtab, &h->c16, &h->seg_keys, &h->seg_keys_sorted,
                     &h->seg_vals, &h->sorted_ql, &h->seg_key, &h->seg_cnt, &h->seg_qoff,
                     &h->seg_items, &h->item_off, &h->seg_n, &h->c16s, &h->item_desc,
-                    &h->probe_slow, &h->jtab8, &h->t_packed, &h->t_rec8};
+                    &h->probe_slow, &h->jtab8, &h->t_packed, &h->t_rec8, &h->t_pos};
   for (DevBuf* bf : bufs) bf->release();
   for (int l = 0; l < HS_MAX_L; ++l) {
     h->t_dirkey[l].release();
@@ -401,6 +402,7 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
   const bool with_rec8 = h->join8_tables_ok && PW == 1;
   HS_HIP(h, h->t_packed.reserve(std::max<size_t>(16, (size_t)L * n * PW * 16)));
   if (with_rec8) HS_HIP(h, h->t_rec8.reserve(std::max<size_t>(16, (size_t)L * n * 16)));
+  HS_HIP(h, h->t_pos.reserve(std::max<size_t>(16, (size_t)L * n * 4)));
   for (int l = 0; l < L; ++l) {
     uint4* const tab_packed = h->t_packed.as<uint4>() + (size_t)l * n * PW;
     HS_HIP(h, h->t_ids[l].reserve(std::max<size_t>(16, (size_t)n * 4)));
@@ -465,6 +467,8 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
     else
       HS_HIP(h, hs_launch_gather_packed(h->packed_all.as<uint4>(), h->t_ids[l].as<uint32_t>(), n, PW,
                                         tab_packed, h->stream));
+    HS_HIP(h, hs_launch_invert_perm(h->t_ids[l].as<uint32_t>(), (uint32_t)n,
+                                    h->t_pos.as<uint32_t>() + (size_t)l * n, h->stream));
     HS_HIP(h, hipEventRecord(h->ev[3], h->stream));
     HS_HIP(h, hipMemcpyAsync(&max_count, d_small + 2, 4, hipMemcpyDeviceToHost, h->stream));
     HS_HIP(h, hipStreamSynchronize(h->stream));
@@ -477,6 +481,7 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
     tb.dir_tuple = h->t_dirtuple[l].as<int32_t>();
     tb.packed = tab_packed;
     tb.ids = h->t_ids[l].as<uint32_t>();
+    tb.pos_of = h->t_pos.as<uint32_t>() + (size_t)l * n;
     tb.nb = nb;
     h->info.n_buckets[l] = nb;
     h->info.max_bucket[l] = max_count;
@@ -525,7 +530,7 @@ hs_status hs_index_build(hs_handle* h, const uint8_t* codes, uint64_t n) {
   h->prof.ms_total = ev_ms(h, 8, 9);
   h->info.n = n;
   h->info.key_seed = seed;
-  uint64_t bytes = h->codes.cap + h->packed_all.cap + h->t_packed.cap + h->t_rec8.cap;
+  uint64_t bytes = h->codes.cap + h->packed_all.cap + h->t_packed.cap + h->t_rec8.cap + h->t_pos.cap;
   for (uint32_t l = 0; l < h->p.L; ++l)
     bytes += h->t_dirkey[l].cap + h->t_dirstart[l].cap + h->t_dirtuple[l].cap + h->t_ids[l].cap;
   h->info.device_bytes = bytes;

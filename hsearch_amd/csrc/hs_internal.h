@@ -103,6 +103,7 @@ struct hs_table_dev {
   const int32_t* dir_tuple;  // [nb][K] bucket ints of the bucket's first member
   const uint4* packed;       // [n][PW] 5-bit packed residue codes in bucket order
   const uint32_t* ids;       // [n] DB ids in bucket order (ascending inside a bucket)
+  const uint32_t* pos_of;    // [n] inverse of ids: sorted position of DB id i in this table
   uint32_t nb;
   uint32_t pad_;
 };
@@ -160,6 +161,8 @@ hipError_t hs_launch_pack(const uint8_t* d_codes, uint64_t n, int k, int alphabe
 hipError_t hs_launch_gather_packed(const uint4* d_packed_all, const uint32_t* d_ids_sorted,
                                    uint64_t n, int PW, uint4* d_out, hipStream_t s);
 hipError_t hs_launch_set_u32(uint32_t* d_p, uint32_t v, hipStream_t s);
+// d_out[d_perm[i]] = i
+hipError_t hs_launch_invert_perm(const uint32_t* d_perm, uint32_t n, uint32_t* d_out, hipStream_t s);
 hipError_t hs_launch_max_u32(const uint32_t* d_in, uint32_t n, uint32_t* d_out, hipStream_t s);
 
 hipError_t hs_launch_probe(const hs_tables_dev& tabs, const int32_t* d_qints, uint32_t nq, int K,

@@ -560,31 +560,100 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
                                                           uint32_t hit_cap,
                                                           uint64_t* __restrict__ hit_key,
                                                           uint64_t* __restrict__ hit_val) {
+  // One wave = 64 survivors, one per lane.  The exact d2 is a serial fp64 chain per survivor, but
+  // its inputs -- 8k doubles of the query's centre row -- are fetched by the WAVE: per position,
+  // the 64 rows' 64-byte pieces go through LDS (4 lanes x 16 B per row: every byte fetched is
+  // used), instead of 64 lanes walking 64 different rows 8 bytes at a time.
+  constexpr int ROWB = 80;  // 64 B of a row + 16 B pad: conflict-free b128 reads
+  __shared__ double s_coords[HS_ALPHABET_PAD * 8];
+  __shared__ __attribute__((aligned(16))) unsigned char s_stage[4][64 * ROWB];
+  __shared__ uint32_t s_q[4][64];
+  __shared__ uint8_t s_code[4][64 * 76];  // the survivors' residue codes, row stride 76 (k <= 75)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int t = tid; t < HS_ALPHABET_PAD * 8; t += 256) s_coords[t] = coords[t];
+  __syncthreads();
   const uint32_t n = min(*prov_count, prov_cap);
-  for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
-    uint32_t ql = prov[e].x;
-    const uint32_t pos = prov[e].y;
-    if (ql == 0xffffffffu) continue;  // unused slot of a wave's reserved block (hs_join_kernel)
+  unsigned char* stage = s_stage[wave];
+  const uint32_t wave_stride = gridDim.x * 4u * 64u;
+  for (uint32_t base = (blockIdx.x * 4u + (uint32_t)wave) * 64u; base < n; base += wave_stride) {
+    const uint32_t e = base + (uint32_t)lane;
+    uint32_t ql = e < n ? prov[e].x : 0xffffffffu;
+    const uint32_t pos = e < n ? prov[e].y : 0u;
+    const bool live = ql != 0xffffffffu;  // unused slot of a wave's reserved block (join kernels)
     // the join kernels name the probe by its position in segment order (no load in their hot loop)
-    if (ql & HS_PROV_INDIRECT) ql = sorted_ql[ql & ~HS_PROV_INDIRECT];
-    const uint32_t q = ql / (uint32_t)L;
-    const int l = (int)(ql % (uint32_t)L);
-    const uint32_t id = tabs.t[l].ids[pos];
-    // exact decision first: most survivors of a coarse filter fail it, and it needs no searching
-    const double d2 = exact_dist2(codes + (uint64_t)id * k, centers + (uint64_t)q * 8 * k, coords, k);
+    if (live && (ql & HS_PROV_INDIRECT)) ql = sorted_ql[ql & ~HS_PROV_INDIRECT];
+    const uint32_t q = live ? ql / (uint32_t)L : 0u;
+    const int l = live ? (int)(ql % (uint32_t)L) : 0;
+    const uint32_t id = live ? tabs.t[l].ids[pos] : 0u;
+    s_q[wave][lane] = q;
+    __builtin_amdgcn_wave_barrier();
+    {  // residue codes of this lane's survivor into LDS (all byte loads in flight at once)
+      const uint8_t* code = codes + (uint64_t)id * k;
+      uint8_t* dst = &s_code[wave][lane * 76];
+      for (int p = 0; p < k; ++p) dst[p] = code[p];
+    }
+    // piece = 16 B: lane fetches pieces lane, lane + 64, ... of the wave's 64 x 64-byte block
+    const int row0 = lane >> 2, part = lane & 3;
+    const double2* src0 = reinterpret_cast<const double2*>(centers + (uint64_t)s_q[wave][row0] * 8 * k) + part;
+    const double2* src1 = reinterpret_cast<const double2*>(centers + (uint64_t)s_q[wave][row0 + 16] * 8 * k) + part;
+    const double2* src2 = reinterpret_cast<const double2*>(centers + (uint64_t)s_q[wave][row0 + 32] * 8 * k) + part;
+    const double2* src3 = reinterpret_cast<const double2*>(centers + (uint64_t)s_q[wave][row0 + 48] * 8 * k) + part;
+    double2* const st0 = reinterpret_cast<double2*>(&stage[row0 * ROWB + part * 16]);
+    double2* const st1 = reinterpret_cast<double2*>(&stage[(row0 + 16) * ROWB + part * 16]);
+    double2* const st2 = reinterpret_cast<double2*>(&stage[(row0 + 32) * ROWB + part * 16]);
+    double2* const st3 = reinterpret_cast<double2*>(&stage[(row0 + 48) * ROWB + part * 16]);
+    // two positions in flight ahead of the one being summed (4 double2 per position of a row;
+    // positions past the end re-read the last one: loads stay unconditional)
+    const int last = 4 * (k - 1);
+    double2 n0 = src0[0], n1 = src1[0], n2 = src2[0], n3 = src3[0];
+    const int o1 = min(4, last);
+    double2 m0 = src0[o1], m1 = src1[o1], m2 = src2[o1], m3 = src3[o1];
+    double d2 = 0.0;
+    for (int p = 0; p < k; ++p) {
+      *st0 = n0;
+      *st1 = n1;
+      *st2 = n2;
+      *st3 = n3;
+      n0 = m0;
+      n1 = m1;
+      n2 = m2;
+      n3 = m3;
+      const int o2 = min(4 * (p + 2), last);
+      m0 = src0[o2];
+      m1 = src1[o2];
+      m2 = src2[o2];
+      m3 = src3[o2];
+      __builtin_amdgcn_wave_barrier();
+      double c[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const double2 v = *reinterpret_cast<const double2*>(&stage[lane * ROWB + j * 16]);
+        c[2 * j] = v.x;
+        c[2 * j + 1] = v.y;
+      }
+      __builtin_amdgcn_wave_barrier();
+      // exact left-to-right fp64, one rounding per operation (PairwiseDistance_square :176-183)
+      const double* xc = s_coords + (int)s_code[wave][lane * 76 + p] * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const double r = __dsub_rn(xc[j], c[j]);
+        d2 = __dadd_rn(d2, __dmul_rn(r, r));
+      }
+    }
     // Search(): d2 <= R*R (motif_both_points.cpp:239); Clustering(): sqrt(d2) <= R
     // (hclust2.cpp:64-71,119-120), selected by a non-NaN r_sqrt.
-    bool hit = (r_sqrt == r_sqrt) ? (__dsqrt_rn(d2) <= r_sqrt) : (d2 <= r2);
-    for (int l2 = 0; l2 < l && hit; ++l2) {  // first-seen dedupe (label[], :233)
-      const uint32_t c2 = qcount[q * L + l2];
-      if (!c2) continue;
-      const uint32_t* ids2 = tabs.t[l2].ids + qstart[q * L + l2];
-      uint32_t lo = 0, hi = c2;
-      while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (ids2[mid] < id) lo = mid + 1; else hi = mid;
+    bool hit = live && ((r_sqrt == r_sqrt) ? (__dsqrt_rn(d2) <= r_sqrt) : (d2 <= r2));
+    // first-seen dedupe (label[], :233): the id was already reported if an EARLIER table's probed
+    // bucket holds it, i.e. if its sorted position in that table falls inside the bucket's range
+    // (one independent 4-byte load per earlier table)
+    if (hit) {
+      bool dup = false;
+      for (int l2 = 0; l2 < l; ++l2) {
+        const uint32_t c2 = qcount[q * L + l2];
+        const uint32_t p2 = tabs.t[l2].pos_of[id];
+        dup = dup || (p2 - qstart[q * L + l2] < c2);
       }
-      if (lo < c2 && ids2[lo] == id) hit = false;
+      hit = !dup;
     }
     if (hit) {
       const uint32_t idx = atomicAdd(hit_count, 1u);
@@ -594,6 +663,12 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void hs_invert_perm_kernel(const uint32_t* __restrict__ perm,
+                                                             uint32_t n, uint32_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[perm[i]] = i;
 }
 
 // Brute force (motif_both_points_noLSH.cpp:27-34,44-50): sqrt form, hit iff !(dis > R).
@@ -822,6 +897,12 @@ hipError_t hs_launch_finalize(const hs_tables_dev& tabs, const uint8_t* d_codes,
                                           d_prov, d_prov_count, prov_cap, d_sorted_ql, k, L, r2,
                                           r_sqrt, q_base,
                                           d_hit_count, hit_cap, d_hit_key, d_hit_val);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_invert_perm(const uint32_t* d_perm, uint32_t n, uint32_t* d_out, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hs_invert_perm_kernel<<<blocks_for(n), 256, 0, s>>>(d_perm, n, d_out);
   return hipGetLastError();
 }
 
