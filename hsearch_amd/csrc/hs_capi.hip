@@ -79,7 +79,6 @@ struct hs_handle {
   // bucket-join workspace
   DevBuf c16s, item_desc, probe_slow, jtab8;
   bool join8_tables_ok = false;  // int8 can carry the coordinate table
-  bool join8_wave = true;        // wave-independent int8 join (HS_JOIN8_VARIANT=lds selects the staged one)
   uint32_t join_min_q = 3, join_min_m = 16;  // segment routing thresholds (HS_JOIN_MIN_Q / _M)
   int join_blocks_per_cu = 2;                // resident workgroups of hs_join_kernel per CU
   DevBuf jtab, c16, seg_keys, seg_keys_sorted, seg_vals, sorted_ql, seg_key, seg_cnt, seg_qoff,
@@ -227,7 +226,6 @@ hs_status hs_create(const hs_params* params, const double* a, const double* b, c
   HS_HIP(h, hipMemcpyAsync(&unsafe8, h->jtab8.as<char>() + 640, 4, hipMemcpyDeviceToHost, h->stream));
   HS_HIP(h, hipStreamSynchronize(h->stream));
   h->join8_tables_ok = (unsafe8 == 0);
-  if (const char* m = getenv("HS_JOIN8_VARIANT")) h->join8_wave = strcmp(m, "lds") != 0;
   if (const char* m = getenv("HS_VERIFY_MODE")) {
     if (!strcmp(m, "stream")) h->verify_mode = 1;
     if (!strcmp(m, "join")) h->verify_mode = 2;
@@ -622,14 +620,11 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, h->seg_cnt.as<uint32_t>(),
                                     h->seg_qoff.as<uint32_t>(), n1, h->stream));
     // work items: one wave's 128 members for the wave-independent int8 join, 512 otherwise
-    jm = (use_i8 && h->join8_wave) ? HS_JM_WAVE : HS_JM_BLOCK;
+    jm = use_i8 ? HS_JM_WAVE : HS_JM_BLOCK;
     HS_CHECK(cut_items(h, nql, jm, d_jstats));
     if (use_i8)
-      HS_HIP(h, (h->join8_wave ? hs_launch_gather_c8t(h->c16.p, h->sorted_ql.as<uint32_t>(),
-                                                     h->seg_qoff.as<uint32_t>(), nql, L, h->c16s.p,
-                                                     h->stream)
-                               : hs_launch_gather_c8(h->c16.p, h->sorted_ql.as<uint32_t>(), nql, L,
-                                                     h->c16s.p, h->stream)));
+      HS_HIP(h, hs_launch_gather_c8t(h->c16.p, h->sorted_ql.as<uint32_t>(), h->seg_qoff.as<uint32_t>(),
+                                     nql, L, h->c16s.p, h->stream));
     else
       HS_HIP(h, hs_launch_gather_c16(h->c16.p, h->sorted_ql.as<uint32_t>(), nql, L, h->c16s.p, h->stream));
   }
@@ -724,16 +719,11 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
                                      nq, k, r2_hi, d_cnt, prov_cap, h->prov.as<uint2>(), nullptr,
                                      nullptr, n_blocks, h->stream));
     } else {
-      if (n_items && use_i8 && h->join8_wave)
+      if (n_items && use_i8)
         HS_HIP(h, hs_launch_join8w(h->item_desc.as<uint4>(), n_items, h->tabs.t[0].packed,
                                    h->t_rec8.as<uint4>(), h->c16s.p, h->jtab8.p, d_cnt, prov_cap,
                                    h->prov.as<uint2>(), d_cnt + 32, h->n_cu * h->join_blocks_per_cu,
                                    h->stream));
-      else if (n_items && use_i8)
-        HS_HIP(h, hs_launch_join8(h->item_desc.as<uint4>(), n_items, h->tabs.t[0].packed,
-                                  h->t_rec8.as<uint4>(), h->sorted_ql.as<uint32_t>(), h->c16s.p,
-                                  h->jtab8.p, d_cnt, prov_cap, h->prov.as<uint2>(),
-                                  h->n_cu * h->join_blocks_per_cu, h->stream));
       else if (n_items)
         HS_HIP(h, hs_launch_join(h->item_desc.as<uint4>(), n_items, h->tabs.t[0].packed,
                                  h->sorted_ql.as<uint32_t>(),

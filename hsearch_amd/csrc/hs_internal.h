@@ -234,18 +234,12 @@ hipError_t hs_launch_jtables8(const double* d_coords, int alphabet, void* d_tab8
                               uint32_t* d_unsafe, hipStream_t s);
 hipError_t hs_launch_qprep8(const double* d_centers, uint32_t nq, int k, double r2,
                             const float* d_scale, void* d_c8, uint32_t* d_unsafe, hipStream_t s);
-hipError_t hs_launch_gather_c8(const void* d_c8, const uint32_t* d_sorted_ql, uint32_t nql, int L,
-                               void* d_out, hipStream_t s);
 hipError_t hs_launch_gather_c8t(const void* d_c8, const uint32_t* d_sorted_ql, const uint32_t* d_seg_qoff,
                                 uint32_t nql, int L, void* d_out, hipStream_t s);
 hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* d_packed_base,
                             const uint4* d_rec_base, const void* d_c8t, const void* d_tab8,
                             uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov,
                             uint32_t* d_item_counter, int n_blocks, hipStream_t s);
-hipError_t hs_launch_join8(const uint4* d_desc, uint32_t n_items, const uint4* d_packed_base,
-                           const uint4* d_rec_base, const uint32_t* d_sorted_ql, const void* d_c8s,
-                           const void* d_tab8, uint32_t* d_prov_count, uint32_t prov_cap,
-                           uint2* d_prov, int n_blocks, hipStream_t s);
 // bucket-ordered packed copy of one table (k <= 25) + the per-entry 16-byte A-row tails of the
 // int8 join (d_out_rec[i] belongs to d_out_packed[i])
 hipError_t hs_launch_gather_rec8(const uint4* d_packed_all, const uint32_t* d_ids_sorted, uint32_t n,

@@ -1,8 +1,9 @@
-// hs_join8.hip -- int8 variant of the bucket-join filter (see hs_join.hip for the structure).
+// hs_join8.hip -- int8 form of the bucket-join filter: the default verify path (hs_join.hip holds
+// the segment/work-item machinery and the fp16 form it falls back to).
 //
-// Same work items, same LDS staging and survivor protocol as hs_join_kernel, but the lower-bound
-// filter is evaluated in FIXED POINT on v_mfma_i32_32x32x32_i8 (K = 32 per instruction at the
-// cycles of the fp16 K = 16 form): 4 MFMAs per 32x32 tile instead of 7.
+// The lower-bound filter is evaluated in FIXED POINT on v_mfma_i32_32x32x32_i8 (K = 32 per
+// instruction at the cycles of the fp16 K = 16 form): 4 MFMAs per 32x32 tile instead of 7.  The
+// kernel is wave-independent: no LDS staging, no workgroup barrier (see hs_join8w_kernel).
 //
 // Quantisation.  s = 127 / max |coordinate| over the 4 table columns the filter uses;
 // x^ = rint(s x), c^ = rint(s c) saturated to +-127 (int8; the extra error of a saturated query
@@ -42,12 +43,8 @@ typedef int intx16 __attribute__((ext_vector_type(16)));
 constexpr int QD = 4;        // table columns used
 constexpr int QROW = 128;    // bytes of a quantised query row (global)
 constexpr int QPIECES = 8;   // 16-byte pieces per row
-constexpr int QLROW = 144;   // LDS row stride in bytes (9 x 16: conflict-free b128)
-constexpr int JQ = 32;       // queries per MFMA column tile
-constexpr int JC = 64;       // queries per LDS chunk (one barrier): two column tiles
-constexpr int JT = 4;        // 32-member row tiles per wave
-constexpr int JM = 4 * JT * 32;  // must equal hs_join.hip's JM (work items are shared)
-constexpr uint32_t JRES = 64;
+constexpr int JT = 4;        // 32-member row tiles per wave: a work item has 32 JT = HS_JM_WAVE members
+constexpr uint32_t JRES = 64;  // survivor slots a wave reserves per counter access
 constexpr int DIG = 13;      // base-127 digits (+1 remainder slot) of -gamma
 constexpr int RDIG = 11;     // base-127 digits (+1 remainder slot) of rho
 
@@ -179,20 +176,6 @@ __global__ __launch_bounds__(256) void hs_qprep8_kernel(const double* __restrict
   }
 }
 
-// rows in SEGMENT order: a chunk of 32 probing queries is one contiguous 4 KB block
-__global__ __launch_bounds__(256) void hs_gather_c8_kernel(const int8_t* __restrict__ c8,
-                                                           const uint32_t* __restrict__ sorted_ql,
-                                                           uint32_t nql, int L,
-                                                           int8_t* __restrict__ out) {
-  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (uint64_t)nql * QPIECES) return;
-  const uint32_t p = (uint32_t)(t / QPIECES);
-  const int g = (int)(t - (uint64_t)p * QPIECES);
-  const uint32_t q = sorted_ql[p] / (uint32_t)L;
-  *reinterpret_cast<uint4*>(out + (uint64_t)p * QROW + g * 16) =
-      *reinterpret_cast<const uint4*>(c8 + (uint64_t)q * QROW + g * 16);
-}
-
 // ------------------------------------------------------------------------------------------ join
 template <int BIT>
 __device__ __forceinline__ uint32_t residue_at(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
@@ -289,188 +272,7 @@ __device__ unsigned long long g_join8_timing[8];
 #define HS_TD(i, dep)
 #endif
 
-__global__ __launch_bounds__(256, 2) void hs_join8_kernel(
-    const uint4* __restrict__ desc, uint32_t n_items, const uint4* __restrict__ packed_base,
-    const uint4* __restrict__ rec_base, const uint32_t* __restrict__ sorted_ql,
-    const int8_t* __restrict__ c8s, const uint4* __restrict__ tab8,
-    uint32_t* __restrict__ prov_count, uint32_t prov_cap, uint2* __restrict__ prov, int ablate) {
-  __shared__ __attribute__((aligned(16))) int8_t sB[2][JC * QLROW];
-  __shared__ uint32_t sTab8[32];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
-#ifdef HS_JOIN_TIMING
-  uint64_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
-#endif
-  if (tid < 32) sTab8[tid] = tab8[tid].x;
-  __syncthreads();
-  // two 16-byte pieces of a chunk per thread: rows tid / 8 and 32 + tid / 8, piece tid % 8
-  const int dst = (tid >> 3) * QLROW + (tid & 7) * 16;
-  const int boff = r * QLROW + h * 16;  // B operand of k-step s: boff + 32 s (bytes)
-  int buf = 0;
-  uint32_t item = blockIdx.x;
-  if (item >= n_items) return;
-  uint32_t res_base = 0, res_used = JRES;
-  if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_sleep(8);
-  uint4 d0 = desc[2 * (uint64_t)item], d1 = desc[2 * (uint64_t)item + 1];
-  uint4 pk[JT], rk[JT], pre, pre2;
-  {
-    const int64_t off = (int64_t)(((uint64_t)d0.y << 32) | (uint64_t)d0.x);
-    const uint4* packed = packed_base + off;
-    const uint4* recs = rec_base + off;
-    const uint32_t idx = d0.w * JM + wave * (32 * JT) + r;
-#pragma unroll
-    for (int t = 0; t < JT; ++t) {
-      const uint32_t m = min(idx + 32 * t, d0.z - 1);
-      pk[t] = packed[m];
-      rk[t] = recs[m];
-    }
-    const uint4* src = reinterpret_cast<const uint4*>(c8s + (uint64_t)(d1.x + d1.y) * QROW);
-    pre = src[tid];
-    pre2 = src[tid + 256];
-  }
-  while (true) {
-    const uint32_t M = d0.z, mt = d0.w;
-    const uint32_t qoff = d1.x, q_begin = d1.y, q_end = d1.z, mstart = d1.w;
-    const uint32_t wbase = mt * JM + wave * (32 * JT);
-    const bool wave_on = wbase < M;
-    const uint32_t next_item = item + gridDim.x;
-    const bool has_next = next_item < n_items;
-    uint4 nd0 = d0, nd1 = d1;
-    if (has_next) {
-      nd0 = desc[2 * (uint64_t)next_item];
-      nd1 = desc[2 * (uint64_t)next_item + 1];
-    }
-    intx4 A[JT][4];
-    if (wave_on) {
-#pragma unroll
-      for (int t = 0; t < JT; ++t) build_afrags8(pk[t], rk[t], h, sTab8, A[t]);
-    }
-    HS_TD(0, __builtin_amdgcn_readfirstlane(A[0][0][0] ^ A[JT - 1][3][3] ^ A[JT - 1][2][0]))
-    for (uint32_t qc0 = q_begin; qc0 < q_end; qc0 += JC) {
-      int8_t* tile0 = sB[buf];
-      *reinterpret_cast<uint4*>(&tile0[dst]) = pre;
-      *reinterpret_cast<uint4*>(&tile0[dst + JQ * QLROW]) = pre2;
-      HS_TD(1, __builtin_amdgcn_readfirstlane(pre.x ^ pre2.x))
-      __syncthreads();
-      HS_T(2)
-      {
-        const bool more = qc0 + JC < q_end;
-        const uint64_t row = more ? (uint64_t)(qoff + qc0 + JC) : (uint64_t)(nd1.x + nd1.y);
-        const uint4* src = reinterpret_cast<const uint4*>(c8s + row * QROW);
-        pre = src[tid];
-        pre2 = src[tid + 256];
-      }
-      if (qc0 == q_begin) {
-        const int64_t off = (int64_t)(((uint64_t)nd0.y << 32) | (uint64_t)nd0.x);
-        const uint4* packed = packed_base + off;
-        const uint4* recs = rec_base + off;
-        const uint32_t idx = nd0.w * JM + wave * (32 * JT) + r;
-#pragma unroll
-        for (int t = 0; t < JT; ++t) {
-          const uint32_t m = min(idx + 32 * t, nd0.z - 1);
-          pk[t] = packed[m];
-          rk[t] = recs[m];
-        }
-      }
-      buf ^= 1;
-      HS_T(3)
-      if (!wave_on) continue;
-#pragma unroll 1
-      for (int half = 0; half < JC / JQ; ++half) {
-      const uint32_t qc = qc0 + (uint32_t)(half * JQ);
-      if (qc >= q_end) break;  // uniform: the second column tile of a ragged last chunk
-      const int8_t* tile = tile0 + half * JQ * QLROW;
-      intx16 acc[JT];
-#pragma unroll
-      for (int t = 0; t < JT; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0;
-      intx4 b0 = *reinterpret_cast<const intx4*>(&tile[boff]);
-      intx4 b1 = *reinterpret_cast<const intx4*>(&tile[boff + 32]);
-#define HS_STEP8(S, B)                                                                       \
-  _Pragma("unroll") for (int t = 0; t < JT; ++t)                                             \
-      acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[t][S], B, acc[t], 0, 0, 0);           \
-  if (S + 2 < 4) B = *reinterpret_cast<const intx4*>(&tile[boff + 32 * (S + 2)]);
-      HS_STEP8(0, b0) HS_STEP8(1, b1) HS_STEP8(2, b0) HS_STEP8(3, b1)
-#undef HS_STEP8
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        __builtin_amdgcn_sched_group_barrier(0x008, JT, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, 2 * JT, 0);
-      // ---- survivors: acc >= 0 (sign bit clear).  "all negative" = sign bit of the AND of all
-      //      accumulators.  D layout: col = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 h.
-      uint32_t sall = 0xffffffffu;
-#pragma unroll
-      for (int t = 0; t < JT; ++t) {
-        uint32_t o[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          o[j] = (uint32_t)acc[t][4 * j] & (uint32_t)acc[t][4 * j + 1] & (uint32_t)acc[t][4 * j + 2] &
-                 (uint32_t)acc[t][4 * j + 3];
-        sall &= (o[0] & o[1]) & (o[2] & o[3]);
-      }
-      const unsigned long long any_pass = __ballot((int)sall >= 0);
-      HS_TD(4, (uint32_t)any_pass ^ (uint32_t)(any_pass >> 32))
-      if (any_pass && !(ablate & 1)) {
-        const bool col_ok = qc + (uint32_t)r < q_end;
-        const uint32_t ql = HS_PROV_INDIRECT | (qoff + qc + (uint32_t)r);
-#pragma unroll
-        for (int t = 0; t < JT; ++t) {
-          uint32_t mask = 0;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) mask |= ((~(uint32_t)acc[t][i]) >> 31) << i;
-          if (!col_ok) mask = 0;
-          while (__ballot(mask != 0)) {
-            uint32_t idx = 0;
-            bool pass = false;
-            if (mask) {
-              const int i = __ffs((int)mask) - 1;
-              mask &= mask - 1;
-              idx = wbase + (uint32_t)(t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h);
-              pass = idx < M;
-            }
-            const unsigned long long m = __ballot(pass);
-            if (m) {
-              const uint32_t cnt = (uint32_t)__popcll(m);
-              if (res_used + cnt > JRES) {
-                if (res_used < JRES && lane >= (int)res_used && res_base + lane < prov_cap)
-                  prov[res_base + lane] = make_uint2(0xffffffffu, 0u);
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(prov_count, (uint32_t)JRES);
-                res_base = __builtin_amdgcn_readfirstlane(base);
-                res_used = 0;
-              }
-              if (pass) {
-                const uint32_t o = res_base + res_used + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (o < prov_cap) prov[o] = make_uint2(ql, mstart + idx);
-              }
-              res_used += cnt;
-            }
-          }
-        }
-      }
-      HS_T(5)
-      }
-    }
-    if (!has_next) break;
-    item = next_item;
-    d0 = nd0;
-    d1 = nd1;
-  }
-  if (res_used < JRES && lane >= (int)res_used && res_base + lane < prov_cap)
-    prov[res_base + lane] = make_uint2(0xffffffffu, 0u);
-#ifdef HS_JOIN_TIMING
-  HS_T(6)
-  if (lane == 0)
-    for (int i = 0; i < 8; ++i) atomicAdd(&g_join8_timing[i], (unsigned long long)tacc[i]);
-#endif
-}
-
-
-// ------------------------------------------------------------------ wave-independent variant
+// --------------------------------------------------------------------------------------- join
 // Query rows in TILE-FRAGMENT order: the 32-query tile starting at segment-order row p0 (a multiple
 // of 32 inside its segment), nr = rows of the tile (32, less at the segment's ragged end), keeps
 // 16-byte piece g = 2 s + h of its row j at uint4 index p0 * 8 + g * nr + j: the B operand of
@@ -828,14 +630,6 @@ hipError_t hs_launch_qprep8(const double* d_centers, uint32_t nq, int k, double 
   return hipGetLastError();
 }
 
-hipError_t hs_launch_gather_c8(const void* d_c8, const uint32_t* d_sorted_ql, uint32_t nql, int L,
-                               void* d_out, hipStream_t s) {
-  if (!nql) return hipSuccess;
-  hs_gather_c8_kernel<<<blocks_for((uint64_t)nql * QPIECES), 256, 0, s>>>(
-      (const int8_t*)d_c8, d_sorted_ql, nql, L, (int8_t*)d_out);
-  return hipGetLastError();
-}
-
 hipError_t hs_launch_gather_c8t(const void* d_c8, const uint32_t* d_sorted_ql, const uint32_t* d_seg_qoff,
                                 uint32_t nql, int L, void* d_out, hipStream_t s) {
   if (!nql) return hipSuccess;
@@ -866,29 +660,6 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
     fprintf(stderr, "join8w timing (wave-cycles): chunk %llu build(+member wait) %llu next-desc+issue %llu first group %llu other groups %llu flush %llu tail %llu | longest wave %llu, mean wave %llu\n",
             t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7],
             (t[0] + t[1] + t[2] + t[3] + t[4] + t[5] + t[6]) / (unsigned long long)(n_blocks * 4));
-    memset(t, 0, sizeof(t));
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_join8_timing), t, sizeof(t));
-  }
-#endif
-  return hipGetLastError();
-}
-
-hipError_t hs_launch_join8(const uint4* d_desc, uint32_t n_items, const uint4* d_packed_base,
-                           const uint4* d_rec_base, const uint32_t* d_sorted_ql, const void* d_c8s,
-                           const void* d_tab8, uint32_t* d_prov_count, uint32_t prov_cap,
-                           uint2* d_prov, int n_blocks, hipStream_t s) {
-  if (!n_items) return hipSuccess;
-  hs_join8_kernel<<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_rec_base, d_sorted_ql,
-                                           (const int8_t*)d_c8s, (const uint4*)d_tab8,
-                                           d_prov_count, prov_cap, d_prov,
-                                           getenv("HS_ABLATE") ? atoi(getenv("HS_ABLATE")) : 0);
-#ifdef HS_JOIN_TIMING
-  {
-    unsigned long long t[8];
-    (void)hipStreamSynchronize(s);
-    (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_join8_timing), sizeof(t));
-    fprintf(stderr, "join8 timing (wave-cycles): build %llu stage %llu barrier %llu prefetch %llu mfma %llu surv %llu tail %llu\n",
-            t[0], t[1], t[2], t[3], t[4], t[5], t[6]);
     memset(t, 0, sizeof(t));
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_join8_timing), t, sizeof(t));
   }

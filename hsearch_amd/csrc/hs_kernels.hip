@@ -736,8 +736,8 @@ static hipError_t launch_hash(const uint8_t* d_codes, const double* d_pts, uint6
   const size_t lds = FROM_CODES ? 256u * (size_t)k : 0;
   const int kc = F % 16 == 0 ? 16 : F % 8 == 0 ? 8 : F % 5 == 0 ? 5 : F % 4 == 0 ? 4 : F % 2 == 0 ? 2 : 1;
   const unsigned chunks = (unsigned)(F / kc);
-  // enough block rows to reach ~8 blocks per CU when the point count alone does not
-  const unsigned gy = std::max(1u, std::min(chunks, 2048u / std::max(blocks, 1u)));
+  // enough block rows to reach ~16 blocks per CU when the point count alone does not
+  const unsigned gy = std::max(1u, std::min(chunks, 4096u / std::max(blocks, 1u)));
   const dim3 grid(blocks, gy);
 #define HS_HASH(KC)                                                                            \
   hs_hash_kernel<KC, FROM_CODES><<<grid, 256, lds, s>>>(d_codes, d_pts, n, k, d_a, d_b, F, W, \
