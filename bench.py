@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 JOIN_K = 112.0     # GEMM depth of hs_join_kernel (fp16)
-JOIN_K_I8 = 128.0  # GEMM depth of hs_join8_kernel (int8)
+JOIN_K_I8 = 128.0  # GEMM depth of hs_join8w_kernel (int8)
 MFMA_I8_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md: I8 MFMA = 2x the BF16 rate per clock
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
 
@@ -239,16 +239,17 @@ def main():
             except Exception:
                 traffic = None
         if join_batches:
-            # dominant kernel = hs_join_kernel, an fp16 MFMA GEMM of depth JOIN_K = 112 (25 positions
-            # x 4 coordinates + 8 extras + 4 pad) per (bucket member, probing query) pair:
-            # 2*112 flop per pair (hsearch_amd/csrc/hs_join.hip).
+            # dominant kernel = the bucket join: an int8 MFMA GEMM of depth 128 (25 positions x 4
+            # coordinates + 28 threshold-digit slots; hs_join8.hip) -- or, when a batch had to fall
+            # back, the fp16 form of depth 112 (hs_join.hip) -- per (bucket member, probing query)
+            # pair: 2 * depth operations per pair.
             j_ms = join_ms / steps
             i8 = join_i8 > 0
             jk = JOIN_K_I8 if i8 else JOIN_K
             peak = MFMA_I8_PEAK_TOPS if i8 else MFMA_F16_PEAK_TFLOPS
             flop = jstat[1] * 2.0 * jk          # real (member, query) pairs routed to the join
             tf = flop / (j_ms * 1e-3) / 1e12 if j_ms > 0 else 0.0
-            roofline = {"bound": "mfma", "kernel": "hs_join8_kernel" if i8 else "hs_join_kernel",
+            roofline = {"bound": "mfma", "kernel": "hs_join8w_kernel" if i8 else "hs_join_kernel",
                         "mfma_dtype": "i8" if i8 else "f16", "gemm_depth": jk, "achieved": tf,
                         "peak": peak, "unit": "TOP/s" if i8 else "TFLOP/s",
                         "frac": tf / peak, "traffic": traffic,

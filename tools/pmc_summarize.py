@@ -1,0 +1,34 @@
+"""Sum the rocprofv3 --pmc passes written by tools/pmc_join.sh for one kernel into a JSON summary
+(and, with --traffic, refresh profiles/traffic_latest.json, which bench.py reports as
+roofline.traffic).  Usage: python tools/pmc_summarize.py gpurun_out/pmc_<tag> <kernel substring>
+<out.json> [--traffic]"""
+import collections, csv, glob, json, sys
+src, kernel, out = sys.argv[1], sys.argv[2], sys.argv[3]
+tot = collections.defaultdict(float); launches = collections.defaultdict(int)
+for f in glob.glob(src + '/p*/*/*_counter_collection.csv'):
+    for row in csv.DictReader(open(f)):
+        if kernel in row['Kernel_Name']:
+            tot[row['Counter_Name']] += float(row['Counter_Value']); launches[row['Counter_Name']] += 1
+# rocprofv3 writes one row per (dispatch, counter, dimension instance) for some counters: count dispatches
+disp = collections.defaultdict(set)
+for f in glob.glob(src + '/p*/*/*_counter_collection.csv'):
+    for row in csv.DictReader(open(f)):
+        if kernel in row['Kernel_Name']:
+            disp[row['Counter_Name']].add(row['Dispatch_Id'])
+res = {"kernel": kernel,
+       "method": "rocprofv3 --kernel-trace --pmc <counters>, one pass per counter group, over `bench.py --steps 1 "
+                 "--warmup 0 --no-cpu-baseline --recall-queries 0` (tools/pmc_join.sh); FETCH_SIZE (KB) doubled per "
+                 "MI355X_MICROARCH.md section HBM (gfx950 tallies the 128-B requests of 16-B/lane streams at 64 B); "
+                 "WRITE_SIZE (KB) taken as is",
+       "counters": {k: {"sum_over_launches": v, "launches": len(disp[k])} for k, v in sorted(tot.items())}}
+if "FETCH_SIZE" in tot:
+    n = max(1, len(disp["FETCH_SIZE"]))
+    res["fetch_size_kb_per_launch"] = tot["FETCH_SIZE"] / n
+    res["write_size_kb_per_launch"] = tot.get("WRITE_SIZE", 0.0) / n
+    res["verify_bytes_per_launch"] = (2.0 * tot["FETCH_SIZE"] + tot.get("WRITE_SIZE", 0.0)) * 1024.0 / n
+    res["launches_per_step"] = 1
+json.dump(res, open(out, 'w'), indent=1)
+if "--traffic" in sys.argv and "FETCH_SIZE" in tot:
+    json.dump(res, open('profiles/traffic_latest.json', 'w'), indent=1)
+print(json.dumps({k: v for k, v in res.items() if k != "counters"}, indent=1))
+for k, v in res["counters"].items(): print("%-32s %.4g (%d launches)" % (k, v["sum_over_launches"], v["launches"]))
