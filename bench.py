@@ -33,8 +33,8 @@ MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF den
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--db-size", dest="n", type=int, default=10_000_000, help="DB k-mers")
     ap.add_argument("--queries", dest="nq", type=int, default=100_000, help="queries per GPU")
     ap.add_argument("--k", type=int, default=25)

@@ -223,6 +223,11 @@ hipError_t hs_launch_seg_order(const uint32_t* d_big_pos, const uint32_t* d_item
 // wave-independent int8 join
 #define HS_JM_BLOCK 512u
 #define HS_JM_WAVE 128u
+// queries per work item of the wave-independent join (a wave re-uses its members' operands over
+// all of them; the staged kernel's items stop at 2048)
+#ifndef HS_JQG_WAVE
+#define HS_JQG_WAVE 8192u
+#endif
 hipError_t hs_launch_gather_c16(const void* d_c16, const uint32_t* d_sorted_ql, uint32_t nql, int L,
                                 void* d_out, hipStream_t s);
 hipError_t hs_launch_join(const uint4* d_desc, uint32_t n_items, const uint4* d_packed_base,

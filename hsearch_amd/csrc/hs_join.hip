@@ -39,7 +39,7 @@ constexpr int JROW = 120;   // LDS row stride in halves: 240 B = 15 x 16 B -> co
 constexpr int JQ = 32;      // queries per chunk (MFMA N)
 constexpr int JT = 4;       // 32-member MFMA row tiles per wave
 constexpr int JM = 4 * JT * 32;  // members per workgroup tile: 512
-constexpr int JQG = 2048;   // queries per work item (<= 64 chunks)
+constexpr int JQG = 2048;   // queries per work item of the staged fp16 kernel (<= 64 chunks)
 constexpr uint32_t JRES = 64;  // survivor slots a wave reserves per atomic
 constexpr float JSLACK = 1.5f;  // 1 for the rounding analysis + 0.5 so that "G < 0" covers "G <= 0"
 
@@ -147,11 +147,12 @@ __global__ __launch_bounds__(256) void hs_seg_route_kernel(const uint64_t* __res
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
   if (j > n_max) return;
   uint32_t it = 0;
+  const uint32_t jqg = jm == HS_JM_WAVE ? HS_JQG_WAVE : (uint32_t)JQG;
   if (j < *n_seg && (seg_key[j] >> shift) < (uint64_t)L) {
     const uint32_t m = qcount[sorted_ql[seg_qoff[j]]];
     const uint32_t nq = seg_cnt[j];
     if (nq >= min_q && m >= min_m) {
-      it = ((m + jm - 1) / jm) * ((nq + JQG - 1) / JQG);
+      it = ((m + jm - 1) / jm) * ((nq + jqg - 1) / jqg);
       // MFMA pairs actually issued (128-row waves x 32-column chunks) vs real pairs
       atomicAdd(stats + 0, (unsigned long long)((m + 32 * JT - 1) / (32 * JT) * (32 * JT)) *
                                ((nq + JQ - 1) / JQ * JQ));
@@ -226,10 +227,11 @@ __global__ __launch_bounds__(256) void hs_item_desc_kernel(hs_tables_dev tabs,
   const uint64_t key = seg_key[seg];
   const uint32_t nQ = seg_cnt[seg], qoff = seg_qoff[seg];
   const uint32_t M = qcount[sorted_ql[qoff]];
+  const uint32_t jqg = jm == HS_JM_WAVE ? HS_JQG_WAVE : (uint32_t)JQG;
   const uint32_t tiles_m = (M + jm - 1) / jm;
   const uint32_t local = item - item_off[lo];
   const uint32_t mt = local % tiles_m, qg = local / tiles_m;
-  const uint32_t q_begin = qg * JQG;
+  const uint32_t q_begin = qg * jqg;
   const uint32_t mstart = (uint32_t)(key & ((1ull << shift) - 1ull));
   // offset (in 16-byte words) from table 0's packed array: base + offset keeps the member loads
   // in the global address space (a pointer rebuilt from integers compiles to flat loads, whose
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256) void hs_item_desc_kernel(hs_tables_dev tabs,
   const int64_t off = (reinterpret_cast<intptr_t>(tabs.t[(uint32_t)(key >> shift)].packed) -
                        reinterpret_cast<intptr_t>(tabs.t[0].packed)) / 16 + (int64_t)mstart;
   desc[2 * (uint64_t)item] = make_uint4((uint32_t)(uint64_t)off, (uint32_t)((uint64_t)off >> 32), M, mt);
-  desc[2 * (uint64_t)item + 1] = make_uint4(qoff, q_begin, min(nQ, q_begin + JQG), mstart);
+  desc[2 * (uint64_t)item + 1] = make_uint4(qoff, q_begin, min(nQ, q_begin + jqg), mstart);
 }
 
 // c16 rows in SEGMENT order, so that a chunk of 32 probing queries is one contiguous 7 KB block
