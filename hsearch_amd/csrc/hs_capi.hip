@@ -71,6 +71,9 @@ struct hs_handle {
   // per-entry records ([L][n], k <= 25 only) at the same entry offsets
   DevBuf t_packed, t_rec8;
   DevBuf t_pos;  // [L][n] sorted position of every DB id in every table (first-seen dedupe)
+  DevBuf dir_base;       // [L + 1] first global bucket number of every table; [L] = nb_total
+  uint32_t nb_total = 0;  // buckets of all tables
+  DevBuf bucket_work;    // per-batch: counts + 3 work arrays over the nb_total + 2 bucket slots
   hs_tables_dev tabs;
   hs_index_info info;
   // query workspace (grown on demand, reused across calls)
@@ -254,7 +257,8 @@ void hs_destroy(hs_handle* h) {
                     &h->io_codes, &h->io_misc, &h->jtab, &h->c16, &h->seg_keys, &h->seg_keys_sorted,
                     &h->seg_vals, &h->sorted_ql, &h->seg_key, &h->seg_cnt, &h->seg_qoff,
                     &h->seg_items, &h->item_off, &h->seg_n, &h->c16s, &h->item_desc,
-                    &h->probe_slow, &h->jtab8, &h->t_packed, &h->t_rec8, &h->t_pos};
+                    &h->probe_slow, &h->jtab8, &h->t_packed, &h->t_rec8, &h->t_pos, &h->dir_base,
+                    &h->bucket_work};
   for (DevBuf* bf : bufs) bf->release();
   for (int l = 0; l < HS_MAX_L; ++l) {
     h->t_dirkey[l].release();
@@ -528,6 +532,19 @@ hs_status hs_index_build(hs_handle* h, const uint8_t* codes, uint64_t n) {
   h->prof.ms_total = ev_ms(h, 8, 9);
   h->info.n = n;
   h->info.key_seed = seed;
+  {  // global bucket numbering over the tables (grouping of probes by bucket at query time)
+    uint32_t base[HS_MAX_L + 1];
+    uint64_t acc = 0;
+    for (uint32_t l = 0; l < h->p.L; ++l) {
+      base[l] = (uint32_t)acc;
+      acc += h->info.n_buckets[l];
+    }
+    if (acc >= 0xfffffff0ull) return fail(h, HS_ERR_INVALID, "too many buckets");
+    base[h->p.L] = (uint32_t)acc;
+    h->nb_total = (uint32_t)acc;
+    HS_HIP(h, h->dir_base.reserve((HS_MAX_L + 1) * 4));
+    HS_HIP(h, hipMemcpy(h->dir_base.p, base, ((size_t)h->p.L + 1) * 4, hipMemcpyHostToDevice));
+  }
   uint64_t bytes = h->codes.cap + h->packed_all.cap + h->t_packed.cap + h->t_rec8.cap + h->t_pos.cap;
   for (uint32_t l = 0; l < h->p.L; ++l)
     bytes += h->t_dirkey[l].cap + h->t_dirstart[l].cap + h->t_dirtuple[l].cap + h->t_ids[l].cap;
@@ -567,14 +584,6 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
                                     h->p.W, h->qints.as<int32_t>(), h->LK, h->stream));
   }
   HS_HIP(h, hipEventRecord(h->ev[1], h->stream));
-  if (!brute) {
-    HS_HIP(h, hs_launch_set_u32(h->nslices.as<uint32_t>() + nql, 0u, h->stream));
-    HS_HIP(h, hs_launch_probe(h->tabs, h->qints.as<int32_t>(), nq, K, L, h->key_seed,
-                              h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
-                              h->nslices.as<uint32_t>(), d_cand,
-                              reinterpret_cast<unsigned long long*>(d_cnt + 2),
-                              h->probe_slow.as<uint32_t>(), h->stream));
-  }
   // Bucket join (hs_join.hip) when fp16 can carry the data and a k-mer is one packed word; the
   // streaming kernel otherwise (and for brute force).  With the join on, segments (bucket x its
   // probing queries) with too few queries to fill MFMA columns still go to the streaming kernel:
@@ -582,6 +591,25 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   bool use_join = !brute && h->verify_mode != 1 && h->join_tables_ok && k <= 25 && r2 < 30000.0;
   // int8 form of the join filter (hs_join8.hip) unless forced to fp16 (mode 3) or not representable
   bool use_i8 = use_join && h->join8_tables_ok && h->verify_mode != 3;
+  if (!brute) {
+    // with a join ahead, the probe also numbers each probe's bucket and ranks it inside (the
+    // grouping of the probes by bucket is then a counting sort: hs_launch_seg_group)
+    uint32_t *bucket_count = nullptr, *qbucket = nullptr, *qrank = nullptr;
+    if (use_join) {
+      HS_HIP(h, h->bucket_work.reserve(4 * ((size_t)h->nb_total + 2) * 4));
+      HS_HIP(h, h->seg_keys.reserve(((size_t)nql + 1) * 8));
+      bucket_count = h->bucket_work.as<uint32_t>();
+      qbucket = h->seg_keys.as<uint32_t>();
+      qrank = qbucket + ((size_t)nql + 1);
+    }
+    HS_HIP(h, hs_launch_set_u32(h->nslices.as<uint32_t>() + nql, 0u, h->stream));
+    HS_HIP(h, hs_launch_probe(h->tabs, h->qints.as<int32_t>(), nq, K, L, h->key_seed,
+                              h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
+                              h->nslices.as<uint32_t>(), d_cand,
+                              reinterpret_cast<unsigned long long*>(d_cnt + 2),
+                              h->probe_slow.as<uint32_t>(), h->dir_base.as<uint32_t>(), h->nb_total,
+                              bucket_count, qbucket, qrank, h->stream));
+  }
   uint32_t* d_unsafe = d_cnt + 8;
   unsigned long long* d_jstats = reinterpret_cast<unsigned long long*>(d_cnt + 10);
   uint32_t n_items = 0, n_slices = 1, jm = HS_JM_BLOCK;
@@ -600,23 +628,20 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, h->seg_items.reserve(n1 * 4));
     HS_HIP(h, h->item_off.reserve(n1 * 4));
     HS_HIP(h, h->seg_n.reserve(64));
-    HS_HIP(h, h->temp.reserve(std::max(std::max(hs_sort_pairs_u64_u32_temp(nql), hs_rle_u64_temp(nql)),
-                                       hs_scan_u32_temp(n1)) + 256));
+    HS_HIP(h, h->temp.reserve(std::max(hs_scan_u32_temp(n1), hs_scan_u32_temp((size_t)h->nb_total + 2)) + 256));
     if (use_i8)
       HS_HIP(h, hs_launch_qprep8(d_centers, nq, k, r2, h->jtab8.as<float>() + 128, h->c16.p, d_unsafe,
                                  h->stream));
     else
       HS_HIP(h, hs_launch_qprep(d_centers, nq, k, r2, h->c16.p, d_unsafe, h->stream));
-    HS_HIP(h, hs_launch_seg_keys(h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(), nql, L, seg_shift,
-                                 h->seg_keys.as<uint64_t>(), h->seg_vals.as<uint32_t>(), h->stream));
-    HS_HIP(h, hs_sort_pairs_u64_u32(h->temp.p, h->temp.cap, h->seg_keys.as<uint64_t>(),
-                                    h->seg_keys_sorted.as<uint64_t>(), h->seg_vals.as<uint32_t>(),
-                                    h->sorted_ql.as<uint32_t>(), nql, seg_shift + bit_width_u32((uint32_t)L),
-                                    h->stream));
     HS_HIP(h, hipMemsetAsync(h->seg_cnt.p, 0, n1 * 4, h->stream));
-    HS_HIP(h, hs_rle_u64(h->temp.p, h->temp.cap, h->seg_keys_sorted.as<uint64_t>(),
-                         h->seg_key.as<uint64_t>(), h->seg_cnt.as<uint32_t>(),
-                         h->seg_n.as<uint32_t>(), nql, h->stream));
+    HS_HIP(h, hs_launch_seg_group(h->tabs, h->dir_base.as<uint32_t>(), L, seg_shift, h->nb_total,
+                                  h->bucket_work.as<uint32_t>(),
+                                  h->bucket_work.as<uint32_t>() + ((size_t)h->nb_total + 2), h->temp.p,
+                                  h->temp.cap, h->seg_keys.as<uint32_t>(),
+                                  h->seg_keys.as<uint32_t>() + n1, nql, h->sorted_ql.as<uint32_t>(),
+                                  h->seg_key.as<uint64_t>(), h->seg_cnt.as<uint32_t>(),
+                                  h->seg_n.as<uint32_t>(), h->stream));
     HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, h->seg_cnt.as<uint32_t>(),
                                     h->seg_qoff.as<uint32_t>(), n1, h->stream));
     // work items: one wave's 128 members for the wave-independent int8 join, 512 otherwise
@@ -666,7 +691,8 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
                                 h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
                                 h->nslices.as<uint32_t>(), d_cand,
                                 reinterpret_cast<unsigned long long*>(d_cnt + 2),
-                              h->probe_slow.as<uint32_t>(), h->stream));
+                                h->probe_slow.as<uint32_t>(), nullptr, 0, nullptr, nullptr, nullptr,
+                                h->stream));
       HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, h->nslices.as<uint32_t>(),
                                       h->slice_off.as<uint32_t>(), (size_t)nql + 1, h->stream));
       n_slices = 1;
@@ -692,7 +718,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   HS_HIP(h, hipEventRecord(h->ev[2], h->stream));
   bool tables_done = !side;
   uint32_t prov_cap = (uint32_t)std::max<size_t>(h->prov.cap / 8, std::max<size_t>(1u << 20, 16ull * nq));
-  uint32_t host_cnt[4] = {0, 0, 0, 0};
+  uint32_t host_cnt[16] = {0};  // [0] survivors [1] hits [2..3] candidates ... [10..13] join statistics
   double ms_verify = 0, ms_final = 0, ms_join = 0;
   uint32_t launches = 0;
   for (;;) {  // retried only when a workspace capacity was exceeded
@@ -753,7 +779,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
                                    h->stream));
     }
     HS_HIP(h, hipEventRecord(h->ev[5], h->stream));
-    HS_HIP(h, hipMemcpyAsync(host_cnt, d_cnt, 16, hipMemcpyDeviceToHost, h->stream));
+    HS_HIP(h, hipMemcpyAsync(host_cnt, d_cnt, 64, hipMemcpyDeviceToHost, h->stream));
     HS_HIP(h, hipStreamSynchronize(h->stream));
     ms_verify += ev_ms(h, 3, 4);
     if (!brute && n_items) ms_join += ev_ms(h, 3, 10);
@@ -780,7 +806,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   h->prof.join_items += n_items;
   if (use_join) {
     unsigned long long js[2] = {0, 0};
-    HS_HIP(h, hipMemcpy(js, d_jstats, 16, hipMemcpyDeviceToHost));
+    memcpy(js, host_cnt + 10, 16);  // d_jstats = d_cnt + 10, read back with the counters
     h->prof.join_pairs_issued += js[0];
     h->prof.join_pairs += js[1];
   }
@@ -820,7 +846,8 @@ static hs_status run_query(hs_handle* h, const double* d_centers, uint64_t nq, d
         HS_HIP(h, hipEventRecord(h->ev[6], h->stream));
         HS_HIP(h, hs_sort_pairs_u64_u64(h->temp.p, h->temp.cap, h->hit_key.as<uint64_t>(),
                                         h->hit_key2.as<uint64_t>(), h->hit_val.as<uint64_t>(),
-                                        h->hit_val2.as<uint64_t>(), nh, 64, h->stream));
+                                        h->hit_val2.as<uint64_t>(), nh,
+                                        37 + bit_width_u32((uint32_t)(q0 + nqb)), h->stream));
         if (total + nh <= cap)
           HS_HIP(h, hs_launch_unpack_hits(h->hit_key2.as<uint64_t>(), h->hit_val2.as<uint64_t>(), nh,
                                           d_hit_q + total, d_hit_id + total,

@@ -30,6 +30,8 @@ __host__ __device__ inline uint64_t hs_key_put(uint64_t h, uint32_t ch) {
   return (h ^ ch) * 0x100000001b3ull;
 }
 __host__ __device__ inline uint64_t hs_key_put_int(uint64_t h, int32_t v) {
+  // the decimal characters of v, most significant first (std::to_string, lsh.hpp:51-59); divisions
+  // by constants only, short numbers (the usual bucket ints) first
   uint32_t m;
   if (v < 0) {
     h = hs_key_put(h, '-');
@@ -37,14 +39,22 @@ __host__ __device__ inline uint64_t hs_key_put_int(uint64_t h, int32_t v) {
   } else {
     m = (uint32_t)v;
   }
-  uint32_t p = 1;
-  while (m / p >= 10) p *= 10;
-  while (p) {
-    uint32_t dgt = m / p;
-    h = hs_key_put(h, '0' + dgt);
-    m -= dgt * p;
-    p /= 10;
+  if (m < 10u) return hs_key_put(h, '0' + m);
+  if (m < 100u) {
+    const uint32_t q = m / 10u;
+    h = hs_key_put(h, '0' + q);
+    return hs_key_put(h, '0' + (m - 10u * q));
   }
+  bool started = false;
+#define HS_DIGIT(P)                            \
+  {                                            \
+    const uint32_t dgt = (m / (P)) % 10u;      \
+    started = started || dgt != 0u;            \
+    if (started) h = hs_key_put(h, '0' + dgt); \
+  }
+  HS_DIGIT(1000000000u) HS_DIGIT(100000000u) HS_DIGIT(10000000u) HS_DIGIT(1000000u) HS_DIGIT(100000u)
+  HS_DIGIT(10000u) HS_DIGIT(1000u) HS_DIGIT(100u) HS_DIGIT(10u) HS_DIGIT(1u)
+#undef HS_DIGIT
   return h;
 }
 __host__ __device__ inline uint64_t hs_key_fin(uint64_t h) {
@@ -168,7 +178,20 @@ hipError_t hs_launch_max_u32(const uint32_t* d_in, uint32_t n, uint32_t* d_out, 
 hipError_t hs_launch_probe(const hs_tables_dev& tabs, const int32_t* d_qints, uint32_t nq, int K,
                            int L, uint32_t seed, uint32_t* d_qstart, uint32_t* d_qcount,
                            uint32_t* d_nslices, uint64_t* d_cand_out, unsigned long long* d_cand_total,
-                           uint32_t* d_slow /* [nq*L + 1] */, hipStream_t s);
+                           uint32_t* d_slow /* [nq*L + 1] */, const uint32_t* d_dir_base,
+                           uint32_t nb_total, uint32_t* d_bucket_count, uint32_t* d_qbucket,
+                           uint32_t* d_qrank, hipStream_t s);
+// With d_bucket_count != null the probe also groups the probes by bucket for the join: global
+// bucket number d_qbucket[ql] = d_dir_base[table] + directory index (nb_total = the pseudo-bucket
+// of probes that found none) and d_qrank[ql] = arrival rank inside it (d_bucket_count[nb_total + 2]).
+// hs_launch_seg_group turns that into sorted_ql / seg_key / seg_cnt / n_seg (a counting sort: the
+// segments come out in bucket-number order, the pseudo-bucket last).
+hipError_t hs_launch_seg_group(const hs_tables_dev& tabs, const uint32_t* d_dir_base, int L, int shift,
+                               uint32_t nb_total, const uint32_t* d_bucket_count,
+                               uint32_t* d_bucket_work /* 3 x (nb_total + 2) */, void* d_temp,
+                               size_t temp_bytes, const uint32_t* d_qbucket, const uint32_t* d_qrank,
+                               uint32_t nql, uint32_t* d_sorted_ql, uint64_t* d_seg_key,
+                               uint32_t* d_seg_cnt, uint32_t* d_n_seg, hipStream_t s);
 hipError_t hs_launch_qtables(const double* d_centers, uint32_t nq, int k, const double* d_coords,
                              int alphabet, float* d_tq, hipStream_t s);
 hipError_t hs_launch_verify(const hs_tables_dev& tabs, const uint32_t* d_qstart,
@@ -195,10 +218,6 @@ hipError_t hs_launch_jtables(const double* d_coords, int alphabet, void* d_tab16
                              uint32_t* d_unsafe, hipStream_t s);
 hipError_t hs_launch_qprep(const double* d_centers, uint32_t nq, int k, double r2, void* d_c16,
                            uint32_t* d_unsafe, hipStream_t s);
-// segment key of a probe = (table << shift) | first sorted position of its bucket; table = L for a
-// probe that found no bucket.  shift = bits of the largest position.
-hipError_t hs_launch_seg_keys(const uint32_t* d_qstart, const uint32_t* d_qcount, uint32_t nql, int L,
-                              int shift, uint64_t* d_keys, uint32_t* d_vals, hipStream_t s);
 // items[j] for joined segments (>= min_q probing queries and >= min_m members), 0 otherwise, and
 // nslices[ql] = 0 for the probes of joined segments; stats[0] += MFMA pairs issued, [1] += real pairs
 hipError_t hs_launch_seg_route(const uint64_t* d_seg_key, const uint32_t* d_seg_cnt,

@@ -115,20 +115,45 @@ __global__ void hs_jtables_kernel(const double* __restrict__ coords, int alphabe
   if (bad) atomicOr(unsafe, 1u);
 }
 
-// ---------------------------------------------------------------------------- segments / items
-// key = (table << 32 | first sorted position of the bucket) for probes that found a bucket.
-__global__ __launch_bounds__(256) void hs_seg_keys_kernel(const uint32_t* __restrict__ qstart,
-                                                          const uint32_t* __restrict__ qcount,
-                                                          uint32_t nql, int L, int shift,
-                                                          uint64_t* __restrict__ keys,
-                                                          uint32_t* __restrict__ vals) {
+// Probes -> segments by a counting sort on the global bucket number (hs_probe_kernel left, per
+// probe, its bucket and its arrival rank inside it):
+//   start = exclusive scan of the bucket counts;  sorted_ql[start[bucket] + rank] = probe;
+//   the non-empty buckets, in bucket order, are the segments: key = (table << shift) | first sorted
+//   position of the bucket, count = probes.  The pseudo-bucket (probes of no bucket) comes last
+//   with table = L and is routed nowhere.
+__global__ __launch_bounds__(256) void hs_seg_scatter_kernel(const uint32_t* __restrict__ qbucket,
+                                                             const uint32_t* __restrict__ qrank,
+                                                             const uint32_t* __restrict__ bucket_start,
+                                                             uint32_t nql,
+                                                             uint32_t* __restrict__ sorted_ql) {
   const uint32_t ql = blockIdx.x * 256 + threadIdx.x;
-  if (ql >= nql) return;
-  const uint32_t l = ql % (uint32_t)L;
-  // (table, first sorted position of the bucket) in as few bits as they need -- the radix sort
-  // that groups the probes runs over those bits only; a probe of no bucket sorts last (table L)
-  keys[ql] = ((uint64_t)(qcount[ql] ? l : (uint32_t)L) << shift) | (qcount[ql] ? qstart[ql] : 0u);
-  vals[ql] = ql;
+  if (ql < nql) sorted_ql[bucket_start[qbucket[ql]] + qrank[ql]] = ql;
+}
+__global__ __launch_bounds__(256) void hs_seg_flag_kernel(const uint32_t* __restrict__ bucket_count,
+                                                          uint32_t n, uint32_t* __restrict__ flag) {
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g <= n) flag[g] = (g < n && bucket_count[g]) ? 1u : 0u;  // flag[n] = 0 closes the scan
+}
+__global__ __launch_bounds__(256) void hs_seg_emit_kernel(hs_tables_dev tabs,
+                                                          const uint32_t* __restrict__ dir_base, int L,
+                                                          int shift,
+                                                          const uint32_t* __restrict__ bucket_count,
+                                                          const uint32_t* __restrict__ flag_pos,
+                                                          uint32_t n /* buckets incl. the pseudo one */,
+                                                          uint64_t* __restrict__ seg_key,
+                                                          uint32_t* __restrict__ seg_cnt,
+                                                          uint32_t* __restrict__ n_seg) {
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g == 0) *n_seg = flag_pos[n];
+  if (g >= n) return;
+  const uint32_t c = bucket_count[g];
+  if (!c) return;
+  int l = 0;
+  while (l < L && g >= dir_base[l + 1]) ++l;  // dir_base[L] = n - 1 = the pseudo-bucket: l = L
+  const uint32_t mstart = l < L ? tabs.t[l].dir_start[g - dir_base[l]] : 0u;
+  const uint32_t j = flag_pos[g];
+  seg_key[j] = ((uint64_t)(uint32_t)l << shift) | mstart;
+  seg_cnt[j] = c;
 }
 
 // Routing: a segment (bucket x its probing queries) goes to the MFMA join when enough queries share
@@ -504,10 +529,25 @@ hipError_t hs_launch_qprep(const double* d_centers, uint32_t nq, int k, double r
   return hipGetLastError();
 }
 
-hipError_t hs_launch_seg_keys(const uint32_t* d_qstart, const uint32_t* d_qcount, uint32_t nql, int L,
-                              int shift, uint64_t* d_keys, uint32_t* d_vals, hipStream_t s) {
+hipError_t hs_launch_seg_group(const hs_tables_dev& tabs, const uint32_t* d_dir_base, int L, int shift,
+                               uint32_t nb_total, const uint32_t* d_bucket_count,
+                               uint32_t* d_bucket_work, void* d_temp, size_t temp_bytes,
+                               const uint32_t* d_qbucket, const uint32_t* d_qrank, uint32_t nql,
+                               uint32_t* d_sorted_ql, uint64_t* d_seg_key, uint32_t* d_seg_cnt,
+                               uint32_t* d_n_seg, hipStream_t s) {
   if (!nql) return hipSuccess;
-  hs_seg_keys_kernel<<<blocks_for(nql), 256, 0, s>>>(d_qstart, d_qcount, nql, L, shift, d_keys, d_vals);
+  const uint32_t n = nb_total + 1;  // buckets incl. the pseudo one; arrays have n + 1 entries
+  uint32_t* start = d_bucket_work;
+  uint32_t* flag = d_bucket_work + (n + 1);
+  uint32_t* flag_pos = d_bucket_work + 2 * (size_t)(n + 1);
+  hipError_t e = hs_exclusive_scan_u32(d_temp, temp_bytes, d_bucket_count, start, (size_t)n + 1, s);
+  if (e != hipSuccess) return e;
+  hs_seg_scatter_kernel<<<blocks_for(nql), 256, 0, s>>>(d_qbucket, d_qrank, start, nql, d_sorted_ql);
+  hs_seg_flag_kernel<<<blocks_for((uint64_t)n + 1), 256, 0, s>>>(d_bucket_count, n, flag);
+  e = hs_exclusive_scan_u32(d_temp, temp_bytes, flag, flag_pos, (size_t)n + 1, s);
+  if (e != hipSuccess) return e;
+  hs_seg_emit_kernel<<<blocks_for(n), 256, 0, s>>>(tabs, d_dir_base, L, shift, d_bucket_count, flag_pos,
+                                                   n, d_seg_key, d_seg_cnt, d_n_seg);
   return hipGetLastError();
 }
 

@@ -250,10 +250,20 @@ __global__ __launch_bounds__(256) void hs_probe_kernel(hs_tables_dev tabs,
                                                        uint32_t* __restrict__ nslices,
                                                        uint64_t* __restrict__ cand_out,
                                                        unsigned long long* __restrict__ cand_total,
-                                                       uint32_t* __restrict__ slow) {
+                                                       uint32_t* __restrict__ slow,
+                                                       const uint32_t* __restrict__ dir_base,
+                                                       uint32_t nb_total,
+                                                       uint32_t* __restrict__ bucket_count,
+                                                       uint32_t* __restrict__ qbucket,
+                                                       uint32_t* __restrict__ qrank) {
   const uint32_t ql = blockIdx.x * 256 + threadIdx.x;
   uint32_t count = 0, start = 0;
+  // grouping of the probes by bucket (for the bucket join): global bucket number and arrival rank;
+  // nb_total = the pseudo-bucket of probes that found none
+  uint32_t gb = nb_total;
+  bool ranked = false;  // false: out of range, or left to hs_probe_slow_kernel
   if (ql < nq * (uint32_t)L) {
+    ranked = true;
     const int l = (int)(ql % (uint32_t)L);
     const int32_t* t = qints + (uint64_t)ql * K;
     uint64_t hk = hs_key_init(seed);
@@ -272,14 +282,34 @@ __global__ __launch_bounds__(256) void hs_probe_kernel(hs_tables_dev tabs,
       if (same) {
         start = tb.dir_start[lo];
         count = tb.dir_start[lo + 1] - start;
+        if (dir_base) gb = dir_base[l] + lo;
       } else {
         slow[1 + atomicAdd(slow, 1u)] = ql;
+        ranked = false;
       }
     }
     qstart[ql] = start;
     qcount[ql] = count;
     nslices[ql] = (count + HS_SLICE - 1) / HS_SLICE;
     if (cand_out) cand_out[ql] = count;
+  }
+  if (bucket_count) {
+    const bool pseudo = ranked && gb == nb_total;
+    // one counter access per wave for the pseudo-bucket (same-address atomics are slow)
+    const unsigned long long pm = __ballot(pseudo);
+    uint32_t rank = 0;
+    if (pm) {
+      const int leader = __ffsll((long long)pm) - 1;
+      uint32_t base = 0;
+      if (lane_id() == leader) base = atomicAdd(&bucket_count[nb_total], (uint32_t)__popcll(pm));
+      base = __shfl(base, leader);
+      rank = base + (uint32_t)__popcll(pm & ((1ull << lane_id()) - 1ull));
+    }
+    if (ranked && !pseudo) rank = atomicAdd(&bucket_count[gb], 1u);
+    if (ranked) {
+      qbucket[ql] = gb;
+      qrank[ql] = rank;
+    }
   }
   unsigned long long c = count;
   for (int off = 32; off; off >>= 1) c += __shfl_xor(c, off);
@@ -296,7 +326,12 @@ __global__ __launch_bounds__(256) void hs_probe_slow_kernel(hs_tables_dev tabs,
                                                             uint32_t* __restrict__ nslices,
                                                             uint64_t* __restrict__ cand_out,
                                                             unsigned long long* __restrict__ cand_total,
-                                                            const uint32_t* __restrict__ slow) {
+                                                            const uint32_t* __restrict__ slow,
+                                                            const uint32_t* __restrict__ dir_base,
+                                                            uint32_t nb_total,
+                                                            uint32_t* __restrict__ bucket_count,
+                                                            uint32_t* __restrict__ qbucket,
+                                                            uint32_t* __restrict__ qrank) {
   const uint32_t total = slow[0];
   for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
     const uint32_t ql = slow[1 + e];
@@ -310,6 +345,7 @@ __global__ __launch_bounds__(256) void hs_probe_slow_kernel(hs_tables_dev tabs,
       const uint32_t mid = (lo + hi) >> 1;
       if (tb.dir_key[mid] < key) lo = mid + 1; else hi = mid;
     }
+    uint32_t gb = nb_total;
     if (lo < tb.nb && tb.dir_key[lo] == key) {
       for (int j = 0; j < K; ++j) u[j] = tb.dir_tuple[(uint64_t)lo * K + j];
       if (hs_key_equal(t, u, K)) {
@@ -319,7 +355,12 @@ __global__ __launch_bounds__(256) void hs_probe_slow_kernel(hs_tables_dev tabs,
         nslices[ql] = (count + HS_SLICE - 1) / HS_SLICE;
         if (cand_out) cand_out[ql] = count;
         atomicAdd(cand_total, (unsigned long long)count);
+        if (dir_base) gb = dir_base[l] + lo;
       }
+    }
+    if (bucket_count) {
+      qbucket[ql] = gb;
+      qrank[ql] = atomicAdd(&bucket_count[gb], 1u);
     }
   }
 }
@@ -829,15 +870,22 @@ hipError_t hs_launch_gather_packed(const uint4* d_packed_all, const uint32_t* d_
 hipError_t hs_launch_probe(const hs_tables_dev& tabs, const int32_t* d_qints, uint32_t nq, int K,
                            int L, uint32_t seed, uint32_t* d_qstart, uint32_t* d_qcount,
                            uint32_t* d_nslices, uint64_t* d_cand_out,
-                           unsigned long long* d_cand_total, uint32_t* d_slow, hipStream_t s) {
+                           unsigned long long* d_cand_total, uint32_t* d_slow,
+                           const uint32_t* d_dir_base, uint32_t nb_total, uint32_t* d_bucket_count,
+                           uint32_t* d_qbucket, uint32_t* d_qrank, hipStream_t s) {
   if (!nq) return hipSuccess;
   hipError_t e = hipMemsetAsync(d_slow, 0, 4, s);
   if (e != hipSuccess) return e;
-  hs_probe_kernel<<<blocks_for((uint64_t)nq * L), 256, 0, s>>>(tabs, d_qints, nq, K, L, seed,
-                                                               d_qstart, d_qcount, d_nslices,
-                                                               d_cand_out, d_cand_total, d_slow);
+  if (d_bucket_count) {
+    e = hipMemsetAsync(d_bucket_count, 0, ((size_t)nb_total + 2) * 4, s);
+    if (e != hipSuccess) return e;
+  }
+  hs_probe_kernel<<<blocks_for((uint64_t)nq * L), 256, 0, s>>>(
+      tabs, d_qints, nq, K, L, seed, d_qstart, d_qcount, d_nslices, d_cand_out, d_cand_total, d_slow,
+      d_dir_base, nb_total, d_bucket_count, d_qbucket, d_qrank);
   hs_probe_slow_kernel<<<64, 256, 0, s>>>(tabs, d_qints, K, L, seed, d_qstart, d_qcount, d_nslices,
-                                          d_cand_out, d_cand_total, d_slow);
+                                          d_cand_out, d_cand_total, d_slow, d_dir_base, nb_total,
+                                          d_bucket_count, d_qbucket, d_qrank);
   return hipGetLastError();
 }
 
