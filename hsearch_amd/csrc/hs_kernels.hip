@@ -696,9 +696,15 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
       }
       hit = !dup;
     }
-    if (hit) {
-      const uint32_t idx = atomicAdd(hit_count, 1u);
-      if (idx < hit_cap) {
+    // one counter access per wave (same-address atomics are slow): hits take consecutive slots
+    const unsigned long long hm = __ballot(hit);
+    if (hm) {
+      const int leader = __ffsll((long long)hm) - 1;
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(hit_count, (uint32_t)__popcll(hm));
+      base = __shfl(base, leader);
+      const uint32_t idx = base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+      if (hit && idx < hit_cap) {
         hit_key[idx] = ((uint64_t)(q_base + q) << 37) | ((uint64_t)l << 32) | id;
         hit_val[idx] = (uint64_t)__double_as_longlong(__dsqrt_rn(d2));
       }
