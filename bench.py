@@ -300,6 +300,14 @@ def main():
             line["radius_recall"] = len(truth & found) / max(len(truth), 1)
             line["recall_queries"] = nr
             line["true_neighbours_in_sample"] = len(truth)
+            # recall@10: |LSH hits of q  ∩  the 10 nearest DB k-mers of q| / 10, the
+            # nearest ones by (d2, id) from the exact exhaustive top-k scan (hs_bruteforce_topk)
+            nn, _ = eng.bruteforce_topk(sub, 10)
+            by_q = {}
+            for qq, ii in zip(lsh["q"].tolist(), lsh["id"].tolist()):
+                by_q.setdefault(qq, set()).add(ii)
+            line["recall_at_10"] = float(np.mean([len(by_q.get(qq, set()) & set(nn[qq].tolist())) / 10.0
+                                                  for qq in range(nr)]))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, a, b, codes, centers)
         print(json.dumps(line))

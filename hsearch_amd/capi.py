@@ -17,7 +17,7 @@ _ALPHABET = "ARNDCQEGHILKMFPSTWYV"
 EXPORTS = ["hs_create", "hs_destroy", "hs_last_error", "hs_get_profile", "hs_version",
            "hs_set_verify_mode", "hs_self_join", "hs_clustering",
            "hs_embed_codes", "hs_hash_codes", "hs_hash_points", "hs_key_string", "hs_key_fingerprint",
-           "hs_key_strings_equal", "hs_index_build",
+           "hs_key_strings_equal", "hs_index_build", "hs_index_build_windows",
            "hs_index_info_get", "hs_query", "hs_query_dev", "hs_bruteforce", "hs_bruteforce_topk"]
 
 
@@ -211,6 +211,25 @@ class Engine:
         assert codes.ndim == 2 and codes.shape[1] == self.k
         self._check(self._lib.hs_index_build(self._h, _vp(codes), C.c_uint64(n)))
         return self.index_info()
+
+    def index_build_windows(self, residues, seq_start):
+        """the DB = every length-k window of every sequence of a concatenated
+        residue-code buffer (kmer_search.cpp:64-83 order).  residues: uint8 codes; seq_start:
+        n_seq + 1 ascending offsets ending at len(residues).  Returns (index info, window start
+        positions [n_windows] uint32); DB id i = window i."""
+        residues = np.ascontiguousarray(residues, dtype=np.uint8)
+        seq_start = np.ascontiguousarray(seq_start, dtype=np.uint64)
+        n_seq = len(seq_start) - 1
+        assert n_seq >= 0 and int(seq_start[-1]) == len(residues)
+        lens = np.diff(seq_start.astype(np.int64))
+        n_win = int(np.maximum(lens - self.k + 1, 0).sum())
+        pos = np.empty(n_win, dtype=np.uint32)
+        n = C.c_uint64(0)
+        self._check(self._lib.hs_index_build_windows(self._h, _vp(residues), C.c_uint64(len(residues)),
+                                                     _vp(seq_start), C.c_uint64(n_seq), C.byref(n),
+                                                     _vp(pos)))
+        assert int(n.value) == n_win
+        return self.index_info(), pos
 
     # -- a8..a10
     def query(self, centers, R, cap=None, want_cand=True):

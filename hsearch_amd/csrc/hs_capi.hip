@@ -494,22 +494,13 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
   return HS_OK;
 }
 
-hs_status hs_index_build(hs_handle* h, const uint8_t* codes, uint64_t n) {
-  if (!h || (n && !codes)) return HS_ERR_INVALID;
-  if (n >= (1ull << 31)) return fail(h, HS_ERR_INVALID, "n must be < 2^31 (ids are 32-bit, as in the reference)");
-  hs_status st = ensure_device(h);
-  if (st) return st;
-  h->built = false;
-  h->n = n;
-  memset(&h->prof, 0, sizeof(h->prof));
-  memset(&h->info, 0, sizeof(h->info));
+// Index build over the n x k residue codes already in h->codes (device): validation + packing,
+// the L tables, the global bucket numbering.
+static hs_status index_build_resident(hs_handle* h, uint64_t n) {
   const int k = (int)h->p.k;
-  HS_HIP(h, h->codes.reserve(std::max<size_t>(16, (size_t)n * k)));
+  hs_status st = HS_OK;
   HS_HIP(h, h->packed_all.reserve(std::max<size_t>(16, (size_t)n * h->PW * 16)));
-  HS_HIP(h, h->counters.reserve(256));
-  HS_HIP(h, hipEventRecord(h->ev[8], h->stream));
   if (n) {
-    HS_HIP(h, hipMemcpyAsync(h->codes.p, codes, (size_t)n * k, hipMemcpyHostToDevice, h->stream));
     HS_HIP(h, hipMemsetAsync(h->counters.p, 0, 256, h->stream));
     HS_HIP(h, hs_launch_pack(h->codes.as<uint8_t>(), n, k, h->alphabet, h->packed_all.as<uint4>(),
                              h->counters.as<uint32_t>(), h->stream));
@@ -551,6 +542,81 @@ hs_status hs_index_build(hs_handle* h, const uint8_t* codes, uint64_t n) {
   h->info.device_bytes = bytes;
   h->built = true;
   return HS_OK;
+}
+
+hs_status hs_index_build(hs_handle* h, const uint8_t* codes, uint64_t n) {
+  if (!h || (n && !codes)) return HS_ERR_INVALID;
+  if (n >= (1ull << 31)) return fail(h, HS_ERR_INVALID, "n must be < 2^31 (ids are 32-bit, as in the reference)");
+  hs_status st = ensure_device(h);
+  if (st) return st;
+  h->built = false;
+  h->n = n;
+  memset(&h->prof, 0, sizeof(h->prof));
+  memset(&h->info, 0, sizeof(h->info));
+  const int k = (int)h->p.k;
+  HS_HIP(h, h->codes.reserve(std::max<size_t>(16, (size_t)n * k)));
+  HS_HIP(h, h->counters.reserve(256));
+  HS_HIP(h, hipEventRecord(h->ev[8], h->stream));
+  if (n) HS_HIP(h, hipMemcpyAsync(h->codes.p, codes, (size_t)n * k, hipMemcpyHostToDevice, h->stream));
+  return index_build_resident(h, n);
+}
+
+// DB = every length-k window of every sequence of a concatenated residue buffer (kmer_search.cpp:
+// 64-83 enumerates them the same way: sequence-major, ascending offset; windows do not cross
+// sequence boundaries, sequences shorter than k contribute none).  The buffer crosses PCIe once
+// (n_residues bytes instead of n_windows * k) and the windows are expanded on the device.
+hs_status hs_index_build_windows(hs_handle* h, const uint8_t* residues, uint64_t n_residues,
+                                 const uint64_t* seq_start, uint64_t n_seq, uint64_t* n_windows,
+                                 uint32_t* window_pos) {
+  if (!h || !n_windows || (n_seq && !seq_start) || (n_residues && !residues)) return HS_ERR_INVALID;
+  *n_windows = 0;
+  hs_status st = ensure_device(h);
+  if (st) return st;
+  const uint64_t k = h->p.k;
+  if (n_residues >= (1ull << 32)) return fail(h, HS_ERR_INVALID, "n_residues must be < 2^32");
+  // first window number of every sequence
+  std::vector<uint32_t> starts((size_t)n_seq + 1), win_off((size_t)n_seq + 1);
+  uint64_t n = 0;
+  for (uint64_t s = 0; s < n_seq; ++s) {
+    if (seq_start[s] > seq_start[s + 1] || seq_start[s + 1] > n_residues)
+      return fail(h, HS_ERR_INVALID, "seq_start must be ascending and end at n_residues");
+    const uint64_t len = seq_start[s + 1] - seq_start[s];
+    starts[s] = (uint32_t)seq_start[s];
+    win_off[s] = (uint32_t)n;
+    n += len >= k ? len - k + 1 : 0;
+    if (n >= (1ull << 31)) return fail(h, HS_ERR_INVALID, "more than 2^31 - 1 windows");
+  }
+  starts[n_seq] = (uint32_t)(n_seq ? seq_start[n_seq] : 0);
+  win_off[n_seq] = (uint32_t)n;
+  h->built = false;
+  h->n = n;
+  memset(&h->prof, 0, sizeof(h->prof));
+  memset(&h->info, 0, sizeof(h->info));
+  HS_HIP(h, h->codes.reserve(std::max<size_t>(16, (size_t)n * k)));
+  HS_HIP(h, h->counters.reserve(256));
+  HS_HIP(h, hipEventRecord(h->ev[8], h->stream));
+  if (n) {
+    DevBuf d_res, d_starts, d_off, d_pos;
+    struct Guard {
+      DevBuf* b[4];
+      ~Guard() { for (DevBuf* x : b) x->release(); }
+    } guard = {{&d_res, &d_starts, &d_off, &d_pos}};
+    HS_HIP(h, d_res.reserve((size_t)n_residues));
+    HS_HIP(h, d_starts.reserve(((size_t)n_seq + 1) * 4));
+    HS_HIP(h, d_off.reserve(((size_t)n_seq + 1) * 4));
+    HS_HIP(h, d_pos.reserve((size_t)n * 4));
+    HS_HIP(h, hipMemcpyAsync(d_res.p, residues, (size_t)n_residues, hipMemcpyHostToDevice, h->stream));
+    HS_HIP(h, hipMemcpyAsync(d_starts.p, starts.data(), ((size_t)n_seq + 1) * 4, hipMemcpyHostToDevice, h->stream));
+    HS_HIP(h, hipMemcpyAsync(d_off.p, win_off.data(), ((size_t)n_seq + 1) * 4, hipMemcpyHostToDevice, h->stream));
+    HS_HIP(h, hs_launch_windows(d_res.as<uint8_t>(), (uint32_t)n_residues, d_starts.as<uint32_t>(),
+                                d_off.as<uint32_t>(), (uint32_t)n_seq, (int)k, h->codes.as<uint8_t>(),
+                                d_pos.as<uint32_t>(), h->stream));
+    if (window_pos)
+      HS_HIP(h, hipMemcpyAsync(window_pos, d_pos.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+  }
+  *n_windows = n;
+  return index_build_resident(h, n);
 }
 
 hs_status hs_index_info_get(const hs_handle* h, hs_index_info* out) {

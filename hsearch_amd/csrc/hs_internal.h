@@ -171,6 +171,11 @@ hipError_t hs_launch_pack(const uint8_t* d_codes, uint64_t n, int k, int alphabe
 hipError_t hs_launch_gather_packed(const uint4* d_packed_all, const uint32_t* d_ids_sorted,
                                    uint64_t n, int PW, uint4* d_out, hipStream_t s);
 hipError_t hs_launch_set_u32(uint32_t* d_p, uint32_t v, hipStream_t s);
+// windows of length k of every sequence of a residue buffer -> codes [n_windows][k] (+ the buffer
+// position of every window); d_win_off[s] = number of the first window of sequence s
+hipError_t hs_launch_windows(const uint8_t* d_residues, uint32_t n_residues, const uint32_t* d_seq_start,
+                             const uint32_t* d_win_off, uint32_t n_seq, int k, uint8_t* d_codes,
+                             uint32_t* d_win_pos, hipStream_t s);
 // d_out[d_perm[i]] = i
 hipError_t hs_launch_invert_perm(const uint32_t* d_perm, uint32_t n, uint32_t* d_out, hipStream_t s);
 hipError_t hs_launch_max_u32(const uint32_t* d_in, uint32_t n, uint32_t* d_out, hipStream_t s);

@@ -712,6 +712,30 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
   }
 }
 
+// One thread per residue position: the position starts a window iff k residues of its own
+// sequence follow it.  Neighbouring threads write neighbouring rows of the codes array.
+__global__ __launch_bounds__(256) void hs_windows_kernel(const uint8_t* __restrict__ residues,
+                                                         uint32_t n_residues,
+                                                         const uint32_t* __restrict__ seq_start,
+                                                         const uint32_t* __restrict__ win_off,
+                                                         uint32_t n_seq, int k,
+                                                         uint8_t* __restrict__ codes,
+                                                         uint32_t* __restrict__ win_pos) {
+  const uint32_t pos = blockIdx.x * 256 + threadIdx.x;
+  if (pos >= n_residues) return;
+  uint32_t lo = 0, hi = n_seq;  // largest s with seq_start[s] <= pos (empty sequences share a start:
+  while (hi - lo > 1) {         // the last of them owns nothing either)
+    const uint32_t mid = (lo + hi) >> 1;
+    if (seq_start[mid] <= pos) lo = mid; else hi = mid;
+  }
+  const uint32_t end = seq_start[lo + 1];
+  if (pos + (uint32_t)k > end) return;
+  const uint32_t id = win_off[lo] + (pos - seq_start[lo]);
+  win_pos[id] = pos;
+  uint8_t* row = codes + (uint64_t)id * k;
+  for (int p = 0; p < k; ++p) row[p] = residues[pos + p];
+}
+
 __global__ __launch_bounds__(256) void hs_invert_perm_kernel(const uint32_t* __restrict__ perm,
                                                              uint32_t n, uint32_t* __restrict__ out) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -951,6 +975,15 @@ hipError_t hs_launch_finalize(const hs_tables_dev& tabs, const uint8_t* d_codes,
                                           d_prov, d_prov_count, prov_cap, d_sorted_ql, k, L, r2,
                                           r_sqrt, q_base,
                                           d_hit_count, hit_cap, d_hit_key, d_hit_val);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_windows(const uint8_t* d_residues, uint32_t n_residues, const uint32_t* d_seq_start,
+                             const uint32_t* d_win_off, uint32_t n_seq, int k, uint8_t* d_codes,
+                             uint32_t* d_win_pos, hipStream_t s) {
+  if (!n_residues || !n_seq) return hipSuccess;
+  hs_windows_kernel<<<blocks_for(n_residues), 256, 0, s>>>(d_residues, n_residues, d_seq_start, d_win_off,
+                                                          n_seq, k, d_codes, d_win_pos);
   return hipGetLastError();
 }
 

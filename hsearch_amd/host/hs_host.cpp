@@ -170,6 +170,146 @@ int Search(const std::vector<Point>& kmers, const std::vector<Point>& centers,
   return HS_OK;
 }
 
+bool ReadProteinFasta(const std::string& path, bool ref_compat_eq_swap, ProteinDB* db) {
+  std::ifstream fin(path.c_str());
+  if (!fin) return false;
+  db->name.clear();
+  db->start.clear();
+  db->residues.clear();
+  db->eq_swapped = ref_compat_eq_swap;
+  std::string line;
+  while (std::getline(fin, line)) {  // protein.hpp:47-66
+    if (!line.empty() && line[line.size() - 1] == '\r') line.erase(line.size() - 1);
+    if (line.empty()) continue;
+    if (line[0] == '>') {
+      db->name.push_back(line.substr(1));
+      continue;
+    }
+    db->start.push_back(db->residues.size());
+    for (size_t i = 0; i < line.size(); ++i) {
+      const char c = line[i];
+      int row = (c >= 'A' && c <= 'Z') ? HS_LETTER_TO_CODE[c - 'A'] : -1;
+      // the reference keeps AA20[row] and embeds base[] of that letter: rows 5 and 6 trade places
+      if (ref_compat_eq_swap && (row == 5 || row == 6)) row = 11 - row;
+      db->residues.push_back(row < 0 ? ProteinDB::kUnknown : (uint8_t)row);
+    }
+  }
+  db->start.push_back(db->residues.size());
+  return true;
+}
+
+int SearchProteins(const ProteinDB& db, uint32_t kmer_length, const std::vector<Point>& centers,
+                   const std::vector<std::string>& center_names, const uint32_t& hash_K,
+                   const uint32_t& hash_L, const double& hash_W, const double& hash_R,
+                   const std::string& output_file, const Planes& planes, int device, std::string* err,
+                   std::vector<uint64_t>* table_sizes, uint64_t* n_windows) {
+  const uint32_t dim = 8 * kmer_length;
+  if (kmer_length == 0 || planes.dim != dim || planes.K != hash_K || planes.L != hash_L ||
+      planes.W != hash_W) {
+    if (err) *err = "planes do not match (dim, K, L, W)";
+    return HS_ERR_INVALID;
+  }
+  // sequences cut at unknown letters: windows never cross a cut, buffer positions stay the file's
+  std::vector<uint8_t> res(db.residues);
+  std::vector<uint64_t> seg;
+  const size_t n_seq = db.start.empty() ? 0 : db.start.size() - 1;
+  for (size_t s = 0; s < n_seq; ++s) {
+    seg.push_back(db.start[s]);
+    for (uint64_t p = db.start[s]; p < db.start[s + 1]; ++p)
+      if (res[p] == ProteinDB::kUnknown) {
+        res[p] = 0;
+        seg.push_back(p);      // the unknown letter ends a segment ...
+        seg.push_back(p + 1);  // ... and forms one of its own (length 1 < k: no window)
+      }
+  }
+  seg.push_back(db.residues.size());
+  if (kmer_length == 1) {  // a length-1 segment would be a window: drop the unknown letters' own
+    if (err) *err = "kmer length 1 is not supported on a FASTA database";
+    return HS_ERR_INVALID;
+  }
+  std::vector<double> flat((size_t)centers.size() * dim);
+  for (size_t i = 0; i < centers.size(); ++i) {
+    if (centers[i].data.size() != dim) {
+      if (err) *err = "centre with the wrong dimension";
+      return HS_ERR_INVALID;
+    }
+    memcpy(&flat[i * dim], centers[i].data.data(), sizeof(double) * dim);
+  }
+  hs_params prm;
+  memset(&prm, 0, sizeof(prm));
+  prm.k = kmer_length;
+  prm.K = hash_K;
+  prm.L = hash_L;
+  prm.W = hash_W;
+  prm.device = device;
+  prm.alphabet = HS_ALPHABET;
+  hs_handle* h = nullptr;
+  hs_status st = hs_create(&prm, planes.a.data(), planes.b.data(), &HS_AA_COORDS[0][0], &h);
+  struct Closer {
+    hs_handle* h;
+    ~Closer() { hs_destroy(h); }
+  };
+  if (st != HS_OK) {
+    if (err) *err = std::string("hs_create: ") + (h ? hs_last_error(h) : "no usable gfx950 device");
+    hs_destroy(h);
+    return st;
+  }
+  Closer closer = {h};
+  uint64_t n_win = 0;
+  std::vector<uint32_t> win_pos(res.size() + 1);  // there are fewer windows than residues
+  st = hs_index_build_windows(h, res.data(), res.size(), seg.data(), seg.size() - 1, &n_win,
+                              win_pos.data());
+  if (st != HS_OK) {
+    if (err) *err = std::string("hs_index_build_windows: ") + hs_last_error(h);
+    return st;
+  }
+  if (n_windows) *n_windows = n_win;
+  if (table_sizes) {
+    hs_index_info info;
+    if (hs_index_info_get(h, &info) == HS_OK) table_sizes->assign(info.n_buckets, info.n_buckets + hash_L);
+  }
+  uint64_t cap = std::max<uint64_t>(1024, 16 * (uint64_t)centers.size()), n_hits = 0;
+  std::vector<uint32_t> hq, hid, ht;
+  std::vector<double> hd;
+  for (;;) {
+    hq.resize(cap);
+    hid.resize(cap);
+    ht.resize(cap);
+    hd.resize(cap);
+    st = hs_query(h, flat.data(), centers.size(), hash_R, hq.data(), hid.data(), ht.data(), hd.data(),
+                  cap, &n_hits, nullptr);
+    if (st == HS_ERR_CAPACITY) {
+      cap = n_hits;
+      continue;
+    }
+    break;
+  }
+  if (st != HS_OK) {
+    if (err) *err = std::string("hs_query: ") + hs_last_error(h);
+    return st;
+  }
+  // the letter whose embedding is the stored row: with the E <-> Q exchange an input E is shown as
+  // Q, which is what the reference's ProteinDB stores and prints
+  const char* letters = HS_CODE_TO_LETTER;
+  std::ofstream fout(output_file.c_str());
+  for (uint64_t i = 0; i < n_hits; ++i) {
+    const uint64_t pos = win_pos[hid[i]];
+    // sequence of the window: largest s with start[s] <= pos
+    const size_t s = (size_t)(std::upper_bound(db.start.begin(), db.start.end() - 1, pos) - db.start.begin()) - 1;
+    std::string token;
+    if (s < db.name.size()) {
+      std::istringstream iss(db.name[s]);
+      iss >> token;
+    }
+    std::string kmer(kmer_length, '?');
+    for (uint32_t p = 0; p < kmer_length; ++p) kmer[p] = letters[db.residues[pos + p]];
+    fout << center_names[hq[i]] << " " << token << "#" << s << "$" << (pos - db.start[s]) << "@" << kmer
+         << "*" << hid[i] << " " << hd[i] << std::endl;
+  }
+  fout.close();
+  return HS_OK;
+}
+
 bool ReadKmerFasta(const std::string& path, std::vector<Kmer>* kmers) {
   std::ifstream fin(path.c_str());
   if (!fin) return false;

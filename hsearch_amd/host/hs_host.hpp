@@ -58,6 +58,35 @@ int Search(const std::vector<Point>& kmers, const std::vector<Point>& centers,
            const double& hash_R, const std::string& output_file, const Planes& planes, int device,
            std::string* err, std::vector<uint64_t>* table_sizes = nullptr);
 
+// ---- FASTA database: k-mers enumerated on the device ------------------------
+// ProteinDB of protein.hpp:41-71: lines starting with '>' are names, every other non-empty line is
+// one whole sequence.  Residues are stored as rows of the coordinate table (include/hs_tables.h);
+// letters outside the 20-letter alphabet -- the reference substitutes rand() % 20 for them,
+// protein.hpp:58-61 -- are stored as kUnknown and no window may contain one.
+// ref_compat_eq_swap reproduces the reference's E <-> Q exchange (it stores AA20[base[c]] and later
+// embeds base[] of THAT letter, protein.hpp:62 + kmer_search.cpp:56); the default
+// is the correct embedding (E -> Glu, Q -> Gln).
+struct ProteinDB {
+  static const uint8_t kUnknown = 255;
+  std::vector<std::string> name;   // '>' lines, without the '>'
+  std::vector<uint64_t> start;     // [n_sequences + 1] into residues
+  std::vector<uint8_t> residues;   // all sequences, concatenated
+  bool eq_swapped = false;
+};
+bool ReadProteinFasta(const std::string& path, bool ref_compat_eq_swap, ProteinDB* db);
+
+// The search of kmer_search.cpp over a FASTA database, with motif_both_points' verification and
+// output: DB = every length-k window (free of unknown letters) of every sequence, enumerated on the
+// device by hs_index_build_windows in kmer_search.cpp:64-83 order; hits are written as
+// "<center> <kmer name> <dist>" in Search()'s order, a k-mer being named like protein2datapoints
+// names its samples (protein2datapoints.cpp:66): <first token of the protein name>#<sequence
+// index>$<offset>@<k letters>*<window number>.  n_windows (optional) receives the DB size.
+int SearchProteins(const ProteinDB& db, uint32_t kmer_length, const std::vector<Point>& centers,
+                   const std::vector<std::string>& center_names, const uint32_t& hash_K,
+                   const uint32_t& hash_L, const double& hash_W, const double& hash_R,
+                   const std::string& output_file, const Planes& planes, int device, std::string* err,
+                   std::vector<uint64_t>* table_sizes = nullptr, uint64_t* n_windows = nullptr);
+
 // Clustering() of hclust2.cpp:86-151.  kmers: name + sequence (letters of the 20-letter alphabet; a
 // letter outside it is replaced by a residue drawn from a generator seeded with `unknown_seed`,
 // where the reference uses rand()%20, hclust2.cpp:54-56).  Writes the reference's clusters file

@@ -8,7 +8,10 @@
 // kmer_search.cpp:186-189 but hard-codes 4,4 here, :380-381 -- 4,4 stay the defaults), --seed
 // (planes are drawn like the reference's LSH constructor but from an explicit seed; default: from
 // std::random_device like the reference), --device, --planes-out (dump the planes), and -g becomes
-// optional (without it the evaluation step is skipped).
+// optional (without it the evaluation step is skipped).  -d may also name a protein FASTA file (the
+// database kmer_search.cpp:180-181 takes): every length-k window of every sequence is then a DB
+// k-mer, enumerated on the device; --ref-compat-eq-swap reproduces the reference's E <-> Q exchange
+// on that path.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -45,7 +48,21 @@ const Opt kOpts[] = {
     {"seed", 's', "seed of the LSH planes [random_device]", false},
     {"device", 'G', "GPU ordinal [0]", false},
     {"planes-out", 'P', "write the planes (binary doubles a[L][K][d] then b[L][K])", false},
+    {"ref-compat-eq-swap", 'Q', "FASTA database: exchange E and Q like the reference's ProteinDB [0]", false},
 };
+
+// A points file has a line of numbers after its first name line; a FASTA file has residue letters.
+bool LooksLikeFasta(const std::string& path) {
+  std::ifstream fin(path.c_str());
+  std::string l1, l2;
+  if (!std::getline(fin, l1) || l1.empty() || l1[0] != '>') return false;
+  while (std::getline(fin, l2))
+    if (!l2.empty()) break;
+  if (l2.empty()) return false;
+  char* end = nullptr;
+  (void)strtod(l2.c_str(), &end);
+  return end == l2.c_str();  // no number at the start of the second line
+}
 
 void Help(const char* prog) {
   fprintf(stderr, "Usage: %s [OPTIONS]\n\nOptions:\n", prog);
@@ -113,17 +130,30 @@ int main(int argc, const char* argv[]) {
   try {
     std::vector<std::string> kmer_names, center_names;
     std::vector<hsearch::Point> kmers, centers;
-    std::cout << "Read Kmers..." << std::endl;
-    if (!hsearch::ReadPointsFile(val["db"], dim, &kmer_names, &kmers)) {
-      fprintf(stderr, "cannot open %s\n", val["db"].c_str());
-      return EXIT_FAILURE;
+    const bool fasta_db = LooksLikeFasta(val["db"]);
+    hsearch::ProteinDB prodb;
+    if (fasta_db) {
+      std::cout << "Read protein sequences from " << val["db"] << std::endl;
+      const bool swap = val.count("ref-compat-eq-swap") && atoi(val["ref-compat-eq-swap"].c_str()) != 0;
+      if (!hsearch::ReadProteinFasta(val["db"], swap, &prodb)) {
+        fprintf(stderr, "cannot open %s\n", val["db"].c_str());
+        return EXIT_FAILURE;
+      }
+      std::cout << "number of proteins " << prodb.start.size() - 1 << std::endl;
+      std::cout << "total length " << prodb.residues.size() << std::endl;
+    } else {
+      std::cout << "Read Kmers..." << std::endl;
+      if (!hsearch::ReadPointsFile(val["db"], dim, &kmer_names, &kmers)) {
+        fprintf(stderr, "cannot open %s\n", val["db"].c_str());
+        return EXIT_FAILURE;
+      }
     }
     std::cout << "Read Centers..." << std::endl;
     if (!hsearch::ReadPointsFile(val["center"], dim, &center_names, &centers)) {
       fprintf(stderr, "cannot open %s\n", val["center"].c_str());
       return EXIT_FAILURE;
     }
-    std::cout << "number of kmers " << kmers.size() << std::endl;
+    if (!fasta_db) std::cout << "number of kmers " << kmers.size() << std::endl;
     std::cout << "number of centers " << centers.size() << std::endl;
     const hsearch::Planes planes = hsearch::DrawPlanes(dim, hash_K, hash_L, hash_W, seed);
     if (val.count("planes-out")) {
@@ -136,8 +166,14 @@ int main(int argc, const char* argv[]) {
     clock_gettime(CLOCK_MONOTONIC, &t0);
     std::string err;
     std::vector<uint64_t> table_sizes;
-    const int st = hsearch::Search(kmers, centers, kmer_names, center_names, hash_K, hash_L, hash_W,
+    uint64_t n_windows = 0;
+    const int st =
+        fasta_db ? hsearch::SearchProteins(prodb, kmer_length, centers, center_names, hash_K, hash_L,
+                                           hash_W, hash_R, val["output"], planes, device, &err,
+                                           &table_sizes, &n_windows)
+                 : hsearch::Search(kmers, centers, kmer_names, center_names, hash_K, hash_L, hash_W,
                                    hash_R, val["output"], planes, device, &err, &table_sizes);
+    if (fasta_db && st == 0) std::cout << "number of kmers " << n_windows << std::endl;
     if (st != 0) {
       fprintf(stderr, "ERROR: %s (status %d)\n", err.c_str(), st);
       return EXIT_FAILURE;

@@ -134,6 +134,19 @@ HS_API int hs_key_strings_equal(const int32_t* x, const int32_t* y, uint32_t K);
  * (hclust2.cpp:74-84): L tables keyed by HashKey string equality, ids ascending inside a bucket.
  * The DB is kept as residue codes (k bytes per k-mer), never as 8k doubles. */
 HS_API hs_status hs_index_build(hs_handle* h, const uint8_t* codes, uint64_t n);
+
+/* SURVEY 8(f) row 1 -- k-mer enumeration on the device.  The DB is every length-k window of every
+ * sequence of one concatenated residue-code buffer: sequence s occupies residues[seq_start[s] ..
+ * seq_start[s+1]), seq_start has n_seq + 1 ascending entries ending at n_residues.  Windows are
+ * numbered the way kmer_search.cpp:64-83 walks them (sequence-major, ascending offset; they do not
+ * cross sequence boundaries; sequences shorter than k contribute none), and that number is the DB
+ * id every other call reports.  *n_windows receives their count; window_pos (optional, one uint32
+ * per window -- call once with NULL to learn the count) receives each window's start position in
+ * the buffer.  Replaces the host loop of BuildLSHTalbe(prodb, ...) kmer_search.cpp:64-83 together
+ * with the build itself; the index is identical to hs_index_build over the materialised windows. */
+HS_API hs_status hs_index_build_windows(hs_handle* h, const uint8_t* residues, uint64_t n_residues,
+                                        const uint64_t* seq_start, uint64_t n_seq,
+                                        uint64_t* n_windows, uint32_t* window_pos);
 HS_API hs_status hs_index_info_get(const hs_handle* h, hs_index_info* out);
 
 /* ---- query = probe + dedupe + verify (rows a8, a9, a10) ---------------------------------------- */

@@ -237,3 +237,37 @@ def test_multi_batch_queries_and_rebuild(oracle):
     want2 = oracle.search(a, b, W, R, oracle.embed_codes(codes2), c2)
     _assert_hits_equal(eng.query(c2, R), want2)
     eng.close()
+
+
+def test_windows_build_matches_explicit_kmers(oracle):
+    """the DB given as a concatenated residue buffer + sequence starts; the
+    windows are enumerated on the device (kmer_search.cpp:64-83 order).  Must equal the index over
+    the explicitly materialised windows, and the oracle's answer over them."""
+    k, K, L, W, R = 25, 4, 4, 100.0, 40.0
+    rng = np.random.default_rng(77)
+    lens = rng.integers(0, 400, size=300)
+    lens[[3, 17, 18, 250]] = [0, k - 1, k, 5]          # empty / too short / exactly one window
+    residues = rng.integers(0, 20, size=int(lens.sum()), dtype=np.uint8)
+    seq_start = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    want_pos = np.concatenate([np.arange(int(s), int(s) + max(int(n) - k + 1, 0))
+                               for s, n in zip(seq_start[:-1], lens)]).astype(np.uint32)
+    codes = np.stack([residues[p:p + k] for p in want_pos])
+    a, b = synth.make_planes(k, K, L, W, seed=21)
+    centers, _ = synth.make_queries(codes, 400, seed=22, jitter=0.25)
+    e1 = Engine(k, K, L, W, a, b)
+    info1 = e1.index_build(codes)
+    e2 = Engine(k, K, L, W, a, b)
+    info2, pos = e2.index_build_windows(residues, seq_start)
+    assert np.array_equal(pos, want_pos)
+    assert info2["n"] == len(codes) and info2["n_buckets"] == info1["n_buckets"]
+    assert info2["max_bucket"] == info1["max_bucket"]
+    got1, got2 = e1.query(centers, R), e2.query(centers, R)
+    assert np.array_equal(got1["cand"], got2["cand"])
+    _assert_hits_equal(got2, got1)
+    _assert_hits_equal(got2, oracle.search(a, b, W, R, oracle.embed_codes(codes), centers))
+    # no sequence long enough: an empty index, queries return nothing
+    info3, pos3 = e2.index_build_windows(residues[:10], np.array([0, 4, 10], dtype=np.uint64))
+    assert info3["n"] == 0 and len(pos3) == 0
+    assert len(e2.query(centers, R)["q"]) == 0
+    e1.close()
+    e2.close()

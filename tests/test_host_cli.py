@@ -144,3 +144,52 @@ def test_hclust2_cli_matches_reference_golden(tmp_path, golden_dir):
         assert open(out).read() == case["clusters_file"]
     r = subprocess.run([binary, "-k", "x"], capture_output=True, text=True)
     assert r.returncode == 0 and "missing required option" in r.stderr    # hclust2.cpp:223-226
+
+
+@pytest.mark.gpu
+def test_cli_fasta_database_matches_points_database(tmp_path, oracle):
+    """-d <proteins.fa> (k-mers enumerated on the device, kmer_search.cpp:64-83
+    order) must give the hits that -d <points of the same k-mers> gives, named like
+    protein2datapoints names its samples (:66); a letter outside the alphabet breaks windows;
+    --ref-compat-eq-swap embeds E as Gln and Q as Glu like the reference's ProteinDB."""
+    import hsearch_amd
+    k, K, L, W, R, seed = 25, 4, 4, 100.0, 40.0, 31
+    rng = np.random.default_rng(5)
+    letters = "ARNDCQEGHILKMFPSTWYV"                 # row order of the coordinate table
+    seqs = ["".join(letters[i] for i in rng.integers(0, 20, size=n)) for n in (120, 24, 25, 300, 80)]
+    seqs[3] = seqs[3][:100] + "X" + seqs[3][101:]    # an unknown letter in the middle
+    seqs[0] = "EQ" + seqs[0][2:]
+    fa = str(tmp_path / "db.fa")
+    with open(fa, "w") as f:
+        for i, s in enumerate(seqs):
+            f.write(">prot%d some description\n%s\n" % (i, s))
+    for swap in (0, 1):
+        names, rows = [], []
+        for i, s in enumerate(seqs):
+            for j in range(len(s) - k + 1):
+                w = s[j:j + k]
+                if "X" in w:
+                    continue
+                emb = w.translate(str.maketrans("EQ", "QE")) if swap else w
+                shown = emb                                  # the reference prints the stored letters
+                names.append("prot%d#%d$%d@%s*%d" % (i, i, j, shown, len(names)))
+                rows.append([letters.index(c) for c in emb])
+        codes = np.array(rows, dtype=np.uint8)
+        pts = oracle.embed_codes(codes)
+        centers = pts[rng.choice(len(pts), 40, replace=False)] + rng.normal(0, 0.3, size=(40, 8 * k))
+        cen, out_fa, out_pt, dbp = [str(tmp_path / n) for n in ("cen", "out_fa", "out_pt", "db.points")]
+        _write_points(cen, centers)
+        with open(dbp, "w") as f:
+            for nm, row in zip(names, pts):
+                f.write(nm + "\n" + " ".join("%.17g" % v for v in row) + "\n")
+        common = ["-c", cen, "-l", str(k), "-K", str(K), "-L", str(L), "-W", repr(W), "-T", repr(R),
+                  "--seed", str(seed)]
+        r1 = subprocess.run([_bin(), "-d", fa, "-o", out_fa, "--ref-compat-eq-swap", str(swap)] + common,
+                            capture_output=True, text=True)
+        assert r1.returncode == 0, r1.stderr
+        assert "number of kmers %d" % len(names) in r1.stdout
+        r2 = subprocess.run([_bin(), "-d", dbp, "-o", out_pt] + common, capture_output=True, text=True)
+        assert r2.returncode == 0, r2.stderr
+        got, want = open(out_fa).read(), open(out_pt).read()
+        assert len(want.splitlines()) >= 40
+        assert got == want
