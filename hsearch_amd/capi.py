@@ -7,9 +7,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 HS_OK, HS_ERR_INVALID, HS_ERR_NO_DEVICE, HS_ERR_HIP, HS_ERR_CAPACITY, HS_ERR_STATE, \
-    HS_ERR_KEY_COLLISION, HS_ERR_NOMEM = range(8)
+    HS_ERR_KEY_COLLISION, HS_ERR_NOMEM, HS_ERR_IO = range(9)
 _STATUS = ["HS_OK", "HS_ERR_INVALID", "HS_ERR_NO_DEVICE", "HS_ERR_HIP", "HS_ERR_CAPACITY",
-           "HS_ERR_STATE", "HS_ERR_KEY_COLLISION", "HS_ERR_NOMEM"]
+           "HS_ERR_STATE", "HS_ERR_KEY_COLLISION", "HS_ERR_NOMEM", "HS_ERR_IO"]
 
 # Row order of the embedding table (include/hs_tables.h HS_CODE_TO_LETTER): BLOSUM order.
 _ALPHABET = "ARNDCQEGHILKMFPSTWYV"
@@ -17,7 +17,7 @@ _ALPHABET = "ARNDCQEGHILKMFPSTWYV"
 EXPORTS = ["hs_create", "hs_destroy", "hs_last_error", "hs_get_profile", "hs_version",
            "hs_set_verify_mode", "hs_self_join", "hs_clustering",
            "hs_embed_codes", "hs_hash_codes", "hs_hash_points", "hs_key_string", "hs_key_fingerprint",
-           "hs_key_strings_equal", "hs_index_build", "hs_index_build_windows",
+           "hs_key_strings_equal", "hs_index_build", "hs_index_build_windows", "hs_index_save", "hs_index_load",
            "hs_index_info_get", "hs_query", "hs_query_dev", "hs_bruteforce", "hs_bruteforce_topk"]
 
 
@@ -230,6 +230,16 @@ class Engine:
                                                      _vp(pos)))
         assert int(n.value) == n_win
         return self.index_info(), pos
+
+    def index_save(self, path):
+        """write the built index (parameters, planes, table, codes, L tables)."""
+        self._check(self._lib.hs_index_save(self._h, str(path).encode()))
+
+    def index_load(self, path):
+        """Restore an index written by index_save into a handle created with the same parameters,
+        planes and coordinate table (HS_ERR_IO otherwise)."""
+        self._check(self._lib.hs_index_load(self._h, str(path).encode()))
+        return self.index_info()
 
     # -- a8..a10
     def query(self, centers, R, cap=None, want_cand=True):

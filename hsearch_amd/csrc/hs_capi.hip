@@ -494,6 +494,31 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
   return HS_OK;
 }
 
+// Common end of hs_index_build* and hs_index_load: info, global bucket numbering, byte count.
+static hs_status finish_index(hs_handle* h) {
+  h->info.n = h->n;
+  h->info.key_seed = h->key_seed;
+  {  // global bucket numbering over the tables (grouping of probes by bucket at query time)
+    uint32_t base[HS_MAX_L + 1];
+    uint64_t acc = 0;
+    for (uint32_t l = 0; l < h->p.L; ++l) {
+      base[l] = (uint32_t)acc;
+      acc += h->info.n_buckets[l];
+    }
+    if (acc >= 0xfffffff0ull) return fail(h, HS_ERR_INVALID, "too many buckets");
+    base[h->p.L] = (uint32_t)acc;
+    h->nb_total = (uint32_t)acc;
+    HS_HIP(h, h->dir_base.reserve((HS_MAX_L + 1) * 4));
+    HS_HIP(h, hipMemcpy(h->dir_base.p, base, ((size_t)h->p.L + 1) * 4, hipMemcpyHostToDevice));
+  }
+  uint64_t bytes = h->codes.cap + h->packed_all.cap + h->t_packed.cap + h->t_rec8.cap + h->t_pos.cap;
+  for (uint32_t l = 0; l < h->p.L; ++l)
+    bytes += h->t_dirkey[l].cap + h->t_dirstart[l].cap + h->t_dirtuple[l].cap + h->t_ids[l].cap;
+  h->info.device_bytes = bytes;
+  h->built = true;
+  return HS_OK;
+}
+
 // Index build over the n x k residue codes already in h->codes (device): validation + packing,
 // the L tables, the global bucket numbering.
 static hs_status index_build_resident(hs_handle* h, uint64_t n) {
@@ -521,27 +546,7 @@ static hs_status index_build_resident(hs_handle* h, uint64_t n) {
   HS_HIP(h, hipEventRecord(h->ev[9], h->stream));
   HS_HIP(h, hipStreamSynchronize(h->stream));
   h->prof.ms_total = ev_ms(h, 8, 9);
-  h->info.n = n;
-  h->info.key_seed = seed;
-  {  // global bucket numbering over the tables (grouping of probes by bucket at query time)
-    uint32_t base[HS_MAX_L + 1];
-    uint64_t acc = 0;
-    for (uint32_t l = 0; l < h->p.L; ++l) {
-      base[l] = (uint32_t)acc;
-      acc += h->info.n_buckets[l];
-    }
-    if (acc >= 0xfffffff0ull) return fail(h, HS_ERR_INVALID, "too many buckets");
-    base[h->p.L] = (uint32_t)acc;
-    h->nb_total = (uint32_t)acc;
-    HS_HIP(h, h->dir_base.reserve((HS_MAX_L + 1) * 4));
-    HS_HIP(h, hipMemcpy(h->dir_base.p, base, ((size_t)h->p.L + 1) * 4, hipMemcpyHostToDevice));
-  }
-  uint64_t bytes = h->codes.cap + h->packed_all.cap + h->t_packed.cap + h->t_rec8.cap + h->t_pos.cap;
-  for (uint32_t l = 0; l < h->p.L; ++l)
-    bytes += h->t_dirkey[l].cap + h->t_dirstart[l].cap + h->t_dirtuple[l].cap + h->t_ids[l].cap;
-  h->info.device_bytes = bytes;
-  h->built = true;
-  return HS_OK;
+  return finish_index(h);
 }
 
 hs_status hs_index_build(hs_handle* h, const uint8_t* codes, uint64_t n) {
@@ -617,6 +622,163 @@ hs_status hs_index_build_windows(hs_handle* h, const uint8_t* residues, uint64_t
   }
   *n_windows = n;
   return index_build_resident(h, n);
+}
+
+// ---- persistent index --------------------------------------------------------------------------
+namespace {
+struct IndexFileHeader {
+  char magic[8];  // "HSIDX001"
+  uint32_t k, K, L, alphabet;
+  double W;
+  uint64_t n;
+  uint32_t key_seed, pad;
+  uint64_t n_buckets[HS_MAX_L], max_bucket[HS_MAX_L];
+};
+struct FileCloser {
+  FILE* f;
+  ~FileCloser() { if (f) fclose(f); }
+};
+}  // namespace
+
+static hs_status write_device(hs_handle* h, FILE* f, const void* d_ptr, size_t bytes, std::vector<char>* tmp) {
+  const size_t CH = (size_t)64 << 20;
+  tmp->resize(std::min(bytes, CH));
+  for (size_t off = 0; off < bytes; off += CH) {
+    const size_t m = std::min(CH, bytes - off);
+    HS_HIP(h, hipMemcpy(tmp->data(), (const char*)d_ptr + off, m, hipMemcpyDeviceToHost));
+    if (fwrite(tmp->data(), 1, m, f) != m) return fail(h, HS_ERR_IO, "short write to the index file");
+  }
+  return HS_OK;
+}
+static hs_status read_device(hs_handle* h, FILE* f, void* d_ptr, size_t bytes, std::vector<char>* tmp) {
+  const size_t CH = (size_t)64 << 20;
+  tmp->resize(std::min(bytes, CH));
+  for (size_t off = 0; off < bytes; off += CH) {
+    const size_t m = std::min(CH, bytes - off);
+    if (fread(tmp->data(), 1, m, f) != m) return fail(h, HS_ERR_IO, "index file truncated");
+    HS_HIP(h, hipMemcpy((char*)d_ptr + off, tmp->data(), m, hipMemcpyHostToDevice));
+  }
+  return HS_OK;
+}
+
+hs_status hs_index_save(hs_handle* h, const char* path) {
+  if (!h || !path) return HS_ERR_INVALID;
+  if (!h->built) return fail(h, HS_ERR_STATE, "hs_index_build has not been called");
+  HS_HIP(h, hipStreamSynchronize(h->stream));
+  FILE* f = fopen(path, "wb");
+  if (!f) return fail(h, HS_ERR_IO, std::string("cannot create ") + path);
+  FileCloser closer = {f};
+  IndexFileHeader hd;
+  memset(&hd, 0, sizeof(hd));
+  memcpy(hd.magic, "HSIDX001", 8);
+  hd.k = h->p.k; hd.K = h->p.K; hd.L = h->p.L; hd.alphabet = (uint32_t)h->alphabet;
+  hd.W = h->p.W; hd.n = h->n; hd.key_seed = h->key_seed;
+  for (uint32_t l = 0; l < h->p.L; ++l) {
+    hd.n_buckets[l] = h->info.n_buckets[l];
+    hd.max_bucket[l] = h->info.max_bucket[l];
+  }
+  if (fwrite(&hd, sizeof(hd), 1, f) != 1) return fail(h, HS_ERR_IO, "short write to the index file");
+  std::vector<char> tmp;
+  const size_t K = h->p.K, n = (size_t)h->n;
+  HS_CHECK(write_device(h, f, h->a.p, (size_t)h->LK * h->d * 8, &tmp));
+  HS_CHECK(write_device(h, f, h->b.p, (size_t)h->LK * 8, &tmp));
+  HS_CHECK(write_device(h, f, h->coords.p, (size_t)HS_ALPHABET_PAD * 8 * 8, &tmp));
+  HS_CHECK(write_device(h, f, h->codes.p, n * h->p.k, &tmp));
+  for (uint32_t l = 0; l < h->p.L; ++l) {
+    const size_t nb = (size_t)h->info.n_buckets[l];
+    HS_CHECK(write_device(h, f, h->t_ids[l].p, n * 4, &tmp));
+    HS_CHECK(write_device(h, f, h->t_dirkey[l].p, nb * 8, &tmp));
+    HS_CHECK(write_device(h, f, h->t_dirstart[l].p, (nb + 1) * 4, &tmp));
+    HS_CHECK(write_device(h, f, h->t_dirtuple[l].p, nb * K * 4, &tmp));
+  }
+  if (fflush(f) != 0) return fail(h, HS_ERR_IO, "short write to the index file");
+  return HS_OK;
+}
+
+hs_status hs_index_load(hs_handle* h, const char* path) {
+  if (!h || !path) return HS_ERR_INVALID;
+  hs_status st = ensure_device(h);
+  if (st) return st;
+  FILE* f = fopen(path, "rb");
+  if (!f) return fail(h, HS_ERR_IO, std::string("cannot open ") + path);
+  FileCloser closer = {f};
+  IndexFileHeader hd;
+  if (fread(&hd, sizeof(hd), 1, f) != 1 || memcmp(hd.magic, "HSIDX001", 8) != 0)
+    return fail(h, HS_ERR_IO, "not an index file");
+  if (hd.k != h->p.k || hd.K != h->p.K || hd.L != h->p.L || hd.alphabet != (uint32_t)h->alphabet ||
+      hd.W != h->p.W || hd.n >= (1ull << 31))
+    return fail(h, HS_ERR_IO, "index file written for other parameters (k, K, L, W, alphabet)");
+  h->built = false;
+  memset(&h->prof, 0, sizeof(h->prof));
+  memset(&h->info, 0, sizeof(h->info));
+  HS_HIP(h, hipStreamSynchronize(h->stream));
+  std::vector<char> tmp, mine;
+  // planes and coordinate table must be the handle's, bit for bit
+  const size_t sizes[3] = {(size_t)h->LK * h->d * 8, (size_t)h->LK * 8, (size_t)HS_ALPHABET_PAD * 8 * 8};
+  const void* dev[3] = {h->a.p, h->b.p, h->coords.p};
+  for (int i = 0; i < 3; ++i) {
+    tmp.resize(sizes[i]);
+    mine.resize(sizes[i]);
+    if (fread(tmp.data(), 1, sizes[i], f) != sizes[i]) return fail(h, HS_ERR_IO, "index file truncated");
+    HS_HIP(h, hipMemcpy(mine.data(), dev[i], sizes[i], hipMemcpyDeviceToHost));
+    if (memcmp(tmp.data(), mine.data(), sizes[i]) != 0)
+      return fail(h, HS_ERR_IO, "index file written for other planes or another coordinate table");
+  }
+  const uint64_t n = hd.n;
+  const int K = (int)h->p.K, L = (int)h->p.L, k = (int)h->p.k, PW = h->PW;
+  h->n = n;
+  h->key_seed = hd.key_seed;
+  HS_HIP(h, h->codes.reserve(std::max<size_t>(16, (size_t)n * k)));
+  HS_HIP(h, h->packed_all.reserve(std::max<size_t>(16, (size_t)n * PW * 16)));
+  HS_HIP(h, h->counters.reserve(256));
+  HS_CHECK(read_device(h, f, h->codes.p, (size_t)n * k, &tmp));
+  if (n) {
+    HS_HIP(h, hipMemsetAsync(h->counters.p, 0, 256, h->stream));
+    HS_HIP(h, hs_launch_pack(h->codes.as<uint8_t>(), n, k, h->alphabet, h->packed_all.as<uint4>(),
+                             h->counters.as<uint32_t>(), h->stream));
+    uint32_t bad = 0;
+    HS_HIP(h, hipMemcpyAsync(&bad, h->counters.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    if (bad) return fail(h, HS_ERR_IO, "index file holds a residue code outside the alphabet");
+  }
+  const bool with_rec8 = h->join8_tables_ok && PW == 1;
+  HS_HIP(h, h->t_packed.reserve(std::max<size_t>(16, (size_t)L * n * PW * 16)));
+  if (with_rec8) HS_HIP(h, h->t_rec8.reserve(std::max<size_t>(16, (size_t)L * n * 16)));
+  HS_HIP(h, h->t_pos.reserve(std::max<size_t>(16, (size_t)L * n * 4)));
+  for (int l = 0; l < L; ++l) {
+    const size_t nb = (size_t)hd.n_buckets[l];
+    if (nb > n) return fail(h, HS_ERR_IO, "index file inconsistent (more buckets than k-mers)");
+    uint4* const tab_packed = h->t_packed.as<uint4>() + (size_t)l * n * PW;
+    HS_HIP(h, h->t_ids[l].reserve(std::max<size_t>(16, (size_t)n * 4)));
+    HS_HIP(h, h->t_dirkey[l].reserve(std::max<size_t>(16, nb * 8)));
+    HS_HIP(h, h->t_dirstart[l].reserve((nb + 1) * 4));
+    HS_HIP(h, h->t_dirtuple[l].reserve(std::max<size_t>(16, nb * K * 4)));
+    HS_CHECK(read_device(h, f, h->t_ids[l].p, (size_t)n * 4, &tmp));
+    HS_CHECK(read_device(h, f, h->t_dirkey[l].p, nb * 8, &tmp));
+    HS_CHECK(read_device(h, f, h->t_dirstart[l].p, (nb + 1) * 4, &tmp));
+    HS_CHECK(read_device(h, f, h->t_dirtuple[l].p, nb * K * 4, &tmp));
+    if (with_rec8)
+      HS_HIP(h, hs_launch_gather_rec8(h->packed_all.as<uint4>(), h->t_ids[l].as<uint32_t>(), (uint32_t)n,
+                                      k, h->jtab8.p, h->jtab8.as<float>() + 128, tab_packed,
+                                      h->t_rec8.as<uint4>() + (size_t)l * n, h->stream));
+    else
+      HS_HIP(h, hs_launch_gather_packed(h->packed_all.as<uint4>(), h->t_ids[l].as<uint32_t>(), n, PW,
+                                        tab_packed, h->stream));
+    HS_HIP(h, hs_launch_invert_perm(h->t_ids[l].as<uint32_t>(), (uint32_t)n,
+                                    h->t_pos.as<uint32_t>() + (size_t)l * n, h->stream));
+    hs_table_dev& tb = h->tabs.t[l];
+    tb.dir_key = h->t_dirkey[l].as<uint64_t>();
+    tb.dir_start = h->t_dirstart[l].as<uint32_t>();
+    tb.dir_tuple = h->t_dirtuple[l].as<int32_t>();
+    tb.packed = tab_packed;
+    tb.ids = h->t_ids[l].as<uint32_t>();
+    tb.pos_of = h->t_pos.as<uint32_t>() + (size_t)l * n;
+    tb.nb = (uint32_t)nb;
+    h->info.n_buckets[l] = nb;
+    h->info.max_bucket[l] = hd.max_bucket[l];
+  }
+  HS_HIP(h, hipStreamSynchronize(h->stream));
+  return finish_index(h);
 }
 
 hs_status hs_index_info_get(const hs_handle* h, hs_index_info* out) {

@@ -42,7 +42,8 @@ typedef enum hs_status {
   HS_ERR_CAPACITY = 4,      /* output buffer too small; required size reported */
   HS_ERR_STATE = 5,         /* e.g. query before hs_index_build */
   HS_ERR_KEY_COLLISION = 6, /* 64-bit key fingerprints collided for every retry seed */
-  HS_ERR_NOMEM = 7
+  HS_ERR_NOMEM = 7,
+  HS_ERR_IO = 8             /* index file missing, truncated, or written for other parameters */
 } hs_status;
 
 /* Replaces the (dimension, hash_K, hash_W) arguments of LSH::LSH (lsh.hpp:10-17) and the
@@ -147,6 +148,15 @@ HS_API hs_status hs_index_build(hs_handle* h, const uint8_t* codes, uint64_t n);
 HS_API hs_status hs_index_build_windows(hs_handle* h, const uint8_t* residues, uint64_t n_residues,
                                         const uint64_t* seq_start, uint64_t n_seq,
                                         uint64_t* n_windows, uint32_t* window_pos);
+/* SURVEY 8(f) row 2 -- persistent index (no reference analogue: the reference rebuilds its tables
+ * on every run, motif_both_points.cpp:206-218).  hs_index_save writes parameters, planes,
+ * coordinate table, residue codes and the L tables (ids + bucket directory) of a built handle;
+ * hs_index_load restores them into a handle created with the SAME parameters, planes and table
+ * (checked bit for bit, HS_ERR_IO otherwise) and re-derives the bucket-ordered copies on the
+ * device: queries then give exactly what they give after hs_index_build. */
+HS_API hs_status hs_index_save(hs_handle* h, const char* path);
+HS_API hs_status hs_index_load(hs_handle* h, const char* path);
+
 HS_API hs_status hs_index_info_get(const hs_handle* h, hs_index_info* out);
 
 /* ---- query = probe + dedupe + verify (rows a8, a9, a10) ---------------------------------------- */

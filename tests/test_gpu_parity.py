@@ -271,3 +271,40 @@ def test_windows_build_matches_explicit_kmers(oracle):
     assert len(e2.query(centers, R)["q"]) == 0
     e1.close()
     e2.close()
+
+
+def test_index_save_load_round_trip(oracle, tmp_path):
+    """a saved index restored into a fresh handle answers exactly like the
+    handle that built it (all verify modes); a file written for other planes is refused."""
+    import hsearch_amd
+    k, K, L, W, R = 25, 8, 5, 150.0, 40.0
+    a, b = synth.make_planes(k, K, L, W, seed=41)
+    codes = synth.make_db(20000, k, seed=42)
+    centers, _ = synth.make_queries(codes, 600, seed=43, jitter=0.25)
+    e1 = Engine(k, K, L, W, a, b)
+    info1 = e1.index_build(codes)
+    want = e1.query(centers, R)
+    path = tmp_path / "index.hsidx"
+    e1.index_save(path)
+    e1.close()
+    e2 = Engine(k, K, L, W, a, b)
+    with pytest.raises(hsearch_amd.HsError):
+        e2.query(centers, R)                           # nothing loaded yet
+    info2 = e2.index_load(path)
+    for f in ("n", "n_buckets", "max_bucket", "key_seed"):
+        assert info2[f] == info1[f], f
+    for mode in ("auto", "stream", "join16"):
+        e2.set_verify_mode(mode)
+        got = e2.query(centers, R)
+        assert np.array_equal(got["cand"], want["cand"])
+        _assert_hits_equal(got, want)
+    _assert_hits_equal(want, oracle.search(a, b, W, R, oracle.embed_codes(codes), centers))
+    e2.close()
+    a2, b2 = synth.make_planes(k, K, L, W, seed=44)
+    e3 = Engine(k, K, L, W, a2, b2)
+    with pytest.raises(hsearch_amd.HsError) as ei:
+        e3.index_load(path)
+    assert "HS_ERR_IO" in str(ei.value)
+    with pytest.raises(hsearch_amd.HsError):
+        e3.index_load(tmp_path / "missing.hsidx")
+    e3.close()
