@@ -197,7 +197,16 @@ hs_status hs_create(const hs_params* params, const double* a, const double* b, c
   HS_HIP(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   for (int i = 0; i < EV_COUNT; ++i) HS_HIP(h, hipEventCreate(&h->ev[i]));
   h->ev_ok = true;
-  HS_HIP(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+  {
+    // lowest priority: the runtime keeps a separate pool of hardware queues per priority level, so
+    // the side stream never shares a queue with the main stream (with the default 4 queues and a
+    // few more streams in the process -- torch's, RCCL's -- two normal-priority streams can land on
+    // the same hardware queue, and the streaming filter would then run AFTER the join instead of
+    // beside it); it is also the right order of service
+    int least = 0, greatest = 0;
+    HS_HIP(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HS_HIP(h, hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, least));
+  }
   for (int i = 0; i < EVX_COUNT; ++i)
     HS_HIP(h, hipEventCreateWithFlags(&h->evx[i], hipEventDisableTiming));
   h->evx_ok = true;
