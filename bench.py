@@ -181,11 +181,11 @@ def main():
                 state["cap"] = int(e.needed * 1.25) + 1024
                 state["out"] = alloc(state["cap"])
         gathered = hdist.allgather_hits(o["q"], o["id"], o["table"], o["dist"], nh, q_offset=q_lo,
-                                        force=use_dist and not os.environ.get("HS_BENCH_SKIP_GATHER"))
+                                        force=use_dist)
         return nh, gathered
 
     def fence():
-        if use_dist and not os.environ.get("HS_BENCH_NO_BARRIER"):
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 

@@ -18,6 +18,9 @@ def shard_bounds(n_total, rank, world):
     return lo, hi
 
 
+_PAD = {"m": 0}   # padded per-rank capacity of the payload, grown on demand and kept across calls
+
+
 def allgather_hits(q, ids, table, distance, n_hits, q_offset=0, group=None, force=False):
     """All-gather hit tuples of every rank.
 
@@ -26,34 +29,51 @@ def allgather_hits(q, ids, table, distance, n_hits, q_offset=0, group=None, forc
     global query index) is added so the result is in global query numbering.  Returns
     (q, ids, table, distance) holding all ranks' hits concatenated in rank order, i.e. in the
     reference's global output order when shards are contiguous blocks.
+
+    One collective per call: every rank contributes one byte buffer [count | q | id | table | dist]
+    padded to a common capacity m (RCCL has no all-gatherv); the counts travel in the same buffer,
+    so the only host round trip is reading them back afterwards.  m follows the largest count any
+    rank has reported (x1.25); a call whose counts exceed it repeats once with a larger m.
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world > 1 and q.is_cuda and dist.get_backend(group) == "gloo":
         # rehearsal mode (ranks sharing GPUs): gloo moves host memory
         q, ids, table, distance = q.cpu(), ids.cpu(), table.cpu(), distance.cpu()
     dev = q.device
-    q = q[:n_hits].to(torch.int64) + int(q_offset)
-    ids = ids[:n_hits].to(torch.int64)
-    table = table[:n_hits].to(torch.int64)
-    distance = distance[:n_hits]
+    n_hits = int(n_hits)
     if world == 1 and not (force and dist.is_initialized()):
-        return q, ids, table, distance
-    counts = torch.zeros(world, dtype=torch.int64, device=dev)
-    mine = torch.tensor([n_hits], dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(counts, mine, group=group)
-    counts_h = counts.cpu().tolist()
-    m = max(max(counts_h), 1)
-    # one payload: 3 int64 columns + the distance bits
-    pack = torch.zeros((4, m), dtype=torch.int64, device=dev)
-    pack[0, :n_hits] = q
-    pack[1, :n_hits] = ids
-    pack[2, :n_hits] = table
-    pack[3, :n_hits] = distance.view(torch.int64)
-    gathered = torch.empty((world, 4, m), dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(gathered.view(world * 4, m), pack, group=group)
-    parts = [gathered[r, :, :counts_h[r]] for r in range(world)]
-    allp = torch.cat(parts, dim=1)
-    return allp[0], allp[1], allp[2], allp[3].view(torch.float64)
+        return (q[:n_hits].to(torch.int64) + int(q_offset), ids[:n_hits].to(torch.int64),
+                table[:n_hits].to(torch.int64), distance[:n_hits])
+    q32 = q[:n_hits].view(torch.int32) + int(q_offset)          # global numbering before the exchange
+    cols = (q32, ids[:n_hits].view(torch.int32), table[:n_hits].view(torch.int32), distance[:n_hits])
+    while True:
+        # m must be the same on every rank: it is derived from exchanged counts only, never from
+        # the local n_hits (a rank with more hits than m sends its count and a truncated payload;
+        # every rank then sees that count and repeats the exchange with the same larger m)
+        m = max(_PAD["m"], 4096)
+        _PAD["m"] = m
+        nbytes = 8 + 20 * m
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        buf[:8].view(torch.int64).fill_(n_hits)
+        n_send = min(n_hits, m)
+        off = 8
+        for c, w in zip(cols, (4, 4, 4, 8)):
+            buf[off:off + w * n_send] = c[:n_send].contiguous().view(torch.uint8)
+            off += w * m
+        gathered = torch.empty((world, nbytes), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(gathered.view(-1), buf, group=group)
+        counts = gathered[:, :8].contiguous().view(torch.int64).view(-1).cpu().tolist()
+        if max(counts) <= m:
+            break
+        _PAD["m"] = (int(max(counts) * 1.25) + 1024 + 1) // 2 * 2  # even: keeps float64 8-aligned
+    out = []
+    off = 8
+    for w, dt in zip((4, 4, 4, 8), (torch.int32, torch.int32, torch.int32, torch.float64)):
+        parts = [gathered[r, off:off + w * counts[r]].view(dt) for r in range(world)]
+        col = torch.cat(parts) if world > 1 else parts[0].clone()
+        out.append(col if dt == torch.float64 else col.to(torch.int64))
+        off += w * m
+    return out[0], out[1], out[2], out[3]
 
 
 def hits_to_numpy(q, ids, table, distance):
