@@ -17,7 +17,7 @@ _ALPHABET = "ARNDCQEGHILKMFPSTWYV"
 EXPORTS = ["hs_create", "hs_destroy", "hs_last_error", "hs_get_profile", "hs_version",
            "hs_set_verify_mode", "hs_self_join", "hs_clustering",
            "hs_embed_codes", "hs_hash_codes", "hs_hash_points", "hs_key_string", "hs_key_fingerprint",
-           "hs_key_strings_equal", "hs_index_build", "hs_index_build_windows", "hs_index_save", "hs_index_load",
+           "hs_key_strings_equal", "hs_index_build", "hs_index_build_windows", "hs_index_save", "hs_index_load", "hs_klsh_draw_planes", "hs_klsh_codes",
            "hs_index_info_get", "hs_query", "hs_query_dev", "hs_bruteforce", "hs_bruteforce_topk"]
 
 
@@ -116,6 +116,40 @@ def key_strings_equal(x, y):
 
 def _vp(arr):
     return arr.ctypes.data_as(C.c_void_p)
+
+
+KLSH_NONE = 0xffffffffffffffff
+_REDUCED_CLASS = {c: k for k, grp in enumerate(["AST", "RKEDQ", "NH", "C", "G", "IVLM", "FYW", "P"])
+                  for c in grp}   # pcluster util.hpp:100-104 (include/hs_tables.h HS_REDUCED_CLASS)
+
+
+def klsh_draw_planes(feat=512, bits=16, sigma=0.2):
+    """The planes KLSH::KLSH draws from its default-seeded engine (lsh.cpp:17-38): (w, b, t)."""
+    w = np.empty((bits, feat)); b = np.empty(bits); t = np.empty(bits)
+    st = load().hs_klsh_draw_planes(C.c_uint32(feat), C.c_uint32(bits), C.c_double(sigma), _vp(w),
+                                    _vp(b), _vp(t))
+    if st != HS_OK:
+        raise HsError(st, "hs_klsh_draw_planes")
+    return w, b, t
+
+
+def klsh_codes(classes, seq_start, w, b, t, device=0):
+    """KLSH code of every sequence of a concatenated buffer of reduced-alphabet
+    classes (pcluster.cpp:11-33 + lsh.cpp:40-49) on the GPU.  Returns (codes uint64 [n_seq] with
+    KLSH_NONE for sequences shorter than 3, uncertain-bit masks uint64 [n_seq])."""
+    classes = np.ascontiguousarray(classes, dtype=np.uint8)
+    seq_start = np.ascontiguousarray(seq_start, dtype=np.uint64)
+    w = np.ascontiguousarray(w, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    n_seq = len(seq_start) - 1
+    codes = np.empty(n_seq, dtype=np.uint64); unc = np.empty(n_seq, dtype=np.uint64)
+    err = C.create_string_buffer(256)
+    st = load().hs_klsh_codes(C.c_int(device), _vp(classes), C.c_uint64(len(classes)), _vp(seq_start),
+                              C.c_uint64(n_seq), _vp(w), _vp(b), _vp(t), C.c_uint32(w.shape[0]),
+                              _vp(codes), _vp(unc), err, C.c_uint32(256))
+    if st != HS_OK:
+        raise HsError(st, err.value.decode())
+    return codes, unc
 
 
 class Engine:

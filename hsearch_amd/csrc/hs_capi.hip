@@ -12,6 +12,7 @@
 //     dir_start [nb+1]      u32  bucket boundaries
 //     dir_tuple [nb][K]     i32  bucket ints of each bucket (exact string check at probe time)
 #include <math.h>
+#include <random>
 #include <string.h>
 
 #include <algorithm>
@@ -631,6 +632,84 @@ hs_status hs_index_build_windows(hs_handle* h, const uint8_t* residues, uint64_t
   }
   *n_windows = n;
   return index_build_resident(h, n);
+}
+
+// ---- KLSH pre-grouping ------------------------------------------------------
+hs_status hs_klsh_draw_planes(uint32_t feat, uint32_t bits, double sigma, double* w, double* b,
+                              double* t) {
+  if (!feat || !bits || bits > 64 || !w || !b || !t) return HS_ERR_INVALID;
+  // KLSH's members in declaration order (lsh.hpp:37-49): three distributions, then the engine,
+  // default-seeded; the constructor body draws t, b, then the feat normals of each bit (:28-37)
+  std::normal_distribution<double> normal(0.0, sigma * sigma);  // sigma^2 as the std deviation, :22
+  std::uniform_real_distribution<double> uniform_1(-1.0, 1.0);
+  std::uniform_real_distribution<double> uniform_pi(0.0, 2.0 * M_PI);
+  std::default_random_engine generator;
+  for (uint32_t i = 0; i < bits; ++i) {
+    t[i] = uniform_1(generator);
+    b[i] = uniform_pi(generator);
+    for (uint32_t j = 0; j < feat; ++j) w[(size_t)i * feat + j] = normal(generator);
+  }
+  return HS_OK;
+}
+
+hs_status hs_klsh_codes(int device, const uint8_t* classes, uint64_t n_residues,
+                        const uint64_t* seq_start, uint64_t n_seq, const double* w, const double* b,
+                        const double* t, uint32_t bits, uint64_t* codes, uint64_t* uncertain, char* err,
+                        uint32_t err_cap) {
+  auto say = [&](hs_status st, const std::string& msg) {
+    if (err && err_cap) {
+      strncpy(err, msg.c_str(), err_cap - 1);
+      err[err_cap - 1] = 0;
+    }
+    return st;
+  };
+  if ((n_seq && (!seq_start || !codes)) || (n_residues && !classes) || !w || !b || !t || !bits || bits > 64)
+    return say(HS_ERR_INVALID, "bad argument");
+  if (!n_seq) return HS_OK;
+  for (uint64_t s = 0; s < n_seq; ++s)
+    if (seq_start[s] > seq_start[s + 1] || seq_start[s + 1] > n_residues)
+      return say(HS_ERR_INVALID, "seq_start must be ascending and end within n_residues");
+  for (uint64_t i = 0; i < n_residues; ++i)
+    if (classes[i] >= HS_KLSH_CLASSES) return say(HS_ERR_INVALID, "residue class outside 0..7");
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
+    return say(HS_ERR_NO_DEVICE, "no usable gfx950 device");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return say(HS_ERR_NO_DEVICE, "no usable gfx950 device");
+#define HS_KL(expr)                                                                          \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return say(e_ == hipErrorOutOfMemory ? HS_ERR_NOMEM : HS_ERR_HIP,                      \
+                 std::string(#expr) + ": " + hipGetErrorString(e_));                         \
+  } while (0)
+  HS_KL(hipSetDevice(device));
+  DevBuf d_cls, d_start, d_w, d_b, d_t, d_codes, d_unc;
+  struct Guard {
+    DevBuf* bufs[7];
+    ~Guard() { for (DevBuf* x : bufs) x->release(); }
+  } guard = {{&d_cls, &d_start, &d_w, &d_b, &d_t, &d_codes, &d_unc}};
+  HS_KL(d_cls.reserve(std::max<size_t>(16, (size_t)n_residues)));
+  HS_KL(d_start.reserve(((size_t)n_seq + 1) * 8));
+  HS_KL(d_w.reserve((size_t)bits * HS_KLSH_FEATURES * 8));
+  HS_KL(d_b.reserve((size_t)bits * 8));
+  HS_KL(d_t.reserve((size_t)bits * 8));
+  HS_KL(d_codes.reserve((size_t)n_seq * 8));
+  HS_KL(d_unc.reserve((size_t)n_seq * 8));
+  if (n_residues) HS_KL(hipMemcpy(d_cls.p, classes, (size_t)n_residues, hipMemcpyHostToDevice));
+  HS_KL(hipMemcpy(d_start.p, seq_start, ((size_t)n_seq + 1) * 8, hipMemcpyHostToDevice));
+  HS_KL(hipMemcpy(d_w.p, w, (size_t)bits * HS_KLSH_FEATURES * 8, hipMemcpyHostToDevice));
+  HS_KL(hipMemcpy(d_b.p, b, (size_t)bits * 8, hipMemcpyHostToDevice));
+  HS_KL(hipMemcpy(d_t.p, t, (size_t)bits * 8, hipMemcpyHostToDevice));
+  HS_KL(hs_launch_klsh(d_cls.as<uint8_t>(), d_start.as<uint64_t>(), n_seq, d_w.as<double>(),
+                       d_b.as<double>(), d_t.as<double>(), bits, d_codes.as<uint64_t>(),
+                       d_unc.as<uint64_t>(), nullptr));
+  HS_KL(hipDeviceSynchronize());
+  HS_KL(hipMemcpy(codes, d_codes.p, (size_t)n_seq * 8, hipMemcpyDeviceToHost));
+  if (uncertain) HS_KL(hipMemcpy(uncertain, d_unc.p, (size_t)n_seq * 8, hipMemcpyDeviceToHost));
+#undef HS_KL
+  return HS_OK;
 }
 
 // ---- persistent index --------------------------------------------------------------------------

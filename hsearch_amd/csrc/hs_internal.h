@@ -176,6 +176,10 @@ hipError_t hs_launch_set_u32(uint32_t* d_p, uint32_t v, hipStream_t s);
 hipError_t hs_launch_windows(const uint8_t* d_residues, uint32_t n_residues, const uint32_t* d_seq_start,
                              const uint32_t* d_win_off, uint32_t n_seq, int k, uint8_t* d_codes,
                              uint32_t* d_win_pos, hipStream_t s);
+// KLSH codes of n_seq sequences of reduced-alphabet classes (one wave per sequence)
+hipError_t hs_launch_klsh(const uint8_t* d_classes, const uint64_t* d_seq_start, uint64_t n_seq,
+                          const double* d_w, const double* d_b, const double* d_t, uint32_t bits,
+                          uint64_t* d_codes, uint64_t* d_uncertain, hipStream_t s);
 // d_out[d_perm[i]] = i
 hipError_t hs_launch_invert_perm(const uint32_t* d_perm, uint32_t n, uint32_t* d_out, hipStream_t s);
 hipError_t hs_launch_max_u32(const uint32_t* d_in, uint32_t n, uint32_t* d_out, hipStream_t s);

@@ -736,6 +736,48 @@ __global__ __launch_bounds__(256) void hs_windows_kernel(const uint8_t* __restri
   for (int p = 0; p < k; ++p) row[p] = residues[pos + p];
 }
 
+// ------------------------------------------------------------------------------------------ KLSH
+// One wave per sequence: 512-bin histogram of its reduced-alphabet 3-mers in LDS (pcluster.cpp:
+// 27-33), then lane i < bits runs the reference's serial dot product over the bins (lsh.cpp:8-15,
+// product rounded, sum rounded) and tests cos(sum + b_i) + t_i >= 0 (lsh.cpp:44-46).
+__global__ __launch_bounds__(256) void hs_klsh_kernel(const uint8_t* __restrict__ classes,
+                                                      const uint64_t* __restrict__ seq_start,
+                                                      uint64_t n_seq, const double* __restrict__ w,
+                                                      const double* __restrict__ b,
+                                                      const double* __restrict__ t, uint32_t bits,
+                                                      uint64_t* __restrict__ codes,
+                                                      uint64_t* __restrict__ uncertain) {
+  __shared__ uint32_t s_hist[4][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t* hist = s_hist[wave];
+  for (uint64_t s = (uint64_t)blockIdx.x * 4 + wave; s < n_seq; s += (uint64_t)gridDim.x * 4) {
+    const uint64_t lo = seq_start[s], len = seq_start[s + 1] - lo;
+    for (int j = lane; j < 512; j += 64) hist[j] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (uint64_t i = lane; i + 3 <= len; i += 64) {
+      const uint8_t* c = classes + lo + i;
+      atomicAdd(&hist[(uint32_t)c[0] + 8u * c[1] + 64u * c[2]], 1u);  // Kmer2Integer util.hpp:244-250
+    }
+    __builtin_amdgcn_wave_barrier();
+    bool bit = false, unc = false;
+    if ((uint32_t)lane < bits) {
+      const double* wi = w + (size_t)lane * 512;
+      double sum = 0.0;
+      for (int j = 0; j < 512; ++j) sum = __dadd_rn(sum, __dmul_rn((double)hist[j], wi[j]));
+      sum = __dadd_rn(sum, b[lane]);
+      const double v = __dadd_rn(cos(sum), t[lane]);
+      bit = v >= 0.0;
+      unc = fabs(v) < 1e-9;
+    }
+    const unsigned long long code = __ballot(bit), um = __ballot(unc);
+    if (lane == 0) {
+      codes[s] = len < 3 ? 0xffffffffffffffffull : code;
+      if (uncertain) uncertain[s] = len < 3 ? 0ull : um;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 __global__ __launch_bounds__(256) void hs_invert_perm_kernel(const uint32_t* __restrict__ perm,
                                                              uint32_t n, uint32_t* __restrict__ out) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -984,6 +1026,16 @@ hipError_t hs_launch_windows(const uint8_t* d_residues, uint32_t n_residues, con
   if (!n_residues || !n_seq) return hipSuccess;
   hs_windows_kernel<<<blocks_for(n_residues), 256, 0, s>>>(d_residues, n_residues, d_seq_start, d_win_off,
                                                           n_seq, k, d_codes, d_win_pos);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_klsh(const uint8_t* d_classes, const uint64_t* d_seq_start, uint64_t n_seq,
+                          const double* d_w, const double* d_b, const double* d_t, uint32_t bits,
+                          uint64_t* d_codes, uint64_t* d_uncertain, hipStream_t s) {
+  if (!n_seq) return hipSuccess;
+  const unsigned blocks = (unsigned)std::min<uint64_t>((n_seq + 3) / 4, 1u << 16);
+  hs_klsh_kernel<<<blocks, 256, 0, s>>>(d_classes, d_seq_start, n_seq, d_w, d_b, d_t, bits, d_codes,
+                                        d_uncertain);
   return hipGetLastError();
 }
 

@@ -310,6 +310,69 @@ int SearchProteins(const ProteinDB& db, uint32_t kmer_length, const std::vector<
   return HS_OK;
 }
 
+bool ReadPclusterFasta(const std::string& path, uint32_t unknown_seed, PclusterDB* db) {
+  std::ifstream fin(path.c_str());
+  if (!fin) return false;
+  db->names.clear();
+  db->seqs.clear();
+  std::mt19937 gen(unknown_seed);
+  std::string line, sequence;
+  bool open = false;
+  while (std::getline(fin, line)) {  // read_proteins.cpp:13-35
+    if (!line.empty() && line[line.size() - 1] == '\r') line.erase(line.size() - 1);
+    if (!line.empty() && line[0] == '>') {
+      if (!sequence.empty()) {
+        db->seqs.push_back(sequence);
+        sequence.clear();
+      }
+      const size_t sp = line.find_first_of(' ');
+      db->names.push_back(sp == std::string::npos ? line.substr(1) : line.substr(1, sp - 1));
+      open = true;
+      continue;
+    }
+    for (size_t i = 0; i < line.size(); ++i) {
+      const char c = line[i];
+      if (c >= 'A' && c <= 'Z' && HS_LETTER_TO_CODE[c - 'A'] >= 0)
+        sequence.push_back(c);
+      else if (isalpha((unsigned char)c))
+        sequence.push_back(HS_CODE_TO_LETTER[gen() % 20]);
+    }
+  }
+  if (!sequence.empty()) db->seqs.push_back(sequence);
+  (void)open;
+  return true;
+}
+
+int PreClustering(const PclusterDB& db, int device,
+                  std::map<uint64_t, std::vector<uint32_t> >* hash_buckets, std::string* err) {
+  hash_buckets->clear();
+  const uint32_t bits = 16;  // pcluster.cpp:13-15: feature_size = 8^HASHLEN, bit_num = 16, sigma = 0.2
+  std::vector<double> w((size_t)bits * HS_KLSH_FEATURES), b(bits), t(bits);
+  hs_status st = hs_klsh_draw_planes(HS_KLSH_FEATURES, bits, 0.2, w.data(), b.data(), t.data());
+  if (st != HS_OK) {
+    if (err) *err = "hs_klsh_draw_planes failed";
+    return st;
+  }
+  std::vector<uint8_t> classes;
+  std::vector<uint64_t> start(1, 0);
+  for (size_t i = 0; i < db.seqs.size(); ++i) {
+    for (size_t p = 0; p < db.seqs[i].size(); ++p)
+      classes.push_back((uint8_t)HS_REDUCED_CLASS[db.seqs[i][p] - 'A']);
+    start.push_back(classes.size());
+  }
+  std::vector<uint64_t> codes(db.seqs.size());
+  char msg[256] = {0};
+  st = hs_klsh_codes(device, classes.data(), classes.size(), start.data(), db.seqs.size(), w.data(),
+                     b.data(), t.data(), bits, codes.data(), nullptr, msg, sizeof(msg));
+  if (st != HS_OK) {
+    if (err) *err = std::string("hs_klsh_codes: ") + msg;
+    return st;
+  }
+  for (size_t i = 0; i < codes.size(); ++i)
+    if (codes[i] != HS_KLSH_NONE) (*hash_buckets)[codes[i]].push_back((uint32_t)i);  // pcluster.cpp:34
+  return HS_OK;
+}
+
 bool ReadKmerFasta(const std::string& path, std::vector<Kmer>* kmers) {
   std::ifstream fin(path.c_str());
   if (!fin) return false;

@@ -15,6 +15,7 @@
 
 #include <stdint.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -86,6 +87,22 @@ int SearchProteins(const ProteinDB& db, uint32_t kmer_length, const std::vector<
                    const uint32_t& hash_L, const double& hash_W, const double& hash_R,
                    const std::string& output_file, const Planes& planes, int device, std::string* err,
                    std::vector<uint64_t>* table_sizes = nullptr, uint64_t* n_windows = nullptr);
+
+// ---- Kernel-LSH pre-grouping of whole proteins (pcluster.cpp:11-81) ---------
+// pcluster's FASTA reader (read_proteins.cpp:6-41): '>' lines start a protein, its name is the
+// text up to the first space, the following lines are concatenated; letters of the 20-letter
+// alphabet are kept, any other alphabetic character is replaced by a residue drawn from a
+// generator seeded with unknown_seed (the reference uses rand() % 20, read_proteins.cpp:30-32),
+// everything else is dropped.
+struct PclusterDB {
+  std::vector<std::string> names, seqs;
+};
+bool ReadPclusterFasta(const std::string& path, uint32_t unknown_seed, PclusterDB* db);
+// PreClustering(proteinDB, hash_buckets): KLSH(8^3, 16, 0.2) codes of all proteins with at least 3
+// residues, computed on `device` (hs_klsh_codes), grouped: buckets[code] = ascending protein
+// indices.  Returns 0 or an hs_status with *err set.
+int PreClustering(const PclusterDB& db, int device,
+                  std::map<uint64_t, std::vector<uint32_t> >* hash_buckets, std::string* err);
 
 // Clustering() of hclust2.cpp:86-151.  kmers: name + sequence (letters of the 20-letter alphabet; a
 // letter outside it is replaced by a residue drawn from a generator seeded with `unknown_seed`,

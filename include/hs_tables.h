@@ -49,4 +49,16 @@ static const char HS_CODE_TO_LETTER[HS_ALPHABET + 1] = "ARNDCQEGHILKMFPSTWYV";
 /* The reference's AA20 (util.hpp:89), used only by the --ref-compat-eq-swap FASTA path. */
 static const char HS_REF_AA20[HS_ALPHABET + 1] = "ARNDCEQGHILKMFPSTWYV";
 
+/* pcluster's reduced 8-class alphabet (pcluster/src/pcluster/util.hpp:100-104, REDUCEDAAINDEX):
+ * [A S T] [R K E D Q] [N H] [C] [G] [I V L M] [F Y W] [P], letter - 'A' -> class, -1 for
+ * B J O U X Z.  KLSH features count 3-mers over these classes: index = c0 + 8 c1 + 64 c2
+ * (Kmer2Integer util.hpp:244-250 with BASEP = 1, 8, 64, ...). */
+#define HS_KLSH_CLASSES 8
+#define HS_KLSH_HASHLEN 3
+#define HS_KLSH_FEATURES 512
+static const signed char HS_REDUCED_CLASS[26] = {
+    /*A*/ 0, /*B*/ -1, /*C*/ 3, /*D*/ 1, /*E*/ 1, /*F*/ 6, /*G*/ 4, /*H*/ 2, /*I*/ 5,
+    /*J*/ -1, /*K*/ 1, /*L*/ 5, /*M*/ 5, /*N*/ 2, /*O*/ -1, /*P*/ 7, /*Q*/ 1, /*R*/ 1,
+    /*S*/ 0, /*T*/ 0, /*U*/ -1, /*V*/ 5, /*W*/ 6, /*X*/ -1, /*Y*/ 6, /*Z*/ -1};
+
 #endif /* HS_TABLES_H */

@@ -157,6 +157,26 @@ HS_API hs_status hs_index_build_windows(hs_handle* h, const uint8_t* residues, u
 HS_API hs_status hs_index_save(hs_handle* h, const char* path);
 HS_API hs_status hs_index_load(hs_handle* h, const char* path);
 
+/* SURVEY 8(f) row 3 -- Kernel-LSH pre-grouping of whole proteins (pcluster.cpp:11-81).
+ * hs_klsh_draw_planes: the planes KLSH::KLSH draws (lsh.cpp:17-38) from its default-seeded
+ * std::default_random_engine (lsh.hpp:49) -- per bit t ~ U(-1,1), b ~ U(0, 2 pi), then `feat`
+ * normals with standard deviation sigma*sigma (sic, lsh.cpp:22).  Host only; w[bits][feat].
+ * hs_klsh_codes: one hash code per sequence of a concatenated buffer of reduced-alphabet classes
+ * (0..7 per residue, include/hs_tables.h HS_REDUCED_CLASS): feature vector = counts of the
+ * sequence's 3-mers (pcluster.cpp:27-33), bit i = (cos(Dot(p, w_i) + b_i) + t_i >= 0) with Dot
+ * strictly left to right in fp64 (KLSH::GetHashValue lsh.cpp:40-49).  Sequences shorter than 3 get
+ * HS_KLSH_NONE (the reference skips them, pcluster.cpp:22-24).  uncertain (optional, [n_seq])
+ * receives a mask of the bits whose |cos(.) + t| is below 1e-9, i.e. where the device's cos and
+ * libm's could disagree on the sign.  Runs on `device`; status only (no handle): err, if given,
+ * receives a message. */
+#define HS_KLSH_NONE 0xffffffffffffffffull
+HS_API hs_status hs_klsh_draw_planes(uint32_t feat, uint32_t bits, double sigma, double* w, double* b,
+                                     double* t);
+HS_API hs_status hs_klsh_codes(int device, const uint8_t* classes, uint64_t n_residues,
+                               const uint64_t* seq_start, uint64_t n_seq, const double* w,
+                               const double* b, const double* t, uint32_t bits, uint64_t* codes,
+                               uint64_t* uncertain, char* err, uint32_t err_cap);
+
 HS_API hs_status hs_index_info_get(const hs_handle* h, hs_index_info* out);
 
 /* ---- query = probe + dedupe + verify (rows a8, a9, a10) ---------------------------------------- */

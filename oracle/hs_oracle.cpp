@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <fstream>
+#include <random>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -374,6 +375,38 @@ double hso_evaluate(const char* ground_truth, const char* hits, double R) {
   }
   if (bad) return NAN;
   return tp / (tp + fn);  // :164
+}
+
+// ---- Kernel-LSH pre-grouping (pcluster) -----------------------------------------------------------
+void hso_klsh_draw_planes(uint32_t feat, uint32_t bits, double sigma, double* w, double* b, double* t) {
+  // member order of KLSH (lsh.hpp:37-49): the distributions, then the default-seeded engine
+  std::normal_distribution<double> normal(0.0, sigma * sigma);          // lsh.cpp:22
+  std::uniform_real_distribution<double> uniform_1(-1.0, 1.0);          // :23
+  std::uniform_real_distribution<double> uniform_pi(0.0, 2.0 * M_PI);   // :24
+  std::default_random_engine generator;                                 // lsh.hpp:49
+  for (uint32_t i = 0; i < bits; ++i) {                                 // :28-37
+    t[i] = uniform_1(generator);
+    b[i] = uniform_pi(generator);
+    for (uint32_t j = 0; j < feat; ++j) w[(size_t)i * feat + j] = normal(generator);
+  }
+}
+
+void hso_klsh_features(const uint8_t* classes, uint64_t len, double* feat) {
+  for (uint32_t j = 0; j < 512; ++j) feat[j] = 0.0;
+  for (uint64_t i = 0; i + 3 <= len; ++i)  // pcluster.cpp:27-29, Kmer2Integer util.hpp:244-250
+    feat[classes[i] + 8u * classes[i + 1] + 64u * classes[i + 2]] += 1.0;
+}
+
+uint64_t hso_klsh_hash(const double* w, const double* b, const double* t, uint32_t feat, uint32_t bits,
+                       const double* p) {
+  uint64_t hash_value = 0;
+  for (uint32_t i = 0; i < bits; ++i) {
+    double sum = 0;  // Dot, lsh.cpp:8-15
+    for (uint32_t j = 0; j < feat; ++j) sum += p[j] * w[(size_t)i * feat + j];
+    sum = sum + b[i];  // :44
+    hash_value |= (uint64_t)((std::cos(sum) + t[i]) >= 0 ? 1 : 0) << i;  // :45-46
+  }
+  return hash_value;
 }
 
 }  // extern "C"

@@ -83,6 +83,19 @@ int hso_clustering_to_file(const double* a, const double* b, uint32_t d, uint32_
  * sorted by (motif, protein) as evaluate2.cpp:88-96 leaves it).  Returns tp/(tp+fn). */
 double hso_evaluate(const char* ground_truth, const char* hits, double R);
 
+/* ---- Kernel-LSH pre-grouping of whole proteins (pcluster) ------------------
+ * Planes of KLSH::KLSH (lsh.cpp:17-38): per bit t ~ U(-1,1), b ~ U(0, 2 pi), then feat normals
+ * N(0, sigma*sigma) -- sigma*sigma is passed as the STANDARD DEVIATION, lsh.cpp:22 -- from one
+ * default-seeded std::default_random_engine (lsh.hpp:49).  w[bits][feat], b[bits], t[bits]. */
+void hso_klsh_draw_planes(uint32_t feat, uint32_t bits, double sigma, double* w, double* b, double* t);
+/* Feature vector of one protein (pcluster.cpp:27-33): counts of its 3-mers over the reduced
+ * classes (0..7 per residue), index = c0 + 8 c1 + 64 c2.  feat[512]; len >= 3. */
+void hso_klsh_features(const uint8_t* classes, uint64_t len, double* feat);
+/* KLSH::GetHashValue (lsh.cpp:40-49): bit i = (cos(Dot(p, w_i) + b_i) + t_i >= 0), Dot strictly
+ * left to right (lsh.cpp:8-15). */
+uint64_t hso_klsh_hash(const double* w, const double* b, const double* t, uint32_t feat, uint32_t bits,
+                       const double* p);
+
 #ifdef __cplusplus
 }
 #endif

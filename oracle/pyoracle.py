@@ -217,6 +217,36 @@ def evaluate(ground_truth_path, hits_path, R):
     return float(lib().hso_evaluate(ground_truth_path.encode(), hits_path.encode(), C.c_double(R)))
 
 
+# ---- KLSH pre-grouping (pcluster) -- restatement
+_REDUCED = {c: k for k, grp in enumerate(["AST", "RKEDQ", "NH", "C", "G", "IVLM", "FYW", "P"]) for c in grp}
+
+
+def klsh_classes(seq):
+    """Reduced-alphabet classes (util.hpp:100-104) of a sequence of the 20 standard letters."""
+    return np.array([_REDUCED[c] for c in seq], dtype=np.uint8)
+
+
+def klsh_draw_planes(feat=512, bits=16, sigma=0.2):
+    w = np.empty((bits, feat)); b = np.empty(bits); t = np.empty(bits)
+    lib().hso_klsh_draw_planes(C.c_uint32(feat), C.c_uint32(bits), C.c_double(sigma), _ptr(w, _dp),
+                               _ptr(b, _dp), _ptr(t, _dp))
+    return w, b, t
+
+
+def klsh_features(classes):
+    classes = np.ascontiguousarray(classes, dtype=np.uint8)
+    feat = np.empty(512)
+    lib().hso_klsh_features(_ptr(classes, _u8p), C.c_uint64(len(classes)), _ptr(feat, _dp))
+    return feat
+
+
+def klsh_hash(w, b, t, feat):
+    w, b, t, feat = _f64(w), _f64(b), _f64(t), _f64(feat)
+    lib().hso_klsh_hash.restype = C.c_uint64
+    return int(lib().hso_klsh_hash(_ptr(w, _dp), _ptr(b, _dp), _ptr(t, _dp), C.c_uint32(w.shape[1]),
+                                   C.c_uint32(w.shape[0]), _ptr(feat, _dp)))
+
+
 # --------------------------------------------------------------- the real reference (oracle/_ref)
 _ref_search = None
 _ref_hclust2 = None
@@ -232,6 +262,21 @@ def ref_search_lib():
         _ref_search = C.CDLL(os.path.join(_HERE, "_ref", "libref_search.so"))
         _ref_search.ref_evaluate.restype = C.c_double
     return _ref_search
+
+
+def ref_klsh_lib():
+    lib_ = C.CDLL(os.path.join(_HERE, "_ref", "libref_klsh.so"))
+    lib_.ref_klsh_hash.restype = C.c_uint64
+    return lib_
+
+
+def ref_klsh(feat=512, bits=16, sigma=0.2):
+    """The reference's own KLSH object: (planes w, b, t, hash function over feature vectors)."""
+    lib_ = ref_klsh_lib()
+    lib_.ref_klsh_create(C.c_uint32(feat), C.c_uint32(bits), C.c_double(sigma))
+    w = np.empty((bits, feat)); b = np.empty(bits); t = np.empty(bits)
+    lib_.ref_klsh_planes(_ptr(w, _dp), _ptr(b, _dp), _ptr(t, _dp))
+    return w, b, t, (lambda f: int(lib_.ref_klsh_hash(_ptr(_f64(f), _dp))))
 
 
 def ref_hclust2_lib():

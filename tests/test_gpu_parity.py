@@ -308,3 +308,30 @@ def test_index_save_load_round_trip(oracle, tmp_path):
     with pytest.raises(hsearch_amd.HsError):
         e3.index_load(tmp_path / "missing.hsidx")
     e3.close()
+
+
+def test_klsh_codes_match_reference_golden(oracle, golden_dir):
+    """hs_klsh_codes against the codes of the reference's own KLSH object, and
+    against the oracle on fresh sequences (short ones are skipped like pcluster.cpp:22-24)."""
+    import os
+    import hsearch_amd
+    z = np.load(os.path.join(golden_dir, "klsh.npz"))
+    codes, unc = hsearch_amd.klsh_codes(z["classes"], z["seq_start"], z["w"], z["b"], z["t"])
+    assert not unc.any()                      # no bit sits on the cos(.) + t = 0 boundary
+    assert np.array_equal(codes, z["codes"])
+    rng = np.random.default_rng(9)
+    lens = rng.integers(0, 3000, size=500)
+    lens[:4] = [0, 1, 2, 3]
+    classes = rng.integers(0, 8, size=int(lens.sum()), dtype=np.uint8)
+    start = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    w, b, t = hsearch_amd.klsh_draw_planes()
+    codes, unc = hsearch_amd.klsh_codes(classes, start, w, b, t)
+    assert not unc.any()
+    for i, n in enumerate(lens):
+        if n < 3:
+            assert codes[i] == hsearch_amd.KLSH_NONE
+        else:
+            f = oracle.klsh_features(classes[int(start[i]):int(start[i + 1])])
+            assert int(codes[i]) == oracle.klsh_hash(w, b, t, f)
+    with pytest.raises(hsearch_amd.HsError):
+        hsearch_amd.klsh_codes(np.array([9], dtype=np.uint8), np.array([0, 1], dtype=np.uint64), w, b, t)

@@ -193,3 +193,37 @@ def test_cli_fasta_database_matches_points_database(tmp_path, oracle):
         got, want = open(out_fa).read(), open(out_pt).read()
         assert len(want.splitlines()) >= 40
         assert got == want
+
+
+@pytest.mark.gpu
+def test_pcluster_pregroup_cli_matches_oracle(tmp_path, oracle):
+    """hs_pcluster_pregroup (pcluster.cpp:11-81 on the GPU) groups proteins
+    exactly as the oracle's KLSH restatement (itself pinned to the reference's KLSH object)."""
+    exe = os.path.join(ROOT, "hsearch_amd", "bin", "hs_pcluster_pregroup")
+    _bin()
+    rng = np.random.default_rng(12)
+    letters = "ARNDCQEGHILKMFPSTWYV"
+    seqs = ["".join(letters[i] for i in rng.integers(0, 20, size=int(n)))
+            for n in rng.integers(1, 900, size=200)]
+    seqs[5] = "AR"                                   # shorter than 3: in no group
+    fa = str(tmp_path / "p.fa")
+    with open(fa, "w") as f:
+        for i, s in enumerate(seqs):
+            f.write(">prot%d description text\n" % i)
+            for j in range(0, len(s), 60):           # multi-line FASTA
+                f.write(s[j:j + 60] + "\n")
+    out = str(tmp_path / "groups.txt")
+    r = subprocess.run([exe, "-d", fa, "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    w, b, t = oracle.klsh_draw_planes()
+    want = {}
+    for i, s in enumerate(seqs):
+        if len(s) >= 3:
+            want.setdefault(oracle.klsh_hash(w, b, t, oracle.klsh_features(oracle.klsh_classes(s))), []).append("prot%d" % i)
+    assert "[NUMBER OF PRE-GROUPS %d]" % len(want) in r.stderr
+    got = {}
+    for ln in open(out):
+        code, name = ln.rstrip("\n").split("\t")
+        got.setdefault(int(code), []).append(name)
+    assert got == want and list(got) == sorted(got)
+    assert subprocess.run([exe], capture_output=True).returncode == 0     # help, exit 0

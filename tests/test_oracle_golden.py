@@ -80,3 +80,23 @@ def test_evaluate(oracle, golden_dir):
         open(gt, "w").write("\n".join(g["ground_truth"]) + "\n")
         open(hits, "w").write("\n".join(g["hits"]) + "\n")
         assert oracle.evaluate(gt, hits, g["R"]) == pytest.approx(g["weighted_recall"], abs=1e-15)
+
+
+def test_klsh_oracle_and_planes_match_reference_golden(oracle, golden_dir):
+    """the KLSH restatement (planes from the default-seeded engine, 3-mer
+    features, serial dot, cos + threshold) against codes produced by the reference's own KLSH object
+    (tests/golden/klsh.npz, tools/gen_golden.py::gen_klsh); the product's host-side plane
+    generator must give the same planes."""
+    import hsearch_amd
+    z = np.load(os.path.join(golden_dir, "klsh.npz"))
+    w, b, t = oracle.klsh_draw_planes(512, 16, 0.2)
+    assert np.array_equal(w, z["w"]) and np.array_equal(b, z["b"]) and np.array_equal(t, z["t"])
+    pw, pb, pt = hsearch_amd.klsh_draw_planes(512, 16, 0.2)
+    assert np.array_equal(pw, z["w"]) and np.array_equal(pb, z["b"]) and np.array_equal(pt, z["t"])
+    st = z["seq_start"].astype(np.int64)
+    for i in range(len(st) - 1):
+        f = oracle.klsh_features(z["classes"][st[i]:st[i + 1]])
+        assert f.sum() == st[i + 1] - st[i] - 2
+        assert oracle.klsh_hash(w, b, t, f) == int(z["codes"][i])
+    assert str(z["first_sequences"][0]) and list(oracle.klsh_classes(str(z["first_sequences"][0]))) == \
+        list(z["classes"][st[0]:st[1]])

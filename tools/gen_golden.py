@@ -158,6 +158,22 @@ def gen_evaluate():
               open(os.path.join(OUT, "evaluate.json"), "w"))
 
 
+def gen_klsh():
+    """the reference's own KLSH object (pcluster lsh.cpp, compiled into
+    oracle/_ref/libref_klsh.so) over PreClustering's features (pcluster.cpp:23-33) of random
+    proteins.  The planes are the default-seeded engine's (lsh.hpp:49): data, not a choice."""
+    w, b, t, refhash = O.ref_klsh(512, 16, 0.2)
+    g = rng(4242)
+    lens = g.integers(3, 700, size=400)
+    lens[:6] = [3, 4, 5, 64, 65, 699]
+    seqs = ["".join(LETTERS[c] for c in g.integers(0, 20, size=int(n))) for n in lens]
+    classes = np.concatenate([O.klsh_classes(s_) for s_ in seqs])
+    starts = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    codes = np.array([refhash(O.klsh_features(O.klsh_classes(s_))) for s_ in seqs], dtype=np.uint64)
+    np.savez_compressed(os.path.join(OUT, "klsh.npz"), w=w, b=b, t=t, classes=classes, seq_start=starts,
+                        codes=codes, first_sequences=np.array(seqs[:6]))
+
+
 def main():
     if not O.have_ref():
         O.build()
@@ -170,6 +186,7 @@ def main():
     gen_pairwise()
     gen_clustering()
     gen_evaluate()
+    gen_klsh()
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("wrote %d files, %.1f KiB" % (len(os.listdir(OUT)), total / 1024))
 
