@@ -42,8 +42,9 @@ def allgather_hits(q, ids, table, distance, n_hits, q_offset=0, group=None, forc
     dev = q.device
     n_hits = int(n_hits)
     if world == 1 and not (force and dist.is_initialized()):
-        return (q[:n_hits].to(torch.int64) + int(q_offset), ids[:n_hits].to(torch.int64),
-                table[:n_hits].to(torch.int64), distance[:n_hits])
+        # nothing to exchange: the rank's own arrays, as views (no conversion kernels in the step)
+        qv = q[:n_hits] if not q_offset else q[:n_hits] + int(q_offset)
+        return qv, ids[:n_hits], table[:n_hits], distance[:n_hits]
     q32 = q[:n_hits].view(torch.int32) + int(q_offset)          # global numbering before the exchange
     cols = (q32, ids[:n_hits].view(torch.int32), table[:n_hits].view(torch.int32), distance[:n_hits])
     while True:
