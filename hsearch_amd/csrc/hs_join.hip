@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void hs_seg_route_kernel(const uint64_t* __res
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
   if (j > n_max) return;
   uint32_t it = 0;
-  const uint32_t jqg = jm == HS_JM_WAVE ? HS_JQG_WAVE : (uint32_t)JQG;
+  const uint32_t jqg = jm < HS_JM_BLOCK ? HS_JQG_WAVE : (uint32_t)JQG;
   if (j < *n_seg && (seg_key[j] >> shift) < (uint64_t)L) {
     const uint32_t m = qcount[sorted_ql[seg_qoff[j]]];
     const uint32_t nq = seg_cnt[j];
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void hs_item_desc_kernel(hs_tables_dev tabs,
   const uint64_t key = seg_key[seg];
   const uint32_t nQ = seg_cnt[seg], qoff = seg_qoff[seg];
   const uint32_t M = qcount[sorted_ql[qoff]];
-  const uint32_t jqg = jm == HS_JM_WAVE ? HS_JQG_WAVE : (uint32_t)JQG;
+  const uint32_t jqg = jm < HS_JM_BLOCK ? HS_JQG_WAVE : (uint32_t)JQG;
   const uint32_t tiles_m = (M + jm - 1) / jm;
   const uint32_t local = item - item_off[lo];
   const uint32_t mt = local % tiles_m, qg = local / tiles_m;

@@ -43,7 +43,6 @@ typedef int intx16 __attribute__((ext_vector_type(16)));
 constexpr int QD = 4;        // table columns used
 constexpr int QROW = 128;    // bytes of a quantised query row (global)
 constexpr int QPIECES = 8;   // 16-byte pieces per row
-constexpr int JT = 4;        // 32-member row tiles per wave: a work item has 32 JT = HS_JM_WAVE members
 constexpr uint32_t JRES = 64;  // survivor slots a wave reserves per counter access
 constexpr int DIG = 13;      // base-127 digits (+1 remainder slot) of -gamma
 constexpr int RDIG = 11;     // base-127 digits (+1 remainder slot) of rho
@@ -378,11 +377,12 @@ __device__ __forceinline__ void emit_survivors(const intx16 (&acc)[GT], int T0, 
   }
 }
 
-// sign bit of the result = AND of the sign bits of the 32 accumulators of a 2-tile group
-__device__ __forceinline__ uint32_t and_tree2(const intx16 (&acc)[2]) {
+// sign bit of the result = AND of the sign bits of the accumulators of a GT-tile group
+template <int GT>
+__device__ __forceinline__ uint32_t and_tree(const intx16 (&acc)[GT]) {
   uint32_t a = 0xffffffffu;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < GT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; i += 2) a = a & (uint32_t)acc[t][i] & (uint32_t)acc[t][i + 1];
   return a;
@@ -394,16 +394,18 @@ __device__ __forceinline__ uint4 uniform4(const uint4 v) {
                     __builtin_amdgcn_readfirstlane(v.z), __builtin_amdgcn_readfirstlane(v.w));
 }
 
-// The wave's 4 row tiles form two accumulator groups X (tiles 0, 1) and Y (tiles 2, 3).  Per
+// The wave's JT row tiles form two accumulator groups X (the first JT/2 tiles) and Y (the rest).  Per
 // query tile: 8 MFMAs into X while the sign test of Y (previous query tile) issues in their gaps,
 // then 8 MFMAs into Y beside the sign test of X -- the vector instructions of the epilogue never
 // stand between two MFMAs of the same wave.
-__global__ __launch_bounds__(256, 2) void hs_join8w_kernel(
+template <int JT>
+__global__ __launch_bounds__(256, JT == 4 ? 2 : 4) void hs_join8w_kernel(
     const uint4* __restrict__ desc, uint32_t n_items, const uint4* __restrict__ packed_base,
     const uint4* __restrict__ rec_base, const uint4* __restrict__ c8t,
     const uint4* __restrict__ tab8, uint32_t* __restrict__ prov_count, uint32_t prov_cap,
     uint2* __restrict__ prov, uint32_t* __restrict__ item_counter, uint32_t G) {
-  static_assert(JT == 4, "two accumulator groups of two row tiles");
+  static_assert(JT == 4 || JT == 2, "two accumulator groups of JT / 2 row tiles");
+  constexpr int GT = JT / 2;
   __shared__ uint32_t sTab8[32];
   const int tid = threadIdx.x, lane = tid & 63;
   // wave-uniform by construction: say so, or every per-item quantity derived from it (descriptor
@@ -504,12 +506,12 @@ __global__ __launch_bounds__(256, 2) void hs_join8w_kernel(
 #undef HS_SWAP
       build_afrags8(pk, rk, h, sTab8, A[t]);
     }
-    HS_TD(1, __builtin_amdgcn_readfirstlane(A[0][0][0] ^ A[JT - 1][3][3] ^ A[JT - 1][2][0] ^ A[1][1][1] ^ A[2][2][2]))
+    HS_TD(1, __builtin_amdgcn_readfirstlane(A[0][0][0] ^ A[JT - 1][3][3] ^ A[JT - 1][2][0] ^ A[1][1][1]))
     HS_LOAD_MEMBERS(nd0)
     HS_T(2)  // descriptor of the next item + issue of its member loads
-    intx16 accX[2], accY[2];
+    intx16 accX[GT], accY[GT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < GT; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) accY[t][i] = -1;  // "no survivor" for the first tile's Y test
     uint32_t prev_qc = q_begin;
@@ -531,44 +533,44 @@ __global__ __launch_bounds__(256, 2) void hs_join8w_kernel(
         const uint32_t qc = qc0 + 32u * (uint32_t)u;
         intx4 (&B)[4] = Bq[u];
         if (u == 0 || qc < q_end) {
-          // ---- phase 1: X <- A[0..1] x B, beside the sign test of Y (previous query tile)
+          // ---- phase 1: X <- A[0..GT) x B, beside the sign test of Y (previous query tile)
 #pragma unroll
-          for (int t = 0; t < 2; ++t)
+          for (int t = 0; t < GT; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) accX[t][i] = 0;
-          const uint32_t sY = and_tree2(accY);
+          const uint32_t sY = and_tree<GT>(accY);
 #pragma unroll
           for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < GT; ++t)
               accX[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[t][s], B[s], accX[t], 0, 0, 0);
 #pragma unroll
-          for (int g = 0; g < 8; ++g) {
+          for (int g = 0; g < 4 * GT; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
           }
           if (__ballot((int)sY >= 0))
-            emit_survivors<2>(accY, 2, prev_qc, qoff, q_end, wbase, M, mstart, lane, res_base,
-                              res_used, prov_count, prov_cap, prov);
-          // ---- phase 2: Y <- A[2..3] x B, beside the sign test of X
+            emit_survivors<GT>(accY, GT, prev_qc, qoff, q_end, wbase, M, mstart, lane, res_base,
+                               res_used, prov_count, prov_cap, prov);
+          // ---- phase 2: Y <- A[GT..JT) x B, beside the sign test of X
 #pragma unroll
-          for (int t = 0; t < 2; ++t)
+          for (int t = 0; t < GT; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) accY[t][i] = 0;
 #pragma unroll
           for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-              accY[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[2 + t][s], B[s], accY[t], 0, 0, 0);
-          const uint32_t sX = and_tree2(accX);
+            for (int t = 0; t < GT; ++t)
+              accY[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[GT + t][s], B[s], accY[t], 0, 0, 0);
+          const uint32_t sX = and_tree<GT>(accX);
 #pragma unroll
-          for (int g = 0; g < 8; ++g) {
+          for (int g = 0; g < 4 * GT; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
           }
           if (__ballot((int)sX >= 0))
-            emit_survivors<2>(accX, 0, qc, qoff, q_end, wbase, M, mstart, lane, res_base, res_used,
-                              prov_count, prov_cap, prov);
+            emit_survivors<GT>(accX, 0, qc, qoff, q_end, wbase, M, mstart, lane, res_base, res_used,
+                               prov_count, prov_cap, prov);
           prev_qc = qc;
         }
         // the same-numbered tile of the next group into the registers just consumed
@@ -582,10 +584,10 @@ __global__ __launch_bounds__(256, 2) void hs_join8w_kernel(
     for (uint32_t gi = 1; gi < n_groups; ++gi) do_group(gi);
     HS_T(4)
     {  // the item's last Y group
-      const uint32_t sY = and_tree2(accY);
+      const uint32_t sY = and_tree<GT>(accY);
       if (__ballot((int)sY >= 0))
-        emit_survivors<2>(accY, 2, prev_qc, qoff, q_end, wbase, M, mstart, lane, res_base, res_used,
-                          prov_count, prov_cap, prov);
+        emit_survivors<GT>(accY, GT, prev_qc, qoff, q_end, wbase, M, mstart, lane, res_base, res_used,
+                           prov_count, prov_cap, prov);
     }
     HS_T(5)
     if (!has_next) break;
@@ -649,9 +651,11 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
   const uint32_t n_waves = (uint32_t)n_blocks * 4u;
   static const uint32_t g_max = getenv("HS_JOIN_CHUNK") ? (uint32_t)atoi(getenv("HS_JOIN_CHUNK")) : 8u;
   const uint32_t G = std::max(2u, std::min(g_max, n_items / (n_waves * 8u)));
-  hs_join8w_kernel<<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_rec_base,
-                                            (const uint4*)d_c8t, (const uint4*)d_tab8, d_prov_count,
-                                            prov_cap, d_prov, d_item_counter, G);
+  // JT = 4 row tiles per wave, 2 waves per SIMD.  (JT = 2 at 4 waves per SIMD, with work items of
+  // 64 members, was measured 1.7x slower: twice the B-tile traffic and per-item work.)
+  hs_join8w_kernel<4><<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_rec_base,
+                                               (const uint4*)d_c8t, (const uint4*)d_tab8, d_prov_count,
+                                               prov_cap, d_prov, d_item_counter, G);
 #ifdef HS_JOIN_TIMING
   {
     unsigned long long t[8];
