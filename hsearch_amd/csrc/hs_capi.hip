@@ -62,6 +62,7 @@ struct hs_handle {
   hipEvent_t evx[EVX_COUNT];
   bool evx_ok = false;
   DevBuf a, b, coords;
+  DevBuf aT;  // the planes transposed, [d][L*K]: what the hash kernels read
   // index
   bool built = false;
   uint64_t n = 0;
@@ -217,6 +218,9 @@ hs_status hs_create(const hs_params* params, const double* a, const double* b, c
   HS_HIP(h, h->coords.reserve(HS_ALPHABET_PAD * 8 * 8));
   HS_HIP(h, hipMemsetAsync(h->coords.p, 0, HS_ALPHABET_PAD * 8 * 8, h->stream));
   HS_HIP(h, hipMemcpyAsync(h->a.p, a, na * 8, hipMemcpyHostToDevice, h->stream));
+  // the hash kernels read the planes dimension-major: aT[i][f], f = l * K + k
+  HS_HIP(h, h->aT.reserve(na * 8));
+  HS_HIP(h, hs_launch_transpose_f64(h->a.as<double>(), h->LK, h->d, h->aT.as<double>(), h->stream));
   HS_HIP(h, hipMemcpyAsync(h->b.p, b, (size_t)h->LK * 8, hipMemcpyHostToDevice, h->stream));
   HS_HIP(h, hipMemcpyAsync(h->coords.p, coords ? coords : &HS_AA_COORDS[0][0],
                            (size_t)h->alphabet * 8 * 8, hipMemcpyHostToDevice, h->stream));
@@ -260,7 +264,7 @@ void hs_destroy(hs_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->p.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  DevBuf* bufs[] = {&h->a, &h->b, &h->coords, &h->codes, &h->packed_all, &h->qints, &h->qstart,
+  DevBuf* bufs[] = {&h->a, &h->aT, &h->b, &h->coords, &h->codes, &h->packed_all, &h->qints, &h->qstart,
                     &h->qcount, &h->nslices, &h->slice_off, &h->tq, &h->prov, &h->hit_key,
                     &h->hit_val, &h->hit_key2, &h->hit_val2, &h->counters, &h->temp,
                     &h->io_centers, &h->io_q, &h->io_id, &h->io_table, &h->io_dist, &h->io_cand,
@@ -316,7 +320,7 @@ hs_status hs_hash_codes(hs_handle* h, const uint8_t* codes, uint64_t n, int32_t*
   HS_HIP(h, h->io_misc.reserve(out_bytes));
   HS_HIP(h, hipMemcpyAsync(h->io_codes.p, codes, (size_t)n * h->p.k, hipMemcpyHostToDevice, h->stream));
   HS_HIP(h, hipEventRecord(h->ev[0], h->stream));
-  HS_HIP(h, hs_launch_hash_codes(h->io_codes.as<uint8_t>(), n, (int)h->p.k, h->a.as<double>(),
+  HS_HIP(h, hs_launch_hash_codes(h->io_codes.as<uint8_t>(), n, (int)h->p.k, h->aT.as<double>(), h->LK,
                                  h->b.as<double>(), h->LK, h->p.W, h->coords.as<double>(),
                                  h->io_misc.as<int32_t>(), h->LK, h->stream));
   HS_HIP(h, hipEventRecord(h->ev[1], h->stream));
@@ -337,7 +341,7 @@ hs_status hs_hash_points(hs_handle* h, const double* points, uint64_t n, int32_t
   HS_HIP(h, h->io_misc.reserve(out_bytes));
   HS_HIP(h, hipMemcpyAsync(h->io_centers.p, points, in_bytes, hipMemcpyHostToDevice, h->stream));
   HS_HIP(h, hipEventRecord(h->ev[0], h->stream));
-  HS_HIP(h, hs_launch_hash_points(h->io_centers.as<double>(), n, (int)h->p.k, h->a.as<double>(),
+  HS_HIP(h, hs_launch_hash_points(h->io_centers.as<double>(), n, (int)h->p.k, h->aT.as<double>(), h->LK,
                                   h->b.as<double>(), h->LK, h->p.W, h->io_misc.as<int32_t>(), h->LK,
                                   h->stream));
   HS_HIP(h, hipEventRecord(h->ev[1], h->stream));
@@ -391,7 +395,7 @@ static hs_status cut_items(hs_handle* h, uint32_t nql, uint32_t jm, unsigned lon
 // ------------------------------------------------------------------------------------- build
 static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
   const uint64_t n = h->n;
-  const int K = (int)h->p.K, L = (int)h->p.L, k = (int)h->p.k, d = h->d, PW = h->PW;
+  const int K = (int)h->p.K, L = (int)h->p.L, k = (int)h->p.k, PW = h->PW;
   *collided = false;
   // scratch shared by all tables
   DevBuf ints, keys, keys_sorted, iota, rle_unique, rle_counts, small, sort_temp, slow_q;
@@ -420,7 +424,7 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
     HS_HIP(h, h->t_ids[l].reserve(std::max<size_t>(16, (size_t)n * 4)));
     HS_HIP(h, hipMemsetAsync(d_small, 0, 64, h->stream));
     HS_HIP(h, hipEventRecord(h->ev[0], h->stream));
-    HS_HIP(h, hs_launch_hash_codes(h->codes.as<uint8_t>(), n, k, h->a.as<double>() + (size_t)l * K * d,
+    HS_HIP(h, hs_launch_hash_codes(h->codes.as<uint8_t>(), n, k, h->aT.as<double>() + (size_t)l * K, h->LK,
                                    h->b.as<double>() + (size_t)l * K, K, h->p.W, h->coords.as<double>(),
                                    ints.as<int32_t>(), K, h->stream));
     HS_HIP(h, hs_launch_keys(ints.as<int32_t>(), n, K, K, seed, keys.as<uint64_t>(),
@@ -896,7 +900,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, h->probe_slow.reserve(((size_t)nql + 1) * 4));
     HS_HIP(h, h->slice_off.reserve(((size_t)nql + 1) * 4));
     HS_HIP(h, h->temp.reserve(hs_scan_u32_temp((size_t)nql + 1) + 256));
-    HS_HIP(h, hs_launch_hash_points(d_centers, nq, k, h->a.as<double>(), h->b.as<double>(), h->LK,
+    HS_HIP(h, hs_launch_hash_points(d_centers, nq, k, h->aT.as<double>(), h->LK, h->b.as<double>(), h->LK,
                                     h->p.W, h->qints.as<int32_t>(), h->LK, h->stream));
   }
   HS_HIP(h, hipEventRecord(h->ev[1], h->stream));

@@ -146,13 +146,16 @@ hipError_t hs_rle_u64(void* temp, size_t temp_bytes, const uint64_t* in, uint64_
 // ---- kernel launchers (hs_kernels.hip) -----------------------------------------------------------
 hipError_t hs_launch_embed(const uint8_t* d_codes, uint64_t n, int k, const double* d_coords,
                            double* d_out, hipStream_t s);
-// buckets out[i*out_stride + f], f in [0,F): exact reference arithmetic.
-hipError_t hs_launch_hash_codes(const uint8_t* d_codes, uint64_t n, int k, const double* d_a,
+// buckets out[i*out_stride + f], f in [0,F): exact reference arithmetic.  d_aT = the plane matrix
+// TRANSPOSED, [8k][ldf] doubles (dimension-major), already offset to the first of the F functions.
+hipError_t hs_launch_hash_codes(const uint8_t* d_codes, uint64_t n, int k, const double* d_aT, int ldf,
                                 const double* d_b, int F, double W, const double* d_coords,
                                 int32_t* d_out, int out_stride, hipStream_t s);
-hipError_t hs_launch_hash_points(const double* d_pts, uint64_t n, int k, const double* d_a,
+hipError_t hs_launch_hash_points(const double* d_pts, uint64_t n, int k, const double* d_aT, int ldf,
                                  const double* d_b, int F, double W, int32_t* d_out, int out_stride,
                                  hipStream_t s);
+// d_out[c][r] = d_in[r][c]
+hipError_t hs_launch_transpose_f64(const double* d_in, int rows, int cols, double* d_out, hipStream_t s);
 // keys[i] = fingerprint(ints[i*stride .. +K)); ids[i] = i (if ids != null)
 hipError_t hs_launch_keys(const int32_t* d_ints, uint64_t n, int stride, int K, uint32_t seed,
                           uint64_t* d_keys, uint32_t* d_ids, hipStream_t s);

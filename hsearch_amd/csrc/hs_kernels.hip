@@ -42,13 +42,17 @@ __global__ __launch_bounds__(256) void hs_embed_kernel(const uint8_t* __restrict
 
 // ------------------------------------------------------------------------------------------- hash
 // One thread = one point; KC accumulators = KC hash functions at a time.  The plane values are
-// wave-uniform (scalar loads), the point's coordinates come from the 20x8 table in LDS (codes) or
-// from its own row (arbitrary points).  Strict i = 0..d-1 order per function, product rounded,
-// then sum rounded -- lsh.hpp:33-42 -- then floor((dot + b) / W) -- lsh.hpp:44-49.
+// wave-uniform (scalar loads) and come from the TRANSPOSED plane matrix aT[i][f] (dimension-major:
+// the KC values of one dimension are one contiguous scalar load), so consecutive vector
+// instructions belong to KC different accumulators -- KC independent dependency chains -- and the
+// next dimension's planes are fetched while the current one is consumed.  The point's coordinates
+// come from the 20x8 table in LDS (codes) or from its own row (arbitrary points).  Per function
+// the order is still strictly i = 0..d-1, product rounded, then sum rounded -- lsh.hpp:33-42 --
+// then floor((dot + b) / W) -- lsh.hpp:44-49.
 template <int KC, bool FROM_CODES>
 __global__ __launch_bounds__(256) void hs_hash_kernel(const uint8_t* __restrict__ codes,
                                                       const double* __restrict__ pts, uint64_t n,
-                                                      int k, const double* __restrict__ a,
+                                                      int k, const double* __restrict__ aT, int ldf,
                                                       const double* __restrict__ b, int F, double W,
                                                       const double* __restrict__ coords,
                                                       int32_t* __restrict__ out, int out_stride) {
@@ -73,7 +77,10 @@ __global__ __launch_bounds__(256) void hs_hash_kernel(const uint8_t* __restrict_
     double acc[KC];
 #pragma unroll
     for (int f = 0; f < KC; ++f) acc[f] = 0.0;
-    const double* ap = a + (size_t)fc * d;
+    const double* ar = aT + fc;  // row i of this chunk: ar + i * ldf (wave-uniform)
+    double p0[KC], p1[KC];       // planes of two consecutive dimensions (scalar registers)
+#pragma unroll
+    for (int f = 0; f < KC; ++f) p0[f] = ar[f];
     for (int pos = 0; pos < k; ++pos) {
       double x[8];
       if (FROM_CODES) {
@@ -85,10 +92,28 @@ __global__ __launch_bounds__(256) void hs_hash_kernel(const uint8_t* __restrict_
         for (int j = 0; j < 8; ++j) x[j] = xrow[8 * pos + j];
       }
 #pragma unroll
-      for (int f = 0; f < KC; ++f) {
-        const double* af = ap + (size_t)f * d + 8 * pos;
+      for (int jj = 0; jj < 4; ++jj) {
+        const int i = 8 * pos + 2 * jj;
+        const double* r1 = ar + (size_t)(i + 1) * ldf;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[f] = __dadd_rn(acc[f], __dmul_rn(x[j], af[j]));
+        for (int f = 0; f < KC; ++f) p1[f] = r1[f];
+        {  // products first, then sums: no instruction waits for the one before it
+          double m[KC];
+#pragma unroll
+          for (int f = 0; f < KC; ++f) m[f] = __dmul_rn(x[2 * jj], p0[f]);
+#pragma unroll
+          for (int f = 0; f < KC; ++f) acc[f] = __dadd_rn(acc[f], m[f]);
+        }
+        const double* r2 = ar + (size_t)min(i + 2, d - 1) * ldf;  // past the end: a harmless re-read
+#pragma unroll
+        for (int f = 0; f < KC; ++f) p0[f] = r2[f];
+        {
+          double m[KC];
+#pragma unroll
+          for (int f = 0; f < KC; ++f) m[f] = __dmul_rn(x[2 * jj + 1], p1[f]);
+#pragma unroll
+          for (int f = 0; f < KC; ++f) acc[f] = __dadd_rn(acc[f], m[f]);
+        }
       }
     }
     if (valid) {
@@ -842,7 +867,7 @@ hipError_t hs_launch_embed(const uint8_t* d_codes, uint64_t n, int k, const doub
 
 template <bool FROM_CODES>
 static hipError_t launch_hash(const uint8_t* d_codes, const double* d_pts, uint64_t n, int k,
-                              const double* d_a, const double* d_b, int F, double W,
+                              const double* d_aT, int ldf, const double* d_b, int F, double W,
                               const double* d_coords, int32_t* d_out, int out_stride, hipStream_t s) {
   if (!n || !F) return hipSuccess;
   const unsigned blocks = blocks_for(n);
@@ -853,7 +878,7 @@ static hipError_t launch_hash(const uint8_t* d_codes, const double* d_pts, uint6
   const unsigned gy = std::max(1u, std::min(chunks, 4096u / std::max(blocks, 1u)));
   const dim3 grid(blocks, gy);
 #define HS_HASH(KC)                                                                            \
-  hs_hash_kernel<KC, FROM_CODES><<<grid, 256, lds, s>>>(d_codes, d_pts, n, k, d_a, d_b, F, W, \
+  hs_hash_kernel<KC, FROM_CODES><<<grid, 256, lds, s>>>(d_codes, d_pts, n, k, d_aT, ldf, d_b, F, W, \
                                                         d_coords, d_out, out_stride)
   if (F % 16 == 0) HS_HASH(16);
   else if (F % 8 == 0) HS_HASH(8);
@@ -865,15 +890,28 @@ static hipError_t launch_hash(const uint8_t* d_codes, const double* d_pts, uint6
   return hipGetLastError();
 }
 
-hipError_t hs_launch_hash_codes(const uint8_t* d_codes, uint64_t n, int k, const double* d_a,
+hipError_t hs_launch_hash_codes(const uint8_t* d_codes, uint64_t n, int k, const double* d_aT, int ldf,
                                 const double* d_b, int F, double W, const double* d_coords,
                                 int32_t* d_out, int out_stride, hipStream_t s) {
-  return launch_hash<true>(d_codes, nullptr, n, k, d_a, d_b, F, W, d_coords, d_out, out_stride, s);
+  return launch_hash<true>(d_codes, nullptr, n, k, d_aT, ldf, d_b, F, W, d_coords, d_out, out_stride, s);
 }
-hipError_t hs_launch_hash_points(const double* d_pts, uint64_t n, int k, const double* d_a,
+hipError_t hs_launch_hash_points(const double* d_pts, uint64_t n, int k, const double* d_aT, int ldf,
                                  const double* d_b, int F, double W, int32_t* d_out, int out_stride,
                                  hipStream_t s) {
-  return launch_hash<false>(nullptr, d_pts, n, k, d_a, d_b, F, W, nullptr, d_out, out_stride, s);
+  return launch_hash<false>(nullptr, d_pts, n, k, d_aT, ldf, d_b, F, W, nullptr, d_out, out_stride, s);
+}
+
+__global__ __launch_bounds__(256) void hs_transpose_f64_kernel(const double* __restrict__ in, int rows,
+                                                               int cols, double* __restrict__ out) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (uint64_t)rows * cols) return;
+  const int r = (int)(t / cols), c = (int)(t % cols);
+  out[(uint64_t)c * rows + r] = in[t];
+}
+hipError_t hs_launch_transpose_f64(const double* d_in, int rows, int cols, double* d_out, hipStream_t s) {
+  if (!rows || !cols) return hipSuccess;
+  hs_transpose_f64_kernel<<<blocks_for((uint64_t)rows * cols), 256, 0, s>>>(d_in, rows, cols, d_out);
+  return hipGetLastError();
 }
 
 hipError_t hs_launch_keys(const int32_t* d_ints, uint64_t n, int stride, int K, uint32_t seed,
