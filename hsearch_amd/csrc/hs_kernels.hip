@@ -281,6 +281,10 @@ __global__ __launch_bounds__(256) void hs_probe_kernel(hs_tables_dev tabs,
                                                        uint32_t* __restrict__ bucket_count,
                                                        uint32_t* __restrict__ qbucket,
                                                        uint32_t* __restrict__ qrank) {
+  // The probe is a chain of dependent memory round trips (tuple, 17 directory steps, bucket tuple):
+  // the K bucket ints of a probe are fetched with 16-byte loads, all in flight at once, and parked
+  // in LDS (s_t[j][thread]: conflict-free), instead of K loads one after the other.
+  __shared__ int32_t s_t[HS_MAX_K * 256];
   const uint32_t ql = blockIdx.x * 256 + threadIdx.x;
   uint32_t count = 0, start = 0;
   // grouping of the probes by bucket (for the bucket join): global bucket number and arrival rank;
@@ -290,9 +294,26 @@ __global__ __launch_bounds__(256) void hs_probe_kernel(hs_tables_dev tabs,
   if (ql < nq * (uint32_t)L) {
     ranked = true;
     const int l = (int)(ql % (uint32_t)L);
-    const int32_t* t = qints + (uint64_t)ql * K;
+    const int32_t* tg = qints + (uint64_t)ql * K;
+    int32_t* t = s_t + threadIdx.x;  // t[256 j] = bucket int j of this probe
+    if ((K & 3) == 0) {
+      int4 v[HS_MAX_K / 4];
+#pragma unroll
+      for (int j4 = 0; j4 < HS_MAX_K / 4; ++j4)
+        if (4 * j4 < K) v[j4] = reinterpret_cast<const int4*>(tg)[j4];
+#pragma unroll
+      for (int j4 = 0; j4 < HS_MAX_K / 4; ++j4)
+        if (4 * j4 < K) {
+          t[256 * (4 * j4)] = v[j4].x;
+          t[256 * (4 * j4 + 1)] = v[j4].y;
+          t[256 * (4 * j4 + 2)] = v[j4].z;
+          t[256 * (4 * j4 + 3)] = v[j4].w;
+        }
+    } else {
+      for (int j = 0; j < K; ++j) t[256 * j] = tg[j];
+    }
     uint64_t hk = hs_key_init(seed);
-    for (int j = 0; j < K; ++j) hk = hs_key_put_int(hk, t[j]);
+    for (int j = 0; j < K; ++j) hk = hs_key_put_int(hk, t[256 * j]);
     const uint64_t key = hs_key_fin(hk);
     const hs_table_dev& tb = tabs.t[l];
     uint32_t lo = 0, hi = tb.nb;
@@ -303,7 +324,19 @@ __global__ __launch_bounds__(256) void hs_probe_kernel(hs_tables_dev tabs,
     if (lo < tb.nb && tb.dir_key[lo] == key) {
       const int32_t* u = tb.dir_tuple + (uint64_t)lo * K;
       bool same = true;
-      for (int j = 0; j < K; ++j) same = same && (t[j] == u[j]);
+      if ((K & 3) == 0) {
+        int4 w[HS_MAX_K / 4];
+#pragma unroll
+        for (int j4 = 0; j4 < HS_MAX_K / 4; ++j4)
+          if (4 * j4 < K) w[j4] = reinterpret_cast<const int4*>(u)[j4];
+#pragma unroll
+        for (int j4 = 0; j4 < HS_MAX_K / 4; ++j4)
+          if (4 * j4 < K)
+            same = same && t[256 * (4 * j4)] == w[j4].x && t[256 * (4 * j4 + 1)] == w[j4].y &&
+                   t[256 * (4 * j4 + 2)] == w[j4].z && t[256 * (4 * j4 + 3)] == w[j4].w;
+      } else {
+        for (int j = 0; j < K; ++j) same = same && (t[256 * j] == u[j]);
+      }
       if (same) {
         start = tb.dir_start[lo];
         count = tb.dir_start[lo + 1] - start;
