@@ -153,7 +153,22 @@ __global__ __launch_bounds__(256) void hs_check_runs_kernel(const uint64_t* __re
   const int32_t* px = ints + (uint64_t)ids[p] * K;
   const int32_t* py = ints + (uint64_t)ids[p - 1] * K;
   bool same = true;
-  for (int j = 0; j < K; ++j) same = same && (px[j] == py[j]);
+  if ((K & 3) == 0) {  // 16-byte loads, all in flight at once
+    int4 vx[HS_MAX_K / 4], vy[HS_MAX_K / 4];
+#pragma unroll
+    for (int j4 = 0; j4 < HS_MAX_K / 4; ++j4)
+      if (4 * j4 < K) {
+        vx[j4] = reinterpret_cast<const int4*>(px)[j4];
+        vy[j4] = reinterpret_cast<const int4*>(py)[j4];
+      }
+#pragma unroll
+    for (int j4 = 0; j4 < HS_MAX_K / 4; ++j4)
+      if (4 * j4 < K)
+        same = same && vx[j4].x == vy[j4].x && vx[j4].y == vy[j4].y && vx[j4].z == vy[j4].z &&
+               vx[j4].w == vy[j4].w;
+  } else {
+    for (int j = 0; j < K; ++j) same = same && (px[j] == py[j]);
+  }
   if (same) return;
   const uint32_t at = atomicAdd(slow, 1u);
   if (at < slow_cap) slow[1 + at] = (uint32_t)p;
