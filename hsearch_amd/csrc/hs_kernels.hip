@@ -131,9 +131,32 @@ __global__ __launch_bounds__(256) void hs_keys_kernel(const int32_t* __restrict_
                                                       int stride, int K, uint32_t seed,
                                                       uint64_t* __restrict__ keys,
                                                       uint32_t* __restrict__ ids) {
+  // the K ints of a point arrive with 16-byte loads, all in flight at once, and wait in LDS
+  // (s_t[j][thread]) for the serial character hash
+  __shared__ int32_t s_t[HS_MAX_K * 256];
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  keys[i] = hs_key_of(ints + i * (uint64_t)stride, K, seed);
+  const int32_t* tg = ints + i * (uint64_t)stride;
+  int32_t* t = s_t + threadIdx.x;
+  if ((K & 3) == 0 && (stride & 3) == 0) {
+    int4 v[HS_MAX_K / 4];
+#pragma unroll
+    for (int j4 = 0; j4 < HS_MAX_K / 4; ++j4)
+      if (4 * j4 < K) v[j4] = reinterpret_cast<const int4*>(tg)[j4];
+#pragma unroll
+    for (int j4 = 0; j4 < HS_MAX_K / 4; ++j4)
+      if (4 * j4 < K) {
+        t[256 * (4 * j4)] = v[j4].x;
+        t[256 * (4 * j4 + 1)] = v[j4].y;
+        t[256 * (4 * j4 + 2)] = v[j4].z;
+        t[256 * (4 * j4 + 3)] = v[j4].w;
+      }
+  } else {
+    for (int j = 0; j < K; ++j) t[256 * j] = tg[j];
+  }
+  uint64_t hk = hs_key_init(seed);
+  for (int j = 0; j < K; ++j) hk = hs_key_put_int(hk, t[256 * j]);
+  keys[i] = hs_key_fin(hk);
   if (ids) ids[i] = (uint32_t)i;
 }
 
