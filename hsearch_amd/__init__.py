@@ -5,9 +5,9 @@ hand-written gfx950 kernels in ``hsearch_amd/csrc``.  This package is a thin cty
 the tests and bench.py; it contains no compute and no CPU fallback: if the library is missing or
 no gfx950 device is present, calls raise.
 """
-from .capi import (KLSH_NONE, Engine, HsError, alphabet, clustering, clusters_file_text,
+from .capi import (KLSH_NONE, ClusterState, Engine, HsError, alphabet, clustering, clusters_file_text,
                    codes_from_letters, key_string, klsh_codes, klsh_draw_planes, lib_path, load,
                    profile_fields)
 
-__all__ = ["KLSH_NONE", "klsh_codes", "klsh_draw_planes", "Engine", "HsError", "alphabet", "clustering", "clusters_file_text", "codes_from_letters", "key_string", "lib_path", "load",
+__all__ = ["KLSH_NONE", "ClusterState", "klsh_codes", "klsh_draw_planes", "Engine", "HsError", "alphabet", "clustering", "clusters_file_text", "codes_from_letters", "key_string", "lib_path", "load",
            "profile_fields"]

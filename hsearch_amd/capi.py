@@ -15,7 +15,9 @@ _STATUS = ["HS_OK", "HS_ERR_INVALID", "HS_ERR_NO_DEVICE", "HS_ERR_HIP", "HS_ERR_
 _ALPHABET = "ARNDCQEGHILKMFPSTWYV"
 
 EXPORTS = ["hs_create", "hs_destroy", "hs_last_error", "hs_get_profile", "hs_version",
-           "hs_set_verify_mode", "hs_self_join", "hs_clustering",
+           "hs_set_verify_mode", "hs_set_planes", "hs_self_join", "hs_self_join_range", "hs_clustering",
+           "hs_clustering_begin", "hs_clustering_table_edges", "hs_clustering_table_apply",
+           "hs_clustering_end",
            "hs_embed_codes", "hs_hash_codes", "hs_hash_points", "hs_key_string", "hs_key_fingerprint",
            "hs_key_strings_equal", "hs_index_build", "hs_index_build_windows", "hs_index_save", "hs_index_load", "hs_klsh_draw_planes", "hs_klsh_codes",
            "hs_index_info_get", "hs_query", "hs_query_dev", "hs_bruteforce", "hs_bruteforce_topk"]
@@ -344,17 +346,21 @@ class Engine:
         return nn, d2
 
     # -- a12
-    def self_join(self, R, sqrt_test=True, cap=None):
-        """All ordered within-bucket pairs (i, j), i != j, within R: dict(i, j, table, dist)."""
+    def self_join(self, R, sqrt_test=True, cap=None, first=0, count=None):
+        """All ordered within-bucket pairs (i, j), i != j, within R: dict(i, j, table, dist);
+        first/count restrict the i side to a block of the indexed k-mers (one rank's shard)."""
         cap = int(cap) if cap is not None else 1 << 16
+        count = self.index_info()["n"] - first if count is None else count
         while True:
             ei = np.empty(cap, dtype=np.uint32)
             ej = np.empty(cap, dtype=np.uint32)
             et = np.empty(cap, dtype=np.uint32)
             ed = np.empty(cap, dtype=np.float64)
             n = C.c_uint64(0)
-            st = self._lib.hs_self_join(self._h, C.c_double(R), C.c_int(1 if sqrt_test else 0),
-                                        _vp(ei), _vp(ej), _vp(et), _vp(ed), C.c_uint64(cap), C.byref(n))
+            st = self._lib.hs_self_join_range(self._h, C.c_uint64(first), C.c_uint64(count),
+                                              C.c_double(R), C.c_int(1 if sqrt_test else 0),
+                                              _vp(ei), _vp(ej), _vp(et), _vp(ed), C.c_uint64(cap),
+                                              C.byref(n))
             if st == HS_ERR_CAPACITY:
                 cap = int(n.value)
                 continue
@@ -385,6 +391,78 @@ def clustering(k, K, L, W, a, b, codes, R, device=0, coords=None):
     if st != HS_OK:
         raise HsError(st, err.value.decode())
     return merged, owner, table
+
+
+class ClusterState:
+    """Clustering() table by table (hs_clustering_begin/.../end): the form the multi-GPU driver
+    (hsearch_amd.dist.clustering_sharded) uses; one GPU with world=1 equals clustering()."""
+
+    def __init__(self, k, K, L, W, a, b, codes, R, device=0, coords=None):
+        self._lib = load()
+        self._a = np.ascontiguousarray(a, dtype=np.float64)
+        self._b = np.ascontiguousarray(b, dtype=np.float64)
+        self._codes = np.ascontiguousarray(codes, dtype=np.uint8)   # kept alive: the state borrows it
+        self.n = self._codes.shape[0]
+        self.L = int(L)
+        assert self._a.shape == (L, K, 8 * k) and self._b.shape == (L, K) and self._codes.shape == (self.n, k)
+        cptr, alpha = None, 0
+        if coords is not None:
+            coords = np.ascontiguousarray(coords, dtype=np.float64)
+            cptr, alpha = _vp(coords), coords.shape[0]
+        params = _Params(int(k), int(K), int(L), float(W), int(device), alpha)
+        self._st = C.c_void_p()
+        self._err = C.create_string_buffer(512)
+        st = self._lib.hs_clustering_begin(C.byref(params), _vp(self._a), _vp(self._b), cptr,
+                                           _vp(self._codes), C.c_uint64(self.n), C.c_double(R),
+                                           C.byref(self._st), self._err, C.c_uint32(512))
+        if st != HS_OK:
+            raise HsError(st, self._err.value.decode())
+        self._cap = 4 * self.n + 1024
+
+    def table_edges(self, l, rank=0, world=1):
+        """This rank's share of table l's within-bucket pairs within R: (i, j, dist), original ids."""
+        while True:
+            ei = np.empty(self._cap, dtype=np.uint32)
+            ej = np.empty(self._cap, dtype=np.uint32)
+            ed = np.empty(self._cap, dtype=np.float64)
+            n = C.c_uint64(0)
+            st = self._lib.hs_clustering_table_edges(self._st, C.c_uint32(l), C.c_uint32(rank),
+                                                     C.c_uint32(world), _vp(ei), _vp(ej), _vp(ed),
+                                                     C.c_uint64(self._cap), C.byref(n), self._err,
+                                                     C.c_uint32(512))
+            if st == HS_ERR_CAPACITY:
+                self._cap = int(n.value)
+                continue
+            if st != HS_OK:
+                raise HsError(st, self._err.value.decode())
+            n = int(n.value)
+            return ei[:n], ej[:n], ed[:n]
+
+    def table_apply(self, l, edge_i, edge_j):
+        """The greedy pass of table l over ALL ranks' edges (any order); host only."""
+        edge_i = np.ascontiguousarray(edge_i, dtype=np.uint32)
+        edge_j = np.ascontiguousarray(edge_j, dtype=np.uint32)
+        assert edge_i.shape == edge_j.shape
+        st = self._lib.hs_clustering_table_apply(self._st, C.c_uint32(l), _vp(edge_i), _vp(edge_j),
+                                                 C.c_uint64(edge_i.shape[0]))
+        if st != HS_OK:
+            raise HsError(st, "hs_clustering_table_apply")
+
+    def end(self):
+        """(merged, owner, absorbed_table); frees the state."""
+        merged = np.empty(self.n, dtype=np.uint8)
+        owner = np.empty(self.n, dtype=np.uint32)
+        table = np.empty(self.n, dtype=np.uint32)
+        st, self._st = self._st, None
+        rc = self._lib.hs_clustering_end(st, _vp(merged), _vp(owner), _vp(table))
+        if rc != HS_OK:
+            raise HsError(rc, "hs_clustering_end")
+        return merged, owner, table
+
+    def __del__(self):
+        if getattr(self, "_st", None):
+            self._lib.hs_clustering_end(self._st, None, None, None)
+            self._st = None
 
 
 def clusters_file_text(merged, owner, table, names=None):

@@ -254,6 +254,20 @@ hs_status hs_create(const hs_params* params, const double* a, const double* b, c
   return HS_OK;
 }
 
+hs_status hs_set_planes(hs_handle* h, const double* a, const double* b) {
+  if (!h || !a || !b) return HS_ERR_INVALID;
+  hs_status st = ensure_device(h);
+  if (st) return st;
+  h->built = false;  // the tables were keyed by the old family
+  const size_t na = (size_t)h->LK * h->d;
+  // the previous family may still be read by work queued on the stream: order the copies after it
+  HS_HIP(h, hipMemcpyAsync(h->a.p, a, na * 8, hipMemcpyHostToDevice, h->stream));
+  HS_HIP(h, hs_launch_transpose_f64(h->a.as<double>(), h->LK, h->d, h->aT.as<double>(), h->stream));
+  HS_HIP(h, hipMemcpyAsync(h->b.p, b, (size_t)h->LK * 8, hipMemcpyHostToDevice, h->stream));
+  HS_HIP(h, hipStreamSynchronize(h->stream));  // a, b are the caller's again
+  return HS_OK;
+}
+
 hs_status hs_set_verify_mode(hs_handle* h, int mode) {
   if (!h || mode < 0 || mode > 3) return HS_ERR_INVALID;
   h->verify_mode = mode;
@@ -1244,13 +1258,22 @@ hs_status hs_bruteforce(hs_handle* h, const double* centers, uint64_t nq, double
 
 hs_status hs_self_join(hs_handle* h, double R, int sqrt_test, uint32_t* edge_i, uint32_t* edge_j,
                        uint32_t* edge_table, double* edge_dist, uint64_t cap, uint64_t* n_edges) {
+  if (!h) return HS_ERR_INVALID;
+  return hs_self_join_range(h, 0, h->n, R, sqrt_test, edge_i, edge_j, edge_table, edge_dist, cap,
+                            n_edges);
+}
+
+hs_status hs_self_join_range(hs_handle* h, uint64_t first, uint64_t count, double R, int sqrt_test,
+                             uint32_t* edge_i, uint32_t* edge_j, uint32_t* edge_table,
+                             double* edge_dist, uint64_t cap, uint64_t* n_edges) {
   if (!h || !n_edges) return HS_ERR_INVALID;
   *n_edges = 0;
   if (!h->built) return fail(h, HS_ERR_STATE, "hs_index_build has not been called");
   if (cap && (!edge_i || !edge_j || !edge_dist)) return HS_ERR_INVALID;
   hs_status st = ensure_device(h);
   if (st) return st;
-  const uint64_t n = h->n;
+  if (first > h->n || count > h->n - first) return fail(h, HS_ERR_INVALID, "range outside the indexed k-mers");
+  const uint64_t n = first + count;
   const uint32_t CH = 1u << 18;  // queries embedded per chunk (8k doubles each)
   uint64_t total = 0;
   std::vector<uint32_t> hq, hid, ht;
@@ -1262,7 +1285,7 @@ hs_status hs_self_join(hs_handle* h, double R, int sqrt_test, uint32_t* edge_i, 
     DevBuf* b[5];
     ~Guard() { for (DevBuf* x : b) x->release(); }
   } guard = {{&centers, &dq, &did, &dt, &dd}};
-  for (uint64_t q0 = 0; q0 < n; q0 += CH) {
+  for (uint64_t q0 = first; q0 < n; q0 += CH) {
     const uint64_t nq = std::min<uint64_t>(CH, n - q0);
     HS_HIP(h, centers.reserve((size_t)nq * h->d * 8));
     HS_HIP(h, hs_launch_embed(h->codes.as<uint8_t>() + q0 * h->p.k, nq, (int)h->p.k,

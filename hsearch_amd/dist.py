@@ -80,3 +80,46 @@ def allgather_hits(q, ids, table, distance, n_hits, q_offset=0, group=None, forc
 def hits_to_numpy(q, ids, table, distance):
     return dict(q=q.cpu().numpy().astype(np.uint32), id=ids.cpu().numpy().astype(np.uint32),
                 table=table.cpu().numpy().astype(np.uint32), dist=distance.cpu().numpy())
+
+
+def allgather_edges(edge_i, edge_j, group=None, device=None):
+    """All ranks' (i, j) edge lists of one clustering table, concatenated in rank order (numpy in,
+    numpy out).  The exchange is allgather_hits' single collective with i in the q column; over
+    RCCL the host arrays pass through `device`."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return np.asarray(edge_i, dtype=np.uint32), np.asarray(edge_j, dtype=np.uint32)
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    n = len(edge_i)
+    ti = torch.from_numpy(np.ascontiguousarray(edge_i, dtype=np.uint32).view(np.int32)).to(dev)
+    tj = torch.from_numpy(np.ascontiguousarray(edge_j, dtype=np.uint32).view(np.int32)).to(dev)
+    zt = torch.zeros(n, dtype=torch.int32, device=dev)
+    zd = torch.zeros(n, dtype=torch.float64, device=dev)
+    gi, gj, _, _ = allgather_hits(ti, tj, zt, zd, n, group=group)
+    return gi.cpu().numpy().astype(np.uint32), gj.cpu().numpy().astype(np.uint32)
+
+
+def clustering_sharded(k, K, L, W, a, b, codes, R, device=0, coords=None, group=None,
+                       rank=None, world=None, gather=None):
+    """Clustering() (hclust2.cpp:86-151) over the ranks of `group`: per table every rank joins its
+    block of the not-yet-absorbed k-mers against the table (hs_clustering_table_edges), the edge
+    lists are all-gathered (the path's one exchange step), and every rank runs the same greedy
+    pass (hs_clustering_table_apply), so all ranks end with identical (merged, owner, table) --
+    identical to the single-GPU hs_clustering.  `gather(edge_i, edge_j) -> (all_i, all_j)` may
+    replace the collective (tests shard on one GPU this way)."""
+    from . import capi
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if gather is None:
+        gdev = None
+        if dist.is_initialized() and dist.get_backend(group) == "nccl":
+            gdev = "cuda:%d" % int(device)
+        gather = lambda ei, ej: allgather_edges(ei, ej, group=group, device=gdev)
+    st = capi.ClusterState(k, K, L, W, a, b, codes, R, device=device, coords=coords)
+    for l in range(int(L)):
+        ei, ej, _ = st.table_edges(l, rank, world)
+        ai, aj = gather(ei, ej)
+        st.table_apply(l, ai, aj)
+    return st.end()

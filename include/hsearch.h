@@ -100,6 +100,10 @@ typedef struct hs_index_info {
 HS_API hs_status hs_create(const hs_params* params, const double* a, const double* b,
                            const double* coords, hs_handle** out);
 HS_API void hs_destroy(hs_handle* h);
+/* A new hash family (same k, K, L, W) for an existing handle: what constructing the next LSHTable
+ * does in Clustering() (hclust2.cpp:104, one fresh family per table).  Drops the index (queries
+ * return HS_ERR_NOT_BUILT until the next build); device buffers are kept. */
+HS_API hs_status hs_set_planes(hs_handle* h, const double* a, const double* b);
 HS_API const char* hs_last_error(const hs_handle* h);
 HS_API hs_status hs_get_profile(const hs_handle* h, hs_profile* out);
 /* Candidate-verification kernel: 0 = auto (bucket join when legal, else streaming), 1 = streaming
@@ -218,6 +222,13 @@ HS_API hs_status hs_self_join(hs_handle* h, double R, int sqrt_test, uint32_t* e
                               uint32_t* edge_j, uint32_t* edge_table, double* edge_dist,
                               uint64_t cap, uint64_t* n_edges);
 
+/* The same for the indexed k-mers [first, first + count) only (as the `i` side): the shard of one
+ * rank when the join of a table is spread over GPUs. */
+HS_API hs_status hs_self_join_range(hs_handle* h, uint64_t first, uint64_t count, double R,
+                                    int sqrt_test, uint32_t* edge_i, uint32_t* edge_j,
+                                    uint32_t* edge_table, double* edge_dist, uint64_t cap,
+                                    uint64_t* n_edges);
+
 /* Replaces Clustering() (hclust2.cpp:86-151) with explicit planes a[L][K][d], b[L][K]: table by
  * table, an LSH table over the not-yet-absorbed k-mers, then greedy leader clustering inside every
  * bucket in ascending id order.  The distance work runs on the GPU (hs_self_join per table), the
@@ -229,6 +240,31 @@ HS_API hs_status hs_clustering(const hs_params* params, const double* a, const d
                                const double* coords, const uint8_t* codes, uint64_t n, double R,
                                uint8_t* merged, uint32_t* owner, uint32_t* absorbed_table,
                                char* err, uint32_t err_cap);
+
+/* Clustering() spread over `world` GPUs: the distance work of a table --
+ * the within-bucket join over the not-yet-absorbed k-mers -- is sharded by the `i` side, one
+ * contiguous block of the active k-mers per rank; the one exchange step is an all-gather of the
+ * edge lists (done by the caller, e.g. over RCCL); the order-dependent greedy pass then runs
+ * identically on every rank.  Per table l = 0..L-1 every rank calls
+ *   hs_clustering_table_edges(st, l, rank, world, ...)  -> its edges (i, j) in ORIGINAL k-mer
+ *                                   numbers, sqrt(d2) <= R, two-call capacity protocol
+ *   <all-gather of the edges>
+ *   hs_clustering_table_apply(st, l, all edges in any order)   (host only, no GPU)
+ * and after the last table hs_clustering_end, which writes the outputs of hs_clustering and frees
+ * the state (outputs may be NULL to just free).  hs_clustering is the world = 1 composition.
+ * `codes` must stay valid until hs_clustering_end. */
+typedef struct hs_cluster_state hs_cluster_state;
+HS_API hs_status hs_clustering_begin(const hs_params* params, const double* a, const double* b,
+                                     const double* coords, const uint8_t* codes, uint64_t n, double R,
+                                     hs_cluster_state** out, char* err, uint32_t err_cap);
+HS_API hs_status hs_clustering_table_edges(hs_cluster_state* st, uint32_t l, uint32_t rank,
+                                           uint32_t world, uint32_t* edge_i, uint32_t* edge_j,
+                                           double* edge_dist, uint64_t cap, uint64_t* n_edges,
+                                           char* err, uint32_t err_cap);
+HS_API hs_status hs_clustering_table_apply(hs_cluster_state* st, uint32_t l, const uint32_t* edge_i,
+                                           const uint32_t* edge_j, uint64_t n_edges);
+HS_API hs_status hs_clustering_end(hs_cluster_state* st, uint8_t* merged, uint32_t* owner,
+                                   uint32_t* absorbed_table);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,58 @@ def test_clustering_matches_oracle(oracle, k, K, L, W, R, fams, per):
     assert ((table != 0xffffffff) == (merged == 2)).all()
 
 
+@pytest.mark.parametrize("world", [2, 3, 7])
+def test_clustering_sharded_equals_single(oracle, world):
+    """the join of every table cut into `world` blocks of the active k-mers
+    (what each rank computes), edges pooled, greedy pass applied -- identical to hs_clustering
+    and to the oracle.  The pooling stands in for the all-gather (tests/test_dist_cpu.py covers
+    the collective itself)."""
+    from hsearch_amd import dist as hdist
+    k, K, L, W, R = 25, 4, 8, 100.0, 60.0
+    rng = np.random.default_rng(23)
+    codes = np.concatenate([_families(rng, k, 40, 50), synth.make_db(2000, k, seed=9)])
+    rng.shuffle(codes)
+    a, b = synth.make_planes(k, K, L, W, seed=43)
+    single = hsearch_amd.clustering(k, K, L, W, a, b, codes, R)
+    st = hsearch_amd.capi.ClusterState(k, K, L, W, a, b, codes, R)
+    n_edges = []
+    for l in range(L):
+        parts = [st.table_edges(l, r, world) for r in range(world)]
+        n_edges.append([len(p[0]) for p in parts])
+        # ranks' lists arrive in rank order from the all-gather; apply must not depend on it
+        order = rng.permutation(world)
+        st.table_apply(l, np.concatenate([parts[r][0] for r in order]),
+                       np.concatenate([parts[r][1] for r in order]))
+    got = st.end()
+    for x, y in zip(got, single):
+        assert np.array_equal(x, y)
+    want_merged, want_owner = oracle.clustering(a, b, W, R, oracle.embed_codes(codes))
+    assert np.array_equal(got[0], want_merged) and np.array_equal(got[1], want_owner)
+    assert sum(map(sum, n_edges)) > 1000 and min(map(max, n_edges)) > 0
+    # the driver with world = 1 (no process group) is the same computation
+    drv = hdist.clustering_sharded(k, K, L, W, a, b, codes, R)
+    for x, y in zip(drv, single):
+        assert np.array_equal(x, y)
+
+
+def test_self_join_range_partitions_the_edges():
+    k, K, L, W, R = 25, 4, 3, 120.0, 50.0
+    rng = np.random.default_rng(6)
+    codes = _families(rng, k, 25, 40)
+    a, b = synth.make_planes(k, K, L, W, seed=3)
+    eng = Engine(k, K, L, W, a, b)
+    eng.index_build(codes)
+    full = eng.self_join(R)
+    cuts = [0, 1, 333, 334, 1000]
+    parts = [eng.self_join(R, first=lo, count=hi - lo) for lo, hi in zip(cuts[:-1], cuts[1:])]
+    for key in ("i", "j", "table", "dist"):
+        assert np.array_equal(np.concatenate([p[key] for p in parts]), full[key])
+    for p, lo, hi in zip(parts, cuts[:-1], cuts[1:]):
+        assert ((p["i"] >= lo) & (p["i"] < hi)).all()
+    with pytest.raises(hsearch_amd.HsError):
+        eng.self_join(R, first=900, count=200)
+
+
 def test_self_join_edges_match_bruteforce_within_buckets(oracle):
     k, K, L, W, R = 25, 4, 3, 120.0, 50.0
     rng = np.random.default_rng(5)

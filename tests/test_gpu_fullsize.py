@@ -95,6 +95,13 @@ def test_config4_clustering_properties():
     merged, owner, table = hsearch_amd.clustering(k, K, L, W, a, b, codes, R)
     m2, o2, t2 = hsearch_amd.clustering(k, K, L, W, a, b, codes, R)       # deterministic
     assert np.array_equal(merged, m2) and np.array_equal(owner, o2) and np.array_equal(table, t2)
+    # the 4-rank form (each table's join cut into 4 blocks, edges pooled) is identical
+    st = hsearch_amd.ClusterState(k, K, L, W, a, b, codes, R)
+    for l in range(L):
+        parts = [st.table_edges(l, r, 4) for r in range(4)]
+        st.table_apply(l, np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]))
+    m4, o4, t4 = st.end()
+    assert np.array_equal(merged, m4) and np.array_equal(owner, o4) and np.array_equal(table, t4)
     absorbed = np.nonzero(merged == 2)[0]
     assert len(absorbed) > 50_000
     assert np.all(merged[owner[absorbed]] == 1)                 # absorbed only by real centers
