@@ -2,11 +2,15 @@
 // number on the search path is computed on the GPU behind include/hsearch.h.
 #include "hs_host.hpp"
 
+#include <errno.h>
 #include <math.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <sys/types.h>
 
 #include <algorithm>
 #include <fstream>
+#include <limits>
 #include <map>
 #include <random>
 #include <sstream>
@@ -537,6 +541,284 @@ double Evaluate(const std::string& ground_truth, const std::string& output_file,
   fout.close();
   if (bad) return NAN;
   return tp / (tp + fn);
+}
+
+namespace {
+
+// An index over `points` that only serves hs_bruteforce: one table, one function (the brute-force
+// scan reads the resident residue codes, not the tables).
+struct ScanEngine {
+  hs_handle* h = nullptr;
+  uint32_t dim = 0;
+  ~ScanEngine() { hs_destroy(h); }
+  int Open(const std::vector<Point>& points, size_t n_points, uint32_t dim_, int device, std::string* err) {
+    dim = dim_;
+    std::vector<double> table;
+    std::vector<uint8_t> codes;
+    std::vector<Point> head;
+    const std::vector<Point>* src = &points;
+    if (n_points < points.size()) {
+      head.assign(points.begin(), points.begin() + n_points);
+      src = &head;
+    }
+    if (!PointsToCodes(*src, dim, &table, &codes, err)) return HS_ERR_INVALID;
+    const Planes planes = DrawPlanes(dim, 1, 1, 1.0, 0);
+    hs_params prm;
+    memset(&prm, 0, sizeof(prm));
+    prm.k = dim / 8;
+    prm.K = 1;
+    prm.L = 1;
+    prm.W = 1.0;
+    prm.device = device;
+    prm.alphabet = (uint32_t)(table.size() / 8);
+    hs_status st = hs_create(&prm, planes.a.data(), planes.b.data(), table.data(), &h);
+    if (st != HS_OK) {
+      if (err) *err = std::string("hs_create: ") + (h ? hs_last_error(h) : "no usable gfx950 device");
+      return st;
+    }
+    st = hs_index_build(h, codes.data(), src->size());
+    if (st != HS_OK && err) *err = std::string("hs_index_build: ") + hs_last_error(h);
+    return st;
+  }
+  // all (centre, point) pairs of centres [c0, c0 + nc) with !(dist > R), centre-major
+  int Scan(const std::vector<Point>& centers, size_t c0, size_t nc, double R, std::vector<uint32_t>* hq,
+           std::vector<uint32_t>* hid, std::vector<double>* hd, uint64_t* n_hits, std::string* err) {
+    std::vector<double> flat(nc * dim);
+    for (size_t i = 0; i < nc; ++i) {
+      if (centers[c0 + i].data.size() != dim) {
+        if (err) *err = "centre with the wrong dimension";
+        return HS_ERR_INVALID;
+      }
+      memcpy(&flat[i * dim], centers[c0 + i].data.data(), sizeof(double) * dim);
+    }
+    uint64_t cap = std::max<uint64_t>(hq->size(), 1024);
+    for (;;) {
+      hq->resize(cap);
+      hid->resize(cap);
+      hd->resize(cap);
+      const hs_status st = hs_bruteforce(h, flat.data(), nc, R, hq->data(), hid->data(), hd->data(), cap, n_hits);
+      if (st == HS_ERR_CAPACITY) {
+        cap = *n_hits;
+        continue;
+      }
+      if (st != HS_OK && err) *err = std::string("hs_bruteforce: ") + hs_last_error(h);
+      return st;
+    }
+  }
+};
+
+}  // namespace
+
+int SearchBruteForce(const std::vector<Point>& kmers, const std::vector<Point>& centers,
+                     const std::vector<std::string>& kmer_names,
+                     const std::vector<std::string>& center_names, const double& hash_R,
+                     const std::string& output_file, int device, std::string* err,
+                     bool write_not_less_than) {
+  if (kmers.empty() || kmers[0].data.empty() || kmers[0].data.size() % 8 != 0) {
+    if (err) *err = "no database points (or dimension not a multiple of 8)";
+    return HS_ERR_INVALID;
+  }
+  const uint32_t dim = (uint32_t)kmers[0].data.size();
+  ScanEngine eng;
+  int st = eng.Open(kmers, kmers.size(), dim, device, err);
+  if (st != HS_OK) return st;
+  std::ofstream fout(output_file.c_str());
+  std::ofstream fnot;
+  if (write_not_less_than) fnot.open((output_file + "notlessthan.txt").c_str());  // :41-43
+  // with the second file every pair comes back (R = inf) and is split here by the reference's
+  // test `dis > hash_R` (:47); centre blocks bound the host buffers to ~2^24 pairs
+  const double R = write_not_less_than ? std::numeric_limits<double>::infinity() : hash_R;
+  const size_t block = write_not_less_than
+                           ? std::max<size_t>(1, (size_t)(1u << 24) / std::max<size_t>(1, kmers.size()))
+                           : centers.size();
+  std::vector<uint32_t> hq, hid;
+  std::vector<double> hd;
+  for (size_t c0 = 0; c0 < centers.size(); c0 += block) {
+    const size_t nc = std::min(block, centers.size() - c0);
+    uint64_t n_hits = 0;
+    st = eng.Scan(centers, c0, nc, R, &hq, &hid, &hd, &n_hits, err);
+    if (st != HS_OK) return st;
+    for (uint64_t i = 0; i < n_hits; ++i) {
+      std::ofstream& f = (write_not_less_than && hd[i] > hash_R) ? fnot : fout;
+      f << center_names[c0 + hq[i]] << " " << kmer_names[hid[i]] << " " << hd[i] << std::endl;
+    }
+  }
+  return HS_OK;
+}
+
+bool SortHitsFile(const std::string& hits_file, uint64_t* n_records) {
+  std::ifstream fin(hits_file.c_str());
+  if (!fin) return false;
+  std::vector<MotifRes> rec;
+  MotifRes r;
+  while (fin >> r.motif >> r.protein >> r.dis) rec.push_back(r);
+  std::sort(rec.begin(), rec.end(), ResLess);  // evaluate2.cpp:88
+  std::ofstream fout((hits_file + "sort.txt").c_str());
+  for (size_t i = 0; i < rec.size(); ++i)
+    fout << rec[i].motif << "\t" << rec[i].protein << "\t" << rec[i].dis << std::endl;  // :91-93
+  if (n_records) *n_records = rec.size();
+  return true;
+}
+
+namespace {
+// weight() of evaluate2.cpp:62-71
+double Weight2(double dis) {
+  if (dis > 49.38) {
+    const double w = dis / (2 * 49.38);
+    if (w > 1) return 1;
+    return dis / (2 * 49.38);
+  }
+  return 1 - dis / (2 * 49.38);
+}
+}  // namespace
+
+double Evaluate2(const std::string& ground_truth, const std::string& hits_file, double* tp_out,
+                 double* fn_out) {
+  std::vector<MotifRes> brute, found;
+  MotifRes r;
+  {
+    std::ifstream fin(ground_truth.c_str());
+    while (fin >> r.motif >> r.protein >> r.dis) brute.push_back(r);
+  }
+  {
+    std::ifstream fin(hits_file.c_str());
+    while (fin >> r.motif >> r.protein >> r.dis) found.push_back(r);
+  }
+  std::sort(brute.begin(), brute.end(), ResLess);   // :88
+  std::sort(found.begin(), found.end(), ResLess);   // :127
+  size_t i = 0, j = 0;
+  double tp = 0.0, fn = 0.0;
+  while (i < brute.size() && j < found.size()) {  // :131-143
+    const int cmp = ResCompare(brute[i], found[j]);
+    if (cmp == 0) {
+      tp += Weight2(brute[i].dis);
+      ++i;
+      ++j;
+    } else if (cmp == 1) {
+      ++j;
+    } else {
+      fn += Weight2(brute[i].dis);
+      ++i;
+    }
+  }
+  for (; i < brute.size(); ++i) fn += Weight2(brute[i].dis);  // :144-147
+  if (tp_out) *tp_out = tp;
+  if (fn_out) *fn_out = fn;
+  return tp / (tp + fn);
+}
+
+bool ReadMotifFamilies(const std::string& path, uint32_t min_size, std::vector<MotifFamily>* families) {
+  std::ifstream fin(path.c_str());
+  if (!fin) return false;
+  families->clear();
+  MotifFamily cur;
+  std::string line;
+  while (std::getline(fin, line)) {  // centerDistanceSmapling.cpp:443-453
+    if (line.size() == 0) continue;
+    if (line[0] == '#') {
+      if (cur.seqs.size() >= min_size) families->push_back(cur);
+      cur.name = line;
+      cur.seqs.clear();
+    } else {
+      cur.seqs.push_back(line);
+    }
+  }
+  if (cur.seqs.size() >= min_size) families->push_back(cur);  // :455-457
+  return true;
+}
+
+bool FamilyCenters(const std::vector<MotifFamily>& families, uint32_t kmer_length,
+                   std::vector<Point>* centers, std::string* err) {
+  const uint32_t dim = 8 * kmer_length;
+  centers->clear();
+  for (size_t f = 0; f < families.size(); ++f) {
+    Point center;
+    center.data.assign(dim, 0.0);
+    const std::vector<std::string>& seqs = families[f].seqs;
+    for (size_t m = 0; m < seqs.size(); ++m) {
+      if (seqs[m].size() != kmer_length) {
+        if (err) *err = "family " + families[f].name + ": member '" + seqs[m] + "' is not a " +
+                        std::to_string(kmer_length) + "-mer";
+        return false;
+      }
+      for (uint32_t p = 0; p < kmer_length; ++p) {
+        const char c = seqs[m][p];
+        const int row = (c >= 'A' && c <= 'Z') ? HS_LETTER_TO_CODE[c - 'A'] : -1;
+        if (row < 0) {
+          if (err) *err = "family " + families[f].name + ": letter outside the 20-letter alphabet in '" + seqs[m] + "'";
+          return false;
+        }
+        for (uint32_t j = 0; j < 8; ++j) center.data[8 * p + j] += HS_AA_COORDS[row][j];  // Center() :69-73
+      }
+    }
+    for (uint32_t j = 0; j < dim; ++j) center.data[j] /= seqs.size();  // :74-76
+    centers->push_back(center);
+  }
+  return true;
+}
+
+bool Cluster2DataPoint(const std::vector<MotifFamily>& families, const std::vector<Point>& centers,
+                       const std::string& output_file) {
+  std::ofstream fout((output_file + "hclust.format.txt").c_str());
+  if (!fout) return false;
+  for (size_t p = 0; p < centers.size(); ++p) {  // :126-134
+    fout << families[p].name << std::endl;
+    fout << centers[p].data[0];
+    for (size_t q = 1; q < centers[p].data.size(); ++q) fout << " " << centers[p].data[q];
+    fout << std::endl;
+  }
+  return true;
+}
+
+int SequenceDatabase2Centers(const std::vector<Point>& kmers_proteins,
+                             const std::vector<Point>& centers, const std::string& output_file,
+                             const std::string& dir, int device, std::string* err) {
+  if (centers.empty() || kmers_proteins.empty()) {
+    if (err) *err = "no centres or no database points";
+    return HS_ERR_INVALID;
+  }
+  const uint32_t dim = (uint32_t)centers[0].data.size();
+  if (mkdir(dir.c_str(), 0777) != 0 && errno != EEXIST) {
+    if (err) *err = "cannot create " + dir;
+    return HS_ERR_IO;
+  }
+  {
+    // :152-161 -- PairwiseDistance (:58-65): sequential fp64, sqrt
+    std::ofstream fcenter((dir + "/" + output_file + "innercenter_protein_centers_0.txt").c_str());
+    if (!fcenter) {
+      if (err) *err = "cannot write into " + dir;
+      return HS_ERR_IO;
+    }
+    for (size_t i = 0; i < centers.size(); ++i)
+      for (size_t j = i + 1; j < centers.size(); ++j) {
+        double dis = 0.0;
+        for (uint32_t t = 0; t < dim; ++t) {
+          const double r = centers[i].data[t] - centers[j].data[t];
+          dis += r * r;
+        }
+        fcenter << sqrt(dis) << std::endl;
+      }
+  }
+  const size_t n_sample = std::min<size_t>(100000, kmers_proteins.size());  // :166-173
+  ScanEngine eng;
+  int st = eng.Open(kmers_proteins, n_sample, dim, device, err);
+  if (st != HS_OK) return st;
+  std::ofstream fout((dir + "/" + output_file + "ramdom_protein_centers_0.txt").c_str());
+  std::vector<uint32_t> hq, hid;
+  std::vector<double> hd;
+  const size_t block = std::max<size_t>(1, (size_t)(1u << 24) / n_sample);
+  for (size_t c0 = 0; c0 < centers.size(); c0 += block) {  // :178-182, centre-major
+    const size_t nc = std::min(block, centers.size() - c0);
+    uint64_t n_hits = 0;
+    st = eng.Scan(centers, c0, nc, std::numeric_limits<double>::infinity(), &hq, &hid, &hd, &n_hits, err);
+    if (st != HS_OK) return st;
+    if (n_hits != (uint64_t)nc * n_sample) {
+      if (err) *err = "brute-force scan returned an incomplete distance matrix";
+      return HS_ERR_STATE;
+    }
+    for (uint64_t i = 0; i < n_hits; ++i) fout << hd[i] << std::endl;
+  }
+  return HS_OK;
 }
 
 }  // namespace hsearch

@@ -123,6 +123,55 @@ int Clustering(const std::vector<Kmer>& kmers, const uint32_t& hash_K, const uin
 // where the reference would exit(0) on an inconsistent ground truth (:68-71).
 double Evaluate(const std::string& ground_truth, const std::string& output_file, const double& hash_R);
 
+// ---- brute force (row a11) ----------------------------------------------------------------------
+// Search() of motif_both_points_noLSH.cpp:36-56: every (centre, k-mer) pair, centre-major, k-mer
+// ascending; "<center> <kmer> <dist>" to output_file unless sqrt(d2) > R.  The reference also
+// writes every excluded pair to <output_file>notlessthan.txt (:41-49, Q x N lines); here only when
+// write_not_less_than is set.  Distances come from hs_bruteforce (exact fp64, reference order).
+int SearchBruteForce(const std::vector<Point>& kmers, const std::vector<Point>& centers,
+                     const std::vector<std::string>& kmer_names,
+                     const std::vector<std::string>& center_names, const double& hash_R,
+                     const std::string& output_file, int device, std::string* err,
+                     bool write_not_less_than = false);
+
+// ---- evaluation tooling ------------------------------------------------------
+// evaluate2.cpp as it runs (:73-95): the hits file sorted by (motif, protein) and written
+// tab-separated to <hits_file>sort.txt -- the ground-truth form evaulate()/Evaluate() expects.
+bool SortHitsFile(const std::string& hits_file, uint64_t* n_records = nullptr);
+// evaluate2.cpp's comparison (:98-153, unreachable in the reference behind the early return :95):
+// weighted recall of hits_file against the ground truth with weight() of :62-71 (49.38 form).
+// ground_truth is sorted here as main() does (:88); returns tp / (tp + fn).
+double Evaluate2(const std::string& ground_truth, const std::string& hits_file, double* tp = nullptr,
+                 double* fn = nullptr);
+
+// ---- motif families -> centroid queries (centerDistanceSmapling.cpp) ---------------------------
+// The motif-family file read by main() (:436-456): a line starting with '#' opens a family (the
+// whole line is its name), every other non-empty line is one member k-mer; families with fewer
+// than min_size members are dropped (MIN_SIZE_CLUSTER = 50, :12).
+struct MotifFamily {
+  std::string name;
+  std::vector<std::string> seqs;
+};
+bool ReadMotifFamilies(const std::string& path, uint32_t min_size, std::vector<MotifFamily>* families);
+// Center() (:67-78) of the members' embeddings (KmerToCoordinates :41-56): coordinate sums in
+// member order, then one division by the member count.  A letter outside the 20-letter alphabet --
+// the reference substitutes rand() % 20 (:47-49) -- or a member of another length is an error.
+bool FamilyCenters(const std::vector<MotifFamily>& families, uint32_t kmer_length,
+                   std::vector<Point>* centers, std::string* err);
+// cluster2datapoint() (:110-136): the centres as a points file <output_file>hclust.format.txt
+// (family name line, then the coordinates), i.e. the `-c` input of motif_both_points.
+bool Cluster2DataPoint(const std::vector<MotifFamily>& families, const std::vector<Point>& centers,
+                       const std::string& output_file);
+// sequencedatabase2centers() (:138-190), the function main() runs: all centre-to-centre distances
+// (i < j) to <dir>/<output_file>innercenter_protein_centers_0.txt, and the distance of each of
+// the first min(100000, N) database points to each centre (centre-major) to
+// <dir>/<output_file>ramdom_protein_centers_0.txt.  The reference hard-codes dir =
+// "./pro2centerdis" (which must exist) and reads 100000 points whatever N is; here dir is created
+// if missing.  The N x C distances are computed on `device` (hs_bruteforce).
+int SequenceDatabase2Centers(const std::vector<Point>& kmers_proteins,
+                             const std::vector<Point>& centers, const std::string& output_file,
+                             const std::string& dir, int device, std::string* err);
+
 }  // namespace hsearch
 
 #endif

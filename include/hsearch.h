@@ -102,7 +102,7 @@ HS_API hs_status hs_create(const hs_params* params, const double* a, const doubl
 HS_API void hs_destroy(hs_handle* h);
 /* A new hash family (same k, K, L, W) for an existing handle: what constructing the next LSHTable
  * does in Clustering() (hclust2.cpp:104, one fresh family per table).  Drops the index (queries
- * return HS_ERR_NOT_BUILT until the next build); device buffers are kept. */
+ * return HS_ERR_STATE until the next build); device buffers are kept. */
 HS_API hs_status hs_set_planes(hs_handle* h, const double* a, const double* b);
 HS_API const char* hs_last_error(const hs_handle* h);
 HS_API hs_status hs_get_profile(const hs_handle* h, hs_profile* out);

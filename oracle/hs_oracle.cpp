@@ -377,6 +377,132 @@ double hso_evaluate(const char* ground_truth, const char* hits, double R) {
   return tp / (tp + fn);  // :164
 }
 
+// ---- exhaustive search as a program (row a11) -----------------------------------------------------
+// Search() of motif_both_points_noLSH.cpp:36-56 with its two files.
+int hso_bruteforce_to_files(const double* db, uint64_t n, const double* centers, uint64_t nq, uint32_t d,
+                            double R, const char* out_path, const char* const* q_names,
+                            const char* const* db_names) {
+  std::ofstream fnot((std::string(out_path) + "notlessthan.txt").c_str());  // :41-43
+  std::ofstream fout(out_path);
+  if (!fout || !fnot) return -1;
+  for (uint64_t i = 0; i < nq; ++i)
+    for (uint64_t j = 0; j < n; ++j) {
+      double dis = sqrt(dist2_sequential(db + j * d, centers + i * d, d));  // :27-34
+      std::ofstream& f = dis > R ? fnot : fout;                             // :47-51
+      f << q_names[i] << " " << db_names[j] << " " << dis << std::endl;
+    }
+  return 0;
+}
+
+// ---- evaluation tooling --------------------------------------------------------
+// evaluate2.cpp as it runs (:73-95): sort by (motif, protein), write <path>sort.txt, tab-separated.
+int64_t hso_sort_hits_file(const char* path) {
+  std::ifstream fin(path);
+  if (!fin) return -1;
+  std::vector<Res> rec;
+  Res r;
+  while (fin >> r.motif >> r.protein >> r.dis) rec.push_back(r);  // :80-82
+  std::sort(rec.begin(), rec.end(), res_less);                    // :88
+  std::ofstream fout((std::string(path) + "sort.txt").c_str());
+  for (size_t i = 0; i < rec.size(); ++i)
+    fout << rec[i].motif << "\t" << rec[i].protein << "\t" << rec[i].dis << std::endl;  // :91-93
+  return (int64_t)rec.size();
+}
+
+double hso_evaluate2_weight(double dis) {  // evaluate2.cpp:62-71
+  if (dis > 49.38) {
+    double w = dis / (2 * 49.38);
+    if (w > 1) return 1;
+    return dis / (2 * 49.38);
+  }
+  return 1 - dis / (2 * 49.38);
+}
+
+// The comparison of evaluate2.cpp:98-153 (behind the early return of :95 in the reference).
+double hso_evaluate2(const char* ground_truth, const char* hits, double* tp_out, double* fn_out) {
+  std::vector<Res> brute, found;
+  Res r;
+  {
+    std::ifstream fin(ground_truth);
+    while (fin >> r.motif >> r.protein >> r.dis) brute.push_back(r);
+  }
+  {
+    std::ifstream fin(hits);
+    while (fin >> r.motif >> r.protein >> r.dis) found.push_back(r);
+  }
+  std::sort(brute.begin(), brute.end(), res_less);
+  std::sort(found.begin(), found.end(), res_less);
+  size_t i = 0, j = 0;
+  double tp = 0.0, fn = 0.0;
+  while (i < brute.size() && j < found.size()) {
+    int cmp = res_cmp(brute[i], found[j]);
+    if (cmp == 0) {
+      tp += hso_evaluate2_weight(brute[i].dis);
+      ++i;
+      ++j;
+    } else if (cmp == 1) {
+      ++j;
+    } else {
+      fn += hso_evaluate2_weight(brute[i].dis);
+      ++i;
+    }
+  }
+  for (; i < brute.size(); ++i) fn += hso_evaluate2_weight(brute[i].dis);
+  if (tp_out) *tp_out = tp;
+  if (fn_out) *fn_out = fn;
+  return tp / (tp + fn);
+}
+
+// ---- motif families -> centroids (centerDistanceSmapling.cpp) -------------------------------------
+// Center() :67-78 over KmerToCoordinates :41-56 of the members; members of family f are
+// codes[first[f] .. first[f+1])[k] (rows of the coordinate table).  centers[n_families][8k].
+void hso_family_centers(const uint8_t* codes, const uint32_t* first, uint32_t n_families, uint32_t k,
+                        double* centers) {
+  const uint32_t d = 8 * k;
+  std::vector<double> pt(d);
+  for (uint32_t f = 0; f < n_families; ++f) {
+    double* c = centers + (size_t)f * d;
+    for (uint32_t j = 0; j < d; ++j) c[j] = 0.0;
+    for (uint32_t m = first[f]; m < first[f + 1]; ++m) {
+      hso_embed_codes(codes + (size_t)m * k, 1, k, pt.data());
+      for (uint32_t j = 0; j < d; ++j) c[j] += pt[j];          // :69-73
+    }
+    for (uint32_t j = 0; j < d; ++j) c[j] /= (first[f + 1] - first[f]);  // :74-76
+  }
+}
+
+// A points file as cluster2datapoint() writes it (:126-134): name line, then the coordinates.
+int hso_write_points_file(const char* path, const char* const* names, const double* pts, uint64_t n,
+                          uint32_t d) {
+  std::ofstream fout(path);
+  if (!fout) return -1;
+  for (uint64_t p = 0; p < n; ++p) {
+    fout << names[p] << std::endl;
+    fout << pts[p * d];
+    for (uint32_t q = 1; q < d; ++q) fout << " " << pts[p * d + q];
+    fout << std::endl;
+  }
+  return 0;
+}
+
+// sequencedatabase2centers() (:138-190): centre-centre distances (i < j) to inner_path, then the
+// distance of every db point (the caller passes the first min(100000, N)) to every centre,
+// centre-major, to random_path.  PairwiseDistance :58-65 (sqrt form).
+int hso_center_sampling(const double* db, uint64_t n, const double* centers, uint64_t nc, uint32_t d,
+                        const char* inner_path, const char* random_path) {
+  std::ofstream fcenter(inner_path);
+  if (!fcenter) return -1;
+  for (uint64_t i = 0; i < nc; ++i)
+    for (uint64_t j = i + 1; j < nc; ++j)
+      fcenter << sqrt(dist2_sequential(centers + i * d, centers + j * d, d)) << std::endl;  // :155-159
+  std::ofstream fout(random_path);
+  if (!fout) return -1;
+  for (uint64_t p = 0; p < nc; ++p)
+    for (uint64_t q = 0; q < n; ++q)
+      fout << sqrt(dist2_sequential(db + q * d, centers + p * d, d)) << std::endl;  // :178-182
+  return 0;
+}
+
 // ---- Kernel-LSH pre-grouping (pcluster) -----------------------------------------------------------
 void hso_klsh_draw_planes(uint32_t feat, uint32_t bits, double sigma, double* w, double* b, double* t) {
   // member order of KLSH (lsh.hpp:37-49): the distributions, then the default-seeded engine

@@ -83,6 +83,27 @@ int hso_clustering_to_file(const double* a, const double* b, uint32_t d, uint32_
  * sorted by (motif, protein) as evaluate2.cpp:88-96 leaves it).  Returns tp/(tp+fn). */
 double hso_evaluate(const char* ground_truth, const char* hits, double R);
 
+/* a11 as a program: Search() of motif_both_points_noLSH.cpp:36-56, hits to out_path and the
+ * excluded pairs to out_path + "notlessthan.txt". */
+int hso_bruteforce_to_files(const double* db, uint64_t n, const double* centers, uint64_t nq, uint32_t d,
+                            double R, const char* out_path, const char* const* q_names,
+                            const char* const* db_names);
+
+/* ---- evaluation tooling and centroid queries ---------------------------------
+ * evaluate2.cpp:73-95 (sorted copy <path>sort.txt; returns the record count, -1 on error),
+ * its weight() :62-71 and the comparison :98-153. */
+int64_t hso_sort_hits_file(const char* path);
+double hso_evaluate2_weight(double dis);
+double hso_evaluate2(const char* ground_truth, const char* hits, double* tp_out, double* fn_out);
+/* centerDistanceSmapling.cpp: Center() of the members' embeddings (:41-78), the points file of
+ * cluster2datapoint() (:126-134), the two distance files of sequencedatabase2centers() (:138-190). */
+void hso_family_centers(const uint8_t* codes, const uint32_t* first, uint32_t n_families, uint32_t k,
+                        double* centers);
+int hso_write_points_file(const char* path, const char* const* names, const double* pts, uint64_t n,
+                          uint32_t d);
+int hso_center_sampling(const double* db, uint64_t n, const double* centers, uint64_t nc, uint32_t d,
+                        const char* inner_path, const char* random_path);
+
 /* ---- Kernel-LSH pre-grouping of whole proteins (pcluster) ------------------
  * Planes of KLSH::KLSH (lsh.cpp:17-38): per bit t ~ U(-1,1), b ~ U(0, 2 pi), then feat normals
  * N(0, sigma*sigma) -- sigma*sigma is passed as the STANDARD DEVIATION, lsh.cpp:22 -- from one

@@ -393,3 +393,100 @@ def parse_clusters(path):
             elif line:
                 clusters[-1].append(int(line))
     return clusters
+
+
+# ---- a11 as a program, SURVEY 8(f) row 4 (evaluate2, centroid builder) -- restatement -----------
+def _cstrs(strs):
+    arr = (C.c_char_p * len(strs))(*[s_.encode() for s_ in strs])
+    return arr
+
+
+def bruteforce_to_files(db, centers, R, out_path, q_names=None, db_names=None):
+    """Search() of motif_both_points_noLSH.cpp:36-56: out_path and out_path + 'notlessthan.txt'."""
+    db, centers = _f64(db), _f64(centers)
+    qn = q_names if q_names is not None else ["c%d" % i for i in range(len(centers))]
+    dn = db_names if db_names is not None else ["k%d" % i for i in range(len(db))]
+    rc = lib().hso_bruteforce_to_files(_ptr(db, _dp), C.c_uint64(db.shape[0]), _ptr(centers, _dp),
+                                       C.c_uint64(centers.shape[0]), C.c_uint32(db.shape[1]),
+                                       C.c_double(R), out_path.encode(), _cstrs(qn), _cstrs(dn))
+    assert rc == 0
+
+
+def sort_hits_file(path):
+    lib().hso_sort_hits_file.restype = C.c_int64
+    return int(lib().hso_sort_hits_file(path.encode()))
+
+
+def evaluate2_weight(dis):
+    lib().hso_evaluate2_weight.restype = C.c_double
+    return float(lib().hso_evaluate2_weight(C.c_double(dis)))
+
+
+def evaluate2(ground_truth_path, hits_path):
+    lib().hso_evaluate2.restype = C.c_double
+    tp, fn = C.c_double(0), C.c_double(0)
+    acc = float(lib().hso_evaluate2(ground_truth_path.encode(), hits_path.encode(), C.byref(tp), C.byref(fn)))
+    return acc, tp.value, fn.value
+
+
+def family_centers(family_codes):
+    """family_codes: list of uint8 arrays [members][k] -> centres [n_families][8k]."""
+    k = family_codes[0].shape[1]
+    first = np.concatenate([[0], np.cumsum([len(f) for f in family_codes])]).astype(np.uint32)
+    codes = np.ascontiguousarray(np.concatenate(family_codes), dtype=np.uint8)
+    out = np.empty((len(family_codes), 8 * k))
+    lib().hso_family_centers(_ptr(codes, _u8p), _ptr(first, _u32p), C.c_uint32(len(family_codes)),
+                             C.c_uint32(k), _ptr(out, _dp))
+    return out
+
+
+def write_points_file(path, names, pts):
+    pts = _f64(pts)
+    rc = lib().hso_write_points_file(path.encode(), _cstrs(names), _ptr(pts, _dp), C.c_uint64(pts.shape[0]),
+                                     C.c_uint32(pts.shape[1]))
+    assert rc == 0
+
+
+def center_sampling(db, centers, inner_path, random_path):
+    db, centers = _f64(db), _f64(centers)
+    rc = lib().hso_center_sampling(_ptr(db, _dp), C.c_uint64(db.shape[0]), _ptr(centers, _dp),
+                                   C.c_uint64(centers.shape[0]), C.c_uint32(db.shape[1]),
+                                   inner_path.encode(), random_path.encode())
+    assert rc == 0
+
+
+# ---- the real reference programs (oracle/_ref) ---------------------------------------------------
+def ref_nolsh_search(db, centers, R, out_path):
+    """names k<i> / c<i>; writes out_path and out_path + 'notlessthan.txt'."""
+    db, centers = _f64(db), _f64(centers)
+    lib_ = C.CDLL(os.path.join(_HERE, "_ref", "libref_nolsh.so"))
+    lib_.refn_search(C.c_uint32(db.shape[1]), _ptr(db, _dp), C.c_uint64(db.shape[0]), _ptr(centers, _dp),
+                     C.c_uint64(centers.shape[0]), C.c_double(R), out_path.encode())
+
+
+def ref_evaluate2_lib():
+    lib_ = C.CDLL(os.path.join(_HERE, "_ref", "libref_evaluate2.so"))
+    lib_.refe_weight.restype = C.c_double
+    return lib_
+
+
+def ref_evaluate2_sort(path):
+    return int(ref_evaluate2_lib().refe_sort(path.encode()))
+
+
+def ref_evaluate2_weight(dis):
+    return float(ref_evaluate2_lib().refe_weight(C.c_double(dis)))
+
+
+def ref_centers_main(workdir, families_path, points_path, k, out_name):
+    lib_ = C.CDLL(os.path.join(_HERE, "_ref", "libref_centers.so"))
+    return int(lib_.refc_main(workdir.encode(), families_path.encode(), points_path.encode(),
+                              C.c_uint32(k), out_name.encode()))
+
+
+def ref_cluster2datapoint(k, names, family_seqs, out_prefix):
+    lib_ = C.CDLL(os.path.join(_HERE, "_ref", "libref_centers.so"))
+    first = np.concatenate([[0], np.cumsum([len(f) for f in family_seqs])]).astype(np.uint32)
+    flat = [s_ for f in family_seqs for s_ in f]
+    return int(lib_.refc_cluster2datapoint(C.c_uint32(k), C.c_uint32(len(names)), _cstrs(names),
+                                           _ptr(first, _u32p), _cstrs(flat), out_prefix.encode()))

@@ -227,3 +227,115 @@ def test_pcluster_pregroup_cli_matches_oracle(tmp_path, oracle):
         got.setdefault(int(code), []).append(name)
     assert got == want and list(got) == sorted(got)
     assert subprocess.run([exe], capture_output=True).returncode == 0     # help, exit 0
+
+
+# ---- row a11 as a program, SURVEY 8(f) row 4: noLSH search, evaluate2, centroid builder ----------
+def _tool(name):
+    _bin()
+    return os.path.join(ROOT, "hsearch_amd", "bin", name)
+
+
+def _points_text(names, pts):
+    return "".join("%s\n%s\n" % (nm, " ".join("%g" % x for x in row)) for nm, row in zip(names, pts))
+
+
+def test_evaluate2_cli_matches_reference_golden(tmp_path, golden_dir):
+    """`evaluate2 <hits>` as the reference runs (evaluate2.cpp:73-95): <hits>sort.txt; host only."""
+    t = json.load(open(os.path.join(golden_dir, "tools.json")))["evaluate2"]
+    hits = str(tmp_path / "bf.txt")
+    open(hits, "w").write(t["hits"])
+    r = subprocess.run([_tool("hs_evaluate2"), hits], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout == hits + "\n"
+    assert open(hits + "sort.txt").read() == t["sorted"]
+    # the comparison behind the reference's early return: a hits file that is a subset
+    lines = t["hits"].strip().split("\n")
+    part = str(tmp_path / "part.txt")
+    open(part, "w").write("\n".join(lines[::2]) + "\nzz_extra k0 1\n")
+    r = subprocess.run([_tool("hs_evaluate2"), hits, part], capture_output=True, text=True)
+    assert r.returncode == 0
+    acc = [ln for ln in r.stdout.split("\n") if ln.startswith("ACCURACY: ")]
+    assert len(acc) == 1 and acc[0].endswith("\t" + part)
+    from oracle import pyoracle as O
+    want, tp, fn = O.evaluate2(hits, part)
+    got = [float(x) for x in acc[0].split("\t")[0].split()[1:]]
+    assert got == [float("%g" % tp), float("%g" % fn), float("%g" % want)] and 0.3 < want < 0.7
+    r = subprocess.run([_tool("hs_evaluate2")], capture_output=True, text=True)
+    assert r.returncode == 0 and "Usage" in r.stderr
+
+
+def test_centroid_points_file_cli_matches_reference_golden(tmp_path, golden_dir):
+    """cluster2datapoint() (centerDistanceSmapling.cpp:110-136): family centroids as the `-c` points
+    file of motif_both_points; host only (no database, no GPU)."""
+    t = json.load(open(os.path.join(golden_dir, "tools.json")))["cluster2datapoint"]
+    fam = str(tmp_path / "fams.txt")
+    with open(fam, "w") as f:
+        for nm, seqs in zip(t["names"], t["families"]):
+            f.write(nm + "\n" + "".join(s_ + "\n" for s_ in seqs))
+        f.write("#too small\n" + t["families"][0][0] + "\n")
+    out = str(tmp_path / "o_")
+    r = subprocess.run([_tool("hs_center_distance_sampling"), "-k", fam, "-l", str(t["k"]), "-o", out,
+                        "-format", "points"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Number of Clusters: 3" in r.stdout
+    assert open(out + "hclust.format.txt").read() == t["points_file"]
+    r = subprocess.run([_tool("hs_center_distance_sampling"), "-k", fam, "-l", "24", "-o", out,
+                        "-format", "points"], capture_output=True, text=True)
+    assert r.returncode == 1 and "24-mer" in r.stderr
+    r = subprocess.run([_tool("hs_center_distance_sampling"), "-k", fam], capture_output=True, text=True)
+    assert r.returncode == 0 and "missing required option" in r.stderr
+
+
+@pytest.mark.gpu
+def test_nolsh_cli_matches_reference_golden(tmp_path, golden_dir):
+    """motif_both_points_noLSH: hits file and (with -notlessthan) the excluded-pairs file, byte for
+    byte what the compiled reference wrote for the same points."""
+    from hsearch_amd import synth
+    t = json.load(open(os.path.join(golden_dir, "tools.json")))["nolsh"]
+    z = np.load(os.path.join(golden_dir, t["file"]))
+    db, cen, out = [str(tmp_path / n) for n in ("db", "cen", "out")]
+    with open(db, "w") as f:
+        for i, row in enumerate(synth.embed(z["codes"])):
+            f.write("k%d\n%s\n" % (i, " ".join("%.17g" % v for v in row)))
+    with open(cen, "w") as f:
+        for i, row in enumerate(z["centers"]):
+            f.write("c%d\n%s\n" % (i, " ".join("%.17g" % v for v in row)))
+    import hashlib
+    for extra in ([], ["-notlessthan"]):
+        if os.path.exists(out + "notlessthan.txt"):
+            os.unlink(out + "notlessthan.txt")
+        r = subprocess.run([_tool("hs_motif_both_points_noLSH"), "-d", db, "-c", cen, "-l", str(t["k"]),
+                            "-T", repr(t["R"]), "-o", out] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert "number of kmers 400" in r.stdout and "Searching takes" in r.stdout
+        assert open(out).read() == t["hits"]
+        if extra:
+            rest = open(out + "notlessthan.txt").read()
+            assert rest.count("\n") == t["notlessthan_lines"]
+            assert hashlib.sha256(rest.encode()).hexdigest() == t["notlessthan_sha256"]
+        else:
+            assert not os.path.exists(out + "notlessthan.txt")
+
+
+@pytest.mark.gpu
+def test_center_distance_sampling_cli_matches_reference_golden(tmp_path, golden_dir):
+    """centerDistanceSmapling as the reference runs it (sequencedatabase2centers): both distance
+    files identical to the compiled reference's (300000 centre-to-k-mer distances on the GPU)."""
+    import hashlib
+    from hsearch_amd import synth
+    t = json.load(open(os.path.join(golden_dir, "tools.json")))["center_sampling"]
+    codes = np.load(os.path.join(golden_dir, t["file"]))["codes"]
+    text = _points_text(["p%d" % i for i in range(len(codes))], synth.embed(codes))
+    assert hashlib.sha256(text.encode()).hexdigest() == t["points_file_sha256"]
+    db, fam = str(tmp_path / "db.points"), str(tmp_path / "fams.txt")
+    open(db, "w").write(text)
+    open(fam, "w").write(t["families_file"])
+    r = subprocess.run([_tool("hs_center_distance_sampling"), "-k", fam, "-d", db, "-l", str(t["k"]),
+                        "-o", "g_"], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    assert "Number of Clusters: 3" in r.stdout
+    sub = tmp_path / "pro2centerdis"
+    assert open(sub / "g_innercenter_protein_centers_0.txt").read() == t["innercenter"]
+    rand = open(sub / "g_ramdom_protein_centers_0.txt").read()
+    assert rand.split("\n")[:8] == t["random_head"] and rand.split("\n")[-9:-1] == t["random_tail"]
+    assert rand.count("\n") == t["random_lines"]
+    assert hashlib.sha256(rand.encode()).hexdigest() == t["random_sha256"]

@@ -100,3 +100,65 @@ def test_klsh_oracle_and_planes_match_reference_golden(oracle, golden_dir):
         assert oracle.klsh_hash(w, b, t, f) == int(z["codes"][i])
     assert str(z["first_sequences"][0]) and list(oracle.klsh_classes(str(z["first_sequences"][0]))) == \
         list(z["classes"][st[0]:st[1]])
+
+
+# ---- row a11 as a program and SURVEY 8(f) row 4 (tools.json: the real reference's files) --------
+def _sha(text):
+    import hashlib
+    return hashlib.sha256(text.encode()).hexdigest()
+
+
+def test_tools_nolsh_files(oracle, golden_dir):
+    t = _load(golden_dir, "tools.json")["nolsh"]
+    z = np.load(os.path.join(golden_dir, t["file"]))
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "bf.txt")
+        oracle.bruteforce_to_files(oracle.embed_codes(z["codes"]), z["centers"], t["R"], p)
+        assert open(p).read() == t["hits"]
+        rest = open(p + "notlessthan.txt").read()
+        assert rest.split("\n")[:5] == t["notlessthan_head"]
+        assert rest.count("\n") == t["notlessthan_lines"] and _sha(rest) == t["notlessthan_sha256"]
+
+
+def test_tools_evaluate2_sort_and_weight(oracle, golden_dir):
+    t = _load(golden_dir, "tools.json")["evaluate2"]
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "hits.txt")
+        open(p, "w").write(t["hits"])
+        assert oracle.sort_hits_file(p) == t["hits"].count("\n")
+        assert open(p + "sort.txt").read() == t["sorted"]
+    assert [oracle.evaluate2_weight(x) for x in t["weight_in"]] == t["weight_out"]
+
+
+def test_tools_cluster2datapoint(oracle, golden_dir):
+    t = _load(golden_dir, "tools.json")["cluster2datapoint"]
+    fams = [np.array([oracle.letters_to_codes(s_)[0] for s_ in f], dtype=np.uint8) for f in t["families"]]
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "hclust.format.txt")
+        oracle.write_points_file(p, t["names"], oracle.family_centers(fams))
+        assert open(p).read() == t["points_file"]
+
+
+def test_tools_center_sampling(oracle, golden_dir):
+    t = _load(golden_dir, "tools.json")["center_sampling"]
+    codes = np.load(os.path.join(golden_dir, t["file"]))["codes"]
+    # the reference reads the database back from the 6-significant-digit points file
+    pts = np.array([[float("%g" % x) for x in row] for row in oracle.embed_codes(codes)])
+    fams, cur = [], None
+    for line in t["families_file"].split("\n"):      # main() :443-457, MIN_SIZE_CLUSTER 50
+        if not line:
+            continue
+        if line[0] == "#":
+            cur = []
+            fams.append(cur)
+        else:
+            cur.append(oracle.letters_to_codes(line)[0])
+    fams = [np.array(f, dtype=np.uint8) for f in fams if len(f) >= 50]
+    assert len(fams) == 3
+    with tempfile.TemporaryDirectory() as d:
+        pi, pr = os.path.join(d, "inner.txt"), os.path.join(d, "rand.txt")
+        oracle.center_sampling(pts, oracle.family_centers(fams), pi, pr)
+        assert open(pi).read() == t["innercenter"]
+        rand = open(pr).read()
+        assert rand.split("\n")[:8] == t["random_head"] and rand.split("\n")[-9:-1] == t["random_tail"]
+        assert rand.count("\n") == t["random_lines"] and _sha(rand) == t["random_sha256"]

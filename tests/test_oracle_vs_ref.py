@@ -71,3 +71,45 @@ def test_clustering():
         a, b = O.ref_planes(5, 200, 4, 8, 100.0)
         O.clustering_to_file(a, b, 100.0, 60.0, O.embed_codes(rows), p2)
         assert open(p1).read() == open(p2).read()
+
+
+def _have(name):
+    return os.path.exists(os.path.join(os.path.dirname(O.__file__), "_ref", name))
+
+
+@pytest.mark.skipif(not _have("libref_nolsh.so"), reason="oracle/_ref/libref_nolsh.so not built")
+@pytest.mark.parametrize("k,R", [(25, 60.0), (15, 35.0), (39, 80.0)])
+def test_nolsh_program_files(k, R):
+    codes, centers = _data(50 + k, 250, 9, k)
+    db = O.embed_codes(codes)
+    with tempfile.TemporaryDirectory() as d:
+        O.ref_nolsh_search(db, centers, R, d + "/r.txt")
+        O.bruteforce_to_files(db, centers, R, d + "/o.txt")
+        for suf in ("", "notlessthan.txt"):
+            assert open(d + "/r.txt" + suf).read() == open(d + "/o.txt" + suf).read()
+        assert 0 < os.path.getsize(d + "/r.txt")
+        # evaluate2 on the hits file the reference just wrote
+        if _have("libref_evaluate2.so"):
+            open(d + "/o2.txt", "w").write(open(d + "/r.txt").read())
+            O.ref_evaluate2_sort(d + "/r.txt")
+            O.sort_hits_file(d + "/o2.txt")
+            assert open(d + "/r.txtsort.txt").read() == open(d + "/o2.txtsort.txt").read()
+
+
+@pytest.mark.skipif(not _have("libref_evaluate2.so"), reason="oracle/_ref/libref_evaluate2.so not built")
+def test_evaluate2_weight():
+    for x in np.concatenate([np.linspace(0, 120, 481), [49.38, 98.76]]):
+        assert O.ref_evaluate2_weight(float(x)) == O.evaluate2_weight(float(x))
+
+
+@pytest.mark.skipif(not _have("libref_centers.so"), reason="oracle/_ref/libref_centers.so not built")
+def test_cluster2datapoint_points_file():
+    r = np.random.default_rng(8)
+    for k in (25, 9):
+        fams = [r.integers(0, 20, (m, k)).astype(np.uint8) for m in (50, 3, 200, 1)]
+        names = ["#f%d with spaces" % i for i in range(len(fams))]
+        seqs = [["".join(LETTERS[c] for c in row) for row in f] for f in fams]
+        with tempfile.TemporaryDirectory() as d:
+            O.ref_cluster2datapoint(k, names, seqs, d + "/r_")
+            O.write_points_file(d + "/o.txt", names, O.family_centers(fams))
+            assert open(d + "/r_hclust.format.txt").read() == open(d + "/o.txt").read()

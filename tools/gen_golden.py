@@ -174,6 +174,83 @@ def gen_klsh():
                         codes=codes, first_sequences=np.array(seqs[:6]))
 
 
+def points_text(names, pts):
+    """A points file as the reference's programs write them (operator<< at default precision)."""
+    return "".join("%s\n%s\n" % (nm, " ".join("%g" % x for x in row)) for nm, row in zip(names, pts))
+
+
+def gen_tools():
+    """Row a11 as a program and SURVEY 8(f) row 4: motif_both_points_noLSH.cpp Search(), evaluate2's
+    main(), centerDistanceSmapling's cluster2datapoint() and its main() -- all the REAL compiled
+    reference (oracle/_ref/libref_nolsh.so, libref_evaluate2.so, libref_centers.so)."""
+    import hashlib
+    sha = lambda t: hashlib.sha256(t.encode()).hexdigest()
+    d = tempfile.mkdtemp()
+    out = {"source": "motif_both_points_noLSH.cpp:36-56, evaluate2.cpp:62-95, "
+                     "centerDistanceSmapling.cpp:41-190,436-477 via oracle/_ref"}
+    # -- exhaustive search: DB k-mers, centres = mutated DB k-mers + small real-valued offsets
+    g = rng(901)
+    k = 25
+    codes = np.repeat(g.integers(0, 20, size=(40, k), dtype=np.uint8), 10, axis=0)   # 40 families
+    for row in codes:
+        for _ in range(int(g.integers(0, 4))):
+            row[g.integers(0, k)] = g.integers(0, 20)
+    g.shuffle(codes)
+    db = O.ref_kmer_to_coordinates(seqs_of(codes), k)
+    qc = codes[g.integers(0, 400, size=12)].copy()
+    for row in qc:
+        for _ in range(int(g.integers(0, 5))):
+            row[g.integers(0, k)] = g.integers(0, 20)
+    centers = O.ref_kmer_to_coordinates(seqs_of(qc), k) + g.normal(0, 0.05, size=(12, 8 * k))
+    hits_path = os.path.join(d, "bf.txt")
+    O.ref_nolsh_search(db, centers, 55.0, hits_path)
+    hits = open(hits_path).read()
+    rest = open(hits_path + "notlessthan.txt").read()
+    assert hits.count("\n") > 12
+    out["nolsh"] = {"file": "tools_nolsh.npz", "k": k, "R": 55.0, "hits": hits,
+                    "notlessthan_sha256": sha(rest), "notlessthan_lines": rest.count("\n"),
+                    "notlessthan_head": rest.split("\n")[:5]}
+    np.savez_compressed(os.path.join(OUT, "tools_nolsh.npz"), codes=codes, centers=centers)
+    # -- evaluate2 as it runs: <file>sort.txt; and its weight()
+    O.ref_evaluate2_sort(hits_path)
+    ws = [0.0, 1.0, 24.5, 49.38, 49.380001, 60.0, 98.76, 98.77, 200.0]
+    out["evaluate2"] = {"hits": hits, "sorted": open(hits_path + "sort.txt").read(),
+                        "weight_in": ws, "weight_out": [O.ref_evaluate2_weight(x) for x in ws]}
+    # -- cluster2datapoint: centroids of 25-mer families as a points file
+    fams = []
+    for m in (50, 64, 131):
+        seed_row = g.integers(0, 20, size=k)
+        rows = np.repeat(seed_row[None, :], m, axis=0)
+        mut = g.random(size=rows.shape) < 0.2
+        rows[mut] = g.integers(0, 20, size=int(mut.sum()))
+        fams.append(rows.astype(np.uint8))
+    names = ["#PF%05d family_%d" % (100 + i, i) for i in range(len(fams))]
+    O.ref_cluster2datapoint(k, names, [seqs_of(f) for f in fams], os.path.join(d, "c2d_"))
+    out["cluster2datapoint"] = {"k": k, "names": names, "families": [seqs_of(f) for f in fams],
+                                "points_file": open(os.path.join(d, "c2d_hclust.format.txt")).read()}
+    # -- the program: families file (one family below MIN_SIZE_CLUSTER, blank lines) + a points
+    #    file of 100000 3-mers (the reference reads that many whatever the file holds)
+    k3, n3 = 3, 100000
+    codes3 = g.integers(0, 20, size=(n3, k3), dtype=np.uint8)
+    pts_text = points_text(["p%d" % i for i in range(n3)], O.ref_kmer_to_coordinates(seqs_of(codes3), k3))
+    open(os.path.join(d, "db.points"), "w").write(pts_text)
+    fam3 = [g.integers(0, 20, size=(m, k3), dtype=np.uint8) for m in (50, 49, 77, 120)]
+    ftxt = "\n"
+    for i, f in enumerate(fam3):
+        ftxt += "#family %d\n" % i + "".join(s_ + "\n" for s_ in seqs_of(f)) + ("\n" if i == 1 else "")
+    open(os.path.join(d, "fams.txt"), "w").write(ftxt)
+    os.mkdir(os.path.join(d, "pro2centerdis"))
+    assert O.ref_centers_main(d, os.path.join(d, "fams.txt"), os.path.join(d, "db.points"), k3, "g_") == 0
+    inner = open(os.path.join(d, "pro2centerdis", "g_innercenter_protein_centers_0.txt")).read()
+    rand = open(os.path.join(d, "pro2centerdis", "g_ramdom_protein_centers_0.txt")).read()
+    out["center_sampling"] = {"file": "tools_centers.npz", "k": k3, "families_file": ftxt,
+                              "points_file_sha256": sha(pts_text), "innercenter": inner,
+                              "random_sha256": sha(rand), "random_lines": rand.count("\n"),
+                              "random_head": rand.split("\n")[:8], "random_tail": rand.split("\n")[-9:-1]}
+    np.savez_compressed(os.path.join(OUT, "tools_centers.npz"), codes=codes3)
+    json.dump(out, open(os.path.join(OUT, "tools.json"), "w"))
+
+
 def main():
     if not O.have_ref():
         O.build()
@@ -187,6 +264,7 @@ def main():
     gen_clustering()
     gen_evaluate()
     gen_klsh()
+    gen_tools()
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("wrote %d files, %.1f KiB" % (len(os.listdir(OUT)), total / 1024))
 
