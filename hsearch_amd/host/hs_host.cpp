@@ -206,7 +206,7 @@ int SearchProteins(const ProteinDB& db, uint32_t kmer_length, const std::vector<
                    const std::vector<std::string>& center_names, const uint32_t& hash_K,
                    const uint32_t& hash_L, const double& hash_W, const double& hash_R,
                    const std::string& output_file, const Planes& planes, int device, std::string* err,
-                   std::vector<uint64_t>* table_sizes, uint64_t* n_windows) {
+                   std::vector<uint64_t>* table_sizes, uint64_t* n_windows, bool best_per_position) {
   const uint32_t dim = 8 * kmer_length;
   if (kmer_length == 0 || planes.dim != dim || planes.K != hash_K || planes.L != hash_L ||
       planes.W != hash_W) {
@@ -296,7 +296,23 @@ int SearchProteins(const ProteinDB& db, uint32_t kmer_length, const std::vector<
   // Q, which is what the reference's ProteinDB stores and prints
   const char* letters = HS_CODE_TO_LETTER;
   std::ofstream fout(output_file.c_str());
-  for (uint64_t i = 0; i < n_hits; ++i) {
+  std::vector<uint64_t> order(n_hits);
+  for (uint64_t i = 0; i < n_hits; ++i) order[i] = i;
+  if (best_per_position) {
+    // kmer_search.cpp:96-121: visit order (table, centre); `it2->second.second > dis` replaces
+    std::sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) {
+      if (hid[x] != hid[y]) return hid[x] < hid[y];
+      if (hd[x] != hd[y]) return hd[x] < hd[y];
+      if (ht[x] != ht[y]) return ht[x] < ht[y];
+      return hq[x] < hq[y];
+    });
+    uint64_t kept = 0;
+    for (uint64_t i = 0; i < n_hits; ++i)
+      if (i == 0 || hid[order[i]] != hid[order[i - 1]]) order[kept++] = order[i];
+    order.resize(kept);
+  }
+  for (uint64_t oi = 0; oi < order.size(); ++oi) {
+    const uint64_t i = order[oi];
     const uint64_t pos = win_pos[hid[i]];
     // sequence of the window: largest s with start[s] <= pos
     const size_t s = (size_t)(std::upper_bound(db.start.begin(), db.start.end() - 1, pos) - db.start.begin()) - 1;
@@ -307,8 +323,12 @@ int SearchProteins(const ProteinDB& db, uint32_t kmer_length, const std::vector<
     }
     std::string kmer(kmer_length, '?');
     for (uint32_t p = 0; p < kmer_length; ++p) kmer[p] = letters[db.residues[pos + p]];
-    fout << center_names[hq[i]] << " " << token << "#" << s << "$" << (pos - db.start[s]) << "@" << kmer
-         << "*" << hid[i] << " " << hd[i] << std::endl;
+    if (best_per_position)
+      fout << token << "#" << s << "$" << (pos - db.start[s]) << "@" << kmer << "*" << hid[i] << " "
+           << center_names[hq[i]] << " " << hd[i] << std::endl;
+    else
+      fout << center_names[hq[i]] << " " << token << "#" << s << "$" << (pos - db.start[s]) << "@" << kmer
+           << "*" << hid[i] << " " << hd[i] << std::endl;
   }
   fout.close();
   return HS_OK;

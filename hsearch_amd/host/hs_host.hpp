@@ -86,7 +86,14 @@ int SearchProteins(const ProteinDB& db, uint32_t kmer_length, const std::vector<
                    const std::vector<std::string>& center_names, const uint32_t& hash_K,
                    const uint32_t& hash_L, const double& hash_W, const double& hash_R,
                    const std::string& output_file, const Planes& planes, int device, std::string* err,
-                   std::vector<uint64_t>* table_sizes = nullptr, uint64_t* n_windows = nullptr);
+                   std::vector<uint64_t>* table_sizes = nullptr, uint64_t* n_windows = nullptr,
+                   bool best_per_position = false);
+// best_per_position: what kmer_search.cpp's Search() accumulates in `matches` (:90,113-121) and
+// never writes -- for every database window with a hit, its nearest centre: tables ascending,
+// centres ascending within a table, replaced only by a strictly smaller distance.  Written as
+// "<kmer name> <center> <dist>", windows ascending.  (The reference's own result is not
+// observable and is computed from mis-hashed windows, kmer_search.cpp:73-80 reads one residue k
+// times; this is the intended reduction over the pinned hit list -- parity unpinned.)
 
 // ---- Kernel-LSH pre-grouping of whole proteins (pcluster.cpp:11-81) ---------
 // pcluster's FASTA reader (read_proteins.cpp:6-41): '>' lines start a protein, its name is the

@@ -49,6 +49,7 @@ const Opt kOpts[] = {
     {"device", 'G', "GPU ordinal [0]", false},
     {"planes-out", 'P', "write the planes (binary doubles a[L][K][d] then b[L][K])", false},
     {"ref-compat-eq-swap", 'Q', "FASTA database: exchange E and Q like the reference's ProteinDB [0]", false},
+    {"best-per-position", 'B', "FASTA database: one line per matched window, its nearest centre (kmer_search) [0]", false},
 };
 
 // A points file has a line of numbers after its first name line; a FASTA file has residue letters.
@@ -170,7 +171,9 @@ int main(int argc, const char* argv[]) {
     const int st =
         fasta_db ? hsearch::SearchProteins(prodb, kmer_length, centers, center_names, hash_K, hash_L,
                                            hash_W, hash_R, val["output"], planes, device, &err,
-                                           &table_sizes, &n_windows)
+                                           &table_sizes, &n_windows,
+                                           val.count("best-per-position") &&
+                                               atoi(val["best-per-position"].c_str()) != 0)
                  : hsearch::Search(kmers, centers, kmer_names, center_names, hash_K, hash_L, hash_W,
                                    hash_R, val["output"], planes, device, &err, &table_sizes);
     if (fasta_db && st == 0) std::cout << "number of kmers " << n_windows << std::endl;

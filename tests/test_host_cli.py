@@ -196,6 +196,56 @@ def test_cli_fasta_database_matches_points_database(tmp_path, oracle):
 
 
 @pytest.mark.gpu
+def test_cli_best_centre_per_position(tmp_path, oracle):
+    """--best-per-position: kmer_search.cpp's `matches` (:90,113-121) -- per database window the
+    nearest centre, visited tables-outer / centres-inner, replaced only when strictly nearer --
+    replayed here over the oracle's hit list of the same windows."""
+    from hsearch_amd import synth
+    k, K, L, W, R, seed = 25, 2, 4, 150.0, 45.0, 33
+    rng = np.random.default_rng(15)
+    letters = "ARNDCQEGHILKMFPSTWYV"
+    base = "".join(letters[i] for i in rng.integers(0, 20, size=60))
+    seqs = []
+    for _ in range(12):                                    # near-copies: windows with many suitors
+        s_ = list(base)
+        for _ in range(3):
+            s_[rng.integers(0, len(s_))] = letters[rng.integers(0, 20)]
+        seqs.append("".join(s_))
+    fa = str(tmp_path / "db.fa")
+    with open(fa, "w") as f:
+        for i, s_ in enumerate(seqs):
+            f.write(">p%d\n%s\n" % (i, s_))
+    names, rows = [], []
+    for i, s_ in enumerate(seqs):
+        for j in range(len(s_) - k + 1):
+            names.append("p%d#%d$%d@%s*%d" % (i, i, j, s_[j:j + k], len(names)))
+            rows.append([letters.index(c) for c in s_[j:j + k]])
+    codes = np.array(rows, dtype=np.uint8)
+    pts = oracle.embed_codes(codes)
+    pick = rng.choice(len(pts), 30, replace=False)
+    centers = np.concatenate([pts[pick[:15]], pts[pick[:15]],                 # exact ties between centres
+                              pts[pick[15:]] + rng.normal(0, 0.3, size=(15, 8 * k))])
+    cen, out = str(tmp_path / "cen"), str(tmp_path / "out")
+    _write_points(cen, centers)
+    r = subprocess.run([_bin(), "-d", fa, "-c", cen, "-o", out, "-l", str(k), "-K", str(K), "-L", str(L),
+                        "-W", repr(W), "-T", repr(R), "--seed", str(seed), "--planes-out", out + ".planes",
+                        "--best-per-position", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    raw = np.fromfile(out + ".planes", dtype=np.float64)
+    a = raw[:L * K * 8 * k].reshape(L, K, 8 * k)
+    b = raw[L * K * 8 * k:].reshape(L, K)
+    res = oracle.search(a, b, W, R, pts, centers)
+    best = {}
+    for t in np.lexsort((res["q"], res["table"])):        # tables outer, centres inner
+        i, q, dist = int(res["id"][t]), int(res["q"][t]), float(res["dist"][t])
+        if i not in best or best[i][1] > dist:
+            best[i] = (q, dist)
+    want = "".join("%s p%d %g\n" % (names[i], best[i][0], best[i][1]) for i in sorted(best))
+    assert open(out).read() == want
+    assert len(best) > 100 and len(set(q for q, _ in best.values())) > 10
+
+
+@pytest.mark.gpu
 def test_pcluster_pregroup_cli_matches_oracle(tmp_path, oracle):
     """hs_pcluster_pregroup (pcluster.cpp:11-81 on the GPU) groups proteins
     exactly as the oracle's KLSH restatement (itself pinned to the reference's KLSH object)."""
