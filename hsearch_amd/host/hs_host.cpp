@@ -4,6 +4,7 @@
 
 #include <errno.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
 #include <sys/types.h>
@@ -15,6 +16,7 @@
 #include <random>
 #include <sstream>
 #include <unordered_map>
+#include <unordered_set>
 
 #include "../../include/hs_tables.h"
 #include "../../include/hsearch.h"
@@ -332,6 +334,52 @@ int SearchProteins(const ProteinDB& db, uint32_t kmer_length, const std::vector<
   }
   fout.close();
   return HS_OK;
+}
+
+int64_t Protein2Datapoints(const ProteinDB& db, uint32_t kmer_length, uint32_t num_of_protein_out,
+                           const std::string& output_file, uint32_t seed) {
+  std::ofstream fout(output_file.c_str());
+  if (!fout) return -1;
+  const size_t n_seq = db.start.empty() ? 0 : db.start.size() - 1;
+  const char* letters = HS_CODE_TO_LETTER;
+  std::unordered_set<std::string> seen;
+  int64_t cnt = 0;
+  srand(seed);
+  for (size_t i = 0; i < n_seq; ++i) {
+    if (i >= num_of_protein_out) break;  // :42
+    const uint64_t len = db.start[i + 1] - db.start[i];
+    if (len < kmer_length) continue;
+    std::string name;
+    if (i < db.name.size()) {
+      std::istringstream iss(db.name[i]);  // :62-64
+      iss >> name;
+    }
+    for (uint64_t j = 0; j + kmer_length <= len;) {
+      const uint64_t pos = db.start[i] + j;
+      std::string kmer(kmer_length, '?');
+      bool known = true;
+      for (uint32_t p = 0; p < kmer_length; ++p) {
+        const uint8_t row = db.residues[pos + p];
+        if (row == ProteinDB::kUnknown) known = false;
+        else kmer[p] = letters[row];
+      }
+      if (!known || seen.find(kmer) != seen.end()) {  // :49-53
+        j += 30 + rand() % 20;
+        continue;
+      }
+      seen.insert(kmer);
+      fout << name << "#" << i << "$" << j << "@" << kmer << "*" << cnt << std::endl;  // :65
+      for (uint32_t p = 0; p < kmer_length; ++p)                                        // :22-28
+        for (uint32_t c = 0; c < 8; ++c) {
+          if (p || c) fout << " ";
+          fout << HS_AA_COORDS[db.residues[pos + p]][c];
+        }
+      fout << std::endl;
+      ++cnt;
+      j += 30 + rand() % 20;  // :70-71
+    }
+  }
+  return cnt;
 }
 
 bool ReadPclusterFasta(const std::string& path, uint32_t unknown_seed, PclusterDB* db) {

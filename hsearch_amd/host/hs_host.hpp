@@ -95,6 +95,18 @@ int SearchProteins(const ProteinDB& db, uint32_t kmer_length, const std::vector<
 // observable and is computed from mis-hashed windows, kmer_search.cpp:73-80 reads one residue k
 // times; this is the intended reduction over the pinned hit list -- parity unpinned.)
 
+// Protein2Datapoints() (protein2datapoints.cpp:33-78): the sampler that makes the `-d` points file
+// of motif_both_points from a FASTA database -- for each of the first num_of_protein_out
+// sequences, windows at offsets 0, then +30..49 (30 + rand() % 20) further each time; a window seen
+// before is skipped (same stride draw); each new one is written as the name line
+// "<first token of the protein name>#<sequence>$<offset>@<letters>*<count>" and the embedding at
+// the stream's default precision.  rand() is seeded with `seed` (the reference: time(NULL)).
+// Sequences shorter than k are skipped (the reference's unsigned `length - k` wraps, :44) and so
+// are windows with a letter outside the alphabet (the reference draws a random residue instead,
+// protein.hpp:58-61).  Returns the number of points written, -1 if the file cannot be written.
+int64_t Protein2Datapoints(const ProteinDB& db, uint32_t kmer_length, uint32_t num_of_protein_out,
+                           const std::string& output_file, uint32_t seed);
+
 // ---- Kernel-LSH pre-grouping of whole proteins (pcluster.cpp:11-81) ---------
 // pcluster's FASTA reader (read_proteins.cpp:6-41): '>' lines start a protein, its name is the
 // text up to the first space, the following lines are concatenated; letters of the 20-letter

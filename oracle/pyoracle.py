@@ -490,3 +490,10 @@ def ref_cluster2datapoint(k, names, family_seqs, out_prefix):
     flat = [s_ for f in family_seqs for s_ in f]
     return int(lib_.refc_cluster2datapoint(C.c_uint32(k), C.c_uint32(len(names)), _cstrs(names),
                                            _ptr(first, _u32p), _cstrs(flat), out_prefix.encode()))
+
+
+def ref_protein2datapoints(fasta_path, k, num_out, out_path, seed):
+    """The real `protein2datapoints` main() with rand() seeded by `seed` (oracle/_ref/libref_p2d.so)."""
+    lib_ = C.CDLL(os.path.join(_HERE, "_ref", "libref_p2d.so"))
+    return int(lib_.refp_main(fasta_path.encode(), C.c_uint32(k), C.c_uint32(num_out), out_path.encode(),
+                              C.c_uint32(seed)))

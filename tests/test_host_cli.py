@@ -389,3 +389,55 @@ def test_center_distance_sampling_cli_matches_reference_golden(tmp_path, golden_
     assert rand.split("\n")[:8] == t["random_head"] and rand.split("\n")[-9:-1] == t["random_tail"]
     assert rand.count("\n") == t["random_lines"]
     assert hashlib.sha256(rand.encode()).hexdigest() == t["random_sha256"]
+
+
+def test_protein2datapoints_cli_matches_reference_golden(tmp_path, golden_dir):
+    """protein2datapoints (FASTA -> sampled k-mers as a points file): names, E <-> Q exchange,
+    skipping of windows already seen and the embedding text, identical to what the compiled
+    reference's own main() wrote under the same rand() seed; host only."""
+    import hashlib
+    t = json.load(open(os.path.join(golden_dir, "tools.json")))["protein2datapoints"]
+    fa, out = str(tmp_path / "p.fa"), str(tmp_path / "p.points")
+    open(fa, "w").write(t["fasta"])
+    for case in t["cases"]:
+        r = subprocess.run([_tool("hs_protein2datapoints"), "-d", fa, "-l", str(t["k"]), "-n",
+                            str(case["num_out"]), "-o", out, "-s", str(case["seed"])],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert "number of proteins 9" in r.stdout
+        text = open(out).read()
+        assert text.split("\n")[0::2][:-1] == case["names"]
+        assert text.split("\n")[1] == case["first_point"]
+        assert hashlib.sha256(text.encode()).hexdigest() == case["sha256"]
+    # the points file feeds the search programs: every record parses back to its k-mer
+    lines = open(out).read().split("\n")
+    assert all(len(lines[2 * i + 1].split()) == 8 * t["k"] for i in range(len(t["cases"][-1]["names"])))
+    # -Q 0: the correct embedding; an input E keeps its letter
+    r = subprocess.run([_tool("hs_protein2datapoints"), "-d", fa, "-l", str(t["k"]), "-n", "1", "-o", out,
+                        "-s", "1", "-Q", "0"], capture_output=True, text=True)
+    assert r.returncode == 0
+    first = t["fasta"].strip().split("\n")[1][:t["k"]]
+    assert open(out).read().split("\n")[0] == "sp|P00000|N0_X#0$0@%s*0" % first
+    r = subprocess.run([_tool("hs_protein2datapoints"), "-d", fa], capture_output=True, text=True)
+    assert r.returncode == 0 and "missing required option" in r.stderr
+
+
+def test_protein2datapoints_cli_matches_live_reference(tmp_path):
+    from oracle import pyoracle as O
+    if not os.path.exists(os.path.join(os.path.dirname(O.__file__), "_ref", "libref_p2d.so")):
+        pytest.skip("oracle/_ref/libref_p2d.so not built")
+    rng = np.random.default_rng(12)
+    letters = "ARNDCQEGHILKMFPSTWYV"
+    seqs = ["".join(letters[c] for c in rng.integers(0, 20, size=int(n))) for n in rng.integers(25, 700, size=25)]
+    seqs[7] = seqs[2]
+    fa = str(tmp_path / "db.fa")
+    with open(fa, "w") as f:
+        for i, s_ in enumerate(seqs):
+            f.write(">prot%d\n%s\n\n" % (i, s_))
+    for seed, k, n in [(1, 25, 25), (2, 25, 3), (3, 9, 100)]:
+        ref, mine = str(tmp_path / "ref.points"), str(tmp_path / "mine.points")
+        assert O.ref_protein2datapoints(fa, k, n, ref, seed) == 0
+        r = subprocess.run([_tool("hs_protein2datapoints"), "-d", fa, "-l", str(k), "-n", str(n), "-o", mine,
+                            "-s", str(seed)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert open(ref).read() == open(mine).read() and os.path.getsize(ref) > 0

@@ -248,6 +248,21 @@ def gen_tools():
                               "random_sha256": sha(rand), "random_lines": rand.count("\n"),
                               "random_head": rand.split("\n")[:8], "random_tail": rand.split("\n")[-9:-1]}
     np.savez_compressed(os.path.join(OUT, "tools_centers.npz"), codes=codes3)
+    # -- protein2datapoints: its own main(), rand() seeded (the one seam of ref_p2d_harness.cpp)
+    lens = [int(x) for x in g.integers(15, 400, size=9)]
+    prots = ["".join(LETTERS[c] for c in g.integers(0, 20, size=n)) for n in lens]
+    prots[4] = prots[1]                      # a repeated protein: windows already seen are skipped
+    prots[6] = prots[6][:15]                 # exactly one window
+    fasta = "\n" + "".join(">sp|P%05d|N%d_X text %d\n%s\n" % (i, i, i, p) for i, p in enumerate(prots))
+    open(os.path.join(d, "p.fa"), "w").write(fasta)
+    cases = []
+    for seed, n_out in ((2026, 9), (5, 4)):
+        assert O.ref_protein2datapoints(os.path.join(d, "p.fa"), 15, n_out, os.path.join(d, "p.points"), seed) == 0
+        text = open(os.path.join(d, "p.points")).read()
+        cases.append({"seed": seed, "num_out": n_out, "sha256": sha(text), "names": text.split("\n")[0::2][:-1],
+                      "first_point": text.split("\n")[1]})
+    out["protein2datapoints"] = {"k": 15, "fasta": fasta, "cases": cases,
+                                 "note": "window strides are 30 + rand() % 20 of glibc's rand() after srand(seed)"}
     json.dump(out, open(os.path.join(OUT, "tools.json"), "w"))
 
 
