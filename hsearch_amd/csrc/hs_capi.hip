@@ -69,6 +69,7 @@ struct hs_handle {
   uint32_t key_seed = 0;
   DevBuf codes, packed_all;
   DevBuf t_dirkey[HS_MAX_L], t_dirstart[HS_MAX_L], t_dirtuple[HS_MAX_L], t_ids[HS_MAX_L];
+  DevBuf t_dirjump[HS_MAX_L];
   // bucket-ordered packed copies of all tables in ONE allocation ([L][n][PW]), and the int8 join's
   // per-entry records ([L][n], k <= 25 only) at the same entry offsets
   DevBuf t_packed, t_rec8;
@@ -290,6 +291,7 @@ void hs_destroy(hs_handle* h) {
   for (DevBuf* bf : bufs) bf->release();
   for (int l = 0; l < HS_MAX_L; ++l) {
     h->t_dirkey[l].release();
+    h->t_dirjump[l].release();
     h->t_dirstart[l].release();
     h->t_dirtuple[l].release();
     h->t_ids[l].release();
@@ -539,9 +541,22 @@ static hs_status finish_index(hs_handle* h) {
     HS_HIP(h, h->dir_base.reserve((HS_MAX_L + 1) * 4));
     HS_HIP(h, hipMemcpy(h->dir_base.p, base, ((size_t)h->p.L + 1) * 4, hipMemcpyHostToDevice));
   }
+  // jump tables of the directories: the top J bits of a fingerprint (2^J >= number of buckets)
+  for (uint32_t l = 0; l < h->p.L; ++l) {
+    const uint32_t nb = (uint32_t)h->info.n_buckets[l];
+    const uint32_t J = (uint32_t)std::max(1, bit_width_u32(nb));
+    const uint32_t n_slots = 1u << J;
+    HS_HIP(h, h->t_dirjump[l].reserve(((size_t)n_slots + 2) * 4));
+    HS_HIP(h, hs_launch_dir_jump(h->t_dirkey[l].as<uint64_t>(), nb, 64 - J, n_slots,
+                                 h->t_dirjump[l].as<uint32_t>(), h->stream));
+    h->tabs.t[l].dir_jump = h->t_dirjump[l].as<uint32_t>();
+    h->tabs.t[l].jump_shift = 64 - J;
+  }
+  HS_HIP(h, hipStreamSynchronize(h->stream));
   uint64_t bytes = h->codes.cap + h->packed_all.cap + h->t_packed.cap + h->t_rec8.cap + h->t_pos.cap;
   for (uint32_t l = 0; l < h->p.L; ++l)
-    bytes += h->t_dirkey[l].cap + h->t_dirstart[l].cap + h->t_dirtuple[l].cap + h->t_ids[l].cap;
+    bytes += h->t_dirkey[l].cap + h->t_dirstart[l].cap + h->t_dirtuple[l].cap + h->t_ids[l].cap +
+             h->t_dirjump[l].cap;
   h->info.device_bytes = bytes;
   h->built = true;
   return HS_OK;

@@ -114,8 +114,9 @@ struct hs_table_dev {
   const uint4* packed;       // [n][PW] 5-bit packed residue codes in bucket order
   const uint32_t* ids;       // [n] DB ids in bucket order (ascending inside a bucket)
   const uint32_t* pos_of;    // [n] inverse of ids: sorted position of DB id i in this table
+  const uint32_t* dir_jump;  // [2^J + 1] first directory entry whose fingerprint's top J bits are >= the slot
   uint32_t nb;
-  uint32_t pad_;
+  uint32_t jump_shift;       // 64 - J
 };
 struct hs_tables_dev {
   hs_table_dev t[HS_MAX_L];
@@ -185,6 +186,9 @@ hipError_t hs_launch_klsh(const uint8_t* d_classes, const uint64_t* d_seq_start,
                           uint64_t* d_codes, uint64_t* d_uncertain, hipStream_t s);
 // d_out[d_perm[i]] = i
 hipError_t hs_launch_invert_perm(const uint32_t* d_perm, uint32_t n, uint32_t* d_out, hipStream_t s);
+// jump[t] = first directory entry with (key >> shift) >= t, t = 0 .. n_slots (jump[n_slots] = nb)
+hipError_t hs_launch_dir_jump(const uint64_t* d_dir_key, uint32_t nb, uint32_t shift, uint32_t n_slots,
+                              uint32_t* d_jump, hipStream_t s);
 hipError_t hs_launch_max_u32(const uint32_t* d_in, uint32_t n, uint32_t* d_out, hipStream_t s);
 
 hipError_t hs_launch_probe(const hs_tables_dev& tabs, const int32_t* d_qints, uint32_t nq, int K,

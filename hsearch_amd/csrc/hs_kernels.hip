@@ -354,7 +354,10 @@ __global__ __launch_bounds__(256) void hs_probe_kernel(hs_tables_dev tabs,
     for (int j = 0; j < K; ++j) hk = hs_key_put_int(hk, t[256 * j]);
     const uint64_t key = hs_key_fin(hk);
     const hs_table_dev& tb = tabs.t[l];
-    uint32_t lo = 0, hi = tb.nb;
+    // fingerprints are uniform: their top J bits (2^J >= nb) index a jump table that leaves about
+    // one directory entry to look at, instead of log2(nb) dependent round trips
+    const uint32_t slot = (uint32_t)(key >> tb.jump_shift);
+    uint32_t lo = tb.dir_jump[slot], hi = tb.dir_jump[slot + 1];
     while (lo < hi) {
       const uint32_t mid = (lo + hi) >> 1;
       if (tb.dir_key[mid] < key) lo = mid + 1; else hi = mid;
@@ -874,6 +877,18 @@ __global__ __launch_bounds__(256) void hs_klsh_kernel(const uint8_t* __restrict_
   }
 }
 
+// Jump table over the sorted directory fingerprints: entry i fills the slots after its
+// predecessor's up to its own; entry nb (one past the end) fills the rest.
+__global__ __launch_bounds__(256) void hs_dir_jump_kernel(const uint64_t* __restrict__ key, uint32_t nb,
+                                                          uint32_t shift, uint32_t n_slots,
+                                                          uint32_t* __restrict__ jump) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i > nb) return;
+  const uint32_t cur = i < nb ? (uint32_t)(key[i] >> shift) : n_slots;
+  const uint32_t first = i ? (uint32_t)(key[i - 1] >> shift) + 1 : 0;
+  for (uint32_t t = first; t <= cur; ++t) jump[t] = (uint32_t)i;
+}
+
 __global__ __launch_bounds__(256) void hs_invert_perm_kernel(const uint32_t* __restrict__ perm,
                                                              uint32_t n, uint32_t* __restrict__ out) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -1145,6 +1160,12 @@ hipError_t hs_launch_klsh(const uint8_t* d_classes, const uint64_t* d_seq_start,
   const unsigned blocks = (unsigned)std::min<uint64_t>((n_seq + 3) / 4, 1u << 16);
   hs_klsh_kernel<<<blocks, 256, 0, s>>>(d_classes, d_seq_start, n_seq, d_w, d_b, d_t, bits, d_codes,
                                         d_uncertain);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_dir_jump(const uint64_t* d_dir_key, uint32_t nb, uint32_t shift, uint32_t n_slots,
+                              uint32_t* d_jump, hipStream_t s) {
+  hs_dir_jump_kernel<<<blocks_for((uint64_t)nb + 1), 256, 0, s>>>(d_dir_key, nb, shift, n_slots, d_jump);
   return hipGetLastError();
 }
 
