@@ -413,16 +413,48 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
   const uint64_t n = h->n;
   const int K = (int)h->p.K, L = (int)h->p.L, k = (int)h->p.k, PW = h->PW;
   *collided = false;
-  // scratch shared by all tables
-  DevBuf ints, keys, keys_sorted, iota, rle_unique, rle_counts, small, sort_temp, slow_q;
+  // scratch shared by all tables.  Hashing (fp64 vector ALU) and grouping (radix sort: memory) of
+  // consecutive tables overlap: table l + 1 is hashed on the side stream into the other half of
+  // the double-buffered ints / keys / iota while table l is sorted on the main stream.
+  DevBuf ints2[2], keys2[2], iota2[2], keys_sorted, rle_unique, rle_counts, small, sort_temp, slow_q;
+  hipEvent_t ev_hashed[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_t[4] = {};
+  // The hash runs on the handle's side stream (lowest priority: the sort's many small kernels get
+  // the CUs they ask for, the hash fills the rest).  Measured at 10 M x 8 tables, repeated builds:
+  // 44 ms without the overlap, 40 ms with it (the sort slows from 20 to 27 ms beside the hash); a
+  // normal-priority stream gave 44 ms; a CU-masked stream (hipExtStreamCreateWithCUMask) reserving
+  // a quarter of the CUs for the sort hung in the second build of a process and was dropped.
+  hipStream_t hash_stream = h->stream2;
+  const bool own_hash_stream = false;
+  const bool serial = getenv("HS_BUILD_SERIAL") != nullptr;  // measurement: no overlap
   struct Guard {
-    DevBuf* b[9];
-    ~Guard() { for (DevBuf* x : b) x->release(); }
-  } guard = {{&ints, &keys, &keys_sorted, &iota, &rle_unique, &rle_counts, &small, &sort_temp, &slow_q}};
-  HS_HIP(h, ints.reserve(std::max<size_t>(16, (size_t)n * K * 4)));
-  HS_HIP(h, keys.reserve(std::max<size_t>(16, (size_t)n * 8)));
+    hs_handle* h;
+    hipStream_t* hs;
+    bool own;
+    hipEvent_t* e[3];
+    int ne[3];
+    DevBuf* b[12];
+    ~Guard() {
+      // nothing may still be running on either stream when the scratch goes away
+      if (*hs) (void)hipStreamSynchronize(*hs);
+      (void)hipStreamSynchronize(h->stream);
+      if (*hs && own) (void)hipStreamDestroy(*hs);
+      for (int g = 0; g < 3; ++g)
+        for (int i = 0; i < ne[g]; ++i)
+          if (e[g][i]) (void)hipEventDestroy(e[g][i]);
+      for (DevBuf* x : b) x->release();
+    }
+  } guard = {h, &hash_stream, own_hash_stream, {ev_hashed, ev_free, ev_t}, {2, 2, 4},
+             {&ints2[0], &ints2[1], &keys2[0], &keys2[1], &iota2[0], &iota2[1], &keys_sorted, &rle_unique,
+              &rle_counts, &small, &sort_temp, &slow_q}};
+  for (int i = 0; i < 2; ++i) {
+    HS_HIP(h, hipEventCreateWithFlags(&ev_hashed[i], hipEventDisableTiming));
+    HS_HIP(h, hipEventCreateWithFlags(&ev_free[i], hipEventDisableTiming));
+    HS_HIP(h, ints2[i].reserve(std::max<size_t>(16, (size_t)n * K * 4)));
+    HS_HIP(h, keys2[i].reserve(std::max<size_t>(16, (size_t)n * 8)));
+    HS_HIP(h, iota2[i].reserve(std::max<size_t>(16, (size_t)n * 4)));
+  }
+  for (int i = 0; i < 4; ++i) HS_HIP(h, hipEventCreate(&ev_t[i]));  // hash start/end per buffer
   HS_HIP(h, keys_sorted.reserve(std::max<size_t>(16, (size_t)n * 8)));
-  HS_HIP(h, iota.reserve(std::max<size_t>(16, (size_t)n * 4)));
   HS_HIP(h, rle_unique.reserve(std::max<size_t>(16, (size_t)n * 8)));
   HS_HIP(h, rle_counts.reserve(std::max<size_t>(16, (size_t)n * 4)));
   HS_HIP(h, small.reserve(64));  // [0]=runs [1]=collision flag [2]=max count
@@ -435,16 +467,34 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
   HS_HIP(h, h->t_packed.reserve(std::max<size_t>(16, (size_t)L * n * PW * 16)));
   if (with_rec8) HS_HIP(h, h->t_rec8.reserve(std::max<size_t>(16, (size_t)L * n * 16)));
   HS_HIP(h, h->t_pos.reserve(std::max<size_t>(16, (size_t)L * n * 4)));
+  // hash + fingerprints of table t into buffer t & 1, on the side stream
+  auto hash_table = [&](int t) -> hs_status {
+    const int u = t & 1;
+    if (t >= 2) HS_HIP(h, hipStreamWaitEvent(hash_stream, ev_free[u], 0));  // table t - 2 is done with it
+    HS_HIP(h, hipEventRecord(ev_t[2 * u], hash_stream));
+    HS_HIP(h, hs_launch_hash_codes(h->codes.as<uint8_t>(), n, k, h->aT.as<double>() + (size_t)t * K, h->LK,
+                                   h->b.as<double>() + (size_t)t * K, K, h->p.W, h->coords.as<double>(),
+                                   ints2[u].as<int32_t>(), K, hash_stream));
+    HS_HIP(h, hs_launch_keys(ints2[u].as<int32_t>(), n, K, K, seed, keys2[u].as<uint64_t>(),
+                             iota2[u].as<uint32_t>(), hash_stream));
+    HS_HIP(h, hipEventRecord(ev_t[2 * u + 1], hash_stream));
+    HS_HIP(h, hipEventRecord(ev_hashed[u], hash_stream));
+    return HS_OK;
+  };
+  {  // the side stream starts after everything queued so far (codes, packing, planes)
+    HS_HIP(h, hipEventRecord(h->evx[EV_FORK], h->stream));
+    HS_HIP(h, hipStreamWaitEvent(hash_stream, h->evx[EV_FORK], 0));
+    HS_CHECK(hash_table(0));
+  }
   for (int l = 0; l < L; ++l) {
     uint4* const tab_packed = h->t_packed.as<uint4>() + (size_t)l * n * PW;
+    DevBuf& ints = ints2[l & 1];
+    DevBuf& keys = keys2[l & 1];
+    DevBuf& iota = iota2[l & 1];
     HS_HIP(h, h->t_ids[l].reserve(std::max<size_t>(16, (size_t)n * 4)));
     HS_HIP(h, hipMemsetAsync(d_small, 0, 64, h->stream));
-    HS_HIP(h, hipEventRecord(h->ev[0], h->stream));
-    HS_HIP(h, hs_launch_hash_codes(h->codes.as<uint8_t>(), n, k, h->aT.as<double>() + (size_t)l * K, h->LK,
-                                   h->b.as<double>() + (size_t)l * K, K, h->p.W, h->coords.as<double>(),
-                                   ints.as<int32_t>(), K, h->stream));
-    HS_HIP(h, hs_launch_keys(ints.as<int32_t>(), n, K, K, seed, keys.as<uint64_t>(),
-                             iota.as<uint32_t>(), h->stream));
+    if (l + 1 < L && !serial) HS_CHECK(hash_table(l + 1));  // runs beside this table's sort
+    HS_HIP(h, hipStreamWaitEvent(h->stream, ev_hashed[l & 1], 0));
     HS_HIP(h, hipEventRecord(h->ev[1], h->stream));
     uint32_t nb = 0, flag = 0, max_count = 0;
     if (n) {
@@ -491,6 +541,7 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
     HS_HIP(h, hs_launch_dir_tuples(h->t_dirstart[l].as<uint32_t>(), h->t_ids[l].as<uint32_t>(),
                                    ints.as<int32_t>(), nb, K, h->t_dirtuple[l].as<int32_t>(),
                                    h->stream));
+    HS_HIP(h, hipEventRecord(ev_free[l & 1], h->stream));  // ints / keys / iota of this table are free
     HS_HIP(h, hipEventRecord(h->ev[2], h->stream));
     if (with_rec8)
       HS_HIP(h, hs_launch_gather_rec8(h->packed_all.as<uint4>(), h->t_ids[l].as<uint32_t>(), (uint32_t)n,
@@ -504,7 +555,11 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
     HS_HIP(h, hipEventRecord(h->ev[3], h->stream));
     HS_HIP(h, hipMemcpyAsync(&max_count, d_small + 2, 4, hipMemcpyDeviceToHost, h->stream));
     HS_HIP(h, hipStreamSynchronize(h->stream));
-    ms_hash += ev_ms(h, 0, 1);
+    if (l + 1 < L && serial) HS_CHECK(hash_table(l + 1));
+    {
+      float ms = 0.f;  // the hash ran on the side stream, possibly beside the previous table's sort
+      if (hipEventElapsedTime(&ms, ev_t[2 * (l & 1)], ev_t[2 * (l & 1) + 1]) == hipSuccess) ms_hash += ms;
+    }
     ms_sort += ev_ms(h, 1, 2);
     ms_gather += ev_ms(h, 2, 3);
     hs_table_dev& tb = h->tabs.t[l];
