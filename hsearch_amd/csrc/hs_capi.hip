@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -38,6 +39,30 @@ struct DevBuf {
   }
   void release() {
     if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// host staging kept across calls (pageable: page-locking 40 MB took longer than a whole
+// Clustering() of 10^6 k-mers; what is saved is the fresh allocation + page faults per call)
+struct HostBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    free(p);
+    cap = 0;
+    p = malloc(bytes);
+    if (!p) return hipErrorOutOfMemory;
+    memset(p, 0, bytes);  // touch the pages here: a device -> host copy into untouched pages crawls
+    cap = bytes;
+    return hipSuccess;
+  }
+  void release() {
+    free(p);
     p = nullptr;
     cap = 0;
   }
@@ -82,6 +107,7 @@ struct hs_handle {
   // query workspace (grown on demand, reused across calls)
   DevBuf qints, qstart, qcount, nslices, slice_off, tq, prov, hit_key, hit_val, hit_key2, hit_val2,
       counters, temp, io_centers, io_q, io_id, io_table, io_dist, io_cand, io_codes, io_misc;
+  HostBuf sj_host;  // hs_self_join_range: hits of one chunk on their way to the edge lists
   // bucket-join workspace
   DevBuf c16s, item_desc, probe_slow, jtab8;
   bool join8_tables_ok = false;  // int8 can carry the coordinate table
@@ -289,6 +315,7 @@ void hs_destroy(hs_handle* h) {
                     &h->probe_slow, &h->jtab8, &h->t_packed, &h->t_rec8, &h->t_pos, &h->dir_base,
                     &h->bucket_work};
   for (DevBuf* bf : bufs) bf->release();
+  h->sj_host.release();
   for (int l = 0; l < HS_MAX_L; ++l) {
     h->t_dirkey[l].release();
     h->t_dirjump[l].release();
@@ -1235,7 +1262,9 @@ static hs_status run_query(hs_handle* h, const double* d_centers, uint64_t nq, d
   HS_HIP(h, hipEventRecord(h->ev[8], h->stream));
   uint64_t total = 0;
   if (nq && h->n && !(brute && R < 0)) {
-    const uint32_t QB = 1u << 17;  // queries per batch: bounds the workspace
+    // queries per batch: bounds the workspace, which grows with nq * L (2^17 at L >= 8; with few
+    // tables -- the one-table indexes of Clustering() -- larger batches, fewer fixed costs)
+    const uint32_t QB = std::max(1u << 17, std::min(1u << 20, (1u << 20) / h->p.L));
     for (uint64_t q0 = 0; q0 < nq; q0 += QB) {
       const uint32_t nqb = (uint32_t)std::min<uint64_t>(QB, nq - q0);
       uint32_t nh = 0;
@@ -1344,20 +1373,26 @@ hs_status hs_self_join_range(hs_handle* h, uint64_t first, uint64_t count, doubl
   if (st) return st;
   if (first > h->n || count > h->n - first) return fail(h, HS_ERR_INVALID, "range outside the indexed k-mers");
   const uint64_t n = first + count;
-  const uint32_t CH = 1u << 18;  // queries embedded per chunk (8k doubles each)
+  const uint32_t CH = 1u << 20;  // queries embedded per chunk (8k doubles each): whole batches of run_query
   uint64_t total = 0;
-  std::vector<uint32_t> hq, hid, ht;
-  std::vector<double> hd;
   hs_profile acc;
   memset(&acc, 0, sizeof(acc));
-  DevBuf centers, dq, did, dt, dd;
-  struct Guard {
-    DevBuf* b[5];
-    ~Guard() { for (DevBuf* x : b) x->release(); }
-  } guard = {{&centers, &dq, &did, &dt, &dd}};
+  // the handle's I/O buffers (host-pointer queries use them the same way) and a pinned staging
+  // area: Clustering() calls this once per table, reallocating 1.6 GB of centres and faulting in
+  // fresh host vectors every time cost more than the join itself
+  DevBuf &centers = h->io_centers, &dq = h->io_q, &did = h->io_id, &dt = h->io_table, &dd = h->io_dist;
+  const bool sj_timing = getenv("HS_CLUSTER_TIMING") != nullptr;
+  auto sj_t0 = std::chrono::steady_clock::now();
+  auto sj_lap = [&](const char* what) {
+    if (!sj_timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "    sj %-10s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - sj_t0).count());
+    sj_t0 = now;
+  };
   for (uint64_t q0 = first; q0 < n; q0 += CH) {
     const uint64_t nq = std::min<uint64_t>(CH, n - q0);
     HS_HIP(h, centers.reserve((size_t)nq * h->d * 8));
+    sj_lap("centers");
     HS_HIP(h, hs_launch_embed(h->codes.as<uint8_t>() + q0 * h->p.k, nq, (int)h->p.k,
                               h->coords.as<double>(), centers.as<double>(), h->stream));
     uint64_t hcap = std::max<uint64_t>(dq.cap / 4, 4 * nq + 1024), nh = 0;
@@ -1377,20 +1412,27 @@ hs_status hs_self_join_range(hs_handle* h, uint64_t first, uint64_t count, doubl
       break;
     }
     if (st != HS_OK) return st;
+    sj_lap("run_query");
     acc.ms_hash += h->prof.ms_hash; acc.ms_probe += h->prof.ms_probe; acc.ms_verify += h->prof.ms_verify;
     acc.ms_join += h->prof.ms_join; acc.ms_finalize += h->prof.ms_finalize; acc.ms_total += h->prof.ms_total;
     acc.candidates += h->prof.candidates; acc.provisional += h->prof.provisional;
     acc.join_pairs += h->prof.join_pairs; acc.join_pairs_issued += h->prof.join_pairs_issued;
     acc.join_items += h->prof.join_items; acc.join_batches += h->prof.join_batches;
     acc.verify_launches += h->prof.verify_launches;
-    hq.resize(nh); hid.resize(nh); ht.resize(nh); hd.resize(nh);
+    HS_HIP(h, h->sj_host.reserve(std::max<size_t>(64, (nh + nh / 8 + 1024) * 20)));
+    sj_lap("host buf");
+    double* const hd = h->sj_host.as<double>();                       // [nh] doubles first: aligned
+    uint32_t* const hq = reinterpret_cast<uint32_t*>(hd + nh);
+    uint32_t* const hid = hq + nh;
+    uint32_t* const ht = hid + nh;
     if (nh) {
-      HS_HIP(h, hipMemcpyAsync(hq.data(), dq.p, nh * 4, hipMemcpyDeviceToHost, h->stream));
-      HS_HIP(h, hipMemcpyAsync(hid.data(), did.p, nh * 4, hipMemcpyDeviceToHost, h->stream));
-      HS_HIP(h, hipMemcpyAsync(ht.data(), dt.p, nh * 4, hipMemcpyDeviceToHost, h->stream));
-      HS_HIP(h, hipMemcpyAsync(hd.data(), dd.p, nh * 8, hipMemcpyDeviceToHost, h->stream));
+      HS_HIP(h, hipMemcpyAsync(hd, dd.p, nh * 8, hipMemcpyDeviceToHost, h->stream));
+      HS_HIP(h, hipMemcpyAsync(hq, dq.p, nh * 4, hipMemcpyDeviceToHost, h->stream));
+      HS_HIP(h, hipMemcpyAsync(hid, did.p, nh * 4, hipMemcpyDeviceToHost, h->stream));
+      HS_HIP(h, hipMemcpyAsync(ht, dt.p, nh * 4, hipMemcpyDeviceToHost, h->stream));
       HS_HIP(h, hipStreamSynchronize(h->stream));
     }
+    sj_lap("d2h");
     for (uint64_t e = 0; e < nh; ++e) {
       const uint64_t i = q0 + hq[e];
       if (i == hid[e]) continue;  // a k-mer is in its own bucket at distance 0

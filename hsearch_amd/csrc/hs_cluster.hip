@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -49,6 +50,19 @@ struct hs_cluster_state {
 };
 
 namespace {
+
+// HS_CLUSTER_TIMING=1: per-phase wall time of every table on stderr
+struct PhaseTimer {
+  bool on;
+  std::chrono::steady_clock::time_point t;
+  PhaseTimer() : on(getenv("HS_CLUSTER_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+  void lap(const char* what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "  %-12s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+    t = now;
+  }
+};
 
 // BuildLSHTalbe (hclust2.cpp:74-84): every k-mer with merged != 2, ascending id
 void start_table(hs_cluster_state* st, uint32_t l) {
@@ -98,7 +112,9 @@ extern "C" hs_status hs_clustering_table_edges(hs_cluster_state* st, uint32_t l,
   if (!st || !n_edges || !world || rank >= world || l >= st->params.L) return HS_ERR_INVALID;
   if (cap && (!edge_i || !edge_j)) return HS_ERR_INVALID;
   *n_edges = 0;
+  PhaseTimer pt;
   start_table(st, l);
+  pt.lap("active list");
   const uint32_t k = st->params.k, K = st->params.K;
   const size_t d = 8 * (size_t)k, na = st->active.size();
   const double* a_l = st->a.data() + (size_t)l * K * d;  // a fresh family per table (hclust2.cpp:104)
@@ -119,15 +135,18 @@ extern "C" hs_status hs_clustering_table_edges(hs_cluster_state* st, uint32_t l,
   hs_handle* h = st->h;
   if (st->built_table != l) {  // a capacity retry of the same table finds its index still there
     st->built_table = 0xffffffffu;
-    st->act_codes.resize(na * (size_t)k);
-    if (na == st->n) {
-      memcpy(st->act_codes.data(), st->codes, na * (size_t)k);
-    } else {
+    const uint8_t* act = st->codes;  // nothing absorbed yet: the caller's array as it is
+    if (na != st->n) {
+      st->act_codes.resize(na * (size_t)k);
       for (size_t t = 0; t < na; ++t)
         memcpy(&st->act_codes[t * k], st->codes + (size_t)st->active[t] * k, k);
+      act = st->act_codes.data();
     }
+    pt.lap("gather codes");
     rc = hs_set_planes(h, a_l, b_l);
-    if (rc == HS_OK) rc = hs_index_build(h, st->act_codes.data(), na);
+    pt.lap("set planes");
+    if (rc == HS_OK) rc = hs_index_build(h, act, na);
+    pt.lap("index build");
     if (rc == HS_OK) st->built_table = l;
   }
   uint64_t ne = 0;
@@ -140,6 +159,7 @@ extern "C" hs_status hs_clustering_table_edges(hs_cluster_state* st, uint32_t l,
   }
   if (rc != HS_OK && rc != HS_ERR_CAPACITY)
     set_err(err, err_cap, std::string("table ") + std::to_string(l) + ": " + hs_last_error(h));
+  pt.lap("self join");
   *n_edges = ne;
   if (rc == HS_OK)  // active numbering -> original k-mer numbers
     for (uint64_t e = 0; e < ne; ++e) {
@@ -152,6 +172,7 @@ extern "C" hs_status hs_clustering_table_edges(hs_cluster_state* st, uint32_t l,
 extern "C" hs_status hs_clustering_table_apply(hs_cluster_state* st, uint32_t l, const uint32_t* edge_i,
                                                const uint32_t* edge_j, uint64_t n_edges) {
   if (!st || l >= st->params.L || (n_edges && (!edge_i || !edge_j))) return HS_ERR_INVALID;
+  PhaseTimer pt;
   start_table(st, l);
   const uint64_t n = st->n;
   // edges in (i, j) order: the greedy pass walks the active k-mers in ascending id, each with its
@@ -161,7 +182,8 @@ extern "C" hs_status hs_clustering_table_apply(hs_cluster_state* st, uint32_t l,
     if (edge_i[e] >= n || edge_j[e] >= n) return HS_ERR_INVALID;
     es[e] = ((uint64_t)edge_i[e] << 32) | edge_j[e];
   }
-  std::sort(es.begin(), es.end());
+  // one rank's list arrives in (i, j) order already, and so does the rank-ordered concatenation
+  if (!std::is_sorted(es.begin(), es.end())) std::sort(es.begin(), es.end());
   std::vector<uint8_t>& merged = st->merged;
   std::vector<uint8_t> pre(n, 0), pushed(n, 0);
   for (uint32_t i : st->active) pre[i] = merged[i] == 1;  // centers at the start of the table (:110-114)
@@ -187,6 +209,7 @@ extern "C" hs_status hs_clustering_table_apply(hs_cluster_state* st, uint32_t l,
       pushed[i] = 1;                  // centers.push_back(i)            (:128-130)
     }
   }
+  pt.lap("greedy pass");
   st->table = 0xffffffffu;  // the next table starts from the new merged[]
   st->built_table = 0xffffffffu;
   return HS_OK;
