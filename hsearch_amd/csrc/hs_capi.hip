@@ -116,6 +116,7 @@ struct hs_handle {
   DevBuf jtab, c16, seg_keys, seg_keys_sorted, seg_vals, sorted_ql, seg_key, seg_cnt, seg_qoff,
       seg_items, item_off, seg_n;
   bool sqrt_test = false;       // hit test sqrt(d2) <= R (hclust2.cpp:119-120) instead of d2 <= R*R
+  uint32_t self_first = HS_NO_SELF;  // self-join: DB id of query 0 of the current run_query
   bool join_tables_ok = false;  // fp16 can carry the coordinate table
   int verify_mode = 0;          // 0 auto, 1 streaming kernel, 2 bucket join
   std::string err;
@@ -1205,7 +1206,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
       HS_HIP(h, hs_launch_finalize(h->tabs, h->codes.as<uint8_t>(), d_centers, h->coords.as<double>(),
                                    h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
                                    h->prov.as<uint2>(), d_cnt, prov_cap, h->sorted_ql.as<uint32_t>(),
-                                   k, L, r2, h->sqrt_test ? R : (double)NAN, q_base, d_cnt + 1,
+                                   k, L, r2, h->sqrt_test ? R : (double)NAN, q_base, h->self_first, d_cnt + 1,
                                    hit_cap, h->hit_key.as<uint64_t>(), h->hit_val.as<uint64_t>(),
                                    h->stream));
     }
@@ -1395,16 +1396,18 @@ hs_status hs_self_join_range(hs_handle* h, uint64_t first, uint64_t count, doubl
     sj_lap("centers");
     HS_HIP(h, hs_launch_embed(h->codes.as<uint8_t>() + q0 * h->p.k, nq, (int)h->p.k,
                               h->coords.as<double>(), centers.as<double>(), h->stream));
-    uint64_t hcap = std::max<uint64_t>(dq.cap / 4, 4 * nq + 1024), nh = 0;
+    uint64_t hcap = std::max<uint64_t>(dq.cap / 4, 3 * nq + 1024), nh = 0;
     for (;;) {
       HS_HIP(h, dq.reserve(hcap * 4));
       HS_HIP(h, did.reserve(hcap * 4));
       HS_HIP(h, dt.reserve(hcap * 4));
       HS_HIP(h, dd.reserve(hcap * 8));
       h->sqrt_test = sqrt_test != 0;
+      h->self_first = (uint32_t)q0;  // the pair of a k-mer with itself is dropped on the device
       st = run_query(h, centers.as<double>(), nq, R, false, dq.as<uint32_t>(), did.as<uint32_t>(),
                      dt.as<uint32_t>(), dd.as<double>(), hcap, &nh, nullptr);
       h->sqrt_test = false;
+      h->self_first = HS_NO_SELF;
       if (st == HS_ERR_CAPACITY) {
         hcap = nh + nh / 8 + 1024;
         continue;

@@ -219,8 +219,11 @@ hipError_t hs_launch_finalize(const hs_tables_dev& tabs, const uint8_t* d_codes,
                               const uint32_t* d_qstart, const uint32_t* d_qcount,
                               const uint2* d_prov, const uint32_t* d_prov_count, uint32_t prov_cap,
                               const uint32_t* d_sorted_ql, int k, int L, double r2, double r_sqrt,
-                              uint32_t q_base, uint32_t* d_hit_count, uint32_t hit_cap,
-                              uint64_t* d_hit_key, uint64_t* d_hit_val, hipStream_t s);
+                              uint32_t q_base, uint32_t self_first, uint32_t* d_hit_count,
+                              uint32_t hit_cap, uint64_t* d_hit_key, uint64_t* d_hit_val, hipStream_t s);
+// self_first: the queries are the indexed k-mers self_first, self_first + 1, ... themselves (the
+// self-join): the pair of a k-mer with itself is not a hit; HS_NO_SELF otherwise
+#define HS_NO_SELF 0xffffffffu
 hipError_t hs_launch_unpack_hits(const uint64_t* d_key, const uint64_t* d_val, uint32_t n,
                                  uint32_t* d_q, uint32_t* d_id, uint32_t* d_table, double* d_dist,
                                  hipStream_t s);

@@ -696,6 +696,7 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
                                                           const uint32_t* __restrict__ sorted_ql,
                                                           int k, int L, double r2,
                                                           double r_sqrt, uint32_t q_base,
+                                                          uint32_t self_first,
                                                           uint32_t* __restrict__ hit_count,
                                                           uint32_t hit_cap,
                                                           uint64_t* __restrict__ hit_key,
@@ -783,6 +784,10 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
     // Search(): d2 <= R*R (motif_both_points.cpp:239); Clustering(): sqrt(d2) <= R
     // (hclust2.cpp:64-71,119-120), selected by a non-NaN r_sqrt.
     bool hit = live && ((r_sqrt == r_sqrt) ? (__dsqrt_rn(d2) <= r_sqrt) : (d2 <= r2));
+    // the self-join drops a k-mer's pair with itself (Clustering() never compares a k-mer with
+    // itself: its id is not in `centers` yet when it is visited, hclust2.cpp:116-131); an equal
+    // k-mer under another id stays
+    if (self_first != HS_NO_SELF && self_first + q_base + q == id) hit = false;
     // first-seen dedupe (label[], :233): the id was already reported if an EARLIER table's probed
     // bucket holds it, i.e. if its sorted position in that table falls inside the bucket's range
     // (one independent 4-byte load per earlier table)
@@ -1135,11 +1140,11 @@ hipError_t hs_launch_finalize(const hs_tables_dev& tabs, const uint8_t* d_codes,
                               const uint32_t* d_qstart, const uint32_t* d_qcount,
                               const uint2* d_prov, const uint32_t* d_prov_count, uint32_t prov_cap,
                               const uint32_t* d_sorted_ql, int k, int L, double r2, double r_sqrt,
-                              uint32_t q_base, uint32_t* d_hit_count, uint32_t hit_cap,
-                              uint64_t* d_hit_key, uint64_t* d_hit_val, hipStream_t s) {
+                              uint32_t q_base, uint32_t self_first, uint32_t* d_hit_count,
+                              uint32_t hit_cap, uint64_t* d_hit_key, uint64_t* d_hit_val, hipStream_t s) {
   hs_finalize_kernel<<<1024, 256, 0, s>>>(tabs, d_codes, d_centers, d_coords, d_qstart, d_qcount,
                                           d_prov, d_prov_count, prov_cap, d_sorted_ql, k, L, r2,
-                                          r_sqrt, q_base,
+                                          r_sqrt, q_base, self_first,
                                           d_hit_count, hit_cap, d_hit_key, d_hit_val);
   return hipGetLastError();
 }
