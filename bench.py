@@ -233,7 +233,11 @@ def main():
         achieved = algo_bytes / (v_ms * 1e-3) / 1e9 if v_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
+        # the PMC passes behind that file were taken on the default workload and kernel choice: the
+        # figure is reported for that workload only (null otherwise)
+        default_workload = (args.n, args.nq, args.k, args.K, args.L, args.W, args.R, args.verify_mode) == \
+            (10_000_000, 100_000, 25, 16, 8, 200.0, 40.0, "auto")
+        if default_workload and os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("verify_bytes_per_launch")
             except Exception:
