@@ -193,6 +193,13 @@ class Engine:
         """'auto' | 'stream' | 'join' -- which filter kernel runs in front of the exact decision."""
         self._check(self._lib.hs_set_verify_mode(self._h, {"auto": 0, "stream": 1, "join": 2, "join16": 3}[mode]))
 
+    def set_planes(self, a, b):
+        """A new hash family of the same shape for this handle (hs_set_planes); drops the index."""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        assert a.shape == (self.L, self.K, self.d) and b.shape == (self.L, self.K)
+        self._check(self._lib.hs_set_planes(self._h, _vp(a), _vp(b)))
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.hs_destroy(self._h)

@@ -335,3 +335,29 @@ def test_klsh_codes_match_reference_golden(oracle, golden_dir):
             assert int(codes[i]) == oracle.klsh_hash(w, b, t, f)
     with pytest.raises(hsearch_amd.HsError):
         hsearch_amd.klsh_codes(np.array([9], dtype=np.uint8), np.array([0, 1], dtype=np.uint64), w, b, t)
+
+
+def test_set_planes_rebuild_equals_fresh_handle(oracle):
+    """hs_set_planes: a handle re-seeded with another family and rebuilt answers like a handle
+    created with that family; queries before the rebuild are refused."""
+    import hsearch_amd
+    k, K, L, W, R, n, nq = 25, 6, 3, 120.0, 45.0, 5000, 300
+    codes = synth.make_db(n, k, seed=21)
+    centers, _ = synth.make_queries(codes, nq, seed=22, jitter=0.2)
+    a1, b1 = synth.make_planes(k, K, L, W, seed=31)
+    a2, b2 = synth.make_planes(k, K, L, W, seed=32)
+    eng = Engine(k, K, L, W, a1, b1)
+    eng.index_build(codes)
+    first = eng.query(centers, R)
+    _assert_hits_equal(first, oracle.search(a1, b1, W, R, oracle.embed_codes(codes), centers))
+    eng.set_planes(a2, b2)
+    with pytest.raises(hsearch_amd.HsError):
+        eng.query(centers, R)                      # the tables were keyed by the old family
+    assert np.array_equal(eng.hash_codes(codes[:50]), oracle.hash_all(a2, b2, W, oracle.embed_codes(codes[:50])))
+    eng.index_build(codes)
+    got = eng.query(centers, R)
+    want = oracle.search(a2, b2, W, R, oracle.embed_codes(codes), centers)
+    _assert_hits_equal(got, want)
+    assert np.array_equal(got["cand"], want["cand"])
+    assert not np.array_equal(first["cand"], got["cand"])
+    eng.close()
