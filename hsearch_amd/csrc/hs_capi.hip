@@ -1141,7 +1141,10 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   // with a join in the batch, the streaming filter's tables and the filter itself go to the side
   // stream and run beside the join kernel (both only append to the survivor list)
   const bool side = !brute && n_items && n_slices;
-  if (brute || n_slices) {
+  // ... and with the int8 join, thin segments are filtered by the join's own integer bound on the
+  // vector ALU (hs_thin8_kernel): no per-query distance tables, next to nothing beside the join
+  const bool thin8 = side && use_i8 && !getenv("HS_NO_THIN8");
+  if ((brute || n_slices) && !thin8) {
     HS_HIP(h, h->tq.reserve((size_t)nq * k * HS_TROW * 4));
     if (!side)
       HS_HIP(h, hs_launch_qtables(d_centers, nq, k, h->coords.as<double>(), h->alphabet,
@@ -1163,13 +1166,20 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     if (side) {
       HS_HIP(h, hipEventRecord(h->evx[EV_FORK], h->stream));
       HS_HIP(h, hipStreamWaitEvent(h->stream2, h->evx[EV_FORK], 0));
-      if (!tables_done)
-        HS_HIP(h, hs_launch_qtables(d_centers, nq, k, h->coords.as<double>(), h->alphabet,
-                                    h->tq.as<float>(), h->stream2));
-      tables_done = true;
-      HS_HIP(h, hs_launch_verify(h->tabs, h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
-                                 h->slice_off.as<uint32_t>(), nql, h->tq.as<float>(), k, L, r2_hi,
-                                 d_cnt, prov_cap, h->prov.as<uint2>(), n_blocks, h->stream2));
+      if (thin8) {
+        HS_HIP(h, hs_launch_thin8(h->tabs, h->t_rec8.as<uint4>(), h->n, h->c16.p, h->jtab8.p,
+                                  h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
+                                  h->slice_off.as<uint32_t>(), nql, L, d_cnt, prov_cap,
+                                  h->prov.as<uint2>(), n_blocks, h->stream2));
+      } else {
+        if (!tables_done)
+          HS_HIP(h, hs_launch_qtables(d_centers, nq, k, h->coords.as<double>(), h->alphabet,
+                                      h->tq.as<float>(), h->stream2));
+        tables_done = true;
+        HS_HIP(h, hs_launch_verify(h->tabs, h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
+                                   h->slice_off.as<uint32_t>(), nql, h->tq.as<float>(), k, L, r2_hi,
+                                   d_cnt, prov_cap, h->prov.as<uint2>(), n_blocks, h->stream2));
+      }
       HS_HIP(h, hipEventRecord(h->evx[EV_JOIN], h->stream2));
     }
     if (brute) {

@@ -279,6 +279,13 @@ hipError_t hs_launch_qprep8(const double* d_centers, uint32_t nq, int k, double 
                             const float* d_scale, void* d_c8, uint32_t* d_unsafe, hipStream_t s);
 hipError_t hs_launch_gather_c8t(const void* d_c8, const uint32_t* d_sorted_ql, const uint32_t* d_seg_qoff,
                                 uint32_t nql, int L, void* d_out, hipStream_t s);
+// thin segments with the int8 join on: the join's filter value per (probe, member) pair on the
+// vector ALU (v_dot4_i32_i8), work items = the streaming kernel's (probe, slice) list
+hipError_t hs_launch_thin8(const hs_tables_dev& tabs, const uint4* d_rec_base, uint64_t n_entries,
+                           const void* d_c8, const void* d_tab8, const uint32_t* d_qstart,
+                           const uint32_t* d_qcount, const uint32_t* d_slice_off, uint32_t nql, int L,
+                           uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov, int n_blocks,
+                           hipStream_t s);
 hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* d_packed_base,
                             const uint4* d_rec_base, const void* d_c8t, const void* d_tab8,
                             uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov,

@@ -614,6 +614,88 @@ __global__ __launch_bounds__(256, JT == 4 ? 2 : 4) void hs_join8w_kernel(
 #endif
 }
 
+// Thin segments (too few probing queries or members for MFMA tiles) with the int8 join on: the SAME
+// filter value as the join kernel -- the 128-term integer dot product of the member's A row and the
+// query's row, v_dot4_i32_i8 instead of MFMA -- one member per lane, work item = one (probe, slice
+// of <= HS_SLICE bucket entries) per wave as in the streaming kernel.  Needs no per-query distance
+// tables: with this kernel the side stream's work beside the join is a few tens of microseconds.
+__global__ __launch_bounds__(256) void hs_thin8_kernel(hs_tables_dev tabs,
+                                                       const uint4* __restrict__ rec_base, uint64_t n_entries,
+                                                       const int8_t* __restrict__ c8,
+                                                       const uint4* __restrict__ tab8,
+                                                       const uint32_t* __restrict__ qstart,
+                                                       const uint32_t* __restrict__ qcount,
+                                                       const uint32_t* __restrict__ slice_off,
+                                                       uint32_t nql, int L,
+                                                       uint32_t* __restrict__ prov_count,
+                                                       uint32_t prov_cap, uint2* __restrict__ prov) {
+  __shared__ uint32_t sTab8[32];
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid < 32) sTab8[tid] = tab8[tid].x;
+  __syncthreads();
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + ((uint32_t)tid >> 6));
+  const uint32_t n_waves = gridDim.x * 4u;
+  const uint32_t total = slice_off[nql];
+  for (uint32_t s = wave; s < total; s += n_waves) {
+    uint32_t lo = 0, hi = nql;  // largest ql with slice_off[ql] <= s
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (slice_off[mid] <= s) lo = mid; else hi = mid;
+    }
+    const uint32_t ql = lo, sl = s - slice_off[ql];
+    const uint32_t q = ql / (uint32_t)L, l = ql % (uint32_t)L;
+    const uint32_t start = qstart[ql] + sl * HS_SLICE;
+    const uint32_t cnt = min((uint32_t)HS_SLICE, qcount[ql] - sl * HS_SLICE);
+    const uint4* packed = tabs.t[l].packed;
+    const uint4* rec = rec_base + (uint64_t)l * n_entries;
+    // the query's row: K index = byte index (hs_qprep8_kernel); wave-uniform
+    const uint4* qrow = reinterpret_cast<const uint4*>(c8 + (uint64_t)q * QROW);
+    int B[32];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const uint4 v = qrow[g];
+      B[4 * g] = (int)v.x;
+      B[4 * g + 1] = (int)v.y;
+      B[4 * g + 2] = (int)v.z;
+      B[4 * g + 3] = (int)v.w;
+    }
+    // words 28..31 of a member's row are constants (build_afrags8, h = 1)
+    int qconst = __builtin_amdgcn_sdot4(0x7f7f0000, B[28], 0, false);
+    qconst = __builtin_amdgcn_sdot4(0x7f7f7f7f, B[29], qconst, false);
+    qconst = __builtin_amdgcn_sdot4(0x7f7f7f7f, B[30], qconst, false);
+    qconst = __builtin_amdgcn_sdot4(0x017f7f7f, B[31], qconst, false);
+    const uint32_t iters = (cnt + 63u) / 64u;
+    for (uint32_t it = 0; it < iters; ++it) {
+      const uint32_t i = it * 64u + (uint32_t)lane;
+      const bool valid = i < cnt;
+      const uint64_t pos = (uint64_t)start + (valid ? i : cnt - 1);
+      const uint4 pk = packed[pos];
+      const uint4 rc = rec[pos];
+      int acc = qconst;
+#define HS_P(P) acc = __builtin_amdgcn_sdot4((int)sTab8[residue_at<5 * P>(pk.x, pk.y, pk.z, pk.w)], B[P], acc, false);
+      HS_P(0) HS_P(1) HS_P(2) HS_P(3) HS_P(4) HS_P(5) HS_P(6) HS_P(7)
+      HS_P(8) HS_P(9) HS_P(10) HS_P(11) HS_P(12) HS_P(13) HS_P(14) HS_P(15)
+      HS_P(16) HS_P(17) HS_P(18) HS_P(19) HS_P(20) HS_P(21) HS_P(22) HS_P(23)
+#undef HS_P
+      acc = __builtin_amdgcn_sdot4((int)rc.x, B[24], acc, false);  // position 24 + the rho digits
+      acc = __builtin_amdgcn_sdot4((int)rc.y, B[25], acc, false);
+      acc = __builtin_amdgcn_sdot4((int)rc.z, B[26], acc, false);
+      acc = __builtin_amdgcn_sdot4((int)rc.w, B[27], acc, false);
+      const bool pass = valid && acc >= 0;
+      const unsigned long long m = __ballot(pass);
+      if (m) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(prov_count, (uint32_t)__popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (pass) {
+          const uint32_t idx = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          if (idx < prov_cap) prov[idx] = make_uint2(ql, (uint32_t)pos);
+        }
+      }
+    }
+  }
+}
+
 inline unsigned blocks_for(uint64_t n, unsigned per = 256) { return (unsigned)((n + per - 1) / per); }
 
 }  // namespace
@@ -678,5 +760,17 @@ hipError_t hs_launch_gather_rec8(const uint4* d_packed_all, const uint32_t* d_id
   hs_gather_rec8_kernel<<<blocks_for(n), 256, 0, s>>>(d_packed_all, d_ids_sorted, n, k,
                                                       (const uint4*)d_tab8, d_scale, d_out_packed,
                                                       d_out_rec);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_thin8(const hs_tables_dev& tabs, const uint4* d_rec_base, uint64_t n_entries,
+                           const void* d_c8, const void* d_tab8, const uint32_t* d_qstart,
+                           const uint32_t* d_qcount, const uint32_t* d_slice_off, uint32_t nql, int L,
+                           uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov, int n_blocks,
+                           hipStream_t s) {
+  if (!nql) return hipSuccess;
+  hs_thin8_kernel<<<n_blocks, 256, 0, s>>>(tabs, d_rec_base, n_entries, (const int8_t*)d_c8,
+                                           (const uint4*)d_tab8, d_qstart, d_qcount, d_slice_off, nql, L,
+                                           d_prov_count, prov_cap, d_prov);
   return hipGetLastError();
 }
