@@ -497,3 +497,11 @@ def ref_protein2datapoints(fasta_path, k, num_out, out_path, seed):
     lib_ = C.CDLL(os.path.join(_HERE, "_ref", "libref_p2d.so"))
     return int(lib_.refp_main(fasta_path.encode(), C.c_uint32(k), C.c_uint32(num_out), out_path.encode(),
                               C.c_uint32(seed)))
+
+
+def ref_hclust3_clustering_file(seed, seqs, k, K, L, W, R, out_path):
+    """hclust3.cpp's Clustering() (the lazy-embedding twin of hclust2's), oracle/_ref/libref_hclust3.so."""
+    lib_ = C.CDLL(os.path.join(_HERE, "_ref", "libref_hclust3.so"))
+    raw = "".join(seqs).encode()
+    lib_.ref2_clustering(C.c_uint32(seed), raw, C.c_uint64(len(seqs)), C.c_uint32(k), C.c_uint32(K),
+                         C.c_uint32(L), C.c_double(W), C.c_double(R), out_path.encode())

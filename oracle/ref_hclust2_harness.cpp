@@ -39,7 +39,13 @@ struct CountingSeedSource {
 #define random_device hs_ref_seam::CountingSeedSource
 #define private public
 #define main hs_ref_unused_main
+// -DHS_REF_HCLUST3 builds the same harness over hclust3.cpp, hclust2's twin that embeds a k-mer every
+// time it is looked at instead of once (KMER::point(), hclust3.cpp:43-45): libref_hclust3.so
+#ifdef HS_REF_HCLUST3
+#include "hclust/src/hclust/hclust3.cpp"
+#else
 #include "hclust/src/hclust/hclust2.cpp"
+#endif
 #undef main
 #undef private
 #undef random_device
@@ -87,7 +93,11 @@ HS_REF_API int ref2_clustering(uint32_t seed, const char* seqs, uint64_t n, uint
   kmers.reserve(n);
   for (uint64_t i = 0; i < n; ++i) {
     std::string s(seqs + i * klen, klen);
+#ifdef HS_REF_HCLUST3
+    kmers.push_back(KMER(std::to_string(i), s));
+#else
     kmers.push_back(KMER(std::to_string(i), s, KmerToCoordinates(s)));
+#endif
   }
   hs_ref_seam::g_next_seed = seed;
   fflush(stdout);

@@ -113,3 +113,29 @@ def test_cluster2datapoint_points_file():
             O.ref_cluster2datapoint(k, names, seqs, d + "/r_")
             O.write_points_file(d + "/o.txt", names, O.family_centers(fams))
             assert open(d + "/r_hclust.format.txt").read() == open(d + "/o.txt").read()
+
+
+@pytest.mark.skipif(not _have("libref_hclust3.so"), reason="oracle/_ref/libref_hclust3.so not built")
+def test_hclust3_is_hclust2():
+    """hclust3.cpp embeds a k-mer each time it is looked at instead of once; same arithmetic, same
+    clusters file -- so the hclust2 operator (oracle, hs_clustering, hs_hclust2) covers it."""
+    r = np.random.default_rng(19)
+    k = 25
+    rows = []
+    for f in r.integers(0, 20, (25, k)):
+        for _ in range(30):
+            row = f.copy()
+            for _ in range(r.integers(0, 5)):
+                row[r.integers(0, k)] = r.integers(0, 20)
+            rows.append(row)
+    rows = np.array(rows, dtype=np.uint8)
+    r.shuffle(rows)
+    seqs = ["".join(LETTERS[c] for c in row) for row in rows]
+    with tempfile.TemporaryDirectory() as d:
+        p2, p3, po = os.path.join(d, "h2"), os.path.join(d, "h3"), os.path.join(d, "port")
+        O.ref_clustering_file(7, seqs, k, 6, 5, 120.0, 55.0, p2)
+        O.ref_hclust3_clustering_file(7, seqs, k, 6, 5, 120.0, 55.0, p3)
+        a, b = O.ref_planes(7, 200, 6, 5, 120.0)
+        O.clustering_to_file(a, b, 120.0, 55.0, O.embed_codes(rows), po)
+        assert open(p2).read() == open(p3).read() == open(po).read()
+        assert open(p2).read().count("#clusterid") < len(seqs)
