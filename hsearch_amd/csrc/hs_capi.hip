@@ -110,6 +110,7 @@ struct hs_handle {
   HostBuf sj_host;  // hs_self_join_range: hits of one chunk on their way to the edge lists
   // bucket-join workspace
   DevBuf c16s, item_desc, probe_slow, jtab8;
+  DevBuf c8b, prov2;  // survivor refinement: second int8 row per query, the refined survivor list
   bool join8_tables_ok = false;  // int8 can carry the coordinate table
   uint32_t join_min_q = 3, join_min_m = 16;  // segment routing thresholds (HS_JOIN_MIN_Q / _M)
   int join_blocks_per_cu = 2;                // resident workgroups of hs_join_kernel per CU
@@ -263,10 +264,12 @@ hs_status hs_create(const hs_params* params, const double* a, const double* b, c
   HS_HIP(h, hipStreamSynchronize(h->stream));
   h->join_tables_ok = (unsafe == 0);
   // int8 table {x^ packed, |x1|^2, L1(x^)} x 32 at bytes 0..511, scale {s, s^2/2} at 512, flag at 640
-  HS_HIP(h, h->jtab8.reserve(1024));
-  HS_HIP(h, hipMemsetAsync(h->jtab8.p, 0, 1024, h->stream));
+  // ... refinement table {x^ 0..3, x^ 4..7, |x|^2, L1s} x 32 at bytes 1024..1535, scale[2..3] = its s, ok
+  HS_HIP(h, h->jtab8.reserve(2048));
+  HS_HIP(h, hipMemsetAsync(h->jtab8.p, 0, 2048, h->stream));
   HS_HIP(h, hs_launch_jtables8(h->coords.as<double>(), h->alphabet, h->jtab8.p, h->jtab8.as<float>() + 128,
-                               reinterpret_cast<uint32_t*>(h->jtab8.as<char>() + 640), h->stream));
+                               reinterpret_cast<uint32_t*>(h->jtab8.as<char>() + 640),
+                               h->jtab8.as<char>() + 1024, h->stream));
   uint32_t unsafe8 = 1;
   HS_HIP(h, hipMemcpyAsync(&unsafe8, h->jtab8.as<char>() + 640, 4, hipMemcpyDeviceToHost, h->stream));
   HS_HIP(h, hipStreamSynchronize(h->stream));
@@ -313,7 +316,7 @@ void hs_destroy(hs_handle* h) {
                     &h->io_codes, &h->io_misc, &h->jtab, &h->c16, &h->seg_keys, &h->seg_keys_sorted,
                     &h->seg_vals, &h->sorted_ql, &h->seg_key, &h->seg_cnt, &h->seg_qoff,
                     &h->seg_items, &h->item_off, &h->seg_n, &h->c16s, &h->item_desc,
-                    &h->probe_slow, &h->jtab8, &h->t_packed, &h->t_rec8, &h->t_pos, &h->dir_base,
+                    &h->probe_slow, &h->jtab8, &h->c8b, &h->prov2, &h->t_packed, &h->t_rec8, &h->t_pos, &h->dir_base,
                     &h->bucket_work};
   for (DevBuf* bf : bufs) bf->release();
   h->sj_host.release();
@@ -1023,6 +1026,9 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   bool use_join = !brute && h->verify_mode != 1 && h->join_tables_ok && k <= 25 && r2 < 30000.0;
   // int8 form of the join filter (hs_join8.hip) unless forced to fp16 (mode 3) or not representable
   bool use_i8 = use_join && h->join8_tables_ok && h->verify_mode != 3;
+  // survivors of the int8 join's 4-column bound pass an 8-column int8 bound before the exact
+  // decision (hs_refine8_kernel); HS_NO_REFINE8 switches it off
+  const bool refine = use_i8 && !getenv("HS_NO_REFINE8");
   if (!brute) {
     // with a join ahead, the probe also numbers each probe's bucket and ranks it inside (the
     // grouping of the probes by bucket is then a counting sort: hs_launch_seg_group)
@@ -1061,9 +1067,11 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, h->item_off.reserve(n1 * 4));
     HS_HIP(h, h->seg_n.reserve(64));
     HS_HIP(h, h->temp.reserve(std::max(hs_scan_u32_temp(n1), hs_scan_u32_temp((size_t)h->nb_total + 2)) + 256));
-    if (use_i8)
+    if (use_i8) {
+      if (refine) HS_HIP(h, h->c8b.reserve((size_t)nq * 128));
       HS_HIP(h, hs_launch_qprep8(d_centers, nq, k, r2, h->jtab8.as<float>() + 128, h->c16.p, d_unsafe,
-                                 h->stream));
+                                 refine ? h->c8b.p : nullptr, h->stream));
+    }
     else
       HS_HIP(h, hs_launch_qprep(d_centers, nq, k, r2, h->c16.p, d_unsafe, h->stream));
     HS_HIP(h, hipMemsetAsync(h->seg_cnt.p, 0, n1 * 4, h->stream));
@@ -1213,9 +1221,23 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
                                       hit_cap, h->hit_key.as<uint64_t>(), h->hit_val.as<uint64_t>(),
                                       h->stream));
     } else {
+      const uint2* fin_list = h->prov.as<uint2>();
+      const uint32_t* fin_count = d_cnt;
+      if (refine && use_i8 && n_items) {
+        // use_i8 may have been dropped after the readback (fp16 fallback): then no second row exists
+        HS_HIP(h, h->prov2.reserve((size_t)prov_cap * 8));
+        HS_HIP(h, hipMemsetAsync(d_cnt + 4, 0, 4, h->stream));
+        HS_HIP(h, hs_launch_refine8(h->tabs, h->prov.as<uint2>(), d_cnt, prov_cap,
+                                    h->sorted_ql.as<uint32_t>(), h->c16.p, h->c8b.p,
+                                    h->jtab8.as<char>() + 1024, h->jtab8.as<float>() + 128, k, L,
+                                    h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
+                                    h->prov2.as<uint2>(), d_cnt + 4, h->stream));
+        fin_list = h->prov2.as<uint2>();
+        fin_count = d_cnt + 4;
+      }
       HS_HIP(h, hs_launch_finalize(h->tabs, h->codes.as<uint8_t>(), d_centers, h->coords.as<double>(),
                                    h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
-                                   h->prov.as<uint2>(), d_cnt, prov_cap, h->sorted_ql.as<uint32_t>(),
+                                   fin_list, fin_count, prov_cap, h->sorted_ql.as<uint32_t>(),
                                    k, L, r2, h->sqrt_test ? R : (double)NAN, q_base, h->self_first, d_cnt + 1,
                                    hit_cap, h->hit_key.as<uint64_t>(), h->hit_val.as<uint64_t>(),
                                    h->stream));
@@ -1227,6 +1249,8 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     if (!brute && n_items) ms_join += ev_ms(h, 3, 10);
     ms_final += ev_ms(h, 4, 5);
     ++launches;
+    if (getenv("HS_DEBUG_REFINE"))
+      fprintf(stderr, "survivors %u -> refined %u -> hits %u\n", host_cnt[0], host_cnt[4], host_cnt[1]);
     if (host_cnt[0] > prov_cap) {
       prov_cap = host_cnt[0] + host_cnt[0] / 8 + 1024;
       continue;

@@ -274,9 +274,17 @@ hipError_t hs_launch_join(const uint4* d_desc, uint32_t n_items, const uint4* d_
                           uint2* d_prov, int n_blocks, hipStream_t s);
 // int8 form of the join filter (hs_join8.hip)
 hipError_t hs_launch_jtables8(const double* d_coords, int alphabet, void* d_tab8, float* d_scale,
-                              uint32_t* d_unsafe, hipStream_t s);
+                              uint32_t* d_unsafe, void* d_tabR, hipStream_t s);
+// d_c8b (may be null): the second row per query (columns 4..7 + the refinement's scalars)
 hipError_t hs_launch_qprep8(const double* d_centers, uint32_t nq, int k, double r2,
-                            const float* d_scale, void* d_c8, uint32_t* d_unsafe, hipStream_t s);
+                            const float* d_scale, void* d_c8, uint32_t* d_unsafe, void* d_c8b,
+                            hipStream_t s);
+// survivors of the 4-column bound -> those that also pass the 8-column bound (compacted, direct form)
+hipError_t hs_launch_refine8(const hs_tables_dev& tabs, const uint2* d_prov, const uint32_t* d_prov_count,
+                             uint32_t prov_cap, const uint32_t* d_sorted_ql, const void* d_c8,
+                             const void* d_c8b, const void* d_tabR, const float* d_scale, int k, int L,
+                             const uint32_t* d_qstart, const uint32_t* d_qcount,
+                             uint2* d_out, uint32_t* d_out_count, hipStream_t s);
 hipError_t hs_launch_gather_c8t(const void* d_c8, const uint32_t* d_sorted_ql, const uint32_t* d_seg_qoff,
                                 uint32_t nql, int L, void* d_out, hipStream_t s);
 // thin segments with the int8 join on: the join's filter value per (probe, member) pair on the

@@ -81,9 +81,12 @@ __device__ __forceinline__ void digits127(int v, int (&d)[ND + 1], bool* overflo
 
 // ---------------------------------------------------------------------------------- tables
 // tab8[aa] = { packed x^ (4 int8), |x1|^2 as float bits, L1(x^), 0 }; scale[0] = s, scale[1] = s^2/2
+// tabR[aa] = { packed x^ of columns 0..3, packed x^ of columns 4..7 (own scale), |x|^2 over all 8
+// columns as float bits, L1(x^ 0..3) | L1(x^ 4..7) << 16 } for the survivor refinement;
+// scale[2] = s of columns 4..7, scale[3] = 1 when that table is usable
 __global__ void hs_jtables8_kernel(const double* __restrict__ coords, int alphabet,
                                    uint4* __restrict__ tab8, float* __restrict__ scale,
-                                   uint32_t* __restrict__ unsafe) {
+                                   uint32_t* __restrict__ unsafe, uint4* __restrict__ tabR) {
   __shared__ double smax[32];
   const int aa = threadIdx.x;
   if (aa >= 32) return;
@@ -114,6 +117,34 @@ __global__ void hs_jtables8_kernel(const double* __restrict__ coords, int alphab
     scale[0] = (float)s;
     scale[1] = (float)(0.5 * s * s);
   }
+  // the other four columns, for hs_refine8_kernel
+  __syncthreads();
+  double m2 = 0.0;
+  for (int j = QD; j < 8; ++j) m2 = fmax(m2, aa < alphabet ? fabs(coords[aa * 8 + j]) : 0.0);
+  smax[aa] = m2;
+  __syncthreads();
+  double mm2 = 0.0;
+  for (int i = 0; i < 32; ++i) mm2 = fmax(mm2, smax[i]);
+  const bool ok2 = mm2 < 1e6;          // NaN or huge: no refinement
+  if (!(mm2 > 0.0) || !ok2) mm2 = 127.0;  // all-zero columns: any scale does
+  const float s2f = (float)(127.0 / mm2);
+  const double s2 = (double)s2f;
+  uint32_t pack2 = 0;
+  int l12 = 0;
+  double n8 = n;
+  for (int j = QD; j < 8; ++j) {
+    const double v = aa < alphabet ? coords[aa * 8 + j] : 0.0;
+    int q = (int)rint(s2 * v);
+    q = max(-127, min(127, q));
+    pack2 |= ((uint32_t)(q & 0xff)) << (8 * (j - QD));
+    l12 += abs(q);
+    n8 += v * v;
+  }
+  tabR[aa] = make_uint4(pack, pack2, __float_as_uint((float)n8), (uint32_t)l1 | ((uint32_t)l12 << 16));
+  if (aa == 0) {
+    scale[2] = s2f;
+    scale[3] = ok2 ? 1.0f : 0.0f;
+  }
 }
 
 // ---------------------------------------------------------------------------------- query prep
@@ -123,7 +154,8 @@ __global__ void hs_jtables8_kernel(const double* __restrict__ coords, int alphab
 __global__ __launch_bounds__(256) void hs_qprep8_kernel(const double* __restrict__ centers, uint32_t nq,
                                                         int k, double r2, const float* __restrict__ scale,
                                                         int8_t* __restrict__ c8,
-                                                        uint32_t* __restrict__ unsafe) {
+                                                        uint32_t* __restrict__ unsafe,
+                                                        int8_t* __restrict__ c8b) {
   const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= nq) return;
   const int lane = lane_id();
@@ -172,6 +204,47 @@ __global__ __launch_bounds__(256) void hs_qprep8_kernel(const double* __restrict
     else if (lane < 14) b = 0;
     else b = (int8_t)d[lane - 14];
     out[100 + lane] = b;
+  }
+  // Row of the other four columns for hs_refine8_kernel: bytes 0..99 = c^ (scale[2]), byte 104 = the
+  // double |c|^2 - R^2 over all 8 columns, bytes 112 / 116 = the floats L1(c^)/2 + saturation
+  // penalty + 2 of columns 0..3 / 4..7 (+inf: this query cannot be refined)
+  if (c8b) {
+    const double s2 = (double)scale[2];
+    int8_t* out2 = c8b + (uint64_t)q * QROW;
+    double nc2 = 0.0, pen2 = 0.0;
+    int l12 = 0;
+    bool bad2 = !(scale[3] > 0.f);
+    for (int i = lane; i < 100; i += 64) {
+      const int pos = i >> 2, j = i & 3;
+      int qv = 0;
+      if (pos < k) {
+        const double v = c[8 * pos + QD + j];
+        nc2 += v * v;
+        const double sv = s2 * v;
+        bad2 = bad2 || !(fabs(sv) < 1.0e6);
+        qv = (int)fmax(-127.0, fmin(127.0, rint(sv)));
+        pen2 += 127.5 * fmax(0.0, fabs(sv - (double)qv) - 0.5);
+        l12 += abs(qv);
+      }
+      out2[i] = (int8_t)qv;
+    }
+    for (int off = 32; off; off >>= 1) {
+      nc2 += __shfl_xor(nc2, off);
+      pen2 += __shfl_xor(pen2, off);
+      l12 += __shfl_xor(l12, off);
+    }
+    const bool any_bad = __ballot(bad || bad2) != 0;
+    if (lane == 0) {
+      *reinterpret_cast<double*>(out2 + 104) = (nc + nc2) - r2;
+      const float inf = __builtin_inff();
+      // rounded up (float): the bound may only get more permissive
+      *reinterpret_cast<float*>(out2 + 112) = any_bad ? inf : __double2float_ru(0.5 * (double)l1 + pen + 2.0);
+      *reinterpret_cast<float*>(out2 + 116) = any_bad ? inf : __double2float_ru(0.5 * (double)l12 + pen2 + 2.0);
+    }
+    if (lane == 1) {
+      *reinterpret_cast<uint32_t*>(out2 + 100) = 0u;
+      *reinterpret_cast<uint64_t*>(out2 + 120) = 0ull;
+    }
   }
 }
 
@@ -696,21 +769,121 @@ __global__ __launch_bounds__(256) void hs_thin8_kernel(hs_tables_dev tabs,
   }
 }
 
+// Survivors of the 4-column int8 bound, refined with all 8 columns before the exact fp64 decision:
+// d2 = |x|^2 + |c|^2 - 2 (x_A.c_A + x_B.c_B) and, per half, s^2 x.c <= x^.c^ + L1(x^)/2 + L1(c^)/2 +
+// dims/4 + saturation penalty (the join's own inequality), so a pair with d2 <= R^2 satisfies
+//   |x|^2 + (|c|^2 - R^2) <= 2 [ (x^A.c^A + E_A) / s_A^2 + (x^B.c^B + E_B) / s_B^2 ].
+// One survivor per lane: 25 table rows (LDS), 2 x 100 query bytes, two v_dot4 per position.  The
+// 4-column bound passes ~10 pairs per true hit, this one ~1.1: hs_finalize_kernel, whose cost is
+// per survivor, gets a list 7-8 times shorter.  One-sided like every filter here.
+__global__ __launch_bounds__(256) void hs_refine8_kernel(hs_tables_dev tabs,
+                                                         const uint2* __restrict__ prov,
+                                                         const uint32_t* __restrict__ prov_count,
+                                                         uint32_t prov_cap,
+                                                         const uint32_t* __restrict__ sorted_ql,
+                                                         const int8_t* __restrict__ c8,
+                                                         const int8_t* __restrict__ c8b,
+                                                         const uint4* __restrict__ tabR,
+                                                         const float* __restrict__ scale, int k, int L,
+                                                         const uint32_t* __restrict__ qstart,
+                                                         const uint32_t* __restrict__ qcount,
+                                                         uint2* __restrict__ out,
+                                                         uint32_t* __restrict__ out_count) {
+  __shared__ uint4 sTabR[32];
+  __shared__ uint2 s_keep[256];
+  __shared__ uint32_t s_n, s_base;
+  const int tid = threadIdx.x;
+  if (tid < 32) sTabR[tid] = tabR[tid];
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  const uint32_t n = min(*prov_count, prov_cap);
+  const double sA = (double)scale[0], sB = (double)scale[2];
+  const double iA = 1.0 / (sA * sA), iB = 1.0 / (sB * sB);
+  const double dims4 = 0.25 * (double)(QD * k);
+  for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
+    const uint32_t e = base + (uint32_t)tid;
+    uint32_t ql = e < n ? prov[e].x : 0xffffffffu;
+    const uint32_t pos = e < n ? prov[e].y : 0u;
+    const bool live = ql != 0xffffffffu;  // unused slot of a wave's reserved block
+    if (live && (ql & HS_PROV_INDIRECT)) ql = sorted_ql[ql & ~HS_PROV_INDIRECT];
+    bool pass = false;
+    if (live) {
+      const uint32_t q = ql / (uint32_t)L, l = ql % (uint32_t)L;
+      const uint4 pk = tabs.t[l].packed[pos];
+      const uint4* ra = reinterpret_cast<const uint4*>(c8 + (uint64_t)q * QROW);
+      const uint4* rb = reinterpret_cast<const uint4*>(c8b + (uint64_t)q * QROW);
+      int A[28], B[28];
+#pragma unroll
+      for (int g = 0; g < 7; ++g) {
+        const uint4 va = ra[g], vb = rb[g];
+        A[4 * g] = (int)va.x; A[4 * g + 1] = (int)va.y; A[4 * g + 2] = (int)va.z; A[4 * g + 3] = (int)va.w;
+        B[4 * g] = (int)vb.x; B[4 * g + 1] = (int)vb.y; B[4 * g + 2] = (int)vb.z; B[4 * g + 3] = (int)vb.w;
+      }
+      const double cq = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(rb) + 104);
+      const float eA = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rb) + 112);
+      const float eB = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rb) + 116);
+      int dotA = 0, dotB = 0;
+      uint32_t l1 = 0;
+      float nx = 0.f;
+#define HS_R(P)                                                                      \
+  if (P < k) {                                                                       \
+    const uint4 row = sTabR[residue_at<5 * P>(pk.x, pk.y, pk.z, pk.w)];              \
+    dotA = __builtin_amdgcn_sdot4((int)row.x, A[P], dotA, false);                    \
+    dotB = __builtin_amdgcn_sdot4((int)row.y, B[P], dotB, false);                    \
+    nx += __uint_as_float(row.z);                                                    \
+    l1 += row.w;                                                                     \
+  }
+      HS_R(0) HS_R(1) HS_R(2) HS_R(3) HS_R(4) HS_R(5) HS_R(6) HS_R(7) HS_R(8) HS_R(9)
+      HS_R(10) HS_R(11) HS_R(12) HS_R(13) HS_R(14) HS_R(15) HS_R(16) HS_R(17) HS_R(18) HS_R(19)
+      HS_R(20) HS_R(21) HS_R(22) HS_R(23) HS_R(24)
+#undef HS_R
+      const double uA = ((double)dotA + 0.5 * (double)(l1 & 0xffffu) + (double)eA + dims4) * iA;
+      const double uB = ((double)dotB + 0.5 * (double)(l1 >> 16) + (double)eB + dims4) * iB;
+      const double lhs = (double)nx + cq, rhs = 2.0 * (uA + uB);
+      // margin: fp32 sums of the row norms (25 x 6e-8 relative) and the roundings of this line
+      pass = !(lhs > rhs + 1e-5 * ((double)nx + fabs(cq) + 1.0));
+      // first-seen rule (label[], motif_both_points.cpp:233), which does not depend on the distance:
+      // a pair whose k-mer sits in the probed bucket of an EARLIER table is never reported here
+      if (pass && l) {
+        const uint32_t id = tabs.t[l].ids[pos];
+        bool dup = false;
+        for (uint32_t l2 = 0; l2 < l; ++l2) {
+          const uint32_t p2 = tabs.t[l2].pos_of[id];
+          dup = dup || (p2 - qstart[q * (uint32_t)L + l2] < qcount[q * (uint32_t)L + l2]);
+        }
+        pass = !dup;
+      }
+    }
+    // block-level compaction: one access to the global counter per block and round (same-address
+    // atomics deliver ~90 per microsecond: one per wave and round took longer than the arithmetic)
+    if (pass) s_keep[atomicAdd(&s_n, 1u)] = make_uint2(ql, pos);
+    __syncthreads();
+    const uint32_t kept = s_n;
+    if (tid == 0 && kept) s_base = atomicAdd(out_count, kept);
+    __syncthreads();
+    if ((uint32_t)tid < kept) out[s_base + (uint32_t)tid] = s_keep[tid];
+    __syncthreads();
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+  }
+}
+
 inline unsigned blocks_for(uint64_t n, unsigned per = 256) { return (unsigned)((n + per - 1) / per); }
 
 }  // namespace
 
 hipError_t hs_launch_jtables8(const double* d_coords, int alphabet, void* d_tab8, float* d_scale,
-                              uint32_t* d_unsafe, hipStream_t s) {
-  hs_jtables8_kernel<<<1, 32, 0, s>>>(d_coords, alphabet, (uint4*)d_tab8, d_scale, d_unsafe);
+                              uint32_t* d_unsafe, void* d_tabR, hipStream_t s) {
+  hs_jtables8_kernel<<<1, 32, 0, s>>>(d_coords, alphabet, (uint4*)d_tab8, d_scale, d_unsafe, (uint4*)d_tabR);
   return hipGetLastError();
 }
 
 hipError_t hs_launch_qprep8(const double* d_centers, uint32_t nq, int k, double r2,
-                            const float* d_scale, void* d_c8, uint32_t* d_unsafe, hipStream_t s) {
+                            const float* d_scale, void* d_c8, uint32_t* d_unsafe, void* d_c8b,
+                            hipStream_t s) {
   if (!nq) return hipSuccess;
   hs_qprep8_kernel<<<blocks_for(nq, 4), 256, 0, s>>>(d_centers, nq, k, r2, d_scale, (int8_t*)d_c8,
-                                                     d_unsafe);
+                                                     d_unsafe, (int8_t*)d_c8b);
   return hipGetLastError();
 }
 
@@ -772,5 +945,16 @@ hipError_t hs_launch_thin8(const hs_tables_dev& tabs, const uint4* d_rec_base, u
   hs_thin8_kernel<<<n_blocks, 256, 0, s>>>(tabs, d_rec_base, n_entries, (const int8_t*)d_c8,
                                            (const uint4*)d_tab8, d_qstart, d_qcount, d_slice_off, nql, L,
                                            d_prov_count, prov_cap, d_prov);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_refine8(const hs_tables_dev& tabs, const uint2* d_prov, const uint32_t* d_prov_count,
+                             uint32_t prov_cap, const uint32_t* d_sorted_ql, const void* d_c8,
+                             const void* d_c8b, const void* d_tabR, const float* d_scale, int k, int L,
+                             const uint32_t* d_qstart, const uint32_t* d_qcount,
+                             uint2* d_out, uint32_t* d_out_count, hipStream_t s) {
+  hs_refine8_kernel<<<1024, 256, 0, s>>>(tabs, d_prov, d_prov_count, prov_cap, d_sorted_ql,
+                                         (const int8_t*)d_c8, (const int8_t*)d_c8b, (const uint4*)d_tabR,
+                                         d_scale, k, L, d_qstart, d_qcount, d_out, d_out_count);
   return hipGetLastError();
 }
