@@ -159,37 +159,56 @@ __global__ __launch_bounds__(256) void hs_qprep8_kernel(const double* __restrict
   const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= nq) return;
   const int lane = lane_id();
-  const double s = (double)scale[0];
+  const double sA = (double)scale[0], sB = (double)scale[2];
   const double* c = centers + (uint64_t)q * 8 * k;
-  int8_t* out = c8 + (uint64_t)q * QROW;
-  double nc = 0.0, pen = 0.0;
-  int l1 = 0;
-  bool bad = false;
-  for (int i = lane; i < 100; i += 64) {
-    const int pos = i >> 2, j = i & 3;
+  int8_t* outA = c8 + (uint64_t)q * QROW;
+  int8_t* outB = c8b ? c8b + (uint64_t)q * QROW : nullptr;
+  // one pass over the 8k doubles of the row (lane i, i + 64, ...: coalesced): coordinate j < 4 of
+  // position p goes to byte 4p + j of the first row, coordinate j >= 4 to byte 4p + j - 4 of the
+  // second; sums per half
+  double ncA = 0.0, penA = 0.0, ncB = 0.0, penB = 0.0;
+  int l1A = 0, l1B = 0;
+  bool badA = false, badB = !(scale[3] > 0.f);
+  const int kk = min(k, 25);
+  for (int i = lane; i < 200; i += 64) {
+    const int pos = i >> 3, j = i & 7;
+    const bool second = j >= QD;
     int qv = 0;
-    if (pos < k) {
-      const double v = c[8 * pos + j];
-      nc += v * v;
-      const double sv = s * v;
-      bad = bad || !(fabs(sv) < 1.0e6);
+    if (pos < kk) {
+      const double v = c[i];
+      const double sv = (second ? sB : sA) * v;
+      const bool bad = !(fabs(sv) < 1.0e6);
       // saturate; a coordinate outside +-127 has a quantisation error n_i > 1/2, which costs at
       // most (127 + 1/2)(|n_i| - 1/2) more in the bound (|x^_i| <= 127, |e_i| <= 1/2)
       qv = (int)fmax(-127.0, fmin(127.0, rint(sv)));
-      pen += 127.5 * fmax(0.0, fabs(sv - (double)qv) - 0.5);
-      l1 += abs(qv);
+      const double pen = 127.5 * fmax(0.0, fabs(sv - (double)qv) - 0.5);
+      if (second) {
+        ncB += v * v;
+        penB += pen;
+        l1B += abs(qv);
+        badB = badB || bad;
+      } else {
+        ncA += v * v;
+        penA += pen;
+        l1A += abs(qv);
+        badA = badA || bad;
+      }
     }
-    out[i] = (int8_t)qv;
+    if (!second) outA[4 * pos + j] = (int8_t)qv;
+    else if (outB) outB[4 * pos + j - QD] = (int8_t)qv;
   }
   for (int off = 32; off; off >>= 1) {
-    nc += __shfl_xor(nc, off);
-    pen += __shfl_xor(pen, off);
-    l1 += __shfl_xor(l1, off);
+    ncA += __shfl_xor(ncA, off);
+    penA += __shfl_xor(penA, off);
+    l1A += __shfl_xor(l1A, off);
+    ncB += __shfl_xor(ncB, off);
+    penB += __shfl_xor(penB, off);
+    l1B += __shfl_xor(l1B, off);
   }
   // gamma = floor(s^2 (nc - R^2)/2 - L1/2 - saturation penalty - 2)
-  const double g = floor(0.5 * s * s * (nc - r2) - 0.5 * (double)l1 - pen - 2.0);
+  const double g = floor(0.5 * sA * sA * (ncA - r2) - 0.5 * (double)l1A - penA - 2.0);
   // a query far outside the table's range would make the filter uselessly permissive
-  bad = bad || !(fabs(g) < 1.0e9) || !(pen < 30000.0);
+  bool bad = badA || !(fabs(g) < 1.0e9) || !(penA < 30000.0);
   int d[DIG + 1];
   const int v = bad ? 0 : -(int)g;
   // -gamma too LARGE for the digits would have to be clamped in the non-permissive direction
@@ -203,47 +222,23 @@ __global__ __launch_bounds__(256) void hs_qprep8_kernel(const double* __restrict
     else if (lane == RDIG) b = (int8_t)-1;
     else if (lane < 14) b = 0;
     else b = (int8_t)d[lane - 14];
-    out[100 + lane] = b;
+    outA[100 + lane] = b;
   }
-  // Row of the other four columns for hs_refine8_kernel: bytes 0..99 = c^ (scale[2]), byte 104 = the
-  // double |c|^2 - R^2 over all 8 columns, bytes 112 / 116 = the floats L1(c^)/2 + saturation
-  // penalty + 2 of columns 0..3 / 4..7 (+inf: this query cannot be refined)
-  if (c8b) {
-    const double s2 = (double)scale[2];
-    int8_t* out2 = c8b + (uint64_t)q * QROW;
-    double nc2 = 0.0, pen2 = 0.0;
-    int l12 = 0;
-    bool bad2 = !(scale[3] > 0.f);
-    for (int i = lane; i < 100; i += 64) {
-      const int pos = i >> 2, j = i & 3;
-      int qv = 0;
-      if (pos < k) {
-        const double v = c[8 * pos + QD + j];
-        nc2 += v * v;
-        const double sv = s2 * v;
-        bad2 = bad2 || !(fabs(sv) < 1.0e6);
-        qv = (int)fmax(-127.0, fmin(127.0, rint(sv)));
-        pen2 += 127.5 * fmax(0.0, fabs(sv - (double)qv) - 0.5);
-        l12 += abs(qv);
-      }
-      out2[i] = (int8_t)qv;
-    }
-    for (int off = 32; off; off >>= 1) {
-      nc2 += __shfl_xor(nc2, off);
-      pen2 += __shfl_xor(pen2, off);
-      l12 += __shfl_xor(l12, off);
-    }
-    const bool any_bad = __ballot(bad || bad2) != 0;
+  // Tail of the second row, for hs_refine8_kernel: byte 104 = the double |c|^2 - R^2 over all 8
+  // columns, bytes 112 / 116 = the floats L1(c^)/2 + saturation penalty + 2 of columns 0..3 / 4..7
+  // (+inf: this query cannot be refined)
+  if (outB) {
+    const bool any_bad = __ballot(bad || badB) != 0;
     if (lane == 0) {
-      *reinterpret_cast<double*>(out2 + 104) = (nc + nc2) - r2;
+      *reinterpret_cast<double*>(outB + 104) = (ncA + ncB) - r2;
       const float inf = __builtin_inff();
       // rounded up (float): the bound may only get more permissive
-      *reinterpret_cast<float*>(out2 + 112) = any_bad ? inf : __double2float_ru(0.5 * (double)l1 + pen + 2.0);
-      *reinterpret_cast<float*>(out2 + 116) = any_bad ? inf : __double2float_ru(0.5 * (double)l12 + pen2 + 2.0);
+      *reinterpret_cast<float*>(outB + 112) = any_bad ? inf : __double2float_ru(0.5 * (double)l1A + penA + 2.0);
+      *reinterpret_cast<float*>(outB + 116) = any_bad ? inf : __double2float_ru(0.5 * (double)l1B + penB + 2.0);
     }
     if (lane == 1) {
-      *reinterpret_cast<uint32_t*>(out2 + 100) = 0u;
-      *reinterpret_cast<uint64_t*>(out2 + 120) = 0ull;
+      *reinterpret_cast<uint32_t*>(outB + 100) = 0u;
+      *reinterpret_cast<uint64_t*>(outB + 120) = 0ull;
     }
   }
 }

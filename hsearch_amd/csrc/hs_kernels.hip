@@ -394,25 +394,34 @@ __global__ __launch_bounds__(256) void hs_probe_kernel(hs_tables_dev tabs,
   }
   if (bucket_count) {
     const bool pseudo = ranked && gb == nb_total;
-    // one counter access per wave for the pseudo-bucket (same-address atomics are slow)
-    const unsigned long long pm = __ballot(pseudo);
+    // one counter access per BLOCK for the pseudo-bucket (same-address atomics are slow): ranks
+    // inside the block from an LDS counter, the block's base from the global one
+    __shared__ uint32_t s_pseudo, s_pbase;
+    if (threadIdx.x == 0) s_pseudo = 0;
+    __syncthreads();
     uint32_t rank = 0;
-    if (pm) {
-      const int leader = __ffsll((long long)pm) - 1;
-      uint32_t base = 0;
-      if (lane_id() == leader) base = atomicAdd(&bucket_count[nb_total], (uint32_t)__popcll(pm));
-      base = __shfl(base, leader);
-      rank = base + (uint32_t)__popcll(pm & ((1ull << lane_id()) - 1ull));
-    }
+    if (pseudo) rank = atomicAdd(&s_pseudo, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_pseudo) s_pbase = atomicAdd(&bucket_count[nb_total], s_pseudo);
+    __syncthreads();
+    if (pseudo) rank += s_pbase;
     if (ranked && !pseudo) rank = atomicAdd(&bucket_count[gb], 1u);
     if (ranked) {
       qbucket[ql] = gb;
       qrank[ql] = rank;
     }
   }
+  // candidate total: one access to the global counter per BLOCK (same-address atomics deliver
+  // ~100 per microsecond chip-wide: one per wave -- 12 500 of them -- was most of this kernel)
   unsigned long long c = count;
   for (int off = 32; off; off >>= 1) c += __shfl_xor(c, off);
-  if (lane_id() == 0 && c) atomicAdd(cand_total, c);
+  __shared__ unsigned long long s_c[4];
+  if (lane_id() == 0) s_c[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long t = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+    if (t) atomicAdd(cand_total, t);
+  }
 }
 
 // Rare path: HashKey STRING equality (lsh.hpp:51-59) between the query's tuple and the tuple of
