@@ -170,21 +170,37 @@ __global__ __launch_bounds__(256) void hs_seg_route_kernel(const uint64_t* __res
                                                            uint32_t* __restrict__ items,
                                                            unsigned long long* __restrict__ stats) {
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-  if (j > n_max) return;
   uint32_t it = 0;
+  unsigned long long issued = 0, real = 0;
   const uint32_t jqg = jm < HS_JM_BLOCK ? HS_JQG_WAVE : (uint32_t)JQG;
-  if (j < *n_seg && (seg_key[j] >> shift) < (uint64_t)L) {
+  if (j <= n_max && j < *n_seg && (seg_key[j] >> shift) < (uint64_t)L) {
     const uint32_t m = qcount[sorted_ql[seg_qoff[j]]];
     const uint32_t nq = seg_cnt[j];
     if (nq >= min_q && m >= min_m) {
       it = ((m + jm - 1) / jm) * ((nq + jqg - 1) / jqg);
       // MFMA pairs actually issued (128-row waves x 32-column chunks) vs real pairs
-      atomicAdd(stats + 0, (unsigned long long)((m + 32 * JT - 1) / (32 * JT) * (32 * JT)) *
-                               ((nq + JQ - 1) / JQ * JQ));
-      atomicAdd(stats + 1, (unsigned long long)m * nq);
+      issued = (unsigned long long)((m + 32 * JT - 1) / (32 * JT) * (32 * JT)) * ((nq + JQ - 1) / JQ * JQ);
+      real = (unsigned long long)m * nq;
     }
   }
-  items[j] = it;
+  if (j <= n_max) items[j] = it;
+  // the two statistics: one pair of global atomics per block (same-address atomics are slow)
+  for (int off = 32; off; off >>= 1) {
+    issued += __shfl_xor(issued, off);
+    real += __shfl_xor(real, off);
+  }
+  __shared__ unsigned long long s_st[4][2];
+  if ((threadIdx.x & 63) == 0) {
+    s_st[threadIdx.x >> 6][0] = issued;
+    s_st[threadIdx.x >> 6][1] = real;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long a = s_st[0][0] + s_st[1][0] + s_st[2][0] + s_st[3][0];
+    const unsigned long long b = s_st[0][1] + s_st[1][1] + s_st[2][1] + s_st[3][1];
+    if (a) atomicAdd(stats + 0, a);
+    if (b) atomicAdd(stats + 1, b);
+  }
 }
 
 // nslices[ql] = 0 for probes whose segment was routed to the join (they keep their slice count,
