@@ -81,6 +81,11 @@ __global__ __launch_bounds__(256) void hs_hash_kernel(const uint8_t* __restrict_
     double p0[KC], p1[KC];       // planes of two consecutive dimensions (scalar registers)
 #pragma unroll
     for (int f = 0; f < KC; ++f) p0[f] = ar[f];
+    double xn[8];  // arbitrary points: the next position's coordinates, fetched one position ahead
+    if (!FROM_CODES) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xn[j] = xrow[j];
+    }
     for (int pos = 0; pos < k; ++pos) {
       double x[8];
       if (FROM_CODES) {
@@ -89,7 +94,10 @@ __global__ __launch_bounds__(256) void hs_hash_kernel(const uint8_t* __restrict_
         for (int j = 0; j < 8; ++j) x[j] = s_coords[c * 8 + j];
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = xrow[8 * pos + j];
+        for (int j = 0; j < 8; ++j) x[j] = xn[j];
+        const int pn = min(pos + 1, k - 1);  // past the end: a harmless re-read
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xn[j] = xrow[8 * pn + j];
       }
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
