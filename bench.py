@@ -114,6 +114,11 @@ def cpu_baseline(args, a, b, codes, centers):
 
 def main():
     args = parse()
+    # stdout carries ONE line, the JSON result: libraries that print there (RCCL announces its
+    # version on stdout when the first communicator is created) are sent to stderr for the whole run
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -314,7 +319,7 @@ def main():
                                                   for qq in range(nr)]))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, a, b, codes, centers)
-        print(json.dumps(line))
+        print(json.dumps(line), file=result_out, flush=True)
     eng.close()
     if use_dist:
         dist.barrier()
