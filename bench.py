@@ -8,9 +8,20 @@ distance -> ordered hits [-> RCCL all-gather of hits when N > 1]) over the rank'
 the queries already resident in HBM.  N > 1: one process per GPU, index replicated, queries
 sharded (weak scaling: 100 k queries per GPU), hits all-gathered.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (hs_verify_kernel) by the
-ALGORITHMIC bytes of SURVEY.md 8(d) over its HIP-event time; `cpu_baseline` times the reference's
-CPU path on a bounded sample of the same workload (rank 0, N = 1 only).
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel over its HIP-event time
+(events on the library's stream): with the bucket join on (the default) that is hs_join8w_kernel,
+an int8 MFMA GEMM of depth 128 per (bucket member, probing query) pair, against the dense int8 MFMA
+peak; with --verify-mode stream (and wherever no join runs) it is hs_verify_kernel, priced by the
+ALGORITHMIC bytes of SURVEY.md 8(d) against 8 TB/s.  `roofline.traffic` = measured HBM bytes per
+launch from profiles/traffic_latest.json, reported only while that file's recorded kernel source
+hash equals the hash of the kernel source this run was built from.  `cpu_baseline` times the
+reference's CPU path (the pinned restatement, oracle/) on a bounded sample of the same workload
+(rank 0, N = 1 only): `value` is the MEASURED rate at the sample's N; the figure scaled to the
+bench's N is reported beside it and labelled as an extrapolation.
+
+Other BASELINE.json configs through the same script (the label in config.workload follows the
+arguments): configs[2]'s per-GPU share `--db-size 100000000 --L 32 --K 20 --queries 125000`,
+configs[4] `--k 39` / `--k 15`.
 """
 import argparse
 import json
@@ -43,11 +54,35 @@ def parse():
     ap.add_argument("--W", type=float, default=200.0)
     ap.add_argument("--R", type=float, default=40.0)
     ap.add_argument("--recall-queries", type=int, default=256)
-    ap.add_argument("--cpu-n", type=int, default=200_000, help="DB sample of the CPU baseline")
+    ap.add_argument("--cpu-n", type=int, default=1_000_000, help="DB sample of the CPU baseline")
     ap.add_argument("--cpu-nq", type=int, default=200, help="query sample of the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify-mode", choices=["auto", "stream", "join", "join16"], default="auto")
+    ap.add_argument("--cpu-ref-n", type=int, default=200_000,
+                    help="DB sample on which the compiled reference (oracle/_ref) is timed beside the port")
     return ap.parse_args()
+
+
+def workload_label(args):
+    """Which BASELINE.json config the arguments are."""
+    shape = "%d x %d-mers, L=%d K=%d W=%g R=%g, %d queries per GPU, index replicated per GPU" % (
+        args.n, args.k, args.L, args.K, args.W, args.R, args.nq)
+    if (args.n, args.k, args.K, args.L) == (10_000_000, 25, 16, 8):
+        return "configs[1]: " + shape
+    if (args.n, args.k, args.K, args.L) == (100_000_000, 25, 20, 32):
+        return "configs[2], one GPU's share (the 10^6 queries are sharded over 8 GPUs): " + shape
+    if args.k != 25:
+        return "configs[4] (mixed lengths), k=%d: %s" % (args.k, shape)
+    return "custom (no BASELINE.json config): " + shape
+
+
+def kernel_source_hash():
+    """sha256 over the sources of the verify kernels: ties profiles/traffic_latest.json to a build."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("hs_join8.hip", "hs_join.hip", "hs_kernels.hip", "hs_internal.h"):
+        h.update(open(os.path.join(ROOT, "hsearch_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def synth_seed_planes():
@@ -56,9 +91,12 @@ def synth_seed_planes():
 
 
 def cpu_baseline(args, a, b, codes, centers):
-    """Reference CPU path on a bounded sample: the first cpu_n DB k-mers, the first cpu_nq
-    queries, same planes.  Bucket populations (hence per-query cost) scale linearly with N, so the
-    queries/s at the bench's N is the measured sample rate x (cpu_n / N); both are reported."""
+    """Reference CPU path on a bounded sample: the first cpu_n DB k-mers (10^6 by default: ~20 s of
+    build + ~6 s of queries on one core), the first cpu_nq queries, same planes.  `value` is the
+    rate MEASURED at that N.  Bucket populations (hence candidates per query) are linear in N, so
+    value x cpu_n / N is an UPPER estimate of the CPU rate at the bench's N (the per-candidate cost
+    grows once the vectors fall out of cache: 417 q/s at N=2*10^5 predicted 83 q/s at 10^6, where
+    35-40 q/s are measured); it is reported as value_scaled_to_bench_n, never as value."""
     from oracle import pyoracle as O
     n_s = min(args.cpu_n, codes.shape[0])
     q_s = min(args.cpu_nq, centers.shape[0])
@@ -73,23 +111,37 @@ def cpu_baseline(args, a, b, codes, centers):
     ix.close()
     qps_sample = q_s / t_query
     out = {
-        "value": qps_sample * n_s / codes.shape[0],
+        "value": qps_sample,
         "unit": "queries/s",
         "cores": 1,
         "kind": "port",
         "sample": ("oracle/hs_oracle.cpp (restatement with the reference's cost structure, pinned "
                    "bit-exact to the compiled reference) on the first %d DB k-mers and first %d "
-                   "queries, same planes: %.1f queries/s measured at N=%d, scaled by %d/%d to the "
-                   "bench N (bucket populations are linear in N); index build %.0f k-mers/s"
-                   % (n_s, q_s, qps_sample, n_s, n_s, codes.shape[0], n_s / t_build)),
+                   "queries of the bench workload, same planes, one thread: %.1f queries/s MEASURED "
+                   "at N=%d (value); index build %.0f k-mers/s; %.1f s of CPU work"
+                   % (n_s, q_s, qps_sample, n_s, n_s / t_build, t_build + t_query)),
         "measured_qps_at_sample": qps_sample,
+        "value_scaled_to_bench_n": qps_sample * n_s / codes.shape[0],
+        "scaling_note": "value x sample_n / bench N: upper estimate (candidates per query are linear "
+                        "in N, the cost per candidate grows with N)",
         "sample_n": n_s, "sample_nq": q_s,
         "build_kmers_per_s": n_s / t_build,
         "sample_hits": int(len(res["q"])),
         "sample_seconds": t_build + t_query,
     }
-    if O.have_ref():
-        # the real compiled reference (oracle/_ref) on the same sample.  Its Search() draws its own
+    if O.have_ref() and args.cpu_ref_n > 0:
+        # the real compiled reference (oracle/_ref) on a smaller sample (its Search() is monolithic:
+        # two full builds per measurement), with the port timed on the same sample beside it.
+        n_r = min(args.cpu_ref_n, n_s)
+        db = db[:n_r]
+        t = time.perf_counter()
+        ixr = O.Index(a, b, args.W, db)
+        tbp = time.perf_counter() - t
+        t = time.perf_counter()
+        ixr.query(cq, args.R)
+        tqp = time.perf_counter() - t
+        ixr.close()
+        # the real compiled reference (oracle/_ref) on that sample.  Its Search() draws its own
         # planes (same distributions, seeded through the harness) and is monolithic, so it is timed
         # with zero centers (build only) and with the sample queries, and the difference is the
         # query loop.  Reported beside the port, which runs the bench's exact planes.
@@ -107,8 +159,9 @@ def cpu_baseline(args, a, b, codes, centers):
         out["reference_check"] = {
             "what": "oracle/_ref: the reference's own Search() compiled from its sources, same "
                     "sample, planes drawn by its own LSH constructor",
-            "measured_qps_at_sample": q_s / tq, "build_kmers_per_s": n_s / tb,
-            "value_scaled_to_bench_n": q_s / tq * n_s / codes.shape[0]}
+            "sample_n": n_r, "sample_nq": q_s,
+            "measured_qps_at_sample": q_s / tq, "build_kmers_per_s": n_r / tb,
+            "port_qps_same_sample": q_s / tqp, "port_build_kmers_per_s": n_r / tbp}
     return out
 
 
@@ -242,9 +295,20 @@ def main():
         # figure is reported for that workload only (null otherwise)
         default_workload = (args.n, args.nq, args.k, args.K, args.L, args.W, args.R, args.verify_mode) == \
             (10_000_000, 100_000, 25, 16, 8, 200.0, 40.0, "auto")
+        traffic_src = None
         if default_workload and os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("verify_bytes_per_launch")
+                tj = json.load(open(tpath))
+                # only while the PMC passes were taken on the kernels this run was built from
+                if tj.get("kernel_source_hash") == kernel_source_hash():
+                    traffic = tj.get("verify_bytes_per_launch")
+                    traffic_src = {"file": "profiles/traffic_latest.json",
+                                   "kernel_source_hash": tj.get("kernel_source_hash"),
+                                   "taken": tj.get("taken")}
+                else:
+                    traffic_src = {"file": "profiles/traffic_latest.json", "stale": True,
+                                   "recorded_hash": tj.get("kernel_source_hash"),
+                                   "current_hash": kernel_source_hash()}
             except Exception:
                 traffic = None
         if join_batches:
@@ -261,20 +325,23 @@ def main():
             roofline = {"bound": "mfma", "kernel": "hs_join8w_kernel" if i8 else "hs_join_kernel",
                         "mfma_dtype": "i8" if i8 else "f16", "gemm_depth": jk, "achieved": tf,
                         "peak": peak, "unit": "TOP/s" if i8 else "TFLOP/s",
-                        "frac": tf / peak, "traffic": traffic,
+                        "frac": tf / peak, "traffic": traffic, "traffic_source": traffic_src,
                         "flop_per_step": flop, "pairs_per_step": jstat[1],
                         "pairs_issued_per_step": jstat[2], "work_items_per_step": jstat[0],
                         "issued_tops": (jstat[2] * 2.0 * jk / (j_ms * 1e-3) / 1e12) if j_ms > 0 else 0.0,
                         "kernel_ms_per_step": j_ms, "streaming_kernel_ms_per_step": v_ms - j_ms,
                         "pairs_streamed_per_step": cand - jstat[1],
                         "launches_per_step": launches / steps,
-                        "hbm_algorithmic_gbs": achieved,
-                        "hbm_algorithmic_frac_of_8TBs": achieved / HBM_PEAK_GBS,
-                        "algorithmic_bytes_per_step": algo_bytes}
+                        # SURVEY 8(d)'s byte count for the same step, for reference only: the join
+                        # re-uses a bucket's rows across the queries probing it, so this is NOT a
+                        # physical rate (it exceeds the HBM peak) and no fraction of 8 TB/s is given
+                        "algorithmic_bytes_per_step": algo_bytes,
+                        "algorithmic_bytes_per_s_nonphysical": achieved * 1e9}
         else:
             roofline = {"bound": "hbm", "kernel": "hs_verify_kernel", "achieved": achieved,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": traffic, "algorithmic_bytes_per_step": algo_bytes,
+                        "traffic": traffic, "traffic_source": traffic_src,
+                        "algorithmic_bytes_per_step": algo_bytes,
                         "kernel_ms_per_step": v_ms, "launches_per_step": launches / steps,
                         "packed_stream_bytes_per_step": cand * 16 * ((k + 24) // 25)}
         line = {
@@ -282,8 +349,7 @@ def main():
             "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d x %d-mers, L=%d K=%d W=%g R=%g, %d queries per GPU, "
-                                   "index replicated per GPU" % (args.n, k, L, K, W, R, args.nq),
+            "config": {"workload": workload_label(args),
                        "db_kmers": args.n, "k": k, "L": L, "K": K, "W": W, "R": R,
                        "queries_per_gpu": args.nq, "parallelism": "query-sharded x%d" % world},
             "roofline": roofline,

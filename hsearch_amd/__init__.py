@@ -6,8 +6,8 @@ the tests and bench.py; it contains no compute and no CPU fallback: if the libra
 no gfx950 device is present, calls raise.
 """
 from .capi import (KLSH_NONE, ClusterState, Engine, HsError, alphabet, clustering, clusters_file_text,
-                   codes_from_letters, key_string, klsh_codes, klsh_draw_planes, lib_path, load,
+                   codes_from_letters, index_file_check, key_string, klsh_codes, klsh_draw_planes, lib_path, load,
                    profile_fields)
 
-__all__ = ["KLSH_NONE", "ClusterState", "klsh_codes", "klsh_draw_planes", "Engine", "HsError", "alphabet", "clustering", "clusters_file_text", "codes_from_letters", "key_string", "lib_path", "load",
+__all__ = ["KLSH_NONE", "ClusterState", "klsh_codes", "klsh_draw_planes", "Engine", "HsError", "alphabet", "clustering", "clusters_file_text", "codes_from_letters", "index_file_check", "key_string", "lib_path", "load",
            "profile_fields"]

@@ -19,7 +19,7 @@ EXPORTS = ["hs_create", "hs_destroy", "hs_last_error", "hs_get_profile", "hs_ver
            "hs_clustering_begin", "hs_clustering_table_edges", "hs_clustering_table_apply",
            "hs_clustering_end",
            "hs_embed_codes", "hs_hash_codes", "hs_hash_points", "hs_key_string", "hs_key_fingerprint",
-           "hs_key_strings_equal", "hs_index_build", "hs_index_build_windows", "hs_index_save", "hs_index_load", "hs_klsh_draw_planes", "hs_klsh_codes",
+           "hs_key_strings_equal", "hs_index_build", "hs_index_build_windows", "hs_index_save", "hs_index_load", "hs_index_file_check", "hs_klsh_draw_planes", "hs_klsh_codes",
            "hs_index_info_get", "hs_query", "hs_query_dev", "hs_bruteforce", "hs_bruteforce_topk"]
 
 
@@ -118,6 +118,15 @@ def key_strings_equal(x, y):
 
 def _vp(arr):
     return arr.ctypes.data_as(C.c_void_p)
+
+
+def index_file_check(path):
+    """Host-only check of an index file (hs_index_file_check): header, payload length + hash and the
+    content rules hs_index_load enforces on the device.  Raises HsError(HS_ERR_IO) naming the fault."""
+    err = C.create_string_buffer(512)
+    st = load().hs_index_file_check(str(path).encode(), err, C.c_uint32(len(err)))
+    if st != HS_OK:
+        raise HsError(st, err.value.decode())
 
 
 KLSH_NONE = 0xffffffffffffffff

@@ -832,37 +832,88 @@ hs_status hs_klsh_codes(int device, const uint8_t* classes, uint64_t n_residues,
 }
 
 // ---- persistent index --------------------------------------------------------------------------
+// File = IndexFileHeader, then the payload: planes a, b, coordinate table (32 x 8 doubles), codes
+// [n][k], and per table ids [n] u32, dir_key [nb] u64, dir_start [nb + 1] u32, dir_tuple [nb][K] i32.
+// The header carries the payload's length and a 64-bit hash of it; hs_index_load checks both, then
+// checks every table's CONTENT on the device before any kernel indexes with it (ids a permutation
+// of 0..n-1 ascending inside a bucket, boundaries strictly ascending from 0 to n, fingerprints
+// strictly ascending and equal to the fingerprint of the bucket's tuple): a corrupt, stale or
+// hand-edited file gives HS_ERR_IO, never an out-of-bounds access.
 namespace {
 struct IndexFileHeader {
-  char magic[8];  // "HSIDX001"
+  char magic[8];  // "HSIDX002"
   uint32_t k, K, L, alphabet;
   double W;
   uint64_t n;
   uint32_t key_seed, pad;
   uint64_t n_buckets[HS_MAX_L], max_bucket[HS_MAX_L];
+  uint64_t payload_bytes, payload_hash;
 };
+const char kIndexMagic[9] = "HSIDX002";
 struct FileCloser {
   FILE* f;
   ~FileCloser() { if (f) fclose(f); }
 };
+// order-dependent 64-bit hash over the payload as a sequence of sections (same sequence on both sides)
+struct PayloadHash {
+  uint64_t h = 0x9e3779b97f4a7c15ull, bytes = 0;
+  static uint64_t mix(uint64_t h, uint64_t w) {
+    h = (h ^ w) * 0xff51afd7ed558ccdull;
+    return h ^ (h >> 29);
+  }
+  void add(const void* p, size_t n) {
+    const unsigned char* c = static_cast<const unsigned char*>(p);
+    h = mix(h, (uint64_t)n);
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+      uint64_t w;
+      memcpy(&w, c + i, 8);
+      h = mix(h, w);
+    }
+    if (i < n) {
+      uint64_t w = 0;
+      memcpy(&w, c + i, n - i);
+      h = mix(h, w);
+    }
+    bytes += n;
+  }
+};
+const size_t kFileChunk = (size_t)64 << 20;
+bool header_shape_ok(const IndexFileHeader& hd) {
+  if (memcmp(hd.magic, kIndexMagic, 8) != 0) return false;
+  if (hd.k < 1 || hd.k > 75 || hd.K < 1 || hd.K > HS_MAX_K || hd.L < 1 || hd.L > HS_MAX_L ||
+      hd.alphabet < 1 || hd.alphabet > HS_ALPHABET_PAD || hd.n >= (1ull << 31))
+    return false;
+  for (uint32_t l = 0; l < hd.L; ++l)
+    if (hd.n_buckets[l] > hd.n || (hd.n != 0) != (hd.n_buckets[l] != 0)) return false;
+  return true;
+}
+uint64_t payload_size(const IndexFileHeader& hd) {
+  uint64_t b = (uint64_t)hd.L * hd.K * 8 * hd.k * 8 + (uint64_t)hd.L * hd.K * 8 + HS_ALPHABET_PAD * 8 * 8 + hd.n * hd.k;
+  for (uint32_t l = 0; l < hd.L; ++l)
+    b += hd.n * 4 + hd.n_buckets[l] * 8 + (hd.n_buckets[l] + 1) * 4 + hd.n_buckets[l] * hd.K * 4;
+  return b;
+}
 }  // namespace
 
-static hs_status write_device(hs_handle* h, FILE* f, const void* d_ptr, size_t bytes, std::vector<char>* tmp) {
-  const size_t CH = (size_t)64 << 20;
-  tmp->resize(std::min(bytes, CH));
-  for (size_t off = 0; off < bytes; off += CH) {
-    const size_t m = std::min(CH, bytes - off);
+static hs_status write_device(hs_handle* h, FILE* f, const void* d_ptr, size_t bytes, std::vector<char>* tmp,
+                              PayloadHash* ph) {
+  tmp->resize(std::min(bytes, kFileChunk));
+  for (size_t off = 0; off < bytes; off += kFileChunk) {
+    const size_t m = std::min(kFileChunk, bytes - off);
     HS_HIP(h, hipMemcpy(tmp->data(), (const char*)d_ptr + off, m, hipMemcpyDeviceToHost));
+    ph->add(tmp->data(), m);
     if (fwrite(tmp->data(), 1, m, f) != m) return fail(h, HS_ERR_IO, "short write to the index file");
   }
   return HS_OK;
 }
-static hs_status read_device(hs_handle* h, FILE* f, void* d_ptr, size_t bytes, std::vector<char>* tmp) {
-  const size_t CH = (size_t)64 << 20;
-  tmp->resize(std::min(bytes, CH));
-  for (size_t off = 0; off < bytes; off += CH) {
-    const size_t m = std::min(CH, bytes - off);
+static hs_status read_device(hs_handle* h, FILE* f, void* d_ptr, size_t bytes, std::vector<char>* tmp,
+                             PayloadHash* ph) {
+  tmp->resize(std::min(bytes, kFileChunk));
+  for (size_t off = 0; off < bytes; off += kFileChunk) {
+    const size_t m = std::min(kFileChunk, bytes - off);
     if (fread(tmp->data(), 1, m, f) != m) return fail(h, HS_ERR_IO, "index file truncated");
+    ph->add(tmp->data(), m);
     HS_HIP(h, hipMemcpy((char*)d_ptr + off, tmp->data(), m, hipMemcpyHostToDevice));
   }
   return HS_OK;
@@ -877,7 +928,7 @@ hs_status hs_index_save(hs_handle* h, const char* path) {
   FileCloser closer = {f};
   IndexFileHeader hd;
   memset(&hd, 0, sizeof(hd));
-  memcpy(hd.magic, "HSIDX001", 8);
+  memcpy(hd.magic, kIndexMagic, 8);
   hd.k = h->p.k; hd.K = h->p.K; hd.L = h->p.L; hd.alphabet = (uint32_t)h->alphabet;
   hd.W = h->p.W; hd.n = h->n; hd.key_seed = h->key_seed;
   for (uint32_t l = 0; l < h->p.L; ++l) {
@@ -886,19 +937,24 @@ hs_status hs_index_save(hs_handle* h, const char* path) {
   }
   if (fwrite(&hd, sizeof(hd), 1, f) != 1) return fail(h, HS_ERR_IO, "short write to the index file");
   std::vector<char> tmp;
+  PayloadHash ph;
   const size_t K = h->p.K, n = (size_t)h->n;
-  HS_CHECK(write_device(h, f, h->a.p, (size_t)h->LK * h->d * 8, &tmp));
-  HS_CHECK(write_device(h, f, h->b.p, (size_t)h->LK * 8, &tmp));
-  HS_CHECK(write_device(h, f, h->coords.p, (size_t)HS_ALPHABET_PAD * 8 * 8, &tmp));
-  HS_CHECK(write_device(h, f, h->codes.p, n * h->p.k, &tmp));
+  HS_CHECK(write_device(h, f, h->a.p, (size_t)h->LK * h->d * 8, &tmp, &ph));
+  HS_CHECK(write_device(h, f, h->b.p, (size_t)h->LK * 8, &tmp, &ph));
+  HS_CHECK(write_device(h, f, h->coords.p, (size_t)HS_ALPHABET_PAD * 8 * 8, &tmp, &ph));
+  HS_CHECK(write_device(h, f, h->codes.p, n * h->p.k, &tmp, &ph));
   for (uint32_t l = 0; l < h->p.L; ++l) {
     const size_t nb = (size_t)h->info.n_buckets[l];
-    HS_CHECK(write_device(h, f, h->t_ids[l].p, n * 4, &tmp));
-    HS_CHECK(write_device(h, f, h->t_dirkey[l].p, nb * 8, &tmp));
-    HS_CHECK(write_device(h, f, h->t_dirstart[l].p, (nb + 1) * 4, &tmp));
-    HS_CHECK(write_device(h, f, h->t_dirtuple[l].p, nb * K * 4, &tmp));
+    HS_CHECK(write_device(h, f, h->t_ids[l].p, n * 4, &tmp, &ph));
+    HS_CHECK(write_device(h, f, h->t_dirkey[l].p, nb * 8, &tmp, &ph));
+    HS_CHECK(write_device(h, f, h->t_dirstart[l].p, (nb + 1) * 4, &tmp, &ph));
+    HS_CHECK(write_device(h, f, h->t_dirtuple[l].p, nb * K * 4, &tmp, &ph));
   }
-  if (fflush(f) != 0) return fail(h, HS_ERR_IO, "short write to the index file");
+  // the header again, now with the payload's length and hash
+  hd.payload_bytes = ph.bytes;
+  hd.payload_hash = ph.h;
+  if (fseek(f, 0, SEEK_SET) != 0 || fwrite(&hd, sizeof(hd), 1, f) != 1 || fflush(f) != 0)
+    return fail(h, HS_ERR_IO, "short write to the index file");
   return HS_OK;
 }
 
@@ -910,16 +966,18 @@ hs_status hs_index_load(hs_handle* h, const char* path) {
   if (!f) return fail(h, HS_ERR_IO, std::string("cannot open ") + path);
   FileCloser closer = {f};
   IndexFileHeader hd;
-  if (fread(&hd, sizeof(hd), 1, f) != 1 || memcmp(hd.magic, "HSIDX001", 8) != 0)
-    return fail(h, HS_ERR_IO, "not an index file");
+  if (fread(&hd, sizeof(hd), 1, f) != 1 || !header_shape_ok(hd))
+    return fail(h, HS_ERR_IO, "not an index file (or written by another version)");
   if (hd.k != h->p.k || hd.K != h->p.K || hd.L != h->p.L || hd.alphabet != (uint32_t)h->alphabet ||
-      hd.W != h->p.W || hd.n >= (1ull << 31))
+      hd.W != h->p.W)
     return fail(h, HS_ERR_IO, "index file written for other parameters (k, K, L, W, alphabet)");
+  if (hd.payload_bytes != payload_size(hd)) return fail(h, HS_ERR_IO, "index file inconsistent (payload length)");
   h->built = false;
   memset(&h->prof, 0, sizeof(h->prof));
   memset(&h->info, 0, sizeof(h->info));
   HS_HIP(h, hipStreamSynchronize(h->stream));
   std::vector<char> tmp, mine;
+  PayloadHash ph;
   // planes and coordinate table must be the handle's, bit for bit
   const size_t sizes[3] = {(size_t)h->LK * h->d * 8, (size_t)h->LK * 8, (size_t)HS_ALPHABET_PAD * 8 * 8};
   const void* dev[3] = {h->a.p, h->b.p, h->coords.p};
@@ -927,6 +985,7 @@ hs_status hs_index_load(hs_handle* h, const char* path) {
     tmp.resize(sizes[i]);
     mine.resize(sizes[i]);
     if (fread(tmp.data(), 1, sizes[i], f) != sizes[i]) return fail(h, HS_ERR_IO, "index file truncated");
+    ph.add(tmp.data(), sizes[i]);
     HS_HIP(h, hipMemcpy(mine.data(), dev[i], sizes[i], hipMemcpyDeviceToHost));
     if (memcmp(tmp.data(), mine.data(), sizes[i]) != 0)
       return fail(h, HS_ERR_IO, "index file written for other planes or another coordinate table");
@@ -938,7 +997,7 @@ hs_status hs_index_load(hs_handle* h, const char* path) {
   HS_HIP(h, h->codes.reserve(std::max<size_t>(16, (size_t)n * k)));
   HS_HIP(h, h->packed_all.reserve(std::max<size_t>(16, (size_t)n * PW * 16)));
   HS_HIP(h, h->counters.reserve(256));
-  HS_CHECK(read_device(h, f, h->codes.p, (size_t)n * k, &tmp));
+  HS_CHECK(read_device(h, f, h->codes.p, (size_t)n * k, &tmp, &ph));
   if (n) {
     HS_HIP(h, hipMemsetAsync(h->counters.p, 0, 256, h->stream));
     HS_HIP(h, hs_launch_pack(h->codes.as<uint8_t>(), n, k, h->alphabet, h->packed_all.as<uint4>(),
@@ -952,18 +1011,34 @@ hs_status hs_index_load(hs_handle* h, const char* path) {
   HS_HIP(h, h->t_packed.reserve(std::max<size_t>(16, (size_t)L * n * PW * 16)));
   if (with_rec8) HS_HIP(h, h->t_rec8.reserve(std::max<size_t>(16, (size_t)L * n * 16)));
   HS_HIP(h, h->t_pos.reserve(std::max<size_t>(16, (size_t)L * n * 4)));
+  uint32_t* d_flag = h->counters.as<uint32_t>() + 16;  // [16] failure bits, [17 + l] largest bucket
+  HS_HIP(h, hipMemsetAsync(d_flag, 0, (1 + HS_MAX_L) * 4, h->stream));
   for (int l = 0; l < L; ++l) {
     const size_t nb = (size_t)hd.n_buckets[l];
-    if (nb > n) return fail(h, HS_ERR_IO, "index file inconsistent (more buckets than k-mers)");
     uint4* const tab_packed = h->t_packed.as<uint4>() + (size_t)l * n * PW;
     HS_HIP(h, h->t_ids[l].reserve(std::max<size_t>(16, (size_t)n * 4)));
     HS_HIP(h, h->t_dirkey[l].reserve(std::max<size_t>(16, nb * 8)));
     HS_HIP(h, h->t_dirstart[l].reserve((nb + 1) * 4));
     HS_HIP(h, h->t_dirtuple[l].reserve(std::max<size_t>(16, nb * K * 4)));
-    HS_CHECK(read_device(h, f, h->t_ids[l].p, (size_t)n * 4, &tmp));
-    HS_CHECK(read_device(h, f, h->t_dirkey[l].p, nb * 8, &tmp));
-    HS_CHECK(read_device(h, f, h->t_dirstart[l].p, (nb + 1) * 4, &tmp));
-    HS_CHECK(read_device(h, f, h->t_dirtuple[l].p, nb * K * 4, &tmp));
+    HS_CHECK(read_device(h, f, h->t_ids[l].p, (size_t)n * 4, &tmp, &ph));
+    HS_CHECK(read_device(h, f, h->t_dirkey[l].p, nb * 8, &tmp, &ph));
+    HS_CHECK(read_device(h, f, h->t_dirstart[l].p, (nb + 1) * 4, &tmp, &ph));
+    HS_CHECK(read_device(h, f, h->t_dirtuple[l].p, nb * K * 4, &tmp, &ph));
+    // content checks BEFORE anything indexes with the table; pos_of comes out of them
+    HS_HIP(h, hs_launch_validate_table(h->t_ids[l].as<uint32_t>(), (uint32_t)n,
+                                       h->t_pos.as<uint32_t>() + (size_t)l * n,
+                                       h->t_dirstart[l].as<uint32_t>(), h->t_dirkey[l].as<uint64_t>(),
+                                       h->t_dirtuple[l].as<int32_t>(), (uint32_t)nb, K, hd.key_seed, d_flag,
+                                       d_flag + 1 + l, h->stream));
+    uint32_t flag = 0;
+    HS_HIP(h, hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, h->stream));
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    if (flag) {
+      char msg[160];
+      snprintf(msg, sizeof(msg), "index file corrupt: table %d fails its content checks (bits 0x%x: 1 id range, 2 id twice, "
+               "4 boundaries, 8 key order, 16 key/tuple, 32 id order)", l, flag);
+      return fail(h, HS_ERR_IO, msg);
+    }
     if (with_rec8)
       HS_HIP(h, hs_launch_gather_rec8(h->packed_all.as<uint4>(), h->t_ids[l].as<uint32_t>(), (uint32_t)n,
                                       k, h->jtab8.p, h->jtab8.as<float>() + 128, tab_packed,
@@ -971,8 +1046,6 @@ hs_status hs_index_load(hs_handle* h, const char* path) {
     else
       HS_HIP(h, hs_launch_gather_packed(h->packed_all.as<uint4>(), h->t_ids[l].as<uint32_t>(), n, PW,
                                         tab_packed, h->stream));
-    HS_HIP(h, hs_launch_invert_perm(h->t_ids[l].as<uint32_t>(), (uint32_t)n,
-                                    h->t_pos.as<uint32_t>() + (size_t)l * n, h->stream));
     hs_table_dev& tb = h->tabs.t[l];
     tb.dir_key = h->t_dirkey[l].as<uint64_t>();
     tb.dir_start = h->t_dirstart[l].as<uint32_t>();
@@ -982,10 +1055,95 @@ hs_status hs_index_load(hs_handle* h, const char* path) {
     tb.pos_of = h->t_pos.as<uint32_t>() + (size_t)l * n;
     tb.nb = (uint32_t)nb;
     h->info.n_buckets[l] = nb;
-    h->info.max_bucket[l] = hd.max_bucket[l];
   }
+  uint32_t maxb[HS_MAX_L] = {0};
+  HS_HIP(h, hipMemcpyAsync(maxb, d_flag + 1, (size_t)L * 4, hipMemcpyDeviceToHost, h->stream));
   HS_HIP(h, hipStreamSynchronize(h->stream));
+  for (int l = 0; l < L; ++l) h->info.max_bucket[l] = maxb[l];  // recomputed, not taken on trust
+  char extra;
+  if (ph.bytes != hd.payload_bytes || ph.h != hd.payload_hash || fread(&extra, 1, 1, f) != 0)
+    return fail(h, HS_ERR_IO, "index file corrupt (payload hash or length does not match the header)");
   return finish_index(h);
+}
+
+// Host-only check of an index file (no GPU, no handle): header, payload length and hash, and the
+// content rules hs_index_load enforces on the device.  HS_OK or HS_ERR_IO with a message.
+hs_status hs_index_file_check(const char* path, char* err, uint32_t err_cap) {
+  auto say = [&](hs_status st, const std::string& msg) {
+    if (err && err_cap) {
+      strncpy(err, msg.c_str(), err_cap - 1);
+      err[err_cap - 1] = 0;
+    }
+    return st;
+  };
+  if (!path) return say(HS_ERR_INVALID, "null path");
+  FILE* f = fopen(path, "rb");
+  if (!f) return say(HS_ERR_IO, std::string("cannot open ") + path);
+  FileCloser closer = {f};
+  IndexFileHeader hd;
+  if (fread(&hd, sizeof(hd), 1, f) != 1 || !header_shape_ok(hd))
+    return say(HS_ERR_IO, "not an index file (or written by another version)");
+  if (hd.payload_bytes != payload_size(hd)) return say(HS_ERR_IO, "payload length does not match the header");
+  PayloadHash ph;
+  std::vector<char> buf;
+  auto section = [&](size_t bytes, std::vector<char>* keep) -> bool {
+    std::vector<char>& dst = keep ? *keep : buf;
+    if (keep) {
+      dst.resize(bytes);
+      if (bytes && fread(dst.data(), 1, bytes, f) != bytes) return false;
+      // hashed in the chunks read_device/write_device use
+      for (size_t off = 0; off < bytes; off += kFileChunk) ph.add(dst.data() + off, std::min(kFileChunk, bytes - off));
+      return true;
+    }
+    dst.resize(std::min(bytes, kFileChunk));
+    for (size_t off = 0; off < bytes; off += kFileChunk) {
+      const size_t m = std::min(kFileChunk, bytes - off);
+      if (fread(dst.data(), 1, m, f) != m) return false;
+      ph.add(dst.data(), m);
+    }
+    return true;
+  };
+  const size_t d = 8 * (size_t)hd.k, LK = (size_t)hd.L * hd.K, n = (size_t)hd.n, K = hd.K;
+  // planes, offsets and the coordinate table are hashed one section each (sizes well under a chunk
+  // for any admissible parameters except the planes of very long k-mers, chunked like the rest)
+  std::vector<char> codes;
+  if (!section(LK * d * 8, nullptr) || !section(LK * 8, nullptr) || !section(HS_ALPHABET_PAD * 8 * 8, nullptr) ||
+      !section(n * hd.k, &codes))
+    return say(HS_ERR_IO, "index file truncated");
+  for (size_t i = 0; i < codes.size(); ++i)
+    if ((unsigned char)codes[i] >= hd.alphabet) return say(HS_ERR_IO, "residue code outside the alphabet");
+  std::vector<char> ids_b, key_b, start_b, tup_b;
+  std::vector<unsigned char> seen;
+  for (uint32_t l = 0; l < hd.L; ++l) {
+    const size_t nb = (size_t)hd.n_buckets[l];
+    if (!section(n * 4, &ids_b) || !section(nb * 8, &key_b) || !section((nb + 1) * 4, &start_b) ||
+        !section(nb * K * 4, &tup_b))
+      return say(HS_ERR_IO, "index file truncated");
+    const uint32_t* ids = reinterpret_cast<const uint32_t*>(ids_b.data());
+    const uint64_t* key = reinterpret_cast<const uint64_t*>(key_b.data());
+    const uint32_t* start = reinterpret_cast<const uint32_t*>(start_b.data());
+    const int32_t* tup = reinterpret_cast<const int32_t*>(tup_b.data());
+    const std::string where = " (table " + std::to_string(l) + ")";
+    seen.assign(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+      if (ids[i] >= n) return say(HS_ERR_IO, "id out of range" + where);
+      if (seen[ids[i]]) return say(HS_ERR_IO, "id listed twice" + where);
+      seen[ids[i]] = 1;
+    }
+    if ((nb ? start[0] : 0u) != 0u || start[nb] != n) return say(HS_ERR_IO, "bucket boundaries do not span 0..n" + where);
+    for (size_t b = 0; b < nb; ++b) {
+      if (!(start[b] < start[b + 1]) || start[b + 1] > n) return say(HS_ERR_IO, "bucket boundaries not ascending" + where);
+      if (b + 1 < nb && !(key[b] < key[b + 1])) return say(HS_ERR_IO, "fingerprints not ascending" + where);
+      if (hs_key_of(tup + b * K, (int)K, hd.key_seed) != key[b])
+        return say(HS_ERR_IO, "a bucket's tuple does not have its fingerprint" + where);
+      for (uint32_t i = start[b] + 1; i < start[b + 1]; ++i)
+        if (!(ids[i - 1] < ids[i])) return say(HS_ERR_IO, "ids not ascending inside a bucket" + where);
+    }
+  }
+  char extra;
+  if (ph.bytes != hd.payload_bytes || ph.h != hd.payload_hash || fread(&extra, 1, 1, f) != 0)
+    return say(HS_ERR_IO, "payload hash or length does not match the header");
+  return HS_OK;
 }
 
 hs_status hs_index_info_get(const hs_handle* h, hs_index_info* out) {

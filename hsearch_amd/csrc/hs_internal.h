@@ -186,6 +186,13 @@ hipError_t hs_launch_klsh(const uint8_t* d_classes, const uint64_t* d_seq_start,
                           uint64_t* d_codes, uint64_t* d_uncertain, hipStream_t s);
 // d_out[d_perm[i]] = i
 hipError_t hs_launch_invert_perm(const uint32_t* d_perm, uint32_t n, uint32_t* d_out, hipStream_t s);
+// hs_index_load: checks of a table read from a file (see hs_validate_*_kernel); writes the inverse
+// permutation into d_pos_of, ORs failure bits into *d_flag, atomicMax of the bucket sizes into
+// *d_max_bucket
+hipError_t hs_launch_validate_table(const uint32_t* d_ids, uint32_t n, uint32_t* d_pos_of,
+                                    const uint32_t* d_dir_start, const uint64_t* d_dir_key,
+                                    const int32_t* d_dir_tuple, uint32_t nb, int K, uint32_t seed,
+                                    uint32_t* d_flag, uint32_t* d_max_bucket, hipStream_t s);
 // jump[t] = first directory entry with (key >> shift) >= t, t = 0 .. n_slots (jump[n_slots] = nb)
 hipError_t hs_launch_dir_jump(const uint64_t* d_dir_key, uint32_t nb, uint32_t shift, uint32_t n_slots,
                               uint32_t* d_jump, hipStream_t s);

@@ -917,6 +917,64 @@ __global__ __launch_bounds__(256) void hs_invert_perm_kernel(const uint32_t* __r
   if (i < n) out[perm[i]] = i;
 }
 
+// hs_index_load: a table read from a file is checked before any kernel indexes with it.
+// flag bits: 1 id out of range, 2 id twice (ids is not a permutation), 4 bucket boundaries not
+// strictly ascending from 0 to n, 8 fingerprints not strictly ascending, 16 a bucket's tuple does
+// not have its fingerprint, 32 ids not ascending inside a bucket (the reference appends ids in
+// ascending order, motif_both_points.cpp:212).  pos_of must be filled with 0xffffffff beforehand;
+// it comes out as the inverse permutation (what hs_invert_perm_kernel writes for a trusted table).
+__global__ __launch_bounds__(256) void hs_validate_ids_kernel(const uint32_t* __restrict__ ids, uint32_t n,
+                                                              uint32_t* __restrict__ pos_of,
+                                                              uint32_t* __restrict__ flag) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t id = ids[i];
+  if (id >= n) {
+    atomicOr(flag, 1u);
+    return;
+  }
+  if (atomicExch(&pos_of[id], i) != 0xffffffffu) atomicOr(flag, 2u);
+}
+
+__global__ __launch_bounds__(256) void hs_validate_dir_kernel(const uint32_t* __restrict__ dir_start,
+                                                              const uint64_t* __restrict__ dir_key,
+                                                              const int32_t* __restrict__ dir_tuple,
+                                                              const uint32_t* __restrict__ ids,
+                                                              uint32_t nb, uint32_t n, int K, uint32_t seed,
+                                                              uint32_t* __restrict__ flag,
+                                                              uint32_t* __restrict__ max_bucket) {
+  const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+  if (b == 0 && ((nb ? dir_start[0] : 0u) != 0u || dir_start[nb] != n || (n != 0u) != (nb != 0u)))
+    atomicOr(flag, 4u);
+  if (b >= nb) return;
+  const uint32_t lo = dir_start[b], hi = dir_start[b + 1];
+  if (!(lo < hi) || hi > n) {
+    atomicOr(flag, 4u);
+    return;
+  }
+  if (b + 1 < nb && !(dir_key[b] < dir_key[b + 1])) atomicOr(flag, 8u);
+  int32_t t[HS_MAX_K];
+  for (int i = 0; i < K; ++i) t[i] = dir_tuple[(uint64_t)b * K + i];
+  if (hs_key_of(t, K, seed) != dir_key[b]) atomicOr(flag, 16u);
+  atomicMax(max_bucket, hi - lo);
+}
+
+// one thread per entry: ids may only descend where a bucket starts (binary search on descents only)
+__global__ __launch_bounds__(256) void hs_validate_order_kernel(const uint32_t* __restrict__ ids,
+                                                                const uint32_t* __restrict__ dir_start,
+                                                                uint32_t nb, uint32_t n,
+                                                                uint32_t* __restrict__ flag) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x + 1;
+  if (i >= n) return;
+  if (ids[i - 1] < ids[i]) return;
+  uint32_t lo = 0, hi = nb;  // is i one of dir_start[0 .. nb)?
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (dir_start[mid] < i) lo = mid + 1; else hi = mid;
+  }
+  if (lo >= nb || dir_start[lo] != i) atomicOr(flag, 32u);
+}
+
 // Brute force (motif_both_points_noLSH.cpp:27-34,44-50): sqrt form, hit iff !(dis > R).
 __global__ __launch_bounds__(256) void hs_bf_finalize_kernel(const uint8_t* __restrict__ codes,
                                                              const double* __restrict__ centers,
@@ -1194,6 +1252,20 @@ hipError_t hs_launch_dir_jump(const uint64_t* d_dir_key, uint32_t nb, uint32_t s
 hipError_t hs_launch_invert_perm(const uint32_t* d_perm, uint32_t n, uint32_t* d_out, hipStream_t s) {
   if (!n) return hipSuccess;
   hs_invert_perm_kernel<<<blocks_for(n), 256, 0, s>>>(d_perm, n, d_out);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_validate_table(const uint32_t* d_ids, uint32_t n, uint32_t* d_pos_of,
+                                    const uint32_t* d_dir_start, const uint64_t* d_dir_key,
+                                    const int32_t* d_dir_tuple, uint32_t nb, int K, uint32_t seed,
+                                    uint32_t* d_flag, uint32_t* d_max_bucket, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(d_pos_of, 0xff, (size_t)n * 4, s);
+  if (e != hipSuccess) return e;
+  if (n) hs_validate_ids_kernel<<<blocks_for(n), 256, 0, s>>>(d_ids, n, d_pos_of, d_flag);
+  hs_validate_dir_kernel<<<std::max(1u, blocks_for(nb)), 256, 0, s>>>(d_dir_start, d_dir_key, d_dir_tuple,
+                                                                      d_ids, nb, n, K, seed, d_flag,
+                                                                      d_max_bucket);
+  if (n > 1) hs_validate_order_kernel<<<blocks_for(n - 1), 256, 0, s>>>(d_ids, d_dir_start, nb, n, d_flag);
   return hipGetLastError();
 }
 

@@ -157,9 +157,17 @@ HS_API hs_status hs_index_build_windows(hs_handle* h, const uint8_t* residues, u
  * coordinate table, residue codes and the L tables (ids + bucket directory) of a built handle;
  * hs_index_load restores them into a handle created with the SAME parameters, planes and table
  * (checked bit for bit, HS_ERR_IO otherwise) and re-derives the bucket-ordered copies on the
- * device: queries then give exactly what they give after hs_index_build. */
+ * device: queries then give exactly what they give after hs_index_build.
+ * The file carries its payload's length and a 64-bit hash; hs_index_load checks them and, before any
+ * kernel indexes with a table, the table's content on the device (ids a permutation of 0..n-1,
+ * ascending inside a bucket; boundaries strictly ascending from 0 to n; fingerprints strictly
+ * ascending and equal to the fingerprint of the bucket's tuple; bucket sizes recomputed): a corrupt,
+ * truncated, stale or hand-edited file yields HS_ERR_IO, never an out-of-bounds access.
+ * hs_index_file_check runs the same checks on the HOST (no GPU, no handle): HS_OK or HS_ERR_IO with
+ * a message in err. */
 HS_API hs_status hs_index_save(hs_handle* h, const char* path);
 HS_API hs_status hs_index_load(hs_handle* h, const char* path);
+HS_API hs_status hs_index_file_check(const char* path, char* err, uint32_t err_cap);
 
 /* SURVEY 8(f) row 3 -- Kernel-LSH pre-grouping of whole proteins (pcluster.cpp:11-81).
  * hs_klsh_draw_planes: the planes KLSH::KLSH draws (lsh.cpp:17-38) from its default-seeded

@@ -1,6 +1,7 @@
 """BASELINE.json's full sizes, where the CPU oracle cannot run: size-independent properties.
 
   configs[1]  10 M 25-mers, L=8, K=16, 100 k queries      (search)
+  configs[2]  100 M 25-mers, L=32, K=20, one GPU's share  (search; 1 M queries / 8 GPUs = 125 k)
   configs[3]  1 M 25-mers all-vs-all + hclust             (clustering)
   configs[4]  mixed k in {15, 25, 39}                      (three indexes, one launch sequence)
 """
@@ -77,6 +78,62 @@ def test_config2_search_properties():
         mine = sorted((d_, i_) for (q_, i_), d_ in zip(zip(bf["q"].tolist(), bf["id"].tolist()), bf["dist"].tolist()) if q_ == qi)
         kk = min(len(mine), 10)
         assert [i_ for _, i_ in mine[:kk]] == nn[qi, :kk].tolist()
+    eng.close()
+
+
+def test_config3_shape_properties():
+    """BASELINE.json configs[2] as ONE GPU sees it: the 100 M-k-mer index replicated (L = 32,
+    K = 20, ~135 GB of the 288 GB), this rank's 125 000 of the 10^6 queries.  The oracle cannot run
+    at this size, so: the interchangeable filter kernels agree hit for hit, the output is in the
+    reference's order (motif_both_points.cpp:224-245), distances are the exact fp64 values, exact
+    copies are found in table 0, and LSH hits are a subset of the exhaustive scan's."""
+    k, K, L, W, R, n, nq = 25, 20, 32, 200.0, 40.0, 100_000_000, 125_000
+    a, b = synth.make_planes(k, K, L, W)
+    codes = synth.make_db(n, k)
+    centers, src = synth.make_queries(codes, nq)
+    eng = Engine(k, K, L, W, a, b)
+    info = eng.index_build(codes)
+    assert info["n"] == n and len(info["n_buckets"]) == L and min(info["n_buckets"]) > 1000
+    assert info["device_bytes"] < 200e9
+    eng.set_verify_mode("join")
+    j = eng.query(centers, R)
+    prof = eng.profile()
+    assert prof["join_i8_batches"] > 0 and prof["join_pairs"] > 0.9 * prof["candidates"]
+    # the streaming filter on a query subsample (it moves 58 MB per query at this size)
+    ns = 20_000
+    eng.set_verify_mode("stream")
+    s = eng.query(centers[:ns], R)
+    assert eng.profile()["join_batches"] == 0
+    cut = int(np.searchsorted(j["q"], ns))
+    assert np.array_equal(j["cand"][:ns], s["cand"])
+    for f in ("q", "id", "table", "dist"):
+        assert np.array_equal(j[f][:cut], s[f]), f
+    eng.set_verify_mode("join16")
+    h = eng.query(centers[:ns], R)
+    for f in ("q", "id", "table", "dist"):
+        assert np.array_equal(h[f], s[f]), f
+    q, ids, tab, dist = j["q"].astype(np.int64), j["id"].astype(np.int64), j["table"].astype(np.int64), j["dist"]
+    key = (q << 40) | (tab << 32) | ids
+    assert np.all(np.diff(key) > 0)                       # query, table of first sight, ascending id
+    assert len(np.unique((q << 32) | ids)) == len(q)      # first-seen dedupe over 32 tables
+    assert tab.max() < L and len(np.unique(tab)) > 8      # later tables do contribute first sights
+    sel = np.random.default_rng(0).choice(len(q), size=min(20000, len(q)), replace=False)
+    d2 = _exact_d2(codes[ids[sel]], centers[q[sel]])
+    assert np.array_equal(np.sqrt(d2), dist[sel])
+    assert np.all(d2 <= R * R)
+    exact = np.nonzero((synth.embed(codes[src[:5000]]) == centers[:5000]).all(axis=1))[0]
+    assert len(exact) > 500
+    first_table = {(qq, ii): tt for qq, ii, tt in zip(q[:cut].tolist(), ids[:cut].tolist(), tab[:cut].tolist())}
+    for qi in exact:
+        assert first_table.get((int(qi), int(src[qi]))) == 0
+    assert np.all(j["cand"].max(axis=0) <= np.array(info["max_bucket"]))
+    # LSH never reports a pair the exhaustive scan lacks; with 32 tables it finds nearly all of them
+    sub = centers[:64]
+    bf = eng.bruteforce(sub, R)
+    truth = set(zip(bf["q"].tolist(), bf["id"].tolist()))
+    found = {(a_, b_) for a_, b_ in zip(q[:cut].tolist(), ids[:cut].tolist()) if a_ < 64}
+    assert found <= truth
+    assert len(found) / len(truth) > 0.9
     eng.close()
 
 

@@ -15,6 +15,8 @@ def _case(seed):
     k = int(r.choice([1, 2, 3, 7, 12, 15, 24, 25, 25, 25, 26, 33, 39, 50]))
     K = int(r.integers(1, 21))
     L = int(r.integers(1, 9))
+    if seed >= 60:      # the second block of cases draws from the whole table range the ABI admits
+        L = int(r.integers(9, 33))
     W = float(r.choice([0.7, 5.0, 30.0, 80.0, 150.0, 250.0, 400.0, 1e4]))
     R = float(r.choice([0.0, 1e-9, 10.0, 25.0, 40.0, 55.0, 80.0, 1e6]))
     n = int(r.choice([1, 2, 17, 300, 2000, 6000]))
@@ -61,7 +63,7 @@ def _case(seed):
                 centers=np.ascontiguousarray(centers), what="%s/%s" % (shape, kind))
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("HS_FUZZ_CASES", "60"))))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("HS_FUZZ_CASES", "84"))))
 def test_random_configuration_matches_oracle(oracle, seed):
     c = _case(seed)
     eng = Engine(c["k"], c["K"], c["L"], c["W"], c["a"], c["b"], coords=c["table"])

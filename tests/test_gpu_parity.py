@@ -44,7 +44,11 @@ def test_bucket_ints_bit_exact(oracle, k, K, L, W):
                                             (25, 4, 4, 50.0, 40.0, 5000, 300),
                                             (15, 4, 6, 60.0, 30.0, 8000, 400),
                                             (39, 8, 4, 150.0, 50.0, 6000, 300),
-                                            (25, 2, 3, 3.0, 40.0, 4000, 200)])
+                                            (25, 2, 3, 3.0, 40.0, 4000, 200),
+                                            # configs[2]'s table shape (L = 32, K = 20) at oracle size
+                                            (25, 20, 32, 200.0, 40.0, 20000, 400),
+                                            (25, 20, 32, 120.0, 45.0, 12000, 300),
+                                            (39, 20, 32, 250.0, 50.0, 6000, 200)])
 def test_search_hits_match_oracle(oracle, k, K, L, W, R, n, nq):
     a, b = synth.make_planes(k, K, L, W)
     codes = synth.make_db(n, k)
@@ -308,6 +312,74 @@ def test_index_save_load_round_trip(oracle, tmp_path):
     with pytest.raises(hsearch_amd.HsError):
         e3.index_load(tmp_path / "missing.hsidx")
     e3.close()
+
+
+def test_index_load_checks_file_content(oracle, tmp_path):
+    """hs_index_load must not trust a file's tables.  (1) The file a handle saves passes
+    the host-side check, and is byte-identical to the one the test helper writes from the ORACLE's
+    bucket ints (so the format is pinned from both sides).  (2) A handle loads the oracle-written
+    file and answers like a handle that built the index.  (3) Bit flips, truncation and
+    self-consistent files that break a content rule (out-of-range / repeated ids, broken bucket
+    boundaries, mis-ordered or mismatched fingerprints) give HS_ERR_IO -- no device fault -- and
+    the handle still works afterwards."""
+    import hsearch_amd
+    import indexfile
+    k, K, L, W, R, n = 25, 6, 4, 120.0, 40.0, 5000
+    a, b = synth.make_planes(k, K, L, W, seed=51)
+    codes = synth.make_db(n, k, seed=52)
+    centers, _ = synth.make_queries(codes, 300, seed=53, jitter=0.2)
+    eng = Engine(k, K, L, W, a, b)
+    info = eng.index_build(codes)
+    want = eng.query(centers, R)
+    saved = tmp_path / "saved.hsidx"
+    eng.index_save(saved)
+    hsearch_amd.index_file_check(saved)
+    tables = indexfile.build_tables(oracle.hash_all(a, b, W, oracle.embed_codes(codes)), seed=info["key_seed"])
+    mine = tmp_path / "oracle.hsidx"
+    indexfile.write(mine, k, K, L, W, a, b, codes, tables, seed=info["key_seed"])
+    assert mine.read_bytes() == saved.read_bytes()
+    e2 = Engine(k, K, L, W, a, b)
+    info2 = e2.index_load(mine)
+    assert info2["n_buckets"] == info["n_buckets"] and info2["max_bucket"] == info["max_bucket"]
+    _assert_hits_equal(e2.query(centers, R), want)
+
+    def ids(s, l=0):
+        return s[4 + 4 * l]
+    tampers = [
+        lambda s: ids(s).__setitem__(5, 10**9),
+        lambda s: ids(s, 2).__setitem__(5, ids(s, 2)[6]),
+        lambda s: s[4 + 2].__setitem__(0, 1),
+        lambda s: s[4 + 2].__setitem__(3, s[4 + 2][2]),
+        lambda s: s[4 + 2].__setitem__(len(s[4 + 2]) - 1, 7),
+        lambda s: s[4 + 2].__setitem__(2, 4_000_000_000),
+        lambda s: s[4 + 1].__setitem__(slice(0, 2), s[4 + 1][[1, 0]]),
+        lambda s: s[4 + 3].__setitem__((0, 0), s[4 + 3][0, 0] + 1),
+        lambda s: s[3].__setitem__((0, 0), 21),
+    ]
+    bad = tmp_path / "bad.hsidx"
+    for t in tampers:
+        indexfile.write(bad, k, K, L, W, a, b, codes, tables, seed=info["key_seed"], tamper=t)
+        with pytest.raises(hsearch_amd.HsError) as ei:
+            e2.index_load(bad)
+        assert "HS_ERR_IO" in str(ei.value)
+        with pytest.raises(hsearch_amd.HsError):
+            e2.query(centers, R)                       # a refused file leaves no half-loaded index
+    data = saved.read_bytes()
+    rng = np.random.default_rng(2)
+    for pos in rng.integers(300, len(data), size=12).tolist():
+        flipped = bytearray(data)
+        flipped[pos] ^= 0x40
+        bad.write_bytes(bytes(flipped))
+        with pytest.raises(hsearch_amd.HsError) as ei:
+            e2.index_load(bad)
+        assert "HS_ERR_IO" in str(ei.value)
+    bad.write_bytes(data[:len(data) // 2])
+    with pytest.raises(hsearch_amd.HsError):
+        e2.index_load(bad)
+    e2.index_load(saved)                               # and the handle is still usable
+    _assert_hits_equal(e2.query(centers, R), want)
+    e2.close()
+    eng.close()
 
 
 def test_klsh_codes_match_reference_golden(oracle, golden_dir):

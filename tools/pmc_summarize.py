@@ -2,7 +2,17 @@
 (and, with --traffic, refresh profiles/traffic_latest.json, which bench.py reports as
 roofline.traffic).  Usage: python tools/pmc_summarize.py gpurun_out/pmc_<tag> <kernel substring>
 <out.json> [--traffic]"""
-import collections, csv, glob, json, sys
+import collections, csv, datetime, glob, hashlib, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_hash():   # = bench.py's: ties the figures to the kernel sources they were taken on
+    h = hashlib.sha256()
+    for f in ("hs_join8.hip", "hs_join.hip", "hs_kernels.hip", "hs_internal.h"):
+        h.update(open(os.path.join(ROOT, "hsearch_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 src, kernel, out = sys.argv[1], sys.argv[2], sys.argv[3]
 tot = collections.defaultdict(float); launches = collections.defaultdict(int)
 for f in glob.glob(src + '/p*/*/*_counter_collection.csv'):
@@ -15,7 +25,8 @@ for f in glob.glob(src + '/p*/*/*_counter_collection.csv'):
     for row in csv.DictReader(open(f)):
         if kernel in row['Kernel_Name']:
             disp[row['Counter_Name']].add(row['Dispatch_Id'])
-res = {"kernel": kernel,
+res = {"kernel": kernel, "kernel_source_hash": kernel_source_hash(),
+       "taken": datetime.date.today().isoformat(),
        "method": "rocprofv3 --kernel-trace --pmc <counters>, one pass per counter group, over `bench.py --steps 1 "
                  "--warmup 0 --no-cpu-baseline --recall-queries 0` (tools/pmc_join.sh); FETCH_SIZE (KB) doubled per "
                  "MI355X_MICROARCH.md section HBM (gfx950 tallies the 128-B requests of 16-B/lane streams at 64 B); "
