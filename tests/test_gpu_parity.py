@@ -47,7 +47,7 @@ def test_bucket_ints_bit_exact(oracle, k, K, L, W):
                                             (25, 2, 3, 3.0, 40.0, 4000, 200),
                                             # configs[2]'s table shape (L = 32, K = 20) at oracle size
                                             (25, 20, 32, 200.0, 40.0, 20000, 400),
-                                            (25, 20, 32, 120.0, 45.0, 12000, 300),
+                                            (25, 20, 32, 320.0, 45.0, 12000, 300),
                                             (39, 20, 32, 250.0, 50.0, 6000, 200)])
 def test_search_hits_match_oracle(oracle, k, K, L, W, R, n, nq):
     a, b = synth.make_planes(k, K, L, W)
