@@ -14,7 +14,7 @@ _STATUS = ["HS_OK", "HS_ERR_INVALID", "HS_ERR_NO_DEVICE", "HS_ERR_HIP", "HS_ERR_
 # Row order of the embedding table (include/hs_tables.h HS_CODE_TO_LETTER): BLOSUM order.
 _ALPHABET = "ARNDCQEGHILKMFPSTWYV"
 
-EXPORTS = ["hs_create", "hs_destroy", "hs_last_error", "hs_get_profile", "hs_version",
+EXPORTS = ["hs_create", "hs_destroy", "hs_last_error", "hs_get_profile", "hs_get_params", "hs_version",
            "hs_set_verify_mode", "hs_set_planes", "hs_self_join", "hs_self_join_range", "hs_clustering",
            "hs_clustering_begin", "hs_clustering_table_edges", "hs_clustering_table_apply",
            "hs_clustering_end",

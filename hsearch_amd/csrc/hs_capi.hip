@@ -177,6 +177,13 @@ hs_status hs_get_profile(const hs_handle* h, hs_profile* out) {
   return HS_OK;
 }
 
+hs_status hs_get_params(const hs_handle* h, hs_params* out) {
+  if (!h || !out) return HS_ERR_INVALID;
+  *out = h->p;
+  out->alphabet = (uint32_t)h->alphabet;
+  return HS_OK;
+}
+
 uint32_t hs_key_string(const int32_t* buckets, uint32_t K, char* out, uint32_t cap) {
   if (K > HS_MAX_K) K = HS_MAX_K;
   char tmp[HS_KEY_CHARS];

@@ -18,7 +18,25 @@ def shard_bounds(n_total, rank, world):
     return lo, hi
 
 
-_PAD = {"m": 0}   # padded per-rank capacity of the payload, grown on demand and kept across calls
+# Per process group: the padded per-rank capacity m of the payload (grown on demand, kept across
+# calls) and the send / receive buffers of that size.  m is derived from EXCHANGED counts only, so it
+# is the same on every rank of a group as long as every rank of the group makes the same sequence of
+# calls on it (which a collective requires anyway); it is keyed by group so that ranks taking part in
+# several groups cannot carry one group's capacity into another's collective.
+_STATE = {}
+
+
+def _group_state(group, dev):
+    key = (id(group) if group is not None else 0, str(dev))
+    st = _STATE.get(key)
+    if st is None:
+        st = _STATE[key] = {"m": 4096, "buf": None, "gathered": None}
+    return st
+
+
+def reset_state():
+    """Forget capacities and buffers (call after destroying a process group)."""
+    _STATE.clear()
 
 
 def allgather_hits(q, ids, table, distance, n_hits, q_offset=0, group=None, force=False):
@@ -47,31 +65,35 @@ def allgather_hits(q, ids, table, distance, n_hits, q_offset=0, group=None, forc
         return qv, ids[:n_hits], table[:n_hits], distance[:n_hits]
     q32 = q[:n_hits].view(torch.int32) + int(q_offset)          # global numbering before the exchange
     cols = (q32, ids[:n_hits].view(torch.int32), table[:n_hits].view(torch.int32), distance[:n_hits])
+    state = _group_state(group, dev)
     while True:
         # m must be the same on every rank: it is derived from exchanged counts only, never from
         # the local n_hits (a rank with more hits than m sends its count and a truncated payload;
         # every rank then sees that count and repeats the exchange with the same larger m)
-        m = max(_PAD["m"], 4096)
-        _PAD["m"] = m
+        m = state["m"]
         nbytes = 8 + 20 * m
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        if state["buf"] is None or state["buf"].numel() != nbytes:
+            # (re)allocated only when m grows: nothing is allocated in a steady-state step
+            state["buf"] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            state["gathered"] = torch.empty((world, nbytes), dtype=torch.uint8, device=dev)
+        buf, gathered = state["buf"], state["gathered"]
         buf[:8].view(torch.int64).fill_(n_hits)
         n_send = min(n_hits, m)
         off = 8
         for c, w in zip(cols, (4, 4, 4, 8)):
             buf[off:off + w * n_send] = c[:n_send].contiguous().view(torch.uint8)
             off += w * m
-        gathered = torch.empty((world, nbytes), dtype=torch.uint8, device=dev)
         dist.all_gather_into_tensor(gathered.view(-1), buf, group=group)
+        # the one host round trip of the exchange: the counts decide how much of each record is live
         counts = gathered[:, :8].contiguous().view(torch.int64).view(-1).cpu().tolist()
         if max(counts) <= m:
             break
-        _PAD["m"] = (int(max(counts) * 1.25) + 1024 + 1) // 2 * 2  # even: keeps float64 8-aligned
+        state["m"] = (int(max(counts) * 1.25) + 1024 + 1) // 2 * 2  # even: keeps float64 8-aligned
     out = []
     off = 8
     for w, dt in zip((4, 4, 4, 8), (torch.int32, torch.int32, torch.int32, torch.float64)):
         parts = [gathered[r, off:off + w * counts[r]].view(dt) for r in range(world)]
-        col = torch.cat(parts) if world > 1 else parts[0].clone()
+        col = torch.cat(parts) if world > 1 else parts[0].clone()   # copies: the buffer is reused
         out.append(col if dt == torch.float64 else col.to(torch.int64))
         off += w * m
     return out[0], out[1], out[2], out[3]

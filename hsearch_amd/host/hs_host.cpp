@@ -11,15 +11,18 @@
 
 #include <algorithm>
 #include <fstream>
+#include <functional>
 #include <limits>
 #include <map>
 #include <random>
 #include <sstream>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 
 #include "../../include/hs_tables.h"
 #include "../../include/hsearch.h"
+#include "../../include/hsearch_dist.h"
 
 namespace hsearch {
 
@@ -99,11 +102,169 @@ bool PointsToCodes(const std::vector<Point>& pts, uint32_t dim, std::vector<doub
   return true;
 }
 
+namespace {
+
+struct SearchHits {
+  std::vector<uint32_t> q, id, table;
+  std::vector<double> dist;
+  uint64_t n = 0;
+};
+struct HandleCloser {
+  hs_handle* h;
+  ~HandleCloser() { hs_destroy(h); }
+};
+
+// The device part of Search(): index build (through `build`, on a fresh handle) and the query loop,
+// on one GPU (devices.size() == 1 and !sharded: hs_query, no communicator) or query-sharded over
+// several: one host thread and one handle per GPU, the index built on every GPU, rank
+// r searching its contiguous block of centres, hits all-gathered over RCCL (hs_comm_query) so that
+// every rank -- rank 0 writes the file -- holds all hits in the reference's order.
+int RunSearch(hs_params prm, const Planes& planes, const double* coords,
+              const std::function<hs_status(hs_handle*, uint32_t rank)>& build, const double* flat,
+              uint64_t nq, double R, const std::vector<int>& devices, bool sharded, SearchHits* out,
+              std::string* err, std::vector<uint64_t>* table_sizes) {
+  const uint32_t world = (uint32_t)devices.size();
+  if (!world) {
+    if (err) *err = "no device given";
+    return HS_ERR_INVALID;
+  }
+  auto open = [&](int device, hs_handle** h, std::string* msg) -> hs_status {
+    hs_params p = prm;
+    p.device = device;
+    hs_status st = hs_create(&p, planes.a.data(), planes.b.data(), coords, h);
+    if (st != HS_OK) {
+      *msg = std::string("hs_create: ") + (*h ? hs_last_error(*h) : "no usable gfx950 device");
+      hs_destroy(*h);
+      *h = nullptr;
+    }
+    return st;
+  };
+  auto sizes = [&](hs_handle* h) {
+    hs_index_info info;
+    if (table_sizes && hs_index_info_get(h, &info) == HS_OK)
+      table_sizes->assign(info.n_buckets, info.n_buckets + prm.L);
+  };
+  if (!sharded) {
+    hs_handle* h = nullptr;
+    std::string msg;
+    hs_status st = open(devices[0], &h, &msg);
+    if (st != HS_OK) {
+      if (err) *err = msg;
+      return st;
+    }
+    HandleCloser closer = {h};
+    st = build(h, 0);
+    if (st != HS_OK) {
+      if (err) *err = std::string("index build: ") + hs_last_error(h);
+      return st;
+    }
+    sizes(h);
+    uint64_t cap = std::max<uint64_t>(1024, 16 * nq);
+    for (;;) {
+      out->q.resize(cap);
+      out->id.resize(cap);
+      out->table.resize(cap);
+      out->dist.resize(cap);
+      st = hs_query(h, flat, nq, R, out->q.data(), out->id.data(), out->table.data(), out->dist.data(),
+                    cap, &out->n, nullptr);
+      if (st == HS_ERR_CAPACITY) {
+        cap = out->n;
+        continue;
+      }
+      break;
+    }
+    if (st != HS_OK && err) *err = std::string("hs_query: ") + hs_last_error(h);
+    return st;
+  }
+  char cerr[256] = "";
+  hs_comm* comm = nullptr;
+  hs_status cst = hs_comm_create(HS_COMM_RCCL_LOCAL, devices.data(), world, &comm, cerr, sizeof(cerr));
+  if (cst != HS_OK) {
+    if (err) *err = std::string("hs_comm_create: ") + cerr;
+    return cst;
+  }
+  const uint64_t d = 8ull * prm.k;
+  std::vector<hs_status> status(world, HS_OK);
+  std::vector<std::string> msgs(world);
+  std::vector<int> built(world, 0);
+  auto rank_main = [&](uint32_t r) {
+    hs_handle* h = nullptr;
+    hs_status st = open(devices[r], &h, &msgs[r]);
+    HandleCloser closer = {h};
+    if (st == HS_OK) {
+      st = build(h, r);
+      if (st != HS_OK) msgs[r] = std::string("index build: ") + hs_last_error(h);
+    }
+    built[r] = st == HS_OK;
+    status[r] = st;
+    // every rank learns whether all indexes stand before anyone enters the exchange
+    hs_comm_barrier(comm, r);
+    for (uint32_t x = 0; x < world; ++x)
+      if (!built[x]) return;
+    if (r == 0) sizes(h);
+    uint64_t lo = 0, hi = 0;
+    hs_shard_bounds(nq, world, r, &lo, &hi);
+    SearchHits mine;  // ranks other than 0 drop theirs
+    SearchHits* dst = r == 0 ? out : &mine;
+    uint64_t cap = std::max<uint64_t>(1024, 16 * nq);
+    for (;;) {  // every rank sees the same total, so every rank repeats (or not) together
+      dst->q.resize(cap);
+      dst->id.resize(cap);
+      dst->table.resize(cap);
+      dst->dist.resize(cap);
+      st = hs_comm_query(comm, r, h, flat + lo * d, hi - lo, (uint32_t)lo, R, dst->q.data(), dst->id.data(),
+                         dst->table.data(), dst->dist.data(), cap, &dst->n);
+      if (st == HS_ERR_CAPACITY) {
+        cap = dst->n;
+        continue;
+      }
+      break;
+    }
+    if (st != HS_OK) msgs[r] = std::string("hs_comm_query: ") + hs_comm_last_error(comm, r);
+    status[r] = st;
+  };
+  std::vector<std::thread> threads;
+  for (uint32_t r = 1; r < world; ++r) threads.emplace_back(rank_main, r);
+  rank_main(0);
+  for (std::thread& t : threads) t.join();
+  hs_comm_destroy(comm);
+  for (uint32_t r = 0; r < world; ++r)
+    if (status[r] != HS_OK) {
+      if (err) *err = "GPU " + std::to_string(devices[r]) + ": " + msgs[r];
+      return status[r];
+    }
+  return HS_OK;
+}
+
+bool FlattenCenters(const std::vector<Point>& centers, uint32_t dim, std::vector<double>* flat, std::string* err) {
+  flat->resize((size_t)centers.size() * dim);
+  for (size_t i = 0; i < centers.size(); ++i) {
+    if (centers[i].data.size() != dim) {
+      if (err) *err = "centre with the wrong dimension";
+      return false;
+    }
+    memcpy(&(*flat)[i * dim], centers[i].data.data(), sizeof(double) * dim);
+  }
+  return true;
+}
+
+}  // namespace
+
 int Search(const std::vector<Point>& kmers, const std::vector<Point>& centers,
            const std::vector<std::string>& kmer_names, const std::vector<std::string>& center_names,
            const uint32_t& hash_K, const uint32_t& hash_L, const double& hash_W,
            const double& hash_R, const std::string& output_file, const Planes& planes, int device,
            std::string* err, std::vector<uint64_t>* table_sizes) {
+  return SearchSharded(kmers, centers, kmer_names, center_names, hash_K, hash_L, hash_W, hash_R, output_file,
+                       planes, std::vector<int>(1, device), false, err, table_sizes);
+}
+
+int SearchSharded(const std::vector<Point>& kmers, const std::vector<Point>& centers,
+                  const std::vector<std::string>& kmer_names, const std::vector<std::string>& center_names,
+                  const uint32_t& hash_K, const uint32_t& hash_L, const double& hash_W,
+                  const double& hash_R, const std::string& output_file, const Planes& planes,
+                  const std::vector<int>& devices, bool use_comm, std::string* err,
+                  std::vector<uint64_t>* table_sizes) {
   const uint32_t dim = planes.dim;
   if (dim == 0 || dim % 8 != 0 || planes.K != hash_K || planes.L != hash_L || planes.W != hash_W) {
     if (err) *err = "planes do not match (dim, K, L, W)";
@@ -112,69 +273,28 @@ int Search(const std::vector<Point>& kmers, const std::vector<Point>& centers,
   std::vector<double> table;
   std::vector<uint8_t> codes;
   if (!PointsToCodes(kmers, dim, &table, &codes, err)) return HS_ERR_INVALID;
-  std::vector<double> flat((size_t)centers.size() * dim);
-  for (size_t i = 0; i < centers.size(); ++i) {
-    if (centers[i].data.size() != dim) {
-      if (err) *err = "centre with the wrong dimension";
-      return HS_ERR_INVALID;
-    }
-    memcpy(&flat[i * dim], centers[i].data.data(), sizeof(double) * dim);
-  }
+  std::vector<double> flat;
+  if (!FlattenCenters(centers, dim, &flat, err)) return HS_ERR_INVALID;
   hs_params prm;
   memset(&prm, 0, sizeof(prm));
   prm.k = dim / 8;
   prm.K = hash_K;
   prm.L = hash_L;
   prm.W = hash_W;
-  prm.device = device;
   prm.alphabet = (uint32_t)(table.size() / 8);
-  hs_handle* h = nullptr;
-  hs_status st = hs_create(&prm, planes.a.data(), planes.b.data(), table.data(), &h);
-  struct Closer {
-    hs_handle* h;
-    ~Closer() { hs_destroy(h); }
-  };
-  if (st != HS_OK) {
-    if (err) *err = std::string("hs_create: ") + (h ? hs_last_error(h) : "no usable gfx950 device");
-    hs_destroy(h);
-    return st;
-  }
-  Closer closer = {h};
-  st = hs_index_build(h, codes.data(), kmers.size());
-  if (st != HS_OK) {
-    if (err) *err = std::string("hs_index_build: ") + hs_last_error(h);
-    return st;
-  }
-  if (table_sizes) {
-    hs_index_info info;
-    if (hs_index_info_get(h, &info) == HS_OK) table_sizes->assign(info.n_buckets, info.n_buckets + hash_L);
-  }
-  uint64_t cap = std::max<uint64_t>(1024, 16 * (uint64_t)centers.size()), n_hits = 0;
-  std::vector<uint32_t> hq, hid, ht;
-  std::vector<double> hd;
-  for (;;) {
-    hq.resize(cap);
-    hid.resize(cap);
-    ht.resize(cap);
-    hd.resize(cap);
-    st = hs_query(h, flat.data(), centers.size(), hash_R, hq.data(), hid.data(), ht.data(), hd.data(),
-                  cap, &n_hits, nullptr);
-    if (st == HS_ERR_CAPACITY) {
-      cap = n_hits;
-      continue;
-    }
-    break;
-  }
-  if (st != HS_OK) {
-    if (err) *err = std::string("hs_query: ") + hs_last_error(h);
-    return st;
-  }
+  SearchHits hits;
+  const int st = RunSearch(prm, planes, table.data(),
+                           [&](hs_handle* h, uint32_t) { return hs_index_build(h, codes.data(), kmers.size()); },
+                           flat.data(), centers.size(), hash_R, devices, use_comm || devices.size() > 1, &hits,
+                           err, table_sizes);
+  if (st != HS_OK) return st;
   std::ofstream fout(output_file.c_str());
-  for (uint64_t i = 0; i < n_hits; ++i)  // :240-241
-    fout << center_names[hq[i]] << " " << kmer_names[hid[i]] << " " << hd[i] << std::endl;
+  for (uint64_t i = 0; i < hits.n; ++i)  // :240-241
+    fout << center_names[hits.q[i]] << " " << kmer_names[hits.id[i]] << " " << hits.dist[i] << std::endl;
   fout.close();
   return HS_OK;
 }
+
 
 bool ReadProteinFasta(const std::string& path, bool ref_compat_eq_swap, ProteinDB* db) {
   std::ifstream fin(path.c_str());
@@ -209,6 +329,17 @@ int SearchProteins(const ProteinDB& db, uint32_t kmer_length, const std::vector<
                    const uint32_t& hash_L, const double& hash_W, const double& hash_R,
                    const std::string& output_file, const Planes& planes, int device, std::string* err,
                    std::vector<uint64_t>* table_sizes, uint64_t* n_windows, bool best_per_position) {
+  return SearchProteinsSharded(db, kmer_length, centers, center_names, hash_K, hash_L, hash_W, hash_R,
+                               output_file, planes, std::vector<int>(1, device), false, err, table_sizes,
+                               n_windows, best_per_position);
+}
+
+int SearchProteinsSharded(const ProteinDB& db, uint32_t kmer_length, const std::vector<Point>& centers,
+                          const std::vector<std::string>& center_names, const uint32_t& hash_K,
+                          const uint32_t& hash_L, const double& hash_W, const double& hash_R,
+                          const std::string& output_file, const Planes& planes,
+                          const std::vector<int>& devices, bool use_comm, std::string* err,
+                          std::vector<uint64_t>* table_sizes, uint64_t* n_windows, bool best_per_position) {
   const uint32_t dim = 8 * kmer_length;
   if (kmer_length == 0 || planes.dim != dim || planes.K != hash_K || planes.L != hash_L ||
       planes.W != hash_W) {
@@ -233,67 +364,33 @@ int SearchProteins(const ProteinDB& db, uint32_t kmer_length, const std::vector<
     if (err) *err = "kmer length 1 is not supported on a FASTA database";
     return HS_ERR_INVALID;
   }
-  std::vector<double> flat((size_t)centers.size() * dim);
-  for (size_t i = 0; i < centers.size(); ++i) {
-    if (centers[i].data.size() != dim) {
-      if (err) *err = "centre with the wrong dimension";
-      return HS_ERR_INVALID;
-    }
-    memcpy(&flat[i * dim], centers[i].data.data(), sizeof(double) * dim);
-  }
+  std::vector<double> flat;
+  if (!FlattenCenters(centers, dim, &flat, err)) return HS_ERR_INVALID;
   hs_params prm;
   memset(&prm, 0, sizeof(prm));
   prm.k = kmer_length;
   prm.K = hash_K;
   prm.L = hash_L;
   prm.W = hash_W;
-  prm.device = device;
   prm.alphabet = HS_ALPHABET;
-  hs_handle* h = nullptr;
-  hs_status st = hs_create(&prm, planes.a.data(), planes.b.data(), &HS_AA_COORDS[0][0], &h);
-  struct Closer {
-    hs_handle* h;
-    ~Closer() { hs_destroy(h); }
-  };
-  if (st != HS_OK) {
-    if (err) *err = std::string("hs_create: ") + (h ? hs_last_error(h) : "no usable gfx950 device");
-    hs_destroy(h);
-    return st;
-  }
-  Closer closer = {h};
   uint64_t n_win = 0;
   std::vector<uint32_t> win_pos(res.size() + 1);  // there are fewer windows than residues
-  st = hs_index_build_windows(h, res.data(), res.size(), seg.data(), seg.size() - 1, &n_win,
-                              win_pos.data());
-  if (st != HS_OK) {
-    if (err) *err = std::string("hs_index_build_windows: ") + hs_last_error(h);
-    return st;
-  }
+  SearchHits hits;
+  const int rst = RunSearch(
+      prm, planes, &HS_AA_COORDS[0][0],
+      [&](hs_handle* h, uint32_t rank) {
+        uint64_t nw = 0;  // every rank enumerates the same windows; rank 0 keeps their positions
+        const hs_status bst = hs_index_build_windows(h, res.data(), res.size(), seg.data(), seg.size() - 1, &nw,
+                                                     rank == 0 ? win_pos.data() : nullptr);
+        if (rank == 0) n_win = nw;
+        return bst;
+      },
+      flat.data(), centers.size(), hash_R, devices, use_comm || devices.size() > 1, &hits, err, table_sizes);
+  if (rst != HS_OK) return rst;
   if (n_windows) *n_windows = n_win;
-  if (table_sizes) {
-    hs_index_info info;
-    if (hs_index_info_get(h, &info) == HS_OK) table_sizes->assign(info.n_buckets, info.n_buckets + hash_L);
-  }
-  uint64_t cap = std::max<uint64_t>(1024, 16 * (uint64_t)centers.size()), n_hits = 0;
-  std::vector<uint32_t> hq, hid, ht;
-  std::vector<double> hd;
-  for (;;) {
-    hq.resize(cap);
-    hid.resize(cap);
-    ht.resize(cap);
-    hd.resize(cap);
-    st = hs_query(h, flat.data(), centers.size(), hash_R, hq.data(), hid.data(), ht.data(), hd.data(),
-                  cap, &n_hits, nullptr);
-    if (st == HS_ERR_CAPACITY) {
-      cap = n_hits;
-      continue;
-    }
-    break;
-  }
-  if (st != HS_OK) {
-    if (err) *err = std::string("hs_query: ") + hs_last_error(h);
-    return st;
-  }
+  const uint64_t n_hits = hits.n;
+  const std::vector<uint32_t>&hq = hits.q, &hid = hits.id, &ht = hits.table;
+  const std::vector<double>& hd = hits.dist;
   // the letter whose embedding is the stored row: with the E <-> Q exchange an input E is shown as
   // Q, which is what the reference's ProteinDB stores and prints
   const char* letters = HS_CODE_TO_LETTER;
@@ -456,6 +553,58 @@ bool ReadKmerFasta(const std::string& path, std::vector<Kmer>* kmers) {
       fin >> km.seq;
       kmers->push_back(km);
     }
+  }
+  return true;
+}
+
+bool ReadPlanesFile(const std::string& path, uint32_t dim, uint32_t K, uint32_t L, double W, Planes* planes,
+                    std::string* err) {
+  std::ifstream fin(path.c_str(), std::ios::binary);
+  if (!fin) {
+    if (err) *err = "cannot open " + path;
+    return false;
+  }
+  planes->dim = dim;
+  planes->K = K;
+  planes->L = L;
+  planes->W = W;
+  planes->a.assign((size_t)L * K * dim, 0.0);
+  planes->b.assign((size_t)L * K, 0.0);
+  fin.read(reinterpret_cast<char*>(planes->a.data()), planes->a.size() * sizeof(double));
+  fin.read(reinterpret_cast<char*>(planes->b.data()), planes->b.size() * sizeof(double));
+  char extra;
+  if (!fin || fin.read(&extra, 1)) {
+    if (err) *err = path + " does not hold L*K*dim + L*K doubles for these -l/-K/-L";
+    return false;
+  }
+  for (double v : planes->a)
+    if (!std::isfinite(v)) {
+      if (err) *err = path + " holds a non-finite plane coefficient";
+      return false;
+    }
+  return true;
+}
+
+bool CentersFromKmers(const std::vector<Kmer>& kmers, uint32_t kmer_length, std::vector<std::string>* names,
+                      std::vector<Point>* centers, std::string* err) {
+  for (const Kmer& km : kmers) {
+    if (km.seq.size() != kmer_length) {
+      if (err) *err = "centre " + km.name + " does not have " + std::to_string(kmer_length) + " residues";
+      return false;
+    }
+    Point pt;
+    pt.data.resize(8 * (size_t)kmer_length);
+    for (uint32_t p = 0; p < kmer_length; ++p) {
+      const char c = km.seq[p];
+      const int row = (c >= 'A' && c <= 'Z') ? HS_LETTER_TO_CODE[c - 'A'] : -1;  // base[], util.hpp:92
+      if (row < 0) {
+        if (err) *err = "centre " + km.name + " has a letter outside the 20-letter alphabet";
+        return false;
+      }
+      for (int j = 0; j < 8; ++j) pt.data[8 * p + j] = HS_AA_COORDS[row][j];  // hclust2.cpp:57-59
+    }
+    names->push_back(km.name);
+    centers->push_back(pt);
   }
   return true;
 }

@@ -24,6 +24,7 @@ namespace hsearch {
 struct Point {
   std::vector<double> data;
 };
+struct Kmer;
 
 // L x K Gaussian normals a ~ N(0,1) (K*dim per table) and offsets b ~ U[0,W), drawn exactly as the
 // reference's LSH constructor does (lsh.hpp:10-31: default_random_engine, normal_distribution,
@@ -59,6 +60,27 @@ int Search(const std::vector<Point>& kmers, const std::vector<Point>& centers,
            const double& hash_R, const std::string& output_file, const Planes& planes, int device,
            std::string* err, std::vector<uint64_t>* table_sizes = nullptr);
 
+// Search() spread over the GPUs `devices` of this node: one host thread and one handle
+// per GPU, the index replicated (built on every GPU), centre i searched by the rank owning its
+// contiguous block (hs_shard_bounds), the hits all-gathered over RCCL (include/hsearch_dist.h) and
+// written by rank 0 -- the same file as Search().  use_comm forces the communicator path with a
+// single GPU too (`--gpus 1`: RCCL with one rank); Search() is SearchSharded({device}, false).
+int SearchSharded(const std::vector<Point>& kmers, const std::vector<Point>& centers,
+                  const std::vector<std::string>& kmer_names, const std::vector<std::string>& center_names,
+                  const uint32_t& hash_K, const uint32_t& hash_L, const double& hash_W,
+                  const double& hash_R, const std::string& output_file, const Planes& planes,
+                  const std::vector<int>& devices, bool use_comm, std::string* err,
+                  std::vector<uint64_t>* table_sizes = nullptr);
+
+// The planes file `--planes-out` writes and `--planes` reads: binary doubles a[L][K][dim], b[L][K].
+bool ReadPlanesFile(const std::string& path, uint32_t dim, uint32_t K, uint32_t L, double W, Planes* planes,
+                    std::string* err);
+// Centres given as k-mers (">name" line, then the k letters -- the k-mer FASTA hclust2.cpp:231-241
+// reads) instead of a points file: embedded exactly from the table (KmerToCoordinates,
+// hclust2.cpp:49-62).  A letter outside the 20-letter alphabet or another length is an error.
+bool CentersFromKmers(const std::vector<Kmer>& kmers, uint32_t kmer_length, std::vector<std::string>* names,
+                      std::vector<Point>* centers, std::string* err);
+
 // ---- FASTA database: k-mers enumerated on the device ------------------------
 // ProteinDB of protein.hpp:41-71: lines starting with '>' are names, every other non-empty line is
 // one whole sequence.  Residues are stored as rows of the coordinate table (include/hs_tables.h);
@@ -88,6 +110,13 @@ int SearchProteins(const ProteinDB& db, uint32_t kmer_length, const std::vector<
                    const std::string& output_file, const Planes& planes, int device, std::string* err,
                    std::vector<uint64_t>* table_sizes = nullptr, uint64_t* n_windows = nullptr,
                    bool best_per_position = false);
+int SearchProteinsSharded(const ProteinDB& db, uint32_t kmer_length, const std::vector<Point>& centers,
+                          const std::vector<std::string>& center_names, const uint32_t& hash_K,
+                          const uint32_t& hash_L, const double& hash_W, const double& hash_R,
+                          const std::string& output_file, const Planes& planes,
+                          const std::vector<int>& devices, bool use_comm, std::string* err,
+                          std::vector<uint64_t>* table_sizes = nullptr, uint64_t* n_windows = nullptr,
+                          bool best_per_position = false);
 // best_per_position: what kmer_search.cpp's Search() accumulates in `matches` (:90,113-121) and
 // never writes -- for every database window with a hit, its nearest centre: tables ascending,
 // centres ascending within a table, replaced only by a strictly smaller distance.  Written as

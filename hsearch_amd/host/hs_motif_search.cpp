@@ -7,8 +7,13 @@
 // error prints to stderr and exits 1 (:387-393).  Additions: -K/-L (the reference parses them in
 // kmer_search.cpp:186-189 but hard-codes 4,4 here, :380-381 -- 4,4 stay the defaults), --seed
 // (planes are drawn like the reference's LSH constructor but from an explicit seed; default: from
-// std::random_device like the reference), --device, --planes-out (dump the planes), and -g becomes
-// optional (without it the evaluation step is skipped).  -d may also name a protein FASTA file (the
+// std::random_device like the reference), --planes <file> (read them instead: the binary doubles
+// --planes-out writes), --device, --gpus n (the centres are sharded over GPUs
+// device .. device+n-1 of this node, one host thread and one replicated index per GPU, hits
+// all-gathered over RCCL and written in the same order -- the output file is the same for every
+// n), and -g becomes optional (without it the evaluation step is skipped).  -c may also name a
+// k-mer FASTA file (">name" + k letters, the format hclust2.cpp:231-241 reads): the centres are
+// then embedded exactly from the table.  -d may also name a protein FASTA file (the
 // database kmer_search.cpp:180-181 takes): every length-k window of every sequence is then a DB
 // k-mer, enumerated on the device; --ref-compat-eq-swap reproduces the reference's E <-> Q exchange
 // on that path.
@@ -46,7 +51,9 @@ const Opt kOpts[] = {
     {"groundtruth", 'g', "groundtruth (sorted brute-force hits); optional", false},
     {"output", 'o', "output file name", true},
     {"seed", 's', "seed of the LSH planes [random_device]", false},
-    {"device", 'G', "GPU ordinal [0]", false},
+    {"device", 'G', "GPU ordinal (the first one with --gpus) [0]", false},
+    {"gpus", 'N', "shard the centres over this many GPUs, hits all-gathered over RCCL [off: one GPU, no communicator]", false},
+    {"planes", 'p', "read the planes from this file (as written by --planes-out) instead of drawing them", false},
     {"planes-out", 'P', "write the planes (binary doubles a[L][K][d] then b[L][K])", false},
     {"ref-compat-eq-swap", 'Q', "FASTA database: exchange E and Q like the reference's ProteinDB [0]", false},
     {"best-per-position", 'B', "FASTA database: one line per matched window, its nearest centre (kmer_search) [0]", false},
@@ -150,32 +157,65 @@ int main(int argc, const char* argv[]) {
       }
     }
     std::cout << "Read Centers..." << std::endl;
-    if (!hsearch::ReadPointsFile(val["center"], dim, &center_names, &centers)) {
+    if (LooksLikeFasta(val["center"])) {
+      std::vector<hsearch::Kmer> ckmers;
+      std::string cerr;
+      if (!hsearch::ReadKmerFasta(val["center"], &ckmers)) {
+        fprintf(stderr, "cannot open %s\n", val["center"].c_str());
+        return EXIT_FAILURE;
+      }
+      if (!hsearch::CentersFromKmers(ckmers, kmer_length, &center_names, &centers, &cerr)) {
+        fprintf(stderr, "ERROR: %s\n", cerr.c_str());
+        return EXIT_FAILURE;
+      }
+    } else if (!hsearch::ReadPointsFile(val["center"], dim, &center_names, &centers)) {
       fprintf(stderr, "cannot open %s\n", val["center"].c_str());
       return EXIT_FAILURE;
     }
     if (!fasta_db) std::cout << "number of kmers " << kmers.size() << std::endl;
     std::cout << "number of centers " << centers.size() << std::endl;
-    const hsearch::Planes planes = hsearch::DrawPlanes(dim, hash_K, hash_L, hash_W, seed);
+    hsearch::Planes planes;
+    if (val.count("planes")) {
+      std::string perr;
+      if (!hsearch::ReadPlanesFile(val["planes"], dim, hash_K, hash_L, hash_W, &planes, &perr)) {
+        fprintf(stderr, "ERROR: %s\n", perr.c_str());
+        return EXIT_FAILURE;
+      }
+    } else {
+      planes = hsearch::DrawPlanes(dim, hash_K, hash_L, hash_W, seed);
+    }
+    const bool use_comm = val.count("gpus") != 0;
+    const int n_gpus = use_comm ? atoi(val["gpus"].c_str()) : 1;
+    if (n_gpus < 1 || n_gpus > 64) {
+      fprintf(stderr, "ERROR: --gpus must be 1..64\n");
+      return EXIT_FAILURE;
+    }
+    std::vector<int> devices;
+    for (int g = 0; g < n_gpus; ++g) devices.push_back(device + g);
     if (val.count("planes-out")) {
       std::ofstream pf(val["planes-out"].c_str(), std::ios::binary);
       pf.write(reinterpret_cast<const char*>(planes.a.data()), planes.a.size() * sizeof(double));
       pf.write(reinterpret_cast<const char*>(planes.b.data()), planes.b.size() * sizeof(double));
     }
-    printf("hash_K = %u hash_L = %u seed = %u\n", hash_K, hash_L, seed);
+    if (val.count("planes"))
+      printf("hash_K = %u hash_L = %u planes = %s\n", hash_K, hash_L, val["planes"].c_str());
+    else
+      printf("hash_K = %u hash_L = %u seed = %u\n", hash_K, hash_L, seed);
+    if (use_comm) printf("gpus = %d (devices %d..%d, RCCL all-gather of hits)\n", n_gpus, device, device + n_gpus - 1);
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     std::string err;
     std::vector<uint64_t> table_sizes;
     uint64_t n_windows = 0;
     const int st =
-        fasta_db ? hsearch::SearchProteins(prodb, kmer_length, centers, center_names, hash_K, hash_L,
-                                           hash_W, hash_R, val["output"], planes, device, &err,
-                                           &table_sizes, &n_windows,
-                                           val.count("best-per-position") &&
-                                               atoi(val["best-per-position"].c_str()) != 0)
-                 : hsearch::Search(kmers, centers, kmer_names, center_names, hash_K, hash_L, hash_W,
-                                   hash_R, val["output"], planes, device, &err, &table_sizes);
+        fasta_db ? hsearch::SearchProteinsSharded(prodb, kmer_length, centers, center_names, hash_K, hash_L,
+                                                  hash_W, hash_R, val["output"], planes, devices, use_comm,
+                                                  &err, &table_sizes, &n_windows,
+                                                  val.count("best-per-position") &&
+                                                      atoi(val["best-per-position"].c_str()) != 0)
+                 : hsearch::SearchSharded(kmers, centers, kmer_names, center_names, hash_K, hash_L, hash_W,
+                                          hash_R, val["output"], planes, devices, use_comm, &err,
+                                          &table_sizes);
     if (fasta_db && st == 0) std::cout << "number of kmers " << n_windows << std::endl;
     if (st != 0) {
       fprintf(stderr, "ERROR: %s (status %d)\n", err.c_str(), st);

@@ -106,6 +106,8 @@ HS_API void hs_destroy(hs_handle* h);
 HS_API hs_status hs_set_planes(hs_handle* h, const double* a, const double* b);
 HS_API const char* hs_last_error(const hs_handle* h);
 HS_API hs_status hs_get_profile(const hs_handle* h, hs_profile* out);
+/* The parameters the handle was created with (alphabet resolved to the row count in use). */
+HS_API hs_status hs_get_params(const hs_handle* h, hs_params* out);
 /* Candidate-verification kernel: 0 = auto (bucket join when legal, else streaming), 1 = streaming
  * scan (hs_verify_kernel), 2 = MFMA bucket join wherever it is legal (int8 hs_join8_kernel, else
  * fp16 hs_join_kernel), 3 = the fp16 join only.  All are filters in front of the same exact fp64

@@ -1,0 +1,81 @@
+/* hsearch_dist.h -- multi-GPU layer of the motif-search hot path (libhsearch_dist.so): queries shard
+ * across the GPUs of one node, the index is replicated per GPU, and the one exchange step is a
+ * variable-length all-gather of hit tuples over RCCL (xGMI) -- SURVEY.md 8(e).
+ *
+ * The reference is single-threaded and single-device: its query loop
+ * (hclust/src/hclust/motif_both_points.cpp:224-245) carries no state from one query to the next
+ * except the per-query label[] reset (:225), which is what makes contiguous query blocks per GPU a
+ * correct partition, and its hits file (:240-241) is written in query order, which is what the
+ * rank-ordered gather restores.
+ *
+ * Usage: one hs_comm for `world` ranks; every rank makes the same sequence of calls, each from its
+ * own host thread (single process, HS_COMM_RCCL_LOCAL / HS_COMM_LOOPBACK) or its own process
+ * (hs_comm_create_rank).  A rank's device pointers live on that rank's GPU.  Status codes and the
+ * two-call capacity protocol are those of hsearch.h.
+ */
+#ifndef HSEARCH_DIST_H
+#define HSEARCH_DIST_H
+
+#include "hsearch.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hs_comm hs_comm;
+
+enum {
+  HS_COMM_RCCL_LOCAL = 0, /* `world` GPUs of THIS process (ncclCommInitAll), one host thread per rank */
+  HS_COMM_LOOPBACK = 1    /* no GPU: every pointer is a HOST pointer, the exchange goes through host
+                             memory.  Test transport for the layout / merge logic; the programs
+                             under hsearch_amd/host never use it. */
+};
+
+/* devices[world]: HIP ordinals of the ranks (ignored for HS_COMM_LOOPBACK; NULL = 0..world-1). */
+HS_API hs_status hs_comm_create(int kind, const int* devices, uint32_t world, hs_comm** out, char* err,
+                                uint32_t err_cap);
+/* One process per GPU: rank 0 obtains an id (hs_comm_unique_id), the launcher hands it to the
+ * other ranks, every rank calls hs_comm_create_rank (ncclCommInitRank).  The returned object
+ * serves this rank only (the `rank` argument of the calls below must be the one given here). */
+#define HS_COMM_ID_BYTES 128
+HS_API hs_status hs_comm_unique_id(char id[HS_COMM_ID_BYTES]);
+HS_API hs_status hs_comm_create_rank(const char id[HS_COMM_ID_BYTES], uint32_t rank, uint32_t world,
+                                     int device, hs_comm** out, char* err, uint32_t err_cap);
+HS_API void hs_comm_destroy(hs_comm* c);
+HS_API uint32_t hs_comm_world(const hs_comm* c);
+HS_API const char* hs_comm_last_error(const hs_comm* c, uint32_t rank);
+
+/* Contiguous query blocks: rank r of `world` owns queries [*lo, *hi) of n; the first n % world
+ * ranks get one more.  (dist.py::shard_bounds is the same rule.) */
+HS_API void hs_shard_bounds(uint64_t n, uint32_t world, uint32_t rank, uint64_t* lo, uint64_t* hi);
+
+/* The exchange step.  Every rank contributes n_local hit tuples (q local to its block, id, table,
+ * dist -- the outputs of hs_query_dev) and the global number q_offset of its first query; every
+ * rank receives all tuples in rank order -- with contiguous blocks that is the reference's file
+ * order -- with q made global.  One RCCL all-gather of per-rank records [q | id | table | dist]
+ * padded to the largest count (RCCL has no all-gatherv); the counts travel first (host memory
+ * between the threads of one process, a 16-byte all-gather between processes).
+ * table / out_table may be NULL (both or neither on all ranks).  When the total exceeds cap,
+ * nothing is written, *n_total holds the need and HS_ERR_CAPACITY is returned on every rank. */
+HS_API hs_status hs_allgather_hits(hs_comm* c, uint32_t rank, const uint32_t* q, const uint32_t* id,
+                                   const uint32_t* table, const double* dist, uint64_t n_local,
+                                   uint32_t q_offset, uint32_t* out_q, uint32_t* out_id,
+                                   uint32_t* out_table, double* out_dist, uint64_t cap,
+                                   uint64_t* n_total);
+
+/* Host-thread rendezvous of the ranks of one process (no-op for a hs_comm_create_rank object). */
+HS_API hs_status hs_comm_barrier(hs_comm* c, uint32_t rank);
+
+/* Query-sharded search of one rank: copies this rank's block of centres (HOST, [nq_local][d]) to
+ * the handle's GPU, runs hs_query_dev, all-gathers the hits over the communicator and returns ALL
+ * ranks' hits in HOST buffers, global order, q global.  `h` must be bound to the rank's device and
+ * hold the (replicated) index.  Same capacity protocol (cap counts the hits of all ranks). */
+HS_API hs_status hs_comm_query(hs_comm* c, uint32_t rank, hs_handle* h, const double* centers,
+                               uint64_t nq_local, uint32_t q_offset, double R, uint32_t* hit_q,
+                               uint32_t* hit_id, uint32_t* hit_table, double* hit_dist, uint64_t cap,
+                               uint64_t* n_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HSEARCH_DIST_H */

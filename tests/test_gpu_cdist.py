@@ -1,0 +1,77 @@
+"""The C++/RCCL multi-GPU layer on the GPU box: one rank (the box has one GPU; RCCL refuses two
+ranks on one device), so this covers the RCCL transport itself -- communicator creation,
+pack kernel -> ncclAllGather -> unpack kernel with device pointers, hs_comm_query against the plain
+query, and the one-process-per-GPU creation path (unique id) -- while the world > 1 layout logic is
+covered on the CPU by tests/test_cdist_cpu.py over the loopback transport."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from hsearch_amd import Engine, capi, cdist, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rccl_allgather_of_device_hits_world1():
+    import torch
+    comm = cdist.Comm(cdist.RCCL_LOCAL, 1, devices=[0])
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 7, 4096, 100_001):
+        q = torch.from_numpy(np.sort(rng.integers(0, 5000, size=n)).astype(np.int32)).to(dev)
+        i = torch.from_numpy(rng.integers(0, 2**31 - 1, size=n).astype(np.int32)).to(dev)
+        t = torch.from_numpy(rng.integers(0, 32, size=n).astype(np.int32)).to(dev)
+        d = torch.from_numpy(rng.random(n) * 40.0).to(dev)
+        cap = n + 3
+        oq, oi, ot = (torch.full((cap,), -1, dtype=torch.int32, device=dev) for _ in range(3))
+        od = torch.full((cap,), -1.0, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        st, tot = comm.allgather_hits(0, q.data_ptr(), i.data_ptr(), t.data_ptr(), d.data_ptr(), n, 1000,
+                                      oq.data_ptr(), oi.data_ptr(), ot.data_ptr(), od.data_ptr(), cap)
+        assert st == capi.HS_OK and tot == n
+        assert torch.equal(oq[:n], q + 1000) and torch.equal(oi[:n], i) and torch.equal(ot[:n], t)
+        assert torch.equal(od[:n], d)
+        assert bool((oq[n:] == -1).all()) and bool((od[n:] == -1.0).all())
+        if n:
+            st, tot = comm.allgather_hits(0, q.data_ptr(), i.data_ptr(), t.data_ptr(), d.data_ptr(), n, 0,
+                                          oq.data_ptr(), oi.data_ptr(), ot.data_ptr(), od.data_ptr(), n - 1)
+            assert st == capi.HS_ERR_CAPACITY and tot == n
+    comm.close()
+
+
+def test_comm_query_equals_plain_query(oracle):
+    k, K, L, W, R, n, nq = 25, 8, 6, 150.0, 40.0, 30000, 900
+    a, b = synth.make_planes(k, K, L, W, seed=61)
+    codes = synth.make_db(n, k, seed=62)
+    centers, _ = synth.make_queries(codes, nq, seed=63, jitter=0.2)
+    eng = Engine(k, K, L, W, a, b, device=0)
+    eng.index_build(codes)
+    want = eng.query(centers, R)
+    assert len(want["q"]) > 100
+    comm = cdist.Comm(cdist.RCCL_LOCAL, 1, devices=[0])
+    got = comm.query(0, eng, centers, 0, R)
+    for f in ("q", "id", "table", "dist"):
+        assert np.array_equal(got[f], want[f]), f
+    # a block in the middle of a larger query set: q comes back global
+    got = comm.query(0, eng, centers[300:500], 300, R, cap=8)       # and the capacity retry
+    sel = (want["q"] >= 300) & (want["q"] < 500)
+    for f in ("q", "id", "table", "dist"):
+        assert np.array_equal(got[f], want[f][sel]), f
+    comm.close()
+    # one process per GPU: unique id -> ncclCommInitRank (world 1 here)
+    lib = cdist.load()
+    uid = C.create_string_buffer(128)
+    assert lib.hs_comm_unique_id(uid) == capi.HS_OK
+    h = C.c_void_p()
+    err = C.create_string_buffer(256)
+    st = lib.hs_comm_create_rank(uid, C.c_uint32(0), C.c_uint32(1), C.c_int(0), C.byref(h), err, C.c_uint32(256))
+    assert st == capi.HS_OK, err.value
+    c2 = cdist.Comm.__new__(cdist.Comm)
+    c2._lib, c2._h, c2.world = lib, h, 1
+    got = c2.query(0, eng, centers, 0, R)
+    for f in ("q", "id", "table", "dist"):
+        assert np.array_equal(got[f], want[f]), f
+    c2.close()
+    eng.close()
+    _ = oracle

@@ -196,6 +196,70 @@ def test_cli_fasta_database_matches_points_database(tmp_path, oracle):
 
 
 @pytest.mark.gpu
+def test_cli_gpus_planes_file_and_kmer_centres(tmp_path, oracle):
+    """SURVEY 8(b) CLI additions: --gpus 1 (the sharded path: host thread per GPU, hits all-gathered
+    over RCCL -- here one rank) writes byte for byte what the plain path writes, for a points and
+    for a FASTA database; --planes <file> reads what --planes-out wrote; -c <k-mers.fa> embeds the
+    centres from the table (KmerToCoordinates, hclust2.cpp:49-62) = a points file of the same."""
+    k, K, L, W, R, seed = 25, 6, 5, 140.0, 40.0, 77
+    rng = np.random.default_rng(11)
+    letters = "ARNDCQEGHILKMFPSTWYV"
+    codes = rng.integers(0, 20, size=(3000, k), dtype=np.uint8)
+    pts = oracle.embed_codes(codes)
+    qcodes = codes[rng.choice(len(codes), 120, replace=False)].copy()
+    for row in qcodes:
+        for _ in range(int(rng.integers(0, 4))):
+            row[rng.integers(0, k)] = rng.integers(0, 20)
+    db, cen, cfa, planes = [str(tmp_path / n) for n in ("db.points", "cen.points", "cen.fa", "planes.bin")]
+    _write_points(db, pts)
+    with open(cen, "w") as f, open(cfa, "w") as g:
+        for i, row in enumerate(qcodes):
+            f.write("c%d\n" % i + " ".join("%.17g" % v for v in oracle.embed_codes(row[None])[0]) + "\n")
+            g.write(">c%d\n%s\n" % (i, "".join(letters[c] for c in row)))
+    common = ["-l", str(k), "-K", str(K), "-L", str(L), "-W", repr(W), "-T", repr(R)]
+
+    def run(out, *extra):
+        r = subprocess.run([_bin(), "-o", str(tmp_path / out)] + common + list(extra), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        return open(tmp_path / out).read(), r.stdout
+    plain, _ = run("plain", "-d", db, "-c", cen, "--seed", str(seed), "--planes-out", planes)
+    assert len(plain.splitlines()) >= 80
+    # the oracle agrees with the plain path (planes read back from the dump)
+    raw = np.fromfile(planes, dtype=np.float64)
+    a = raw[:L * K * 8 * k].reshape(L, K, 8 * k)
+    b = raw[L * K * 8 * k:].reshape(L, K)
+    want = oracle.search(a, b, W, R, pts, oracle.embed_codes(qcodes))
+    assert [ln.split()[:2] for ln in plain.splitlines()] == [["c%d" % q, "p%d" % i] for q, i in zip(want["q"], want["id"])]
+    sharded, so = run("gpus1", "-d", db, "-c", cen, "--seed", str(seed), "--gpus", "1")
+    assert "gpus = 1" in so and sharded == plain
+    from_file, so = run("planes", "-d", db, "-c", cen, "--planes", planes)
+    assert "planes = " in so and from_file == plain
+    kmer_centres, _ = run("cfa", "-d", db, "-c", cfa, "--planes", planes, "--gpus", "1")
+    assert kmer_centres == plain
+    # a wrong-sized planes file, a centre of another length, and more GPUs than the box has
+    r = subprocess.run([_bin(), "-o", str(tmp_path / "x"), "-d", db, "-c", cen, "--planes", planes, "-l", str(k),
+                        "-K", str(K + 1), "-L", str(L), "-W", repr(W), "-T", repr(R)], capture_output=True, text=True)
+    assert r.returncode == 1 and "does not hold" in r.stderr
+    with open(cfa, "a") as g:
+        g.write(">short\nARND\n")
+    r = subprocess.run([_bin(), "-o", str(tmp_path / "x"), "-d", db, "-c", cfa, "--planes", planes] + common,
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "does not have" in r.stderr
+    import torch
+    r = subprocess.run([_bin(), "-o", str(tmp_path / "x"), "-d", db, "-c", cen, "--planes", planes, "--gpus",
+                        str(torch.cuda.device_count() + 1)] + common, capture_output=True, text=True)
+    assert r.returncode == 1 and "GPU" in r.stderr
+    # FASTA database through the sharded path
+    fa = str(tmp_path / "db.fa")
+    with open(fa, "w") as f:
+        for i in range(6):
+            f.write(">prot%d x\n%s\n" % (i, "".join(letters[c] for c in rng.integers(0, 20, size=200))))
+    p1, _ = run("fa_plain", "-d", fa, "-c", cen, "--planes", planes)
+    p2, _ = run("fa_gpus1", "-d", fa, "-c", cen, "--planes", planes, "--gpus", "1")
+    assert p1 == p2
+
+
+@pytest.mark.gpu
 def test_cli_best_centre_per_position(tmp_path, oracle):
     """--best-per-position: kmer_search.cpp's `matches` (:90,113-121) -- per database window the
     nearest centre, visited tables-outer / centres-inner, replaced only when strictly nearer --
