@@ -15,7 +15,7 @@ _STATUS = ["HS_OK", "HS_ERR_INVALID", "HS_ERR_NO_DEVICE", "HS_ERR_HIP", "HS_ERR_
 _ALPHABET = "ARNDCQEGHILKMFPSTWYV"
 
 EXPORTS = ["hs_create", "hs_destroy", "hs_last_error", "hs_get_profile", "hs_get_params", "hs_version",
-           "hs_set_verify_mode", "hs_set_planes", "hs_self_join", "hs_self_join_range", "hs_clustering",
+           "hs_set_verify_mode", "hs_set_hash_mode", "hs_set_planes", "hs_self_join", "hs_self_join_range", "hs_clustering",
            "hs_clustering_begin", "hs_clustering_table_edges", "hs_clustering_table_apply",
            "hs_clustering_end",
            "hs_embed_codes", "hs_hash_codes", "hs_hash_points", "hs_key_string", "hs_key_fingerprint",
@@ -41,7 +41,8 @@ class _Profile(C.Structure):
                 ("ms_total", C.c_double), ("candidates", C.c_uint64), ("provisional", C.c_uint64),
                 ("hits", C.c_uint64), ("verify_launches", C.c_uint64), ("join_batches", C.c_uint64),
                 ("ms_join", C.c_double), ("join_items", C.c_uint64), ("join_pairs", C.c_uint64),
-                ("join_pairs_issued", C.c_uint64), ("join_i8_batches", C.c_uint64)]
+                ("join_pairs_issued", C.c_uint64), ("join_i8_batches", C.c_uint64),
+                ("hash_values", C.c_uint64), ("hash_flagged", C.c_uint64)]
 
 
 class _IndexInfo(C.Structure):
@@ -201,6 +202,11 @@ class Engine:
     def set_verify_mode(self, mode):
         """'auto' | 'stream' | 'join' -- which filter kernel runs in front of the exact decision."""
         self._check(self._lib.hs_set_verify_mode(self._h, {"auto": 0, "stream": 1, "join": 2, "join16": 3}[mode]))
+
+    def set_hash_mode(self, mode, eps_scale=1.0):
+        """'auto' | 'exact' | 'mfma' -- how the bucket ints are evaluated (identical results)."""
+        self._check(self._lib.hs_set_hash_mode(self._h, {"auto": 0, "exact": 1, "mfma": 2}[mode],
+                                               C.c_double(eps_scale)))
 
     def set_planes(self, a, b):
         """A new hash family of the same shape for this handle (hs_set_planes); drops the index."""

@@ -116,6 +116,16 @@ struct hs_handle {
   int join_blocks_per_cu = 2;                // resident workgroups of hs_join_kernel per CU
   DevBuf jtab, c16, seg_keys, seg_keys_sorted, seg_vals, sorted_ql, seg_key, seg_cnt, seg_qoff,
       seg_items, item_off, seg_n;
+  // projection on the matrix cores (hs_proj.hip): quantised planes in both tilings, per-function
+  // constants, the quantised coordinate table, flag lists (0/1: the two tables in flight during a
+  // build, 2: queries and the hash entry points) and their counters {reserved, real} x 3
+  int proj_S = 0;               // k-steps the MFMA pass is compiled for (0: k too long)
+  bool proj_usable = false;     // S > 0 and the buffers below are filled for the current planes
+  bool proj_auto = false;       // ... and the error bound is narrow enough for the auto mode
+  int hash_mode = 0;            // 0 auto, 1 exact fp64 kernel, 2 MFMA pass wherever usable
+  double proj_eps_scale = 1.0;
+  double proj_est = 0.0;        // typical half-width of the bound, in bucket units
+  DevBuf proj_aq_all, proj_aq_tab, proj_fn, proj_tab, proj_stats, proj_flags[3], proj_cnt, proj_xq, proj_xmeta;
   bool sqrt_test = false;       // hit test sqrt(d2) <= R (hclust2.cpp:119-120) instead of d2 <= R*R
   uint32_t self_first = HS_NO_SELF;  // self-join: DB id of query 0 of the current run_query
   bool join_tables_ok = false;  // fp16 can carry the coordinate table
@@ -160,6 +170,105 @@ float filter_bound(double r2) {
 
 hs_status ensure_device(hs_handle* h) {
   HS_HIP(h, hipSetDevice(h->p.device));
+  return HS_OK;
+}
+
+
+// (Re)quantise the handle's planes -- and, the first time, its coordinate table -- for the MFMA
+// projection, and decide whether the auto mode uses it: the bound's typical half-width, in bucket
+// units, is est = (da k max|row|_1 + dx max|a^|_1) / W; about 2 est of all values are recomputed.
+hs_status setup_projection(hs_handle* h, bool table_too) {
+  h->proj_usable = false;
+  h->proj_auto = false;
+  h->proj_S = hs_proj_steps((int)h->p.k);
+  if (!h->proj_S) return HS_OK;
+  const int S = h->proj_S, LK = h->LK, L = (int)h->p.L;
+  const size_t tile = (size_t)S * 2 * 64 * 16;
+  const size_t all_bytes = (size_t)((LK + 31) / 32) * tile, tab_bytes = (size_t)L * tile;
+  HS_HIP(h, h->proj_aq_all.reserve(all_bytes));
+  HS_HIP(h, h->proj_aq_tab.reserve(tab_bytes));
+  HS_HIP(h, h->proj_fn.reserve((size_t)LK * 32));
+  HS_HIP(h, h->proj_tab.reserve(sizeof(hs_proj_table)));
+  HS_HIP(h, h->proj_stats.reserve(64));
+  HS_HIP(h, h->proj_cnt.reserve(64));
+  HS_HIP(h, hipMemsetAsync(h->proj_aq_all.p, 0, all_bytes, h->stream));
+  HS_HIP(h, hipMemsetAsync(h->proj_aq_tab.p, 0, tab_bytes, h->stream));
+  HS_HIP(h, hipMemsetAsync(h->proj_stats.p, 0, 64, h->stream));
+  if (table_too)
+    HS_HIP(h, hs_launch_quant_table(h->coords.as<double>(), h->alphabet, h->proj_tab.as<hs_proj_table>(), h->stream));
+  HS_HIP(h, hs_launch_quant_planes(h->a.as<double>(), h->b.as<double>(), LK, h->d, (int)h->p.K, S, h->p.W,
+                                   h->proj_eps_scale, h->proj_aq_all.p, h->proj_aq_tab.p, h->proj_fn.p,
+                                   h->proj_stats.as<unsigned long long>(), h->stream));
+  unsigned long long stats[3] = {0, 0, 0};
+  hs_proj_table tab;
+  HS_HIP(h, hipMemcpyAsync(stats, h->proj_stats.p, 24, hipMemcpyDeviceToHost, h->stream));
+  HS_HIP(h, hipMemcpyAsync(&tab, h->proj_tab.p, sizeof(tab), hipMemcpyDeviceToHost, h->stream));
+  HS_HIP(h, hipStreamSynchronize(h->stream));
+  double da, a1;
+  memcpy(&da, &stats[0], 8);
+  memcpy(&a1, &stats[1], 8);
+  h->proj_usable = true;
+  h->proj_est = h->proj_eps_scale * (da * (double)h->p.k * tab.l1max + tab.dx * a1) / h->p.W;
+  // auto: at most ~3 % of the values recomputed, every function and the table representable
+  h->proj_auto = !tab.unsafe && !stats[2] && h->proj_est <= 1.0 / 64.0;
+  return HS_OK;
+}
+
+inline bool use_projection(const hs_handle* h) {
+  return h->proj_usable && (h->hash_mode == 2 || (h->hash_mode == 0 && h->proj_auto));
+}
+
+// Bucket ints of functions [f0, f0 + F) -- one whole table (table >= 0: f0 = table * K, F = K) or
+// all of them (table < 0) -- for n points given as codes or as doubles, into out[i * out_stride + f - f0],
+// on stream s: the MFMA pass + exact recomputation of the flagged values, or the exact kernel alone.
+// set = which flag list / counter pair to use (two tables are in flight during a build).
+hs_status hash_dispatch(hs_handle* h, const uint8_t* d_codes, const double* d_pts, uint64_t n, int table,
+                        int32_t* out, int out_stride, int set, hipStream_t s) {
+  const int K = (int)h->p.K, k = (int)h->p.k;
+  const int f0 = table >= 0 ? table * K : 0, F = table >= 0 ? K : h->LK;
+  if (!n) return HS_OK;
+  if (!use_projection(h) || n >= (1ull << 31)) {
+    if (d_codes)
+      HS_HIP(h, hs_launch_hash_codes(d_codes, n, k, h->aT.as<double>() + f0, h->LK, h->b.as<double>() + f0, F,
+                                     h->p.W, h->coords.as<double>(), out, out_stride, s));
+    else
+      HS_HIP(h, hs_launch_hash_points(d_pts, n, k, h->aT.as<double>() + f0, h->LK, h->b.as<double>() + f0, F,
+                                      h->p.W, out, out_stride, s));
+    return HS_OK;
+  }
+  const int S = h->proj_S;
+  const size_t tile = (size_t)S * 2 * 64;  // uint4 per function tile
+  const uint4* aq = table >= 0 ? h->proj_aq_tab.as<uint4>() + (size_t)table * tile : h->proj_aq_all.as<uint4>();
+  const char* fn = h->proj_fn.as<char>() + (size_t)f0 * 32;
+  // room for 1/32 of the values (the auto mode expects ~ 2 est <= 1/32 of them at worst) plus the
+  // slack of the per-wave reservations (2 n_cu x 4 waves x 128 slots); when the list overflows the
+  // fix kernel recomputes everything, which is still correct
+  const uint64_t want = (uint64_t)n * (uint64_t)F / 32 + (1u << 20);
+  const uint32_t cap = (uint32_t)std::min<uint64_t>(want, 1ull << 28);
+  HS_HIP(h, h->proj_flags[set].reserve((size_t)cap * 8));
+  uint32_t* cnt = h->proj_cnt.as<uint32_t>() + 2 * set;
+  HS_HIP(h, hipMemsetAsync(cnt, 0, 8, s));
+  if (!d_codes) {
+    HS_HIP(h, h->proj_xq.reserve((size_t)n * S * 64));
+    HS_HIP(h, h->proj_xmeta.reserve((size_t)n * 24));
+    HS_HIP(h, hs_launch_quant_points(d_pts, n, k, S, h->proj_xq.p, h->proj_xmeta.as<double>(), s));
+  }
+  HS_HIP(h, hs_launch_proj(d_codes, h->proj_xq.p, h->proj_xmeta.as<double>(), n, k, S, aq, fn, F,
+                           h->proj_tab.as<hs_proj_table>(), h->p.W, out, out_stride,
+                           h->proj_flags[set].as<uint2>(), cap, cnt, h->n_cu, s));
+  HS_HIP(h, hs_launch_proj_fix(d_codes, d_pts, n, k, h->aT.as<double>() + f0, h->LK, h->b.as<double>() + f0, F,
+                               h->p.W, h->coords.as<double>(), out, out_stride, h->proj_flags[set].as<uint2>(),
+                               cap, cnt, s));
+  return HS_OK;
+}
+
+// after a synchronisation of the stream the hash ran on: add the pass's statistics to the profile
+hs_status hash_account(hs_handle* h, uint64_t n, int F, int set) {
+  if (!use_projection(h) || !n || n >= (1ull << 31)) return HS_OK;
+  uint32_t c[2] = {0, 0};
+  HS_HIP(h, hipMemcpy(c, h->proj_cnt.as<uint32_t>() + 2 * set, 8, hipMemcpyDeviceToHost));
+  h->prof.hash_values += n * (uint64_t)F;
+  h->prof.hash_flagged += c[1];
   return HS_OK;
 }
 
@@ -281,6 +390,11 @@ hs_status hs_create(const hs_params* params, const double* a, const double* b, c
   HS_HIP(h, hipMemcpyAsync(&unsafe8, h->jtab8.as<char>() + 640, 4, hipMemcpyDeviceToHost, h->stream));
   HS_HIP(h, hipStreamSynchronize(h->stream));
   h->join8_tables_ok = (unsafe8 == 0);
+  if (const char* m = getenv("HS_HASH_MODE")) {
+    if (!strcmp(m, "exact")) h->hash_mode = 1;
+    if (!strcmp(m, "mfma")) h->hash_mode = 2;
+  }
+  HS_CHECK(setup_projection(h, true));
   if (const char* m = getenv("HS_VERIFY_MODE")) {
     if (!strcmp(m, "stream")) h->verify_mode = 1;
     if (!strcmp(m, "join")) h->verify_mode = 2;
@@ -303,6 +417,20 @@ hs_status hs_set_planes(hs_handle* h, const double* a, const double* b) {
   HS_HIP(h, hs_launch_transpose_f64(h->a.as<double>(), h->LK, h->d, h->aT.as<double>(), h->stream));
   HS_HIP(h, hipMemcpyAsync(h->b.p, b, (size_t)h->LK * 8, hipMemcpyHostToDevice, h->stream));
   HS_HIP(h, hipStreamSynchronize(h->stream));  // a, b are the caller's again
+  return setup_projection(h, false);
+}
+
+hs_status hs_set_hash_mode(hs_handle* h, int mode, double eps_scale) {
+  if (!h || mode < 0 || mode > 2 || !(eps_scale >= 1.0) || !(eps_scale < 1e12)) return HS_ERR_INVALID;
+  hs_status st = ensure_device(h);
+  if (st) return st;
+  h->hash_mode = mode;
+  if (eps_scale != h->proj_eps_scale) {
+    h->proj_eps_scale = eps_scale;
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->stream2) HS_HIP(h, hipStreamSynchronize(h->stream2));
+    return setup_projection(h, false);
+  }
   return HS_OK;
 }
 
@@ -324,7 +452,9 @@ void hs_destroy(hs_handle* h) {
                     &h->seg_vals, &h->sorted_ql, &h->seg_key, &h->seg_cnt, &h->seg_qoff,
                     &h->seg_items, &h->item_off, &h->seg_n, &h->c16s, &h->item_desc,
                     &h->probe_slow, &h->jtab8, &h->c8b, &h->prov2, &h->t_packed, &h->t_rec8, &h->t_pos, &h->dir_base,
-                    &h->bucket_work};
+                    &h->bucket_work, &h->proj_aq_all, &h->proj_aq_tab, &h->proj_fn, &h->proj_tab, &h->proj_stats,
+                    &h->proj_flags[0], &h->proj_flags[1], &h->proj_flags[2], &h->proj_cnt, &h->proj_xq,
+                    &h->proj_xmeta};
   for (DevBuf* bf : bufs) bf->release();
   h->sj_host.release();
   for (int l = 0; l < HS_MAX_L; ++l) {
@@ -374,15 +504,14 @@ hs_status hs_hash_codes(hs_handle* h, const uint8_t* codes, uint64_t n, int32_t*
   HS_HIP(h, h->io_misc.reserve(out_bytes));
   HS_HIP(h, hipMemcpyAsync(h->io_codes.p, codes, (size_t)n * h->p.k, hipMemcpyHostToDevice, h->stream));
   HS_HIP(h, hipEventRecord(h->ev[0], h->stream));
-  HS_HIP(h, hs_launch_hash_codes(h->io_codes.as<uint8_t>(), n, (int)h->p.k, h->aT.as<double>(), h->LK,
-                                 h->b.as<double>(), h->LK, h->p.W, h->coords.as<double>(),
-                                 h->io_misc.as<int32_t>(), h->LK, h->stream));
+  HS_CHECK(hash_dispatch(h, h->io_codes.as<uint8_t>(), nullptr, n, -1, h->io_misc.as<int32_t>(), h->LK, 2,
+                         h->stream));
   HS_HIP(h, hipEventRecord(h->ev[1], h->stream));
   HS_HIP(h, hipMemcpyAsync(buckets, h->io_misc.p, out_bytes, hipMemcpyDeviceToHost, h->stream));
   HS_HIP(h, hipStreamSynchronize(h->stream));
   memset(&h->prof, 0, sizeof(h->prof));
   h->prof.ms_hash = h->prof.ms_total = ev_ms(h, 0, 1);
-  return HS_OK;
+  return hash_account(h, n, h->LK, 2);
 }
 
 hs_status hs_hash_points(hs_handle* h, const double* points, uint64_t n, int32_t* buckets) {
@@ -395,15 +524,14 @@ hs_status hs_hash_points(hs_handle* h, const double* points, uint64_t n, int32_t
   HS_HIP(h, h->io_misc.reserve(out_bytes));
   HS_HIP(h, hipMemcpyAsync(h->io_centers.p, points, in_bytes, hipMemcpyHostToDevice, h->stream));
   HS_HIP(h, hipEventRecord(h->ev[0], h->stream));
-  HS_HIP(h, hs_launch_hash_points(h->io_centers.as<double>(), n, (int)h->p.k, h->aT.as<double>(), h->LK,
-                                  h->b.as<double>(), h->LK, h->p.W, h->io_misc.as<int32_t>(), h->LK,
-                                  h->stream));
+  HS_CHECK(hash_dispatch(h, nullptr, h->io_centers.as<double>(), n, -1, h->io_misc.as<int32_t>(), h->LK, 2,
+                         h->stream));
   HS_HIP(h, hipEventRecord(h->ev[1], h->stream));
   HS_HIP(h, hipMemcpyAsync(buckets, h->io_misc.p, out_bytes, hipMemcpyDeviceToHost, h->stream));
   HS_HIP(h, hipStreamSynchronize(h->stream));
   memset(&h->prof, 0, sizeof(h->prof));
   h->prof.ms_hash = h->prof.ms_total = ev_ms(h, 0, 1);
-  return HS_OK;
+  return hash_account(h, n, h->LK, 2);
 }
 
 static inline int bit_width_u32(uint32_t v) {
@@ -510,9 +638,7 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
     const int u = t & 1;
     if (t >= 2) HS_HIP(h, hipStreamWaitEvent(hash_stream, ev_free[u], 0));  // table t - 2 is done with it
     HS_HIP(h, hipEventRecord(ev_t[2 * u], hash_stream));
-    HS_HIP(h, hs_launch_hash_codes(h->codes.as<uint8_t>(), n, k, h->aT.as<double>() + (size_t)t * K, h->LK,
-                                   h->b.as<double>() + (size_t)t * K, K, h->p.W, h->coords.as<double>(),
-                                   ints2[u].as<int32_t>(), K, hash_stream));
+    HS_CHECK(hash_dispatch(h, h->codes.as<uint8_t>(), nullptr, n, t, ints2[u].as<int32_t>(), K, u, hash_stream));
     HS_HIP(h, hs_launch_keys(ints2[u].as<int32_t>(), n, K, K, seed, keys2[u].as<uint64_t>(),
                              iota2[u].as<uint32_t>(), hash_stream));
     HS_HIP(h, hipEventRecord(ev_t[2 * u + 1], hash_stream));
@@ -600,6 +726,7 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
     }
     ms_sort += ev_ms(h, 1, 2);
     ms_gather += ev_ms(h, 2, 3);
+    HS_CHECK(hash_account(h, n, K, l & 1));  // table l's hash has completed (its sort waited for it)
     hs_table_dev& tb = h->tabs.t[l];
     tb.dir_key = h->t_dirkey[l].as<uint64_t>();
     tb.dir_start = h->t_dirstart[l].as<uint32_t>();
@@ -1180,8 +1307,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, h->probe_slow.reserve(((size_t)nql + 1) * 4));
     HS_HIP(h, h->slice_off.reserve(((size_t)nql + 1) * 4));
     HS_HIP(h, h->temp.reserve(hs_scan_u32_temp((size_t)nql + 1) + 256));
-    HS_HIP(h, hs_launch_hash_points(d_centers, nq, k, h->aT.as<double>(), h->LK, h->b.as<double>(), h->LK,
-                                    h->p.W, h->qints.as<int32_t>(), h->LK, h->stream));
+    HS_CHECK(hash_dispatch(h, nullptr, d_centers, nq, -1, h->qints.as<int32_t>(), h->LK, 2, h->stream));
   }
   HS_HIP(h, hipEventRecord(h->ev[1], h->stream));
   // Bucket join (hs_join.hip) when fp16 can carry the data and a k-mer is one packed word; the
@@ -1327,6 +1453,8 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   bool tables_done = !side;
   uint32_t prov_cap = (uint32_t)std::max<size_t>(h->prov.cap / 8, std::max<size_t>(1u << 20, 16ull * nq));
   uint32_t host_cnt[16] = {0};  // [0] survivors [1] hits [2..3] candidates ... [10..13] join statistics
+  uint32_t host_proj[2] = {0, 0};  // MFMA projection of the queries: {slots reserved, values flagged}
+  const bool proj_stats = !brute && use_projection(h);
   double ms_verify = 0, ms_final = 0, ms_join = 0;
   uint32_t launches = 0;
   for (;;) {  // retried only when a workspace capacity was exceeded
@@ -1409,6 +1537,8 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     }
     HS_HIP(h, hipEventRecord(h->ev[5], h->stream));
     HS_HIP(h, hipMemcpyAsync(host_cnt, d_cnt, 64, hipMemcpyDeviceToHost, h->stream));
+    if (proj_stats)
+      HS_HIP(h, hipMemcpyAsync(host_proj, h->proj_cnt.as<uint32_t>() + 4, 8, hipMemcpyDeviceToHost, h->stream));
     HS_HIP(h, hipStreamSynchronize(h->stream));
     ms_verify += ev_ms(h, 3, 4);
     if (!brute && n_items) ms_join += ev_ms(h, 3, 10);
@@ -1423,6 +1553,10 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     break;  // hit_count <= prov_count <= prov_cap <= hit_cap
   }
   h->prof.ms_hash += ev_ms(h, 0, 1);
+  if (proj_stats) {
+    h->prof.hash_values += (uint64_t)nq * h->LK;
+    h->prof.hash_flagged += host_proj[1];
+  }
   h->prof.ms_probe += ev_ms(h, 1, 2);
   h->prof.ms_verify += ms_verify;
   h->prof.ms_finalize += ms_final;
@@ -1621,6 +1755,7 @@ hs_status hs_self_join_range(hs_handle* h, uint64_t first, uint64_t count, doubl
     acc.join_pairs += h->prof.join_pairs; acc.join_pairs_issued += h->prof.join_pairs_issued;
     acc.join_items += h->prof.join_items; acc.join_batches += h->prof.join_batches;
     acc.verify_launches += h->prof.verify_launches;
+    acc.hash_values += h->prof.hash_values; acc.hash_flagged += h->prof.hash_flagged;
     HS_HIP(h, h->sj_host.reserve(std::max<size_t>(64, (nh + nh / 8 + 1024) * 20)));
     sj_lap("host buf");
     double* const hd = h->sj_host.as<double>();                       // [nh] doubles first: aligned

@@ -144,6 +144,41 @@ size_t hs_rle_u64_temp(size_t n);
 hipError_t hs_rle_u64(void* temp, size_t temp_bytes, const uint64_t* in, uint64_t* unique_out,
                       uint32_t* counts_out, uint32_t* runs_out, size_t n, hipStream_t s);
 
+// ---- projection on the matrix cores (hs_proj.hip) ------------------------------------------------
+// The coordinate table in 16-bit fixed point for the codes path: per residue the high and low digit
+// bytes of its 8 coordinates, an upper bound of its 1-norm, the scale 2^-ex and dx = 2^-(ex+1).
+struct hs_proj_table {
+  uint4 dig[HS_ALPHABET_PAD];   // {X1[0..3], X1[4..7], X0[0..3], X0[4..7]}
+  double l1[HS_ALPHABET_PAD];
+  double sx, dx, l1max;
+  uint32_t unsafe, pad;
+};
+// k-steps (of 32 dimensions) the MFMA pass is compiled for: 4, 7, 10 or 13; 0 = k too long (> 52)
+int hs_proj_steps(int k);
+hipError_t hs_launch_quant_table(const double* d_coords, int alphabet, hs_proj_table* d_tab, hipStream_t s);
+// planes -> digit fragments for the all-functions tiling (d_aq_all: ceil(F/32) tiles) and the
+// per-table tiling (d_aq_tab: one tile per table; both zero-filled by the caller, S*2*64 uint4 per
+// tile) + constants d_fn[F] (4 doubles each); d_stats[3] (zeroed): max da, max |a^|_1 as double
+// bits, and 1 if a function cannot be quantised
+hipError_t hs_launch_quant_planes(const double* d_a, const double* d_b, int F, int d, int K, int S, double W,
+                                  double eps_scale, void* d_aq_all, void* d_aq_tab, void* d_fn,
+                                  unsigned long long* d_stats, hipStream_t s);
+// points -> d_xq [n][S*4] uint4 + d_xmeta [n][3]
+hipError_t hs_launch_quant_points(const double* d_pts, uint64_t n, int k, int S, void* d_xq, double* d_xmeta,
+                                  hipStream_t s);
+// fast pass: bucket ints of F functions (d_aq / d_fn already offset to the first of them) for n
+// points given as codes (d_codes != null) or as quantised points; uncertain values are appended to
+// d_flags (*d_flag_count zeroed by the caller) ...
+hipError_t hs_launch_proj(const uint8_t* d_codes, const void* d_xq, const double* d_xmeta, uint64_t n, int k,
+                          int S, const void* d_aq, const void* d_fn, int F, const hs_proj_table* d_tab,
+                          double W, int32_t* d_out, int out_stride, uint2* d_flags, uint32_t flag_cap,
+                          uint32_t* d_flag_count, int n_cu, hipStream_t s);
+// ... and recomputed here in the reference's operation order (everything, if the list overflowed)
+hipError_t hs_launch_proj_fix(const uint8_t* d_codes, const double* d_pts, uint64_t n, int k, const double* d_aT,
+                              int ldf, const double* d_b, int F, double W, const double* d_coords,
+                              int32_t* d_out, int out_stride, const uint2* d_flags, uint32_t flag_cap,
+                              const uint32_t* d_flag_count, hipStream_t s);
+
 // ---- kernel launchers (hs_kernels.hip) -----------------------------------------------------------
 hipError_t hs_launch_embed(const uint8_t* d_codes, uint64_t n, int k, const double* d_coords,
                            double* d_out, hipStream_t s);

@@ -79,6 +79,9 @@ typedef struct hs_profile {
   uint64_t join_pairs;     /* (member, query) pairs routed to the join */
   uint64_t join_pairs_issued; /* MFMA rows x columns actually issued for them (padding included) */
   uint64_t join_i8_batches;   /* of join_batches: those run by the int8 form (hs_join8_kernel) */
+  uint64_t hash_values;       /* bucket ints produced by the MFMA projection pass (hs_proj_kernel) ... */
+  uint64_t hash_flagged;      /* ... of which this many lay within the error bound of a bucket boundary
+                                 and were recomputed in the reference's fp64 order (hs_proj_fix_kernel) */
 } hs_profile;
 
 typedef struct hs_index_info {
@@ -114,6 +117,14 @@ HS_API hs_status hs_get_params(const hs_handle* h, hs_params* out);
  * decision, so results are identical; the environment variable HS_VERIFY_MODE=stream|join|join16
  * sets the default of new handles. */
 HS_API hs_status hs_set_verify_mode(hs_handle* h, int mode);
+/* How LSH::HashBucketIndex (lsh.hpp:33-49) is evaluated: 0 = auto (the int8 MFMA projection with a
+ * proven error bound, values within the bound of a bucket boundary recomputed in the reference's
+ * fp64 order -- hs_proj.hip -- unless the bound is so wide that most values would be recomputed,
+ * or k > 52), 1 = the exact fp64 vector-ALU kernel only, 2 = the MFMA pass wherever it is compiled
+ * (k <= 52).  Bucket integers are bit-identical in every mode.  eps_scale >= 1 inflates the error
+ * bound (tests: more values take the recompute path); 1 is the proven bound.  The environment
+ * variable HS_HASH_MODE=exact|mfma sets the default of new handles. */
+HS_API hs_status hs_set_hash_mode(hs_handle* h, int mode, double eps_scale);
 HS_API const char* hs_version(void);
 
 /* ---- embedding + hashing (rows a2, a4, a5, a6) ----------------------------------------------- */
