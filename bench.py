@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- motif queries/s of the LSH search hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): 10 M synthetic 25-mers, L = 8 tables, K = 16, W = 200,
-R = 40, 100 k queries per GPU (DB k-mers with 0..4 substitutions), index resident in HBM.
+Workload (BASELINE.json configs[1]): 10 M synthetic 25-mers, L = 8 tables, K = 16, R = 40,
+100 k queries per GPU (DB k-mers with 0..4 substitutions), index resident in HBM.  W = 212: the
+smallest W of the committed sweep (tools/recall_sweep.py -> profiles/r02_recall_sweep_c2*.json:
+W = 200 .. 220 in steps of 4, 6000 queries against the exhaustive scan) whose radius recall reaches
+0.9, which is how SURVEY.md 8(d) fixes W (`--W 200` is the round-1 workload: recall 0.88).
 A "step" = one pass of the query hot path (hash queries -> probe -> verify -> dedupe/exact
 distance -> ordered hits [-> RCCL all-gather of hits when N > 1]) over the rank's query batch, with
 the queries already resident in HBM.  N > 1: one process per GPU, index replicated, queries
@@ -51,9 +54,13 @@ def parse():
     ap.add_argument("--k", type=int, default=25)
     ap.add_argument("--K", type=int, default=16)
     ap.add_argument("--L", type=int, default=8)
-    ap.add_argument("--W", type=float, default=200.0)
+    ap.add_argument("--W", type=float, default=212.0,
+                    help="bucket width; 212 = smallest W with radius recall >= 0.9 at the default shape "
+                         "(profiles/r02_recall_sweep_c2_fine.json)")
     ap.add_argument("--R", type=float, default=40.0)
     ap.add_argument("--recall-queries", type=int, default=256)
+    ap.add_argument("--planted-members", type=int, default=12,
+                    help="members of each planted family of the recall@10 DB variant (0: skip)")
     ap.add_argument("--cpu-n", type=int, default=1_000_000, help="DB sample of the CPU baseline")
     ap.add_argument("--cpu-nq", type=int, default=200, help="query sample of the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -163,6 +170,46 @@ def cpu_baseline(args, a, b, codes, centers):
             "measured_qps_at_sample": q_s / tq, "build_kmers_per_s": n_r / tb,
             "port_qps_same_sample": q_s / tqp, "port_build_kmers_per_s": n_r / tbp}
     return out
+
+
+def planted_family_recall(args, eng, codes, a, b, device):
+    """recall@10 where it carries information (SURVEY 8(d) defines it; on the i.i.d. DB only the
+    k-mer a query was mutated from lies within R, so at most 1 of its 10 nearest can be a hit): a
+    DB variant in which every recall query has a planted family -- `planted_members` DB k-mers that
+    are its source k-mer with 1..2 substitutions, all within R of the query -- so the 10 nearest
+    neighbours are family members an LSH search is supposed to find.  Same planes, same W; the
+    variant is a copy of the bench DB with nr * planted_members rows overwritten."""
+    from hsearch_amd import Engine, synth
+    nr, m, k = min(args.recall_queries, args.nq), args.planted_members, args.k
+    rng = np.random.Generator(np.random.MT19937(synth.SEED_DB + 77))
+    db = codes.copy()
+    centre = rng.integers(0, 20, size=(nr, k), dtype=np.uint8)
+    rows = rng.choice(len(db), size=nr * m, replace=False)
+    fam = np.repeat(centre, m, axis=0)
+    for s in range(2):
+        sel = np.nonzero(rng.integers(0, 2, size=len(fam)) + (s == 0) > 0)[0]   # 1 or 2 substitutions
+        fam[sel, rng.integers(0, k, size=len(sel))] = rng.integers(0, 20, size=len(sel), dtype=np.uint8)
+    db[rows] = fam
+    q = centre.copy()
+    sel = np.nonzero(rng.integers(0, 2, size=nr))[0]
+    q[sel, rng.integers(0, k, size=len(sel))] = rng.integers(0, 20, size=len(sel), dtype=np.uint8)
+    centers = synth.embed(q)
+    e2 = Engine(k, args.K, args.L, args.W, a, b, device=device)
+    e2.index_build(db)
+    lsh = e2.query(centers, args.R, want_cand=False)
+    nn, nd2 = e2.bruteforce_topk(centers, 10)
+    bf = e2.bruteforce(centers, args.R)
+    e2.close()
+    by_q = {}
+    for qq, ii in zip(lsh["q"].tolist(), lsh["id"].tolist()):
+        by_q.setdefault(qq, set()).add(ii)
+    truth = set(zip(bf["q"].tolist(), bf["id"].tolist()))
+    found = set(zip(lsh["q"].tolist(), lsh["id"].tolist()))
+    return {"recall_at_10": float(np.mean([len(by_q.get(i, set()) & set(nn[i].tolist())) / 10.0 for i in range(nr)])),
+            "radius_recall": len(truth & found) / max(len(truth), 1),
+            "queries": nr, "members_per_family": m,
+            "tenth_neighbour_within_R": float(np.mean(nd2[:, 9] <= args.R * args.R)),
+            "true_neighbours_within_R": len(truth)}
 
 
 def main():
@@ -294,7 +341,7 @@ def main():
         # the PMC passes behind that file were taken on the default workload and kernel choice: the
         # figure is reported for that workload only (null otherwise)
         default_workload = (args.n, args.nq, args.k, args.K, args.L, args.W, args.R, args.verify_mode) == \
-            (10_000_000, 100_000, 25, 16, 8, 200.0, 40.0, "auto")
+            (10_000_000, 100_000, 25, 16, 8, 212.0, 40.0, "auto")
         traffic_src = None
         if default_workload and os.path.exists(tpath):
             try:
@@ -383,6 +430,16 @@ def main():
                 by_q.setdefault(qq, set()).add(ii)
             line["recall_at_10"] = float(np.mean([len(by_q.get(qq, set()) & set(nn[qq].tolist())) / 10.0
                                                   for qq in range(nr)]))
+        if nr > 0 and args.planted_members > 0:
+            line["planted_family_recall"] = planted_family_recall(args, eng, codes, a, b, dev_index)
+        sweep = os.path.join(ROOT, "profiles", "r02_recall_sweep_c2_fine.json")
+        if os.path.exists(sweep) and (args.n, args.k, args.K, args.L, args.R) == (10_000_000, 25, 16, 8, 40.0):
+            sj = json.load(open(sweep))
+            line["recall_sweep"] = {"file": "profiles/r02_recall_sweep_c2_fine.json (coarse grid: r02_recall_sweep_c2.json)",
+                                    "smallest_W_with_radius_recall_0.9": sj["smallest_W_with_radius_recall_0.9"],
+                                    "points": [{"W": r["W"], "radius_recall": round(r["radius_recall"], 4),
+                                                "candidates_per_query": round(r["candidates_per_query"])}
+                                               for r in sj["sweep"]]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, a, b, codes, centers)
         print(json.dumps(line), file=result_out, flush=True)

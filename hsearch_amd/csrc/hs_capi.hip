@@ -96,7 +96,7 @@ struct hs_handle {
   DevBuf t_dirkey[HS_MAX_L], t_dirstart[HS_MAX_L], t_dirtuple[HS_MAX_L], t_ids[HS_MAX_L];
   DevBuf t_dirjump[HS_MAX_L];
   // bucket-ordered packed copies of all tables in ONE allocation ([L][n][PW]), and the int8 join's
-  // per-entry records ([L][n], k <= 25 only) at the same entry offsets
+  // per-entry records ([L][n], k <= 50 only) at the same entry numbers
   DevBuf t_packed, t_rec8;
   DevBuf t_pos;  // [L][n] sorted position of every DB id in every table (first-seen dedupe)
   DevBuf dir_base;       // [L + 1] first global bucket number of every table; [L] = nb_total
@@ -629,7 +629,7 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
   HS_HIP(h, sort_temp.reserve(temp_bytes));
   uint32_t* d_small = small.as<uint32_t>();
   double ms_hash = 0, ms_sort = 0, ms_gather = 0;
-  const bool with_rec8 = h->join8_tables_ok && PW == 1;
+  const bool with_rec8 = h->join8_tables_ok && k <= 50;
   HS_HIP(h, h->t_packed.reserve(std::max<size_t>(16, (size_t)L * n * PW * 16)));
   if (with_rec8) HS_HIP(h, h->t_rec8.reserve(std::max<size_t>(16, (size_t)L * n * 16)));
   HS_HIP(h, h->t_pos.reserve(std::max<size_t>(16, (size_t)L * n * 4)));
@@ -1141,7 +1141,7 @@ hs_status hs_index_load(hs_handle* h, const char* path) {
     HS_HIP(h, hipStreamSynchronize(h->stream));
     if (bad) return fail(h, HS_ERR_IO, "index file holds a residue code outside the alphabet");
   }
-  const bool with_rec8 = h->join8_tables_ok && PW == 1;
+  const bool with_rec8 = h->join8_tables_ok && k <= 50;
   HS_HIP(h, h->t_packed.reserve(std::max<size_t>(16, (size_t)L * n * PW * 16)));
   if (with_rec8) HS_HIP(h, h->t_rec8.reserve(std::max<size_t>(16, (size_t)L * n * 16)));
   HS_HIP(h, h->t_pos.reserve(std::max<size_t>(16, (size_t)L * n * 4)));
@@ -1314,9 +1314,12 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   // streaming kernel otherwise (and for brute force).  With the join on, segments (bucket x its
   // probing queries) with too few queries to fill MFMA columns still go to the streaming kernel:
   // both kernels append survivors to the same list in front of the same exact decision.
-  bool use_join = !brute && h->verify_mode != 1 && h->join_tables_ok && k <= 25 && r2 < 30000.0;
-  // int8 form of the join filter (hs_join8.hip) unless forced to fp16 (mode 3) or not representable
-  bool use_i8 = use_join && h->join8_tables_ok && h->verify_mode != 3;
+  // fp16 form: k <= 25 only; int8 form (hs_join8.hip): k <= 50 (6 or 8 k-steps for two packed words)
+  const bool can16 = h->join_tables_ok && k <= 25;
+  const bool can8 = h->join8_tables_ok && k <= 50 && h->verify_mode != 3;
+  bool use_join = !brute && h->verify_mode != 1 && r2 < 30000.0 && (can16 || can8);
+  // int8 form of the join filter unless forced to fp16 (mode 3) or not representable
+  bool use_i8 = use_join && can8;
   // survivors of the int8 join's 4-column bound pass an 8-column int8 bound before the exact
   // decision (hs_refine8_kernel); HS_NO_REFINE8 switches it off
   const bool refine = use_i8 && !getenv("HS_NO_REFINE8");
@@ -1359,7 +1362,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, h->seg_n.reserve(64));
     HS_HIP(h, h->temp.reserve(std::max(hs_scan_u32_temp(n1), hs_scan_u32_temp((size_t)h->nb_total + 2)) + 256));
     if (use_i8) {
-      if (refine) HS_HIP(h, h->c8b.reserve((size_t)nq * 128));
+      if (refine) HS_HIP(h, h->c8b.reserve((size_t)nq * hs_join8_row_bytes(k)));
       HS_HIP(h, hs_launch_qprep8(d_centers, nq, k, r2, h->jtab8.as<float>() + 128, h->c16.p, d_unsafe,
                                  refine ? h->c8b.p : nullptr, h->stream));
     }
@@ -1376,11 +1379,11 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, h->seg_cnt.as<uint32_t>(),
                                     h->seg_qoff.as<uint32_t>(), n1, h->stream));
     // work items: one wave's 128 members for the wave-independent int8 join, 512 otherwise
-    jm = use_i8 ? HS_JM_WAVE : HS_JM_BLOCK;
+    jm = use_i8 ? hs_join8_members_per_item(k) : HS_JM_BLOCK;
     HS_CHECK(cut_items(h, nql, jm, d_jstats));
     if (use_i8)
       HS_HIP(h, hs_launch_gather_c8t(h->c16.p, h->sorted_ql.as<uint32_t>(), h->seg_qoff.as<uint32_t>(),
-                                     nql, L, h->c16s.p, h->stream));
+                                     nql, L, k, h->c16s.p, h->stream));
     else
       HS_HIP(h, hs_launch_gather_c16(h->c16.p, h->sorted_ql.as<uint32_t>(), nql, L, h->c16s.p, h->stream));
   }
@@ -1397,7 +1400,10 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, hipMemcpyAsync(&n_slices, h->slice_off.as<uint32_t>() + nql, 4, hipMemcpyDeviceToHost,
                              h->stream));
     HS_HIP(h, hipStreamSynchronize(h->stream));
-    if (use_i8 && unsafe) {
+    if (use_i8 && unsafe && !can16) {
+      // a query int8 cannot carry and no fp16 form for this k: the batch streams (below)
+      use_i8 = false;
+    } else if (use_i8 && unsafe) {
       // a query int8 cannot carry: redo the query rows in fp16 (segments and items are shared)
       use_i8 = false;
       HS_HIP(h, hipMemsetAsync(d_unsafe, 0, 4, h->stream));
@@ -1433,7 +1439,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
       HS_HIP(h, hs_launch_item_desc(h->tabs, h->seg_key.as<uint64_t>(), h->seg_cnt.as<uint32_t>(),
                                     h->seg_qoff.as<uint32_t>(), h->item_off.as<uint32_t>(), nql,
                                     h->sorted_ql.as<uint32_t>(), h->qcount.as<uint32_t>(), n_items, jm,
-                                    seg_shift, h->seg_vals.as<uint32_t>(), h->item_desc.as<uint4>(),
+                                    seg_shift, h->seg_vals.as<uint32_t>(), h->PW, h->item_desc.as<uint4>(),
                                     h->stream));
     }
   }
@@ -1470,7 +1476,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
       if (thin8) {
         HS_HIP(h, hs_launch_thin8(h->tabs, h->t_rec8.as<uint4>(), h->n, h->c16.p, h->jtab8.p,
                                   h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
-                                  h->slice_off.as<uint32_t>(), nql, L, d_cnt, prov_cap,
+                                  h->slice_off.as<uint32_t>(), nql, L, k, d_cnt, prov_cap,
                                   h->prov.as<uint2>(), n_blocks, h->stream2));
       } else {
         if (!tables_done)
@@ -1490,7 +1496,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     } else {
       if (n_items && use_i8)
         HS_HIP(h, hs_launch_join8w(h->item_desc.as<uint4>(), n_items, h->tabs.t[0].packed,
-                                   h->t_rec8.as<uint4>(), h->c16s.p, h->jtab8.p, d_cnt, prov_cap,
+                                   h->t_rec8.as<uint4>(), h->c16s.p, h->jtab8.p, k, d_cnt, prov_cap,
                                    h->prov.as<uint2>(), d_cnt + 32, h->n_cu * h->join_blocks_per_cu,
                                    h->stream));
       else if (n_items)

@@ -291,7 +291,7 @@ hipError_t hs_launch_item_desc(const hs_tables_dev& tabs, const uint64_t* d_seg_
                                const uint32_t* d_seg_cnt,
                                const uint32_t* d_seg_qoff, const uint32_t* d_item_off, uint32_t n_max,
                                const uint32_t* d_sorted_ql, const uint32_t* d_qcount, uint32_t n_items,
-                               uint32_t jm, int shift, const uint32_t* d_order, uint4* d_desc,
+                               uint32_t jm, int shift, const uint32_t* d_order, int PW, uint4* d_desc,
                                hipStream_t s);
 // item numbering order of the segments: many-query segments first (stable two-class partition):
 // d_big[n + 1] flags (last = 0) -> exclusive scan -> d_order[n], d_items_ordered[n]
@@ -328,16 +328,20 @@ hipError_t hs_launch_refine8(const hs_tables_dev& tabs, const uint2* d_prov, con
                              const uint32_t* d_qstart, const uint32_t* d_qcount,
                              uint2* d_out, uint32_t* d_out_count, hipStream_t s);
 hipError_t hs_launch_gather_c8t(const void* d_c8, const uint32_t* d_sorted_ql, const uint32_t* d_seg_qoff,
-                                uint32_t nql, int L, void* d_out, hipStream_t s);
+                                uint32_t nql, int L, int k, void* d_out, hipStream_t s);
+// bytes of a quantised int8 row (32 per k-step: 128 for k <= 25, 192 for k <= 41, 256 for k <= 50) and
+// the members of one work item of the wave-independent int8 join (128 / 64)
+int hs_join8_row_bytes(int k);
+uint32_t hs_join8_members_per_item(int k);
 // thin segments with the int8 join on: the join's filter value per (probe, member) pair on the
 // vector ALU (v_dot4_i32_i8), work items = the streaming kernel's (probe, slice) list
 hipError_t hs_launch_thin8(const hs_tables_dev& tabs, const uint4* d_rec_base, uint64_t n_entries,
                            const void* d_c8, const void* d_tab8, const uint32_t* d_qstart,
-                           const uint32_t* d_qcount, const uint32_t* d_slice_off, uint32_t nql, int L,
+                           const uint32_t* d_qcount, const uint32_t* d_slice_off, uint32_t nql, int L, int k,
                            uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov, int n_blocks,
                            hipStream_t s);
 hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* d_packed_base,
-                            const uint4* d_rec_base, const void* d_c8t, const void* d_tab8,
+                            const uint4* d_rec_base, const void* d_c8t, const void* d_tab8, int k,
                             uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov,
                             uint32_t* d_item_counter, int n_blocks, hipStream_t s);
 // bucket-ordered packed copy of one table (k <= 25) + the per-entry 16-byte A-row tails of the

@@ -179,7 +179,8 @@ __global__ __launch_bounds__(256) void hs_seg_route_kernel(const uint64_t* __res
     if (nq >= min_q && m >= min_m) {
       it = ((m + jm - 1) / jm) * ((nq + jqg - 1) / jqg);
       // MFMA pairs actually issued (128-row waves x 32-column chunks) vs real pairs
-      issued = (unsigned long long)((m + 32 * JT - 1) / (32 * JT) * (32 * JT)) * ((nq + JQ - 1) / JQ * JQ);
+      const uint32_t rm = jm < HS_JM_BLOCK ? jm : 32u * JT;  // rows of one wave's member tile
+      issued = (unsigned long long)((m + rm - 1) / rm * rm) * ((nq + JQ - 1) / JQ * JQ);
       real = (unsigned long long)m * nq;
     }
   }
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256) void hs_item_desc_kernel(hs_tables_dev tabs,
                                                            const uint32_t* __restrict__ sorted_ql,
                                                            const uint32_t* __restrict__ qcount,
                                                            uint32_t n_items, uint32_t jm, int shift,
-                                                           const uint32_t* __restrict__ order,
+                                                           const uint32_t* __restrict__ order, int PW,
                                                            uint4* __restrict__ desc) {
   const uint32_t item = blockIdx.x * 256 + threadIdx.x;
   if (item >= n_items) return;
@@ -274,11 +275,12 @@ __global__ __launch_bounds__(256) void hs_item_desc_kernel(hs_tables_dev tabs,
   const uint32_t mt = local % tiles_m, qg = local / tiles_m;
   const uint32_t q_begin = qg * jqg;
   const uint32_t mstart = (uint32_t)(key & ((1ull << shift) - 1ull));
-  // offset (in 16-byte words) from table 0's packed array: base + offset keeps the member loads
-  // in the global address space (a pointer rebuilt from integers compiles to flat loads, whose
-  // lgkmcnt accounting stalls the LDS waits of the MFMA loop)
+  // ENTRY number of the segment's first member counted from table 0's first entry (an entry = PW
+  // 16-byte words of the packed array, one record of the record array): base + offset keeps the
+  // member loads in the global address space (a pointer rebuilt from integers compiles to flat
+  // loads, whose lgkmcnt accounting stalls the LDS waits of the MFMA loop)
   const int64_t off = (reinterpret_cast<intptr_t>(tabs.t[(uint32_t)(key >> shift)].packed) -
-                       reinterpret_cast<intptr_t>(tabs.t[0].packed)) / 16 + (int64_t)mstart;
+                       reinterpret_cast<intptr_t>(tabs.t[0].packed)) / (16 * (int64_t)PW) + (int64_t)mstart;
   desc[2 * (uint64_t)item] = make_uint4((uint32_t)(uint64_t)off, (uint32_t)((uint64_t)off >> 32), M, mt);
   desc[2 * (uint64_t)item + 1] = make_uint4(qoff, q_begin, min(nQ, q_begin + jqg), mstart);
 }
@@ -596,12 +598,12 @@ hipError_t hs_launch_item_desc(const hs_tables_dev& tabs, const uint64_t* d_seg_
                                const uint32_t* d_seg_cnt,
                                const uint32_t* d_seg_qoff, const uint32_t* d_item_off, uint32_t n_max,
                                const uint32_t* d_sorted_ql, const uint32_t* d_qcount, uint32_t n_items,
-                               uint32_t jm, int shift, const uint32_t* d_order, uint4* d_desc,
+                               uint32_t jm, int shift, const uint32_t* d_order, int PW, uint4* d_desc,
                                hipStream_t s) {
   if (!n_items) return hipSuccess;
   hs_item_desc_kernel<<<blocks_for(n_items), 256, 0, s>>>(tabs, d_seg_key, d_seg_cnt, d_seg_qoff, d_item_off,
                                                           n_max, d_sorted_ql, d_qcount, n_items, jm, shift,
-                                                          d_order, d_desc);
+                                                          d_order, PW, d_desc);
   return hipGetLastError();
 }
 

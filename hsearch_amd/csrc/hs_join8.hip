@@ -23,6 +23,13 @@
 // its digits is clamped in the permissive direction (the filter may only pass MORE); a gamma too
 // negative to represent marks the batch unsafe.
 //
+// Longer k-mers (26..50 residues, two packed words): the same row with more k-steps -- KS = 6 (k <= 41)
+// or 8 (k <= 50) instead of 4; coordinates at bytes 4p + j as before, the 28 digit slots are always
+// the LAST 28 bytes of the row (bytes 32 KS - 28 ..), the member's record is the 16 bytes
+// 32 KS - 32 .. 32 KS - 17 of its row (x^ of position 8 KS - 8 if the k-mer has one, then the rho
+// slots).  Such work items are 64 members (two row tiles) per wave: the A operands of 128 members
+// over 6 or 8 k-steps would not leave room for the query tiles in flight.
+//
 // rho depends on the member only, so it is evaluated ONCE, at index build: hs_gather_rec8_kernel
 // writes, next to the bucket-ordered packed copy, a 16-byte record per entry = bytes 96..111 of the
 // member's A row (x^ of position 24, then the 12 rho slots).  The join kernel then builds a member's
@@ -41,8 +48,8 @@ typedef int intx4 __attribute__((ext_vector_type(4)));
 typedef int intx16 __attribute__((ext_vector_type(16)));
 
 constexpr int QD = 4;        // table columns used
-constexpr int QROW = 128;    // bytes of a quantised query row (global)
-constexpr int QPIECES = 8;   // 16-byte pieces per row
+// k-steps of 32 bytes in a row: 4 (k <= 25), 6 (k <= 41), 8 (k <= 50); row = 32 KS bytes = 2 KS pieces
+__host__ __device__ constexpr int ks_of(int k) { return k <= 25 ? 4 : k <= 41 ? 6 : 8; }
 constexpr uint32_t JRES = 64;  // survivor slots a wave reserves per counter access
 constexpr int DIG = 13;      // base-127 digits (+1 remainder slot) of -gamma
 constexpr int RDIG = 11;     // base-127 digits (+1 remainder slot) of rho
@@ -148,9 +155,8 @@ __global__ void hs_jtables8_kernel(const double* __restrict__ coords, int alphab
 }
 
 // ---------------------------------------------------------------------------------- query prep
-// c8[q] (128 bytes): byte 4p + j = c^ of coordinate j (< 4) of position p (< min(k, 25)), zeros
-// up to byte 99; spare slots: bytes 100..111 = (-127 x11, -1), 112..113 = 0, 114..127 = the digits
-// of -gamma.
+// c8[q] (ROW = 32 KS bytes): byte 4p + j = c^ of coordinate j (< 4) of position p (< k), zeros up to
+// byte ROW - 29; the last 28 bytes: (-127 x11, -1), 0, 0, then the 14 digits of -gamma.
 __global__ __launch_bounds__(256) void hs_qprep8_kernel(const double* __restrict__ centers, uint32_t nq,
                                                         int k, double r2, const float* __restrict__ scale,
                                                         int8_t* __restrict__ c8,
@@ -159,22 +165,22 @@ __global__ __launch_bounds__(256) void hs_qprep8_kernel(const double* __restrict
   const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= nq) return;
   const int lane = lane_id();
+  const int ROW = 32 * ks_of(k), TAIL = ROW - 28;
   const double sA = (double)scale[0], sB = (double)scale[2];
   const double* c = centers + (uint64_t)q * 8 * k;
-  int8_t* outA = c8 + (uint64_t)q * QROW;
-  int8_t* outB = c8b ? c8b + (uint64_t)q * QROW : nullptr;
+  int8_t* outA = c8 + (uint64_t)q * ROW;
+  int8_t* outB = c8b ? c8b + (uint64_t)q * ROW : nullptr;
   // one pass over the 8k doubles of the row (lane i, i + 64, ...: coalesced): coordinate j < 4 of
   // position p goes to byte 4p + j of the first row, coordinate j >= 4 to byte 4p + j - 4 of the
-  // second; sums per half
+  // second; sums per half.  Positions k .. TAIL/4 - 1 are zero bytes.
   double ncA = 0.0, penA = 0.0, ncB = 0.0, penB = 0.0;
   int l1A = 0, l1B = 0;
   bool badA = false, badB = !(scale[3] > 0.f);
-  const int kk = min(k, 25);
-  for (int i = lane; i < 200; i += 64) {
+  for (int i = lane; i < 2 * TAIL; i += 64) {
     const int pos = i >> 3, j = i & 7;
     const bool second = j >= QD;
     int qv = 0;
-    if (pos < kk) {
+    if (pos < k) {
       const double v = c[i];
       const double sv = (second ? sB : sA) * v;
       const bool bad = !(fabs(sv) < 1.0e6);
@@ -222,23 +228,23 @@ __global__ __launch_bounds__(256) void hs_qprep8_kernel(const double* __restrict
     else if (lane == RDIG) b = (int8_t)-1;
     else if (lane < 14) b = 0;
     else b = (int8_t)d[lane - 14];
-    outA[100 + lane] = b;
+    outA[TAIL + lane] = b;
   }
-  // Tail of the second row, for hs_refine8_kernel: byte 104 = the double |c|^2 - R^2 over all 8
-  // columns, bytes 112 / 116 = the floats L1(c^)/2 + saturation penalty + 2 of columns 0..3 / 4..7
-  // (+inf: this query cannot be refined)
+  // Tail of the second row, for hs_refine8_kernel: byte ROW - 24 = the double |c|^2 - R^2 over all 8
+  // columns, bytes ROW - 16 / ROW - 12 = the floats L1(c^)/2 + saturation penalty + 2 of columns
+  // 0..3 / 4..7 (+inf: this query cannot be refined)
   if (outB) {
     const bool any_bad = __ballot(bad || badB) != 0;
     if (lane == 0) {
-      *reinterpret_cast<double*>(outB + 104) = (ncA + ncB) - r2;
+      *reinterpret_cast<double*>(outB + ROW - 24) = (ncA + ncB) - r2;
       const float inf = __builtin_inff();
       // rounded up (float): the bound may only get more permissive
-      *reinterpret_cast<float*>(outB + 112) = any_bad ? inf : __double2float_ru(0.5 * (double)l1A + penA + 2.0);
-      *reinterpret_cast<float*>(outB + 116) = any_bad ? inf : __double2float_ru(0.5 * (double)l1B + penB + 2.0);
+      *reinterpret_cast<float*>(outB + ROW - 16) = any_bad ? inf : __double2float_ru(0.5 * (double)l1A + penA + 2.0);
+      *reinterpret_cast<float*>(outB + ROW - 12) = any_bad ? inf : __double2float_ru(0.5 * (double)l1B + penB + 2.0);
     }
     if (lane == 1) {
-      *reinterpret_cast<uint32_t*>(outB + 100) = 0u;
-      *reinterpret_cast<uint64_t*>(outB + 120) = 0ull;
+      *reinterpret_cast<uint32_t*>(outB + ROW - 28) = 0u;
+      *reinterpret_cast<uint64_t*>(outB + ROW - 8) = 0ull;
     }
   }
 }
@@ -256,36 +262,85 @@ __device__ __forceinline__ uint32_t residue_at(uint32_t x, uint32_t y, uint32_t 
   }
 }
 
+// A k-mer's residues as ONE little-endian bit stream, 5 bits per position (position p at bit 5p):
+// the packed form keeps 25 residues per 16-byte word (3 pad bits), so the second word is stitched
+// on at bit 125.  v[0..7]; positions past the k-mer read as residue 0.
+struct Stream256 {
+  uint32_t v[8];
+};
+template <int PW>
+__device__ __forceinline__ Stream256 stitch(const uint4 w0, const uint4 w1) {
+  Stream256 s;
+  s.v[0] = w0.x;
+  s.v[1] = w0.y;
+  s.v[2] = w0.z;
+  if constexpr (PW == 1) {
+    s.v[3] = w0.w;
+    s.v[4] = s.v[5] = s.v[6] = s.v[7] = 0u;
+  } else {
+    s.v[3] = (w0.w & 0x1fffffffu) | (w1.x << 29);
+    s.v[4] = __funnelshift_r(w1.x, w1.y, 3);
+    s.v[5] = __funnelshift_r(w1.y, w1.z, 3);
+    s.v[6] = __funnelshift_r(w1.z, w1.w, 3);
+    s.v[7] = w1.w >> 3;
+  }
+  return s;
+}
+// residue at compile-time bit BIT of a stream (after an optional uniform shift of the whole stream)
+template <int BIT>
+__device__ __forceinline__ uint32_t stream_at(const Stream256& s) {
+  constexpr int wi = BIT >> 5, sh = BIT & 31;
+  if constexpr (wi > 7) return 0u;
+  else if constexpr (sh > 27 && wi < 7) return __funnelshift_r(s.v[wi], s.v[wi + 1], sh) & 31u;
+  else return (s.v[wi] >> sh) & 31u;
+}
+
 __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
   return ((uint32_t)a & 0xffu) | (((uint32_t)b & 0xffu) << 8) | (((uint32_t)c & 0xffu) << 16) |
          (((uint32_t)d & 0xffu) << 24);
 }
 
-// A operands (4 k-steps) of one 32-member row tile for lane (r, h): k-step s < 3 carries positions
-// 8s + 4h + {0,1,2,3} (positions >= k meet zero query bytes, so their rows need no masking);
-// k-step 3 = the entry's prebuilt record (h = 0) or the constant factors of the gamma slots (h = 1).
-__device__ __forceinline__ void build_afrags8(const uint4 pk, const uint4 rec, int h,
-                                              const uint32_t* sTab8, intx4 (&A)[4]) {
-  // lanes of the upper half take positions 4..7, 12..15, ...: shift the word down by 20 bits
-  const uint32_t sh = 20u * (uint32_t)h;
-  const uint32_t x = __funnelshift_r(pk.x, pk.y, sh), y = __funnelshift_r(pk.y, pk.z, sh),
-                 z = __funnelshift_r(pk.z, pk.w, sh), w = pk.w >> sh;
+// A operands (KS k-steps) of one 32-member row tile for lane (r, h): k-step s < KS - 1 carries
+// positions 8s + 4h + {0,1,2,3} (positions >= k meet zero query bytes, so their rows need no
+// masking); the last k-step = the entry's prebuilt record (h = 0) or the constant factors of the
+// gamma slots (h = 1).
+template <int KS, int PW>
+__device__ __forceinline__ void build_afrags8(const uint4 pk, const uint4 pk1, const uint4 rec, int h,
+                                              const uint32_t* sTab8, intx4 (&A)[KS]) {
+  if constexpr (PW == 1) {
+    // lanes of the upper half take positions 4..7, 12..15, ...: shift the word down by 20 bits
+    const uint32_t sh = 20u * (uint32_t)h;
+    const uint32_t x = __funnelshift_r(pk.x, pk.y, sh), y = __funnelshift_r(pk.y, pk.z, sh),
+                   z = __funnelshift_r(pk.z, pk.w, sh), w = pk.w >> sh;
 #define HS_A8(S, M) A[S][M] = (int)sTab8[residue_at<40 * S + 5 * M>(x, y, z, w)];
-  HS_A8(0, 0) HS_A8(0, 1) HS_A8(0, 2) HS_A8(0, 3)
-  HS_A8(1, 0) HS_A8(1, 1) HS_A8(1, 2) HS_A8(1, 3)
-  HS_A8(2, 0) HS_A8(2, 1) HS_A8(2, 2) HS_A8(2, 3)
+    HS_A8(0, 0) HS_A8(0, 1) HS_A8(0, 2) HS_A8(0, 3)
+    HS_A8(1, 0) HS_A8(1, 1) HS_A8(1, 2) HS_A8(1, 3)
+    HS_A8(2, 0) HS_A8(2, 1) HS_A8(2, 2) HS_A8(2, 3)
 #undef HS_A8
+  } else {
+    Stream256 st = stitch<2>(pk, pk1);
+    const uint32_t sh = 20u * (uint32_t)h;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) st.v[i] = __funnelshift_r(st.v[i], st.v[i + 1], sh);
+    st.v[7] >>= sh;
+#define HS_A8(S, M) A[S][M] = (int)sTab8[stream_at<40 * (S) + 5 * (M)>(st)];
+#define HS_A8S(S) HS_A8(S, 0) HS_A8(S, 1) HS_A8(S, 2) HS_A8(S, 3)
+    HS_A8S(0) HS_A8S(1) HS_A8S(2) HS_A8S(3) HS_A8S(4)
+    if constexpr (KS == 8) { HS_A8S(5) HS_A8S(6) }
+#undef HS_A8S
+#undef HS_A8
+  }
   constexpr uint32_t C127 = 0x7f7f7f7fu;
-  A[3][0] = h ? 0x7f7f0000 : (int)rec.x;          // bytes 112, 113 unused; 114.. = 127
-  A[3][1] = h ? (int)C127 : (int)rec.y;
-  A[3][2] = h ? (int)C127 : (int)rec.z;
-  A[3][3] = h ? 0x017f7f7f : (int)rec.w;          // byte 127 = 1 (remainder slot of -gamma)
+  A[KS - 1][0] = h ? 0x7f7f0000 : (int)rec.x;          // bytes ROW-16, ROW-15 unused; ROW-14.. = 127
+  A[KS - 1][1] = h ? (int)C127 : (int)rec.y;
+  A[KS - 1][2] = h ? (int)C127 : (int)rec.z;
+  A[KS - 1][3] = h ? 0x017f7f7f : (int)rec.w;          // last byte = 1 (remainder slot of -gamma)
 }
 
 // index build: bucket-ordered packed copy of one table + the 16-byte A-row tail of every entry
 __global__ __launch_bounds__(256) void hs_gather_rec8_kernel(const uint4* __restrict__ packed_all,
                                                              const uint32_t* __restrict__ ids,
-                                                             uint32_t n, int k,
+                                                             uint32_t n, int k, int PW,
                                                              const uint4* __restrict__ tab8,
                                                              const float* __restrict__ scale,
                                                              uint4* __restrict__ out_packed,
@@ -295,31 +350,34 @@ __global__ __launch_bounds__(256) void hs_gather_rec8_kernel(const uint4* __rest
   __syncthreads();
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t >= n) return;
-  const uint4 pk = packed_all[ids[t]];
-  out_packed[t] = pk;
-  const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
-  const int kk = min(k, 25);
+  const int plast = 8 * ks_of(k) - 8;  // the position whose x^ opens the record (if the k-mer has it)
   double nx = 0.0;
   int l1 = 0;
-  uint32_t x24 = 0;
+  uint32_t xlast = 0;
+  for (int wd = 0; wd < PW; ++wd) {
+    const uint4 pk = packed_all[(uint64_t)ids[t] * PW + wd];
+    out_packed[(uint64_t)t * PW + wd] = pk;
+    const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
 #pragma unroll
-  for (int p = 0; p < 25; ++p) {
-    const int bit = 5 * p, wi = bit >> 5, sh = bit & 31;
-    uint32_t c = w[wi] >> sh;
-    if (sh > 27) c |= w[wi + 1] << (32 - sh);
-    const uint4 row = sTab[c & 31u];
-    if (p < kk) {
-      nx += (double)__uint_as_float(row.y);
-      l1 += (int)row.z;
-      if (p == 24) x24 = row.x;
+    for (int r = 0; r < 25; ++r) {
+      const int bit = 5 * r, wi = bit >> 5, sh = bit & 31;
+      uint32_t c = w[wi] >> sh;
+      if (sh > 27) c |= w[wi + 1] << (32 - sh);
+      const uint4 row = sTab[c & 31u];
+      const int p = 25 * wd + r;
+      if (p < k) {
+        nx += (double)__uint_as_float(row.y);
+        l1 += (int)row.z;
+        if (p == plast) xlast = row.x;
+      }
     }
   }
   // rho = floor(s^2 |x1|^2 / 2 - L1(x^)/2 - dims/4 - 2); the 2 absorbs the fp32 roundings of
   // scale[1] and of the table's squared norms
-  const double rho = floor((double)scale[1] * nx - 0.5 * (double)l1 - 0.25 * (double)(QD * kk) - 2.0);
+  const double rho = floor((double)scale[1] * nx - 0.5 * (double)l1 - 0.25 * (double)(QD * k) - 2.0);
   int d[RDIG + 1];
   digits127<RDIG>((int)rho, d, nullptr);  // too large -> clamped down: more permissive, never less
-  out_rec[t] = make_uint4(x24, pack4(d[0], d[1], d[2], d[3]), pack4(d[4], d[5], d[6], d[7]),
+  out_rec[t] = make_uint4(xlast, pack4(d[0], d[1], d[2], d[3]), pack4(d[4], d[5], d[6], d[7]),
                           pack4(d[8], d[9], d[10], d[11]));
 }
 
@@ -347,7 +405,7 @@ __device__ unsigned long long g_join8_timing[8];
 __global__ __launch_bounds__(256) void hs_gather_c8t_kernel(const int8_t* __restrict__ c8,
                                                             const uint32_t* __restrict__ sorted_ql,
                                                             const uint32_t* __restrict__ seg_qoff,
-                                                            uint32_t nql, int L,
+                                                            uint32_t nql, int L, int pieces,
                                                             uint4* __restrict__ out) {
   const uint32_t p = blockIdx.x * 256 + threadIdx.x;
   if (p >= nql) return;
@@ -360,10 +418,9 @@ __global__ __launch_bounds__(256) void hs_gather_c8t_kernel(const int8_t* __rest
   const uint32_t local = p - qoff, tile = local >> 5, j = local & 31u;
   const uint32_t nr = min(32u, nQ - (tile << 5));
   const uint32_t q = sorted_ql[p] / (uint32_t)L;
-  const uint4* src = reinterpret_cast<const uint4*>(c8 + (uint64_t)q * QROW);
-  uint4* dst = out + (uint64_t)(qoff + (tile << 5)) * QPIECES + j;
-#pragma unroll
-  for (int g = 0; g < QPIECES; ++g) dst[(uint32_t)g * nr] = src[g];
+  const uint4* src = reinterpret_cast<const uint4*>(c8) + (uint64_t)q * pieces;
+  uint4* dst = out + (uint64_t)(qoff + (tile << 5)) * pieces + j;
+  for (int g = 0; g < pieces; ++g) dst[(uint32_t)g * nr] = src[g];
 }
 
 // No LDS staging and no workgroup barrier: a work item is 128 bucket members x <= 2048 probing
@@ -372,12 +429,13 @@ __global__ __launch_bounds__(256) void hs_gather_c8t_kernel(const int8_t* __rest
 // boundaries).  Waves take their first item by position and every further one from a global
 // counter (two items ahead, so the descriptor and the packed members are there in time): a stall
 // -- survivor bookkeeping, a late load -- costs that wave only, and no wave idles at the end.
-__device__ __forceinline__ void load_btile(intx4 (&B)[4], const uint4* __restrict__ c8t, uint32_t row0,
+template <int KS>
+__device__ __forceinline__ void load_btile(intx4 (&B)[KS], const uint4* __restrict__ c8t, uint32_t row0,
                                            uint32_t nr, int lane) {
-  const uint4* base = c8t + (uint64_t)row0 * QPIECES;
+  const uint4* base = c8t + (uint64_t)row0 * (2 * KS);
   if (nr == 32u) {  // full tile: piece (s, h) of row r sits at 64 s + lane
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < KS; ++s) {
       const uint4 v = base[64 * s + lane];
       B[s] = intx4{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
     }
@@ -385,7 +443,7 @@ __device__ __forceinline__ void load_btile(intx4 (&B)[4], const uint4* __restric
     const uint32_t r = (uint32_t)lane & 31u, h = (uint32_t)lane >> 5;
     const uint32_t j = min(r, nr - 1u) + h * nr;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < KS; ++s) {
       const uint4 v = base[(uint32_t)(2 * s) * nr + j];
       B[s] = intx4{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
     }
@@ -466,14 +524,16 @@ __device__ __forceinline__ uint4 uniform4(const uint4 v) {
 // query tile: 8 MFMAs into X while the sign test of Y (previous query tile) issues in their gaps,
 // then 8 MFMAs into Y beside the sign test of X -- the vector instructions of the epilogue never
 // stand between two MFMAs of the same wave.
-template <int JT>
-__global__ __launch_bounds__(256, JT == 4 ? 2 : 4) void hs_join8w_kernel(
+template <int JT, int KS>
+__global__ __launch_bounds__(256, 2) void hs_join8w_kernel(
     const uint4* __restrict__ desc, uint32_t n_items, const uint4* __restrict__ packed_base,
     const uint4* __restrict__ rec_base, const uint4* __restrict__ c8t,
     const uint4* __restrict__ tab8, uint32_t* __restrict__ prov_count, uint32_t prov_cap,
     uint2* __restrict__ prov, uint32_t* __restrict__ item_counter, uint32_t G) {
   static_assert(JT == 4 || JT == 2, "two accumulator groups of JT / 2 row tiles");
+  static_assert(KS == 4 || KS == 6 || KS == 8, "k-steps of a row");
   constexpr int GT = JT / 2;
+  constexpr int PW = KS == 4 ? 1 : 2;  // packed words per member
   __shared__ uint32_t sTab8[32];
   const int tid = threadIdx.x, lane = tid & 63;
   // wave-uniform by construction: say so, or every per-item quantity derived from it (descriptor
@@ -516,18 +576,22 @@ __global__ __launch_bounds__(256, JT == 4 ? 2 : 4) void hs_join8w_kernel(
     nd1 = uniform4(desc[2 * (uint64_t)next_item + 1]);
   }
   uint4 mk[JT];                  // lanes of the lower half: packed member, upper half: its record
+  uint4 mk1[PW == 2 ? JT : 1];   // second packed word of the member (k > 25)
   constexpr int NB = 3;          // B tiles in flight per wave: the one in use + two prefetched
   constexpr uint32_t GQ = 32 * NB;  // queries per group of NB tiles
-  intx4 Bq[NB][4];
+  intx4 Bq[NB][KS];
   // one 16-byte load per lane and row tile: the lower half-wave fetches the packed members, the
   // upper half their records; the halves trade them at build time (v_permlane32_swap)
 #define HS_LOAD_MEMBERS(D0)                                                              \
   {                                                                                      \
+    /* off_ = entry number of the segment's first member (record index; packed index / PW) */ \
     const int64_t off_ = (int64_t)(((uint64_t)(D0).y << 32) | (uint64_t)(D0).x);         \
-    const uint4* src_ = (h ? rec_base : packed_base) + off_;                             \
     const uint32_t idx_ = (D0).w * (32 * JT) + r;                                        \
-    _Pragma("unroll") for (int t = 0; t < JT; ++t)                                       \
-      mk[t] = src_[min(idx_ + 32 * t, (D0).z - 1)];                                      \
+    _Pragma("unroll") for (int t = 0; t < JT; ++t) {                                     \
+      const int64_t e_ = off_ + (int64_t)min(idx_ + 32 * t, (D0).z - 1);                 \
+      mk[t] = h ? rec_base[e_] : packed_base[e_ * PW];                                   \
+      if constexpr (PW == 2) mk1[t] = packed_base[e_ * PW + 1];                          \
+    }                                                                                    \
   }
   // Waves start an item's query tiles at a wave-dependent pair and wrap around: resident waves
   // work on neighbouring items of the same (bucket, query group); walking the tiles in lock step
@@ -560,7 +624,7 @@ __global__ __launch_bounds__(256, JT == 4 ? 2 : 4) void hs_join8w_kernel(
       nnd0 = uniform4(desc[2 * (uint64_t)pf_item]);
       nnd1 = uniform4(desc[2 * (uint64_t)pf_item + 1]);
     }
-    intx4 A[JT][4];
+    intx4 A[JT][KS];
 #pragma unroll
     for (int t = 0; t < JT; ++t) {
       uint4 pk, rk;  // after the swap: pk = the lower half's value, rk = the upper half's, in all lanes
@@ -572,7 +636,9 @@ __global__ __launch_bounds__(256, JT == 4 ? 2 : 4) void hs_join8w_kernel(
   }
       HS_SWAP(x) HS_SWAP(y) HS_SWAP(z) HS_SWAP(w)
 #undef HS_SWAP
-      build_afrags8(pk, rk, h, sTab8, A[t]);
+      uint4 pk1 = pk;
+      if constexpr (PW == 2) pk1 = mk1[t];
+      build_afrags8<KS, PW>(pk, pk1, rk, h, sTab8, A[t]);
     }
     HS_TD(1, __builtin_amdgcn_readfirstlane(A[0][0][0] ^ A[JT - 1][3][3] ^ A[JT - 1][2][0] ^ A[1][1][1]))
     HS_LOAD_MEMBERS(nd0)
@@ -599,7 +665,7 @@ __global__ __launch_bounds__(256, JT == 4 ? 2 : 4) void hs_join8w_kernel(
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
         const uint32_t qc = qc0 + 32u * (uint32_t)u;
-        intx4 (&B)[4] = Bq[u];
+        intx4 (&B)[KS] = Bq[u];
         if (u == 0 || qc < q_end) {
           // ---- phase 1: X <- A[0..GT) x B, beside the sign test of Y (previous query tile)
 #pragma unroll
@@ -608,12 +674,12 @@ __global__ __launch_bounds__(256, JT == 4 ? 2 : 4) void hs_join8w_kernel(
             for (int i = 0; i < 16; ++i) accX[t][i] = 0;
           const uint32_t sY = and_tree<GT>(accY);
 #pragma unroll
-          for (int s = 0; s < 4; ++s)
+          for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int t = 0; t < GT; ++t)
               accX[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[t][s], B[s], accX[t], 0, 0, 0);
 #pragma unroll
-          for (int g = 0; g < 4 * GT; ++g) {
+          for (int g = 0; g < KS * GT; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
           }
@@ -626,13 +692,13 @@ __global__ __launch_bounds__(256, JT == 4 ? 2 : 4) void hs_join8w_kernel(
 #pragma unroll
             for (int i = 0; i < 16; ++i) accY[t][i] = 0;
 #pragma unroll
-          for (int s = 0; s < 4; ++s)
+          for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int t = 0; t < GT; ++t)
               accY[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[GT + t][s], B[s], accY[t], 0, 0, 0);
           const uint32_t sX = and_tree<GT>(accX);
 #pragma unroll
-          for (int g = 0; g < 4 * GT; ++g) {
+          for (int g = 0; g < KS * GT; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
           }
@@ -687,6 +753,7 @@ __global__ __launch_bounds__(256, JT == 4 ? 2 : 4) void hs_join8w_kernel(
 // query's row, v_dot4_i32_i8 instead of MFMA -- one member per lane, work item = one (probe, slice
 // of <= HS_SLICE bucket entries) per wave as in the streaming kernel.  Needs no per-query distance
 // tables: with this kernel the side stream's work beside the join is a few tens of microseconds.
+template <int KS>
 __global__ __launch_bounds__(256) void hs_thin8_kernel(hs_tables_dev tabs,
                                                        const uint4* __restrict__ rec_base, uint64_t n_entries,
                                                        const int8_t* __restrict__ c8,
@@ -694,9 +761,11 @@ __global__ __launch_bounds__(256) void hs_thin8_kernel(hs_tables_dev tabs,
                                                        const uint32_t* __restrict__ qstart,
                                                        const uint32_t* __restrict__ qcount,
                                                        const uint32_t* __restrict__ slice_off,
-                                                       uint32_t nql, int L,
+                                                       uint32_t nql, int L, int k,
                                                        uint32_t* __restrict__ prov_count,
                                                        uint32_t prov_cap, uint2* __restrict__ prov) {
+  constexpr int PW = KS == 4 ? 1 : 2;
+  constexpr int NW = 8 * KS;  // dwords of a row
   __shared__ uint32_t sTab8[32];
   const int tid = threadIdx.x, lane = tid & 63;
   if (tid < 32) sTab8[tid] = tab8[tid].x;
@@ -717,38 +786,44 @@ __global__ __launch_bounds__(256) void hs_thin8_kernel(hs_tables_dev tabs,
     const uint4* packed = tabs.t[l].packed;
     const uint4* rec = rec_base + (uint64_t)l * n_entries;
     // the query's row: K index = byte index (hs_qprep8_kernel); wave-uniform
-    const uint4* qrow = reinterpret_cast<const uint4*>(c8 + (uint64_t)q * QROW);
-    int B[32];
+    const uint4* qrow = reinterpret_cast<const uint4*>(c8) + (uint64_t)q * (2 * KS);
+    int B[NW];
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
+    for (int g = 0; g < 2 * KS; ++g) {
       const uint4 v = qrow[g];
       B[4 * g] = (int)v.x;
       B[4 * g + 1] = (int)v.y;
       B[4 * g + 2] = (int)v.z;
       B[4 * g + 3] = (int)v.w;
     }
-    // words 28..31 of a member's row are constants (build_afrags8, h = 1)
-    int qconst = __builtin_amdgcn_sdot4(0x7f7f0000, B[28], 0, false);
-    qconst = __builtin_amdgcn_sdot4(0x7f7f7f7f, B[29], qconst, false);
-    qconst = __builtin_amdgcn_sdot4(0x7f7f7f7f, B[30], qconst, false);
-    qconst = __builtin_amdgcn_sdot4(0x017f7f7f, B[31], qconst, false);
+    // the last four dwords of a member's row are constants (build_afrags8, h = 1)
+    int qconst = __builtin_amdgcn_sdot4(0x7f7f0000, B[NW - 4], 0, false);
+    qconst = __builtin_amdgcn_sdot4(0x7f7f7f7f, B[NW - 3], qconst, false);
+    qconst = __builtin_amdgcn_sdot4(0x7f7f7f7f, B[NW - 2], qconst, false);
+    qconst = __builtin_amdgcn_sdot4(0x017f7f7f, B[NW - 1], qconst, false);
     const uint32_t iters = (cnt + 63u) / 64u;
     for (uint32_t it = 0; it < iters; ++it) {
       const uint32_t i = it * 64u + (uint32_t)lane;
       const bool valid = i < cnt;
       const uint64_t pos = (uint64_t)start + (valid ? i : cnt - 1);
-      const uint4 pk = packed[pos];
+      const uint4 pk = packed[pos * PW];
+      uint4 pk1 = pk;
+      if constexpr (PW == 2) pk1 = packed[pos * PW + 1];
+      const Stream256 st = stitch<PW>(pk, pk1);
       const uint4 rc = rec[pos];
       int acc = qconst;
-#define HS_P(P) acc = __builtin_amdgcn_sdot4((int)sTab8[residue_at<5 * P>(pk.x, pk.y, pk.z, pk.w)], B[P], acc, false);
-      HS_P(0) HS_P(1) HS_P(2) HS_P(3) HS_P(4) HS_P(5) HS_P(6) HS_P(7)
-      HS_P(8) HS_P(9) HS_P(10) HS_P(11) HS_P(12) HS_P(13) HS_P(14) HS_P(15)
-      HS_P(16) HS_P(17) HS_P(18) HS_P(19) HS_P(20) HS_P(21) HS_P(22) HS_P(23)
+      // positions 0 .. 8 KS - 9 by table lookup (those past the k-mer meet zero query bytes)
+#define HS_P(P) if ((P) < NW - 8 && (P) < k) acc = __builtin_amdgcn_sdot4((int)sTab8[stream_at<5 * (P)>(st)], B[(P) < NW ? (P) : 0], acc, false);
+#define HS_P8(P) HS_P(P) HS_P(P + 1) HS_P(P + 2) HS_P(P + 3) HS_P(P + 4) HS_P(P + 5) HS_P(P + 6) HS_P(P + 7)
+      HS_P8(0) HS_P8(8) HS_P8(16)
+      if constexpr (KS > 4) { HS_P8(24) HS_P8(32) }
+      if constexpr (KS > 6) { HS_P8(40) HS_P8(48) }
+#undef HS_P8
 #undef HS_P
-      acc = __builtin_amdgcn_sdot4((int)rc.x, B[24], acc, false);  // position 24 + the rho digits
-      acc = __builtin_amdgcn_sdot4((int)rc.y, B[25], acc, false);
-      acc = __builtin_amdgcn_sdot4((int)rc.z, B[26], acc, false);
-      acc = __builtin_amdgcn_sdot4((int)rc.w, B[27], acc, false);
+      acc = __builtin_amdgcn_sdot4((int)rc.x, B[NW - 8], acc, false);  // position 8 KS - 8 + the rho digits
+      acc = __builtin_amdgcn_sdot4((int)rc.y, B[NW - 7], acc, false);
+      acc = __builtin_amdgcn_sdot4((int)rc.z, B[NW - 6], acc, false);
+      acc = __builtin_amdgcn_sdot4((int)rc.w, B[NW - 5], acc, false);
       const bool pass = valid && acc >= 0;
       const unsigned long long m = __ballot(pass);
       if (m) {
@@ -771,6 +846,7 @@ __global__ __launch_bounds__(256) void hs_thin8_kernel(hs_tables_dev tabs,
 // One survivor per lane: 25 table rows (LDS), 2 x 100 query bytes, two v_dot4 per position.  The
 // 4-column bound passes ~10 pairs per true hit, this one ~1.1: hs_finalize_kernel, whose cost is
 // per survivor, gets a list 7-8 times shorter.  One-sided like every filter here.
+template <int PW>
 __global__ __launch_bounds__(256) void hs_refine8_kernel(hs_tables_dev tabs,
                                                          const uint2* __restrict__ prov,
                                                          const uint32_t* __restrict__ prov_count,
@@ -784,6 +860,8 @@ __global__ __launch_bounds__(256) void hs_refine8_kernel(hs_tables_dev tabs,
                                                          const uint32_t* __restrict__ qcount,
                                                          uint2* __restrict__ out,
                                                          uint32_t* __restrict__ out_count) {
+  constexpr int NPOS = 25 * PW;              // positions a packed k-mer can hold
+  constexpr int NPC = (NPOS + 3) / 4;        // 16-byte pieces of a row that carry coordinates
   __shared__ uint4 sTabR[32];
   __shared__ uint2 s_keep[256];
   __shared__ uint32_t s_n, s_base;
@@ -792,6 +870,7 @@ __global__ __launch_bounds__(256) void hs_refine8_kernel(hs_tables_dev tabs,
   if (tid == 0) s_n = 0;
   __syncthreads();
   const uint32_t n = min(*prov_count, prov_cap);
+  const int ROW = 32 * ks_of(k);
   const double sA = (double)scale[0], sB = (double)scale[2];
   const double iA = 1.0 / (sA * sA), iB = 1.0 / (sB * sB);
   const double dims4 = 0.25 * (double)(QD * k);
@@ -804,38 +883,44 @@ __global__ __launch_bounds__(256) void hs_refine8_kernel(hs_tables_dev tabs,
     bool pass = false;
     if (live) {
       const uint32_t q = ql / (uint32_t)L, l = ql % (uint32_t)L;
-      const uint4 pk = tabs.t[l].packed[pos];
-      const uint4* ra = reinterpret_cast<const uint4*>(c8 + (uint64_t)q * QROW);
-      const uint4* rb = reinterpret_cast<const uint4*>(c8b + (uint64_t)q * QROW);
-      int A[28], B[28];
+      const uint4 pk = tabs.t[l].packed[(uint64_t)pos * PW];
+      uint4 pk1 = pk;
+      if constexpr (PW == 2) pk1 = tabs.t[l].packed[(uint64_t)pos * PW + 1];
+      const Stream256 st = stitch<PW>(pk, pk1);
+      const char* rowa = reinterpret_cast<const char*>(c8) + (uint64_t)q * ROW;
+      const char* rowb = reinterpret_cast<const char*>(c8b) + (uint64_t)q * ROW;
+      const uint4* ra = reinterpret_cast<const uint4*>(rowa);
+      const uint4* rb = reinterpret_cast<const uint4*>(rowb);
+      int A[4 * NPC], B[4 * NPC];
 #pragma unroll
-      for (int g = 0; g < 7; ++g) {
+      for (int g = 0; g < NPC; ++g) {
         const uint4 va = ra[g], vb = rb[g];
         A[4 * g] = (int)va.x; A[4 * g + 1] = (int)va.y; A[4 * g + 2] = (int)va.z; A[4 * g + 3] = (int)va.w;
         B[4 * g] = (int)vb.x; B[4 * g + 1] = (int)vb.y; B[4 * g + 2] = (int)vb.z; B[4 * g + 3] = (int)vb.w;
       }
-      const double cq = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(rb) + 104);
-      const float eA = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rb) + 112);
-      const float eB = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(rb) + 116);
+      const double cq = *reinterpret_cast<const double*>(rowb + ROW - 24);
+      const float eA = *reinterpret_cast<const float*>(rowb + ROW - 16);
+      const float eB = *reinterpret_cast<const float*>(rowb + ROW - 12);
       int dotA = 0, dotB = 0;
       uint32_t l1 = 0;
       float nx = 0.f;
 #define HS_R(P)                                                                      \
-  if (P < k) {                                                                       \
-    const uint4 row = sTabR[residue_at<5 * P>(pk.x, pk.y, pk.z, pk.w)];              \
-    dotA = __builtin_amdgcn_sdot4((int)row.x, A[P], dotA, false);                    \
-    dotB = __builtin_amdgcn_sdot4((int)row.y, B[P], dotB, false);                    \
+  if ((P) < NPOS && (P) < k) {                                                       \
+    const uint4 row = sTabR[stream_at<5 * (P)>(st)];                                 \
+    dotA = __builtin_amdgcn_sdot4((int)row.x, A[(P) < NPOS ? (P) : 0], dotA, false); \
+    dotB = __builtin_amdgcn_sdot4((int)row.y, B[(P) < NPOS ? (P) : 0], dotB, false); \
     nx += __uint_as_float(row.z);                                                    \
     l1 += row.w;                                                                     \
   }
-      HS_R(0) HS_R(1) HS_R(2) HS_R(3) HS_R(4) HS_R(5) HS_R(6) HS_R(7) HS_R(8) HS_R(9)
-      HS_R(10) HS_R(11) HS_R(12) HS_R(13) HS_R(14) HS_R(15) HS_R(16) HS_R(17) HS_R(18) HS_R(19)
-      HS_R(20) HS_R(21) HS_R(22) HS_R(23) HS_R(24)
+#define HS_R10(P) HS_R(P) HS_R(P + 1) HS_R(P + 2) HS_R(P + 3) HS_R(P + 4) HS_R(P + 5) HS_R(P + 6) HS_R(P + 7) HS_R(P + 8) HS_R(P + 9)
+      HS_R10(0) HS_R10(10) HS_R(20) HS_R(21) HS_R(22) HS_R(23) HS_R(24)
+      if constexpr (PW == 2) { HS_R10(25) HS_R10(35) HS_R(45) HS_R(46) HS_R(47) HS_R(48) HS_R(49) }
+#undef HS_R10
 #undef HS_R
       const double uA = ((double)dotA + 0.5 * (double)(l1 & 0xffffu) + (double)eA + dims4) * iA;
       const double uB = ((double)dotB + 0.5 * (double)(l1 >> 16) + (double)eB + dims4) * iB;
       const double lhs = (double)nx + cq, rhs = 2.0 * (uA + uB);
-      // margin: fp32 sums of the row norms (25 x 6e-8 relative) and the roundings of this line
+      // margin: fp32 sums of the row norms (k x 6e-8 relative) and the roundings of this line
       pass = !(lhs > rhs + 1e-5 * ((double)nx + fabs(cq) + 1.0));
       // first-seen rule (label[], motif_both_points.cpp:233), which does not depend on the distance:
       // a pair whose k-mer sits in the probed bucket of an EARLIER table is never reported here
@@ -882,16 +967,19 @@ hipError_t hs_launch_qprep8(const double* d_centers, uint32_t nq, int k, double 
   return hipGetLastError();
 }
 
+int hs_join8_row_bytes(int k) { return 32 * ks_of(k); }
+uint32_t hs_join8_members_per_item(int k) { return k <= 25 ? 128u : 64u; }
+
 hipError_t hs_launch_gather_c8t(const void* d_c8, const uint32_t* d_sorted_ql, const uint32_t* d_seg_qoff,
-                                uint32_t nql, int L, void* d_out, hipStream_t s) {
+                                uint32_t nql, int L, int k, void* d_out, hipStream_t s) {
   if (!nql) return hipSuccess;
   hs_gather_c8t_kernel<<<blocks_for(nql), 256, 0, s>>>((const int8_t*)d_c8, d_sorted_ql, d_seg_qoff, nql,
-                                                       L, (uint4*)d_out);
+                                                       L, 2 * ks_of(k), (uint4*)d_out);
   return hipGetLastError();
 }
 
 hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* d_packed_base,
-                            const uint4* d_rec_base, const void* d_c8t, const void* d_tab8,
+                            const uint4* d_rec_base, const void* d_c8t, const void* d_tab8, int k,
                             uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov,
                             uint32_t* d_item_counter, int n_blocks, hipStream_t s) {
   if (!n_items) return hipSuccess;
@@ -901,11 +989,19 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
   const uint32_t n_waves = (uint32_t)n_blocks * 4u;
   static const uint32_t g_max = getenv("HS_JOIN_CHUNK") ? (uint32_t)atoi(getenv("HS_JOIN_CHUNK")) : 8u;
   const uint32_t G = std::max(2u, std::min(g_max, n_items / (n_waves * 8u)));
-  // JT = 4 row tiles per wave, 2 waves per SIMD.  (JT = 2 at 4 waves per SIMD, with work items of
-  // 64 members, was measured 1.7x slower: twice the B-tile traffic and per-item work.)
-  hs_join8w_kernel<4><<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_rec_base,
-                                               (const uint4*)d_c8t, (const uint4*)d_tab8, d_prov_count,
-                                               prov_cap, d_prov, d_item_counter, G);
+  // k <= 25: JT = 4 row tiles per wave (128 members), 4 k-steps, 2 waves per SIMD.  (JT = 2 at 4
+  // waves per SIMD, with work items of 64 members, was measured 1.7x slower there: twice the B-tile
+  // traffic and per-item work.)  k > 25: 64 members per wave over 6 or 8 k-steps -- the operands of
+  // 128 members would not leave registers for the query tiles in flight.
+#define HS_J8(JT_, KS_)                                                                               \
+  hs_join8w_kernel<JT_, KS_><<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_rec_base,     \
+                                                      (const uint4*)d_c8t, (const uint4*)d_tab8,      \
+                                                      d_prov_count, prov_cap, d_prov, d_item_counter, G)
+  const int KS = ks_of(k);
+  if (KS == 4) HS_J8(4, 4);
+  else if (KS == 6) HS_J8(2, 6);
+  else HS_J8(2, 8);
+#undef HS_J8
 #ifdef HS_JOIN_TIMING
   {
     unsigned long long t[8];
@@ -925,7 +1021,7 @@ hipError_t hs_launch_gather_rec8(const uint4* d_packed_all, const uint32_t* d_id
                                  int k, const void* d_tab8, const float* d_scale, uint4* d_out_packed,
                                  uint4* d_out_rec, hipStream_t s) {
   if (!n) return hipSuccess;
-  hs_gather_rec8_kernel<<<blocks_for(n), 256, 0, s>>>(d_packed_all, d_ids_sorted, n, k,
+  hs_gather_rec8_kernel<<<blocks_for(n), 256, 0, s>>>(d_packed_all, d_ids_sorted, n, k, hs_packed_words(k),
                                                       (const uint4*)d_tab8, d_scale, d_out_packed,
                                                       d_out_rec);
   return hipGetLastError();
@@ -933,13 +1029,19 @@ hipError_t hs_launch_gather_rec8(const uint4* d_packed_all, const uint32_t* d_id
 
 hipError_t hs_launch_thin8(const hs_tables_dev& tabs, const uint4* d_rec_base, uint64_t n_entries,
                            const void* d_c8, const void* d_tab8, const uint32_t* d_qstart,
-                           const uint32_t* d_qcount, const uint32_t* d_slice_off, uint32_t nql, int L,
+                           const uint32_t* d_qcount, const uint32_t* d_slice_off, uint32_t nql, int L, int k,
                            uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov, int n_blocks,
                            hipStream_t s) {
   if (!nql) return hipSuccess;
-  hs_thin8_kernel<<<n_blocks, 256, 0, s>>>(tabs, d_rec_base, n_entries, (const int8_t*)d_c8,
-                                           (const uint4*)d_tab8, d_qstart, d_qcount, d_slice_off, nql, L,
-                                           d_prov_count, prov_cap, d_prov);
+#define HS_T8(KS_)                                                                                      \
+  hs_thin8_kernel<KS_><<<n_blocks, 256, 0, s>>>(tabs, d_rec_base, n_entries, (const int8_t*)d_c8,       \
+                                                (const uint4*)d_tab8, d_qstart, d_qcount, d_slice_off,  \
+                                                nql, L, k, d_prov_count, prov_cap, d_prov)
+  const int KS = ks_of(k);
+  if (KS == 4) HS_T8(4);
+  else if (KS == 6) HS_T8(6);
+  else HS_T8(8);
+#undef HS_T8
   return hipGetLastError();
 }
 
@@ -948,8 +1050,13 @@ hipError_t hs_launch_refine8(const hs_tables_dev& tabs, const uint2* d_prov, con
                              const void* d_c8b, const void* d_tabR, const float* d_scale, int k, int L,
                              const uint32_t* d_qstart, const uint32_t* d_qcount,
                              uint2* d_out, uint32_t* d_out_count, hipStream_t s) {
-  hs_refine8_kernel<<<1024, 256, 0, s>>>(tabs, d_prov, d_prov_count, prov_cap, d_sorted_ql,
-                                         (const int8_t*)d_c8, (const int8_t*)d_c8b, (const uint4*)d_tabR,
-                                         d_scale, k, L, d_qstart, d_qcount, d_out, d_out_count);
+  if (k <= 25)
+    hs_refine8_kernel<1><<<1024, 256, 0, s>>>(tabs, d_prov, d_prov_count, prov_cap, d_sorted_ql,
+                                              (const int8_t*)d_c8, (const int8_t*)d_c8b, (const uint4*)d_tabR,
+                                              d_scale, k, L, d_qstart, d_qcount, d_out, d_out_count);
+  else
+    hs_refine8_kernel<2><<<1024, 256, 0, s>>>(tabs, d_prov, d_prov_count, prov_cap, d_sorted_ql,
+                                              (const int8_t*)d_c8, (const int8_t*)d_c8b, (const uint4*)d_tabR,
+                                              d_scale, k, L, d_qstart, d_qcount, d_out, d_out_count);
   return hipGetLastError();
 }

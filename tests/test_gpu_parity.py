@@ -67,13 +67,48 @@ def test_search_hits_match_oracle(oracle, k, K, L, W, R, n, nq):
         _assert_hits_equal(got, want)
         prof = eng.profile()
         assert prof["candidates"] == int(want["cand"].sum())
-        if mode == "stream" or k > 25:
-            assert prof["join_batches"] == 0
+        if mode == "stream" or k > 50 or (k > 25 and mode == "join16"):
+            assert prof["join_batches"] == 0          # no fp16 form for two packed words
+        elif k > 25:
+            assert prof["join_i8_batches"] == prof["join_batches"]
         elif W >= 50.0:
             assert prof["join_batches"] > 0      # the MFMA bucket join really ran
             assert 0 < prof["join_pairs"] <= prof["candidates"]
             # "join"/"auto" = the int8 kernel, "join16" = the fp16 kernel
             assert (prof["join_i8_batches"] > 0) == (mode != "join16")
+    eng.close()
+
+
+@pytest.mark.parametrize("k", [26, 33, 39, 41, 42, 49, 50])
+def test_long_kmers_through_the_int8_join(oracle, k):
+    """k in 26..50 (two packed words; configs[4]'s k = 39): the int8 bucket join with 6 (k <= 41) or 8
+    k-steps and 64-member work items, its thin-segment and refinement kernels.  Coarse keys so that
+    buckets are big and shared by many queries; DIMENSION = 8k (motif_both_points.cpp:337-338)."""
+    K, L, W, R, n, nq = 3, 3, 500.0, 52.0, 20011, 1203
+    a, b = synth.make_planes(k, K, L, W, seed=15)
+    codes = synth.make_db(n, k, seed=16)
+    centers, _ = synth.make_queries(codes, nq, seed=17, jitter=0.2)
+    eng = Engine(k, K, L, W, a, b)
+    info = eng.index_build(codes)
+    assert max(info["max_bucket"]) > 1000
+    want = oracle.search(a, b, W, R, oracle.embed_codes(codes), centers)
+    assert len(want["q"]) > 200
+    for mode in ("join", "auto", "stream"):
+        eng.set_verify_mode(mode)
+        got = eng.query(centers, R)
+        assert np.array_equal(got["cand"], want["cand"])
+        _assert_hits_equal(got, want)
+        prof = eng.profile()
+        if mode == "stream":
+            assert prof["join_batches"] == 0
+        else:
+            assert prof["join_i8_batches"] > 0 and prof["join_pairs"] > 0.5 * prof["candidates"]
+    # a query int8 cannot carry: no fp16 form for long k-mers, the batch streams
+    wide = centers[:64].copy()
+    wide[:8, ::8] += 9.0
+    eng.set_verify_mode("join")
+    _assert_hits_equal(eng.query(wide, R), oracle.search(a, b, W, R, oracle.embed_codes(codes), wide))
+    assert eng.profile()["join_batches"] == 0
     eng.close()
 
 
