@@ -748,6 +748,301 @@ __global__ __launch_bounds__(256, 2) void hs_join8w_kernel(
 #endif
 }
 
+// ------------------------------------------------------------------------ join, 16x16x64 shape
+// The same work items, operands and filter value on v_mfma_i32_16x16x64_i8 (k <= 25).  Both shapes
+// take the same cycles per operation; the chip, which lowers its clock under this load, holds a
+// higher clock on the 16x16 shape: tools/ubench/mfma_shape.hip measures 2.7-3.1 POP/s for the
+// 32x32x32 loop on random operands whether the pipe is 100 %, 70 % or 55 % busy (power, not issue
+// slots, is the limit) and 3.2-3.6 POP/s for the 16x16x64 loop at 100 % and 70 %.
+//
+// Operand layout (checked by tools/ubench/mfma16_i8_layout.hip): lane (n = lane & 15, q = lane >> 4)
+// holds row / column n, bytes 64 s + 16 q .. + 15 of k-step s (two k-steps of 64 bytes); result
+// register i of that lane = row 4 q + i, column n.  A wave's 128 members are 8 row tiles of 16; a
+// 32-query tile is two column tiles.  Per query tile: group X = row tiles 0..3 (16 MFMAs), group
+// Y = row tiles 4..7, the sign test of one group in the gaps of the other group's MFMAs, as in
+// hs_join8w_kernel.  In k-step 1 the lanes q = 0, 1 carry positions 16..23, q = 2 the member's
+// record (position 24 + the rho digits), q = 3 the constant factors of the gamma slots.  The query
+// rows are read from the same tile-fragment array (piece g of row j of a tile with nr rows at
+// g nr + j): lane (n, q) takes piece 4 s + q of row 16 c + n for column tile c.
+typedef int intx4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void load_btile_x(intx4 (&B)[2][2], const uint4* __restrict__ c8t, uint32_t row0,
+                                             uint32_t nr, int lane) {
+  // piece 4 s + q of row 16 c + n of a tile with nr rows sits at (4 s + q) nr + row.  One code path
+  // for full and ragged tiles (rows past the end repeat the last one; masked later): a wave-uniform
+  // base per k-step (scalar registers) plus two per-lane byte offsets -- the loads are of the
+  // scalar-base + vector-offset form and their number never depends on the tile
+  const char* t0 = reinterpret_cast<const char*>(c8t + (uint64_t)row0 * 8);
+  const char* t1 = t0 + (uint64_t)nr * 64u;
+  const uint32_t n = (uint32_t)lane & 15u, q = (uint32_t)lane >> 4;
+  const uint32_t qn = q * nr;
+  const uint32_t o0 = (qn + min(n, nr - 1u)) * 16u, o1 = (qn + min(16u + n, nr - 1u)) * 16u;
+  const uint4 v00 = *reinterpret_cast<const uint4*>(t0 + o0), v01 = *reinterpret_cast<const uint4*>(t0 + o1);
+  const uint4 v10 = *reinterpret_cast<const uint4*>(t1 + o0), v11 = *reinterpret_cast<const uint4*>(t1 + o1);
+  B[0][0] = intx4{(int)v00.x, (int)v00.y, (int)v00.z, (int)v00.w};
+  B[0][1] = intx4{(int)v01.x, (int)v01.y, (int)v01.z, (int)v01.w};
+  B[1][0] = intx4{(int)v10.x, (int)v10.y, (int)v10.z, (int)v10.w};
+  B[1][1] = intx4{(int)v11.x, (int)v11.y, (int)v11.z, (int)v11.w};
+}
+
+// sign bit of the result = AND of the sign bits of a group's 4 x 2 accumulator tiles
+__device__ __forceinline__ uint32_t and_tree_x(const intx4 (&acc)[4][2]) {
+  uint32_t a = 0xffffffffu;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      a = a & (uint32_t)acc[t][c][0] & (uint32_t)acc[t][c][1] & (uint32_t)acc[t][c][2] & (uint32_t)acc[t][c][3];
+  return a;
+}
+
+// Survivors of one group (row tiles T0 .. T0 + 3) against the 32 queries at segment-relative offset qc
+__device__ __forceinline__ void emit_survivors_x(const intx4 (&acc)[4][2], int T0, uint32_t qc, uint32_t qoff,
+                                                 uint32_t q_end, uint32_t wbase, uint32_t M, uint32_t mstart,
+                                                 int lane, uint32_t& res_base, uint32_t& res_used,
+                                                 uint32_t* __restrict__ prov_count, uint32_t prov_cap,
+                                                 uint2* __restrict__ prov) {
+  const uint32_t n = (uint32_t)lane & 15u, q = (uint32_t)lane >> 4;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const uint32_t any = (uint32_t)acc[t][c][0] & (uint32_t)acc[t][c][1] & (uint32_t)acc[t][c][2] &
+                           (uint32_t)acc[t][c][3];
+      if (!__ballot((int)any >= 0)) continue;  // no survivor in this 16 x 16 tile
+      uint32_t mask = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mask |= (acc[t][c][i] >= 0 ? 1u : 0u) << i;
+      const uint32_t col = qc + 16u * (uint32_t)c + n;
+      if (!(col < q_end)) mask = 0u;
+      const uint32_t ql = HS_PROV_INDIRECT | (qoff + col);
+      while (__ballot(mask != 0)) {
+        uint32_t idx = 0;
+        bool pass = false;
+        if (mask) {
+          const int i = __ffs((int)mask) - 1;
+          mask &= mask - 1;
+          idx = wbase + (uint32_t)(16 * (T0 + t)) + 4u * q + (uint32_t)i;
+          pass = idx < M;
+        }
+        const unsigned long long m = __ballot(pass);
+        if (m) {
+          const uint32_t cnt = (uint32_t)__popcll(m);
+          if (res_used + cnt > JRES) {
+            if (res_used < JRES && lane >= (int)res_used && res_base + lane < prov_cap)
+              prov[res_base + lane] = make_uint2(0xffffffffu, 0u);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(prov_count, (uint32_t)JRES);
+            res_base = __builtin_amdgcn_readfirstlane(base);
+            res_used = 0;
+          }
+          if (pass) {
+            const uint32_t o = res_base + res_used + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (o < prov_cap) prov[o] = make_uint2(ql, mstart + idx);
+          }
+          res_used += cnt;
+        }
+      }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void hs_join8x_kernel(
+    const uint4* __restrict__ desc, uint32_t n_items, const uint4* __restrict__ packed_base,
+    const uint4* __restrict__ rec_base, const uint4* __restrict__ c8t,
+    const uint4* __restrict__ tab8, uint32_t* __restrict__ prov_count, uint32_t prov_cap,
+    uint2* __restrict__ prov, uint32_t* __restrict__ item_counter, uint32_t G) {
+  constexpr int RT = 8;  // row tiles of 16 members per wave
+  __shared__ uint32_t sTab8[32];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, q = lane >> 4, up = lane >> 5;
+  if (tid < 32) sTab8[tid] = tab8[tid].x;
+  __syncthreads();  // the only one: the table is read-only from here on
+  const uint32_t first_dynamic = gridDim.x * 4u * G;
+  uint32_t item = (blockIdx.x * 4u + (uint32_t)wave) * G;
+  if (item >= n_items) return;
+  uint32_t res_base = 0, res_used = JRES;
+  uint32_t next_chunk_v = 0;
+  if (lane == 0) next_chunk_v = atomicAdd(item_counter, G);
+  uint32_t pf_item = item, pf_chunk_end = item + G;
+#define HS_ADVANCE_PF()                                                                  \
+  {                                                                                      \
+    ++pf_item;                                                                           \
+    if (pf_item == pf_chunk_end) {                                                       \
+      pf_item = first_dynamic + __builtin_amdgcn_readfirstlane(next_chunk_v);            \
+      pf_chunk_end = pf_item + G;                                                        \
+      if (lane == 0 && pf_item < n_items) next_chunk_v = atomicAdd(item_counter, G);     \
+    }                                                                                    \
+  }
+  uint4 d0 = uniform4(desc[2 * (uint64_t)item]), d1 = uniform4(desc[2 * (uint64_t)item + 1]);
+  HS_ADVANCE_PF()
+  uint32_t next_item = pf_item;
+  uint4 nd0 = d0, nd1 = d1;
+  if (next_item < n_items) {
+    nd0 = uniform4(desc[2 * (uint64_t)next_item]);
+    nd1 = uniform4(desc[2 * (uint64_t)next_item + 1]);
+  }
+  uint4 mk[RT];                  // lanes 0..31: packed member 16 t + n, lanes 32..63: its record
+  constexpr int NB = 3;          // B tiles in flight per wave: the one in use + two prefetched
+  constexpr uint32_t GQ = 32 * NB;
+  intx4 Bq[NB][2][2];
+#define HS_LOAD_MEMBERS(D0)                                                              \
+  {                                                                                      \
+    const int64_t off_ = (int64_t)(((uint64_t)(D0).y << 32) | (uint64_t)(D0).x);         \
+    const uint4* src_ = (up ? rec_base : packed_base) + off_;                            \
+    const uint32_t idx_ = (D0).w * 128u + (uint32_t)n;                                   \
+    _Pragma("unroll") for (int t = 0; t < RT; ++t)                                       \
+      mk[t] = src_[min(idx_ + 16 * t, (D0).z - 1)];                                      \
+  }
+  const uint32_t skew = ((blockIdx.x * 4u + (uint32_t)wave) * 40503u) & 0xffffu;
+#define HS_N_GROUPS(D1) (((D1).z - (D1).y + GQ - 1u) / GQ)
+#define HS_FIRST_Q(D1) ((D1).y + GQ * ((skew * HS_N_GROUPS(D1)) >> 16))
+#define HS_LOAD_GROUP(ROW, Q0, QEND)                                                             \
+  _Pragma("unroll") for (int u = 0; u < NB; ++u) {                                               \
+    const uint32_t qu_ = (Q0) + 32u * u < (QEND) ? (Q0) + 32u * u : (Q0);                        \
+    load_btile_x(Bq[u], c8t, (ROW) + qu_, min(32u, (QEND) - qu_), lane);                         \
+  }
+  HS_LOAD_MEMBERS(d0)
+  {
+    const uint32_t q0 = HS_FIRST_Q(d1);
+    HS_LOAD_GROUP(d1.x, q0, d1.z)
+  }
+  while (true) {
+    const uint32_t M = d0.z, mt = d0.w;
+    const uint32_t qoff = d1.x, q_begin = d1.y, q_end = d1.z, mstart = d1.w;
+    const uint32_t wbase = mt * 128u;
+    const bool has_next = next_item < n_items;
+    HS_ADVANCE_PF()  // pf_item = the item after next
+    uint4 nnd0 = nd0, nnd1 = nd1;
+    if (pf_item < n_items) {
+      nnd0 = uniform4(desc[2 * (uint64_t)pf_item]);
+      nnd1 = uniform4(desc[2 * (uint64_t)pf_item + 1]);
+    }
+    // ---- A operands of the item's 128 members
+    intx4 A[RT][2];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      uint4 pk, rk;  // after the swap: pk = the lower half's value, rk = the upper half's, in all lanes
+#define HS_SWAP(C)                                                                        \
+  {                                                                                       \
+    const auto sw_ = __builtin_amdgcn_permlane32_swap(mk[t].C, mk[t].C, false, false);    \
+    pk.C = sw_[0];                                                                        \
+    rk.C = sw_[1];                                                                        \
+  }
+      HS_SWAP(x) HS_SWAP(y) HS_SWAP(z) HS_SWAP(w)
+#undef HS_SWAP
+      // positions 4 q + m (k-step 0) and 16 + 4 q + m (k-step 1, q < 2): the word shifted down by
+      // 20 q bits has them at bits 5 m and 80 + 5 m
+      uint32_t x = pk.x, y = pk.y, z = pk.z, w = pk.w;
+      if (q >= 2) {
+        x = y;
+        y = z;
+        z = w;
+        w = 0u;
+      }
+      const uint32_t bs = (20u * (uint32_t)q) & 31u;  // 0, 20, 8, 28
+      x = __funnelshift_r(x, y, bs);
+      y = __funnelshift_r(y, z, bs);
+      z = __funnelshift_r(z, w, bs);
+      w = w >> bs;
+      A[t][0] = intx4{(int)sTab8[residue_at<0>(x, y, z, w)], (int)sTab8[residue_at<5>(x, y, z, w)],
+                      (int)sTab8[residue_at<10>(x, y, z, w)], (int)sTab8[residue_at<15>(x, y, z, w)]};
+      const intx4 lk = intx4{(int)sTab8[residue_at<80>(x, y, z, w)], (int)sTab8[residue_at<85>(x, y, z, w)],
+                             (int)sTab8[residue_at<90>(x, y, z, w)], (int)sTab8[residue_at<95>(x, y, z, w)]};
+      const intx4 rc = intx4{(int)rk.x, (int)rk.y, (int)rk.z, (int)rk.w};
+      const intx4 cn = intx4{0x7f7f0000, 0x7f7f7f7f, 0x7f7f7f7f, 0x017f7f7f};
+      A[t][1] = q < 2 ? lk : (q == 2 ? rc : cn);
+    }
+    HS_LOAD_MEMBERS(nd0)
+    intx4 accX[4][2], accY[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) accY[t][c] = intx4{-1, -1, -1, -1};  // "no survivor" for the first Y test
+    uint32_t prev_qc = q_begin;
+    const uint32_t n_groups = HS_N_GROUPS(d1);
+    uint32_t qc0 = HS_FIRST_Q(d1);
+    auto do_group = [&](uint32_t gi) {
+      uint32_t nrow = qoff, nq0 = qc0 + GQ, nqend = q_end;
+      if (nq0 >= q_end) nq0 = q_begin;
+      if (gi + 1 == n_groups) {
+        nrow = nd1.x;
+        nq0 = HS_FIRST_Q(nd1);
+        nqend = nd1.z;
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const uint32_t qc = qc0 + 32u * (uint32_t)u;
+        intx4 (&B)[2][2] = Bq[u];
+        if (u == 0 || qc < q_end) {
+          // ---- phase 1: X <- row tiles 0..3 x B, beside the sign test of Y (previous query tile)
+          const uint32_t sY = and_tree_x(accY);
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int c = 0; c < 2; ++c)
+                accX[t][c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t][s], B[s][c],
+                                                                   s ? accX[t][c] : intx4{0, 0, 0, 0}, 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 16; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+          }
+          if (__ballot((int)sY >= 0))
+            emit_survivors_x(accY, 4, prev_qc, qoff, q_end, wbase, M, mstart, lane, res_base, res_used,
+                             prov_count, prov_cap, prov);
+          // ---- phase 2: Y <- row tiles 4..7 x B, beside the sign test of X
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int c = 0; c < 2; ++c)
+                accY[t][c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[4 + t][s], B[s][c],
+                                                                   s ? accY[t][c] : intx4{0, 0, 0, 0}, 0, 0, 0);
+          const uint32_t sX = and_tree_x(accX);
+#pragma unroll
+          for (int g = 0; g < 16; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+          }
+          if (__ballot((int)sX >= 0))
+            emit_survivors_x(accX, 0, qc, qoff, q_end, wbase, M, mstart, lane, res_base, res_used,
+                             prov_count, prov_cap, prov);
+          prev_qc = qc;
+        }
+        const uint32_t nb = nq0 + 32u * (uint32_t)u < nqend ? nq0 + 32u * (uint32_t)u : nq0;
+        load_btile_x(B, c8t, nrow + nb, min(32u, nqend - nb), lane);
+      }
+      qc0 = nq0;
+    };
+    do_group(0);
+    for (uint32_t gi = 1; gi < n_groups; ++gi) do_group(gi);
+    {  // the item's last Y group
+      const uint32_t sY = and_tree_x(accY);
+      if (__ballot((int)sY >= 0))
+        emit_survivors_x(accY, 4, prev_qc, qoff, q_end, wbase, M, mstart, lane, res_base, res_used,
+                         prov_count, prov_cap, prov);
+    }
+    if (!has_next) break;
+    item = next_item;
+    next_item = pf_item;
+    d0 = nd0;
+    d1 = nd1;
+    nd0 = nnd0;
+    nd1 = nnd1;
+  }
+#undef HS_ADVANCE_PF
+#undef HS_LOAD_GROUP
+#undef HS_N_GROUPS
+#undef HS_LOAD_MEMBERS
+#undef HS_FIRST_Q
+  if (res_used < JRES && lane >= (int)res_used && res_base + lane < prov_cap)
+    prov[res_base + lane] = make_uint2(0xffffffffu, 0u);
+}
+
 // Thin segments (too few probing queries or members for MFMA tiles) with the int8 join on: the SAME
 // filter value as the join kernel -- the 128-term integer dot product of the member's A row and the
 // query's row, v_dot4_i32_i8 instead of MFMA -- one member per lane, work item = one (probe, slice
@@ -998,7 +1293,13 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
                                                       (const uint4*)d_c8t, (const uint4*)d_tab8,      \
                                                       d_prov_count, prov_cap, d_prov, d_item_counter, G)
   const int KS = ks_of(k);
-  if (KS == 4) HS_J8(4, 4);
+  // k <= 25: the 16x16x64 form by default (HS_JOIN_SHAPE=32 selects the 32x32x32 form)
+  static const bool shape32 = getenv("HS_JOIN_SHAPE") && atoi(getenv("HS_JOIN_SHAPE")) == 32;
+  if (KS == 4 && !shape32)
+    hs_join8x_kernel<<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_rec_base, (const uint4*)d_c8t,
+                                              (const uint4*)d_tab8, d_prov_count, prov_cap, d_prov,
+                                              d_item_counter, G);
+  else if (KS == 4) HS_J8(4, 4);
   else if (KS == 6) HS_J8(2, 6);
   else HS_J8(2, 8);
 #undef HS_J8

@@ -10,7 +10,9 @@ typedef int intx4 __attribute__((ext_vector_type(4)));
 typedef int intx16 __attribute__((ext_vector_type(16)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 
-template <int SHAPE>
+// SLEEP > 0: each wave idles 64 * SLEEP cycles per tile, so the matrix pipe is busy only part of the
+// time (the join kernel's regime: ~65 %): does the shape still matter when the loop is not saturated?
+template <int SHAPE, int SLEEP>
 __global__ __launch_bounds__(256, 2) void k(int iters, const uint4* __restrict__ rnd, int* out,
                                             unsigned long long* cyc) {
   const int gid = blockIdx.x * 256 + threadIdx.x;
@@ -53,6 +55,7 @@ __global__ __launch_bounds__(256, 2) void k(int iters, const uint4* __restrict__
 #pragma unroll
         for (int i = 0; i < 4; ++i) sall &= (uint32_t)acc[t][i];
     }
+    if (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
     if (__ballot((int)sall >= 0) == 0x123456789ull) keep += sall;
     B[0][0] ^= (int)(sall & 0x01010101u);  // loop-carried, keeps the data moving
   }
@@ -71,10 +74,19 @@ int main() {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int iters = 40000;
   for (int rep = 0; rep < 3; ++rep)
-    for (int shape = 0; shape < 2; ++shape) {
+    for (int var = 0; var < 6; ++var) {
+      const int shape = var & 1, sl = var >> 1;
       CK(hipMemset(cyc, 0, 8));
       CK(hipEventRecord(e0));
-      if (shape) k<1><<<512, 256>>>(iters, rnd, out, cyc); else k<0><<<512, 256>>>(iters, rnd, out, cyc);
+      switch (var) {
+        case 0: k<0, 0><<<512, 256>>>(iters, rnd, out, cyc); break;
+        case 1: k<1, 0><<<512, 256>>>(iters, rnd, out, cyc); break;
+        case 2: k<0, 8><<<512, 256>>>(iters, rnd, out, cyc); break;
+        case 3: k<1, 8><<<512, 256>>>(iters, rnd, out, cyc); break;
+        case 4: k<0, 16><<<512, 256>>>(iters, rnd, out, cyc); break;
+        default: k<1, 16><<<512, 256>>>(iters, rnd, out, cyc); break;
+      }
+      if (rep == 0 && shape == 0) printf("-- sleep %d x 64 cycles per tile\n", sl * 8);
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       unsigned long long c; CK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
