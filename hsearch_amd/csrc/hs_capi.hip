@@ -109,10 +109,14 @@ struct hs_handle {
       counters, temp, io_centers, io_q, io_id, io_table, io_dist, io_cand, io_codes, io_misc;
   HostBuf sj_host;  // hs_self_join_range: hits of one chunk on their way to the edge lists
   // bucket-join workspace
-  DevBuf c16s, item_desc, probe_slow, jtab8;
+  DevBuf c16s, item_desc, probe_slow, jtab8, slice_ql;
   DevBuf c8b, prov2;  // survivor refinement: second int8 row per query, the refined survivor list
   bool join8_tables_ok = false;  // int8 can carry the coordinate table
-  uint32_t join_min_q = 3, join_min_m = 16;  // segment routing thresholds (HS_JOIN_MIN_Q / _M)
+  // segment routing thresholds (HS_JOIN_MIN_Q / _M): segments with fewer probing queries or members
+  // go to the per-pair filters instead of the join.  1 / 1 = everything through the join: its
+  // persistent waves leave no room for a kernel beside it, and the per-pair filter run before it
+  // cost 0.3 ms at C2 (a chain of dependent loads per probe) against 0.06 ms of extra join time
+  uint32_t join_min_q = 1, join_min_m = 1;
   int join_blocks_per_cu = 2;                // resident workgroups of hs_join_kernel per CU
   DevBuf jtab, c16, seg_keys, seg_keys_sorted, seg_vals, sorted_ql, seg_key, seg_cnt, seg_qoff,
       seg_items, item_off, seg_n;
@@ -454,7 +458,7 @@ void hs_destroy(hs_handle* h) {
                     &h->probe_slow, &h->jtab8, &h->c8b, &h->prov2, &h->t_packed, &h->t_rec8, &h->t_pos, &h->dir_base,
                     &h->bucket_work, &h->proj_aq_all, &h->proj_aq_tab, &h->proj_fn, &h->proj_tab, &h->proj_stats,
                     &h->proj_flags[0], &h->proj_flags[1], &h->proj_flags[2], &h->proj_cnt, &h->proj_xq,
-                    &h->proj_xmeta};
+                    &h->proj_xmeta, &h->slice_ql};
   for (DevBuf* bf : bufs) bf->release();
   h->sj_host.release();
   for (int l = 0; l < HS_MAX_L; ++l) {
@@ -1297,7 +1301,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   const float r2_hi = filter_bound(r2);
   const int n_blocks = h->n_cu * 8;
   uint32_t* d_cnt = h->counters.as<uint32_t>();
-  HS_HIP(h, hipMemsetAsync(d_cnt, 0, 64, h->stream));
+  HS_HIP(h, hipMemsetAsync(d_cnt, 0, 256, h->stream));  // incl. the join's item counter (d_cnt + 32)
   HS_HIP(h, hipEventRecord(h->ev[0], h->stream));
   if (!brute) {
     HS_HIP(h, h->qints.reserve((size_t)nq * h->LK * 4));
@@ -1443,12 +1447,19 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
                                     h->stream));
     }
   }
-  // with a join in the batch, the streaming filter's tables and the filter itself go to the side
-  // stream and run beside the join kernel (both only append to the survivor list)
-  const bool side = !brute && n_items && n_slices;
-  // ... and with the int8 join, thin segments are filtered by the join's own integer bound on the
-  // vector ALU (hs_thin8_kernel): no per-query distance tables, next to nothing beside the join
-  const bool thin8 = side && use_i8 && !getenv("HS_NO_THIN8");
+  // ... with the int8 join, thin segments are filtered by the join's own integer bound on the
+  // vector ALU (hs_thin8_kernel): no per-query distance tables.  It runs BEFORE the join on the same
+  // stream: the join's persistent waves take every register of every SIMD, so nothing runs beside
+  // it anyway -- a kernel launched on a side stream first only delays the join's start (and one
+  // launched later waits for the join's tail)
+  const bool thin8 = !brute && n_items && n_slices && use_i8 && !getenv("HS_NO_THIN8");
+  // without it (fp16 join, HS_NO_THIN8) the streaming filter and its tables go to the side stream
+  const bool side = !brute && n_items && n_slices && !thin8;
+  if (thin8) {
+    HS_HIP(h, h->slice_ql.reserve((size_t)n_slices * 4));
+    HS_HIP(h, hs_launch_slice_map(h->nslices.as<uint32_t>(), h->slice_off.as<uint32_t>(), nql,
+                                  h->slice_ql.as<uint32_t>(), h->stream));
+  }
   if ((brute || n_slices) && !thin8) {
     HS_HIP(h, h->tq.reserve((size_t)nq * k * HS_TROW * 4));
     if (!side)
@@ -1470,23 +1481,22 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, h->hit_val.reserve((size_t)hit_cap * 8));
     HS_HIP(h, hipMemsetAsync(d_cnt, 0, 8, h->stream));
     HS_HIP(h, hipEventRecord(h->ev[3], h->stream));
+    if (launches) HS_HIP(h, hipMemsetAsync(d_cnt + 32, 0, 4, h->stream));  // retry: the item counter again
+    if (thin8)
+      HS_HIP(h, hs_launch_thin8(h->tabs, h->t_rec8.as<uint4>(), h->n, h->c16.p, h->jtab8.p,
+                                h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
+                                h->slice_off.as<uint32_t>(), h->slice_ql.as<uint32_t>(), nql, L, k, d_cnt,
+                                prov_cap, h->prov.as<uint2>(), n_blocks, h->stream));
     if (side) {
       HS_HIP(h, hipEventRecord(h->evx[EV_FORK], h->stream));
       HS_HIP(h, hipStreamWaitEvent(h->stream2, h->evx[EV_FORK], 0));
-      if (thin8) {
-        HS_HIP(h, hs_launch_thin8(h->tabs, h->t_rec8.as<uint4>(), h->n, h->c16.p, h->jtab8.p,
-                                  h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
-                                  h->slice_off.as<uint32_t>(), nql, L, k, d_cnt, prov_cap,
-                                  h->prov.as<uint2>(), n_blocks, h->stream2));
-      } else {
-        if (!tables_done)
-          HS_HIP(h, hs_launch_qtables(d_centers, nq, k, h->coords.as<double>(), h->alphabet,
-                                      h->tq.as<float>(), h->stream2));
-        tables_done = true;
-        HS_HIP(h, hs_launch_verify(h->tabs, h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
-                                   h->slice_off.as<uint32_t>(), nql, h->tq.as<float>(), k, L, r2_hi,
-                                   d_cnt, prov_cap, h->prov.as<uint2>(), n_blocks, h->stream2));
-      }
+      if (!tables_done)
+        HS_HIP(h, hs_launch_qtables(d_centers, nq, k, h->coords.as<double>(), h->alphabet,
+                                    h->tq.as<float>(), h->stream2));
+      tables_done = true;
+      HS_HIP(h, hs_launch_verify(h->tabs, h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
+                                 h->slice_off.as<uint32_t>(), nql, h->tq.as<float>(), k, L, r2_hi,
+                                 d_cnt, prov_cap, h->prov.as<uint2>(), n_blocks, h->stream2));
       HS_HIP(h, hipEventRecord(h->evx[EV_JOIN], h->stream2));
     }
     if (brute) {
@@ -1494,6 +1504,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
                                      nq, k, r2_hi, d_cnt, prov_cap, h->prov.as<uint2>(), nullptr,
                                      nullptr, n_blocks, h->stream));
     } else {
+      HS_HIP(h, hipEventRecord(h->ev[11], h->stream));  // the join kernel alone: ev[11] .. ev[10]
       if (n_items && use_i8)
         HS_HIP(h, hs_launch_join8w(h->item_desc.as<uint4>(), n_items, h->tabs.t[0].packed,
                                    h->t_rec8.as<uint4>(), h->c16s.p, h->jtab8.p, k, d_cnt, prov_cap,
@@ -1508,7 +1519,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
       HS_HIP(h, hipEventRecord(h->ev[10], h->stream));
       if (side)
         HS_HIP(h, hipStreamWaitEvent(h->stream, h->evx[EV_JOIN], 0));
-      else if (n_slices)
+      else if (n_slices && !thin8)
         HS_HIP(h, hs_launch_verify(h->tabs, h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
                                    h->slice_off.as<uint32_t>(), nql, h->tq.as<float>(), k, L, r2_hi,
                                    d_cnt, prov_cap, h->prov.as<uint2>(), n_blocks, h->stream));
@@ -1547,7 +1558,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
       HS_HIP(h, hipMemcpyAsync(host_proj, h->proj_cnt.as<uint32_t>() + 4, 8, hipMemcpyDeviceToHost, h->stream));
     HS_HIP(h, hipStreamSynchronize(h->stream));
     ms_verify += ev_ms(h, 3, 4);
-    if (!brute && n_items) ms_join += ev_ms(h, 3, 10);
+    if (!brute && n_items) ms_join += ev_ms(h, 11, 10);
     ms_final += ev_ms(h, 4, 5);
     ++launches;
     if (getenv("HS_DEBUG_REFINE"))

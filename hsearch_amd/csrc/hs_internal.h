@@ -337,9 +337,12 @@ uint32_t hs_join8_members_per_item(int k);
 // vector ALU (v_dot4_i32_i8), work items = the streaming kernel's (probe, slice) list
 hipError_t hs_launch_thin8(const hs_tables_dev& tabs, const uint4* d_rec_base, uint64_t n_entries,
                            const void* d_c8, const void* d_tab8, const uint32_t* d_qstart,
-                           const uint32_t* d_qcount, const uint32_t* d_slice_off, uint32_t nql, int L, int k,
-                           uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov, int n_blocks,
-                           hipStream_t s);
+                           const uint32_t* d_qcount, const uint32_t* d_slice_off, const uint32_t* d_slice_ql,
+                           uint32_t nql, int L, int k, uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov,
+                           int n_blocks, hipStream_t s);
+// d_slice_ql[d_slice_off[ql] + s] = ql: the probe of every (probe, slice) work item
+hipError_t hs_launch_slice_map(const uint32_t* d_nslices, const uint32_t* d_slice_off, uint32_t nql,
+                               uint32_t* d_slice_ql, hipStream_t s);
 hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* d_packed_base,
                             const uint4* d_rec_base, const void* d_c8t, const void* d_tab8, int k,
                             uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov,

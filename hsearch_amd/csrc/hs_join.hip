@@ -176,7 +176,10 @@ __global__ __launch_bounds__(256) void hs_seg_route_kernel(const uint64_t* __res
   if (j <= n_max && j < *n_seg && (seg_key[j] >> shift) < (uint64_t)L) {
     const uint32_t m = qcount[sorted_ql[seg_qoff[j]]];
     const uint32_t nq = seg_cnt[j];
-    if (nq >= min_q && m >= min_m) {
+    // thin segments (few probing queries or few members) go to the per-pair filter; a BIG bucket goes
+    // to the join whatever its query count: its mostly empty query tile costs next to nothing there,
+    // while the per-pair filter would walk its thousands of members in one chain of dependent loads
+    if ((nq >= min_q && m >= min_m) || m >= 512u) {
       it = ((m + jm - 1) / jm) * ((nq + jqg - 1) / jqg);
       // MFMA pairs actually issued (128-row waves x 32-column chunks) vs real pairs
       const uint32_t rm = jm < HS_JM_BLOCK ? jm : 32u * JT;  // rows of one wave's member tile

@@ -1049,38 +1049,41 @@ __global__ __launch_bounds__(256, 2) void hs_join8x_kernel(
 // of <= HS_SLICE bucket entries) per wave as in the streaming kernel.  Needs no per-query distance
 // tables: with this kernel the side stream's work beside the join is a few tens of microseconds.
 template <int KS>
-__global__ __launch_bounds__(256) void hs_thin8_kernel(hs_tables_dev tabs,
+__global__ __launch_bounds__(256) void hs_thin8_kernel(const uint4* __restrict__ packed_base,
                                                        const uint4* __restrict__ rec_base, uint64_t n_entries,
                                                        const int8_t* __restrict__ c8,
                                                        const uint4* __restrict__ tab8,
                                                        const uint32_t* __restrict__ qstart,
                                                        const uint32_t* __restrict__ qcount,
                                                        const uint32_t* __restrict__ slice_off,
+                                                       const uint32_t* __restrict__ slice_ql,
                                                        uint32_t nql, int L, int k,
                                                        uint32_t* __restrict__ prov_count,
                                                        uint32_t prov_cap, uint2* __restrict__ prov) {
+  // Work item = one (probe, slice of <= HS_SLICE bucket entries), taken by a GROUP OF 16 LANES: four
+  // items per wave at a time.  Thin segments are mostly tiny buckets (< 16 members) or big buckets
+  // probed by one or two queries; an item is a chain of dependent loads (probe -> bucket range ->
+  // query row -> members), so the kernel's time is that latency times the items per wave -- four
+  // chains per wave in flight instead of one.
   constexpr int PW = KS == 4 ? 1 : 2;
   constexpr int NW = 8 * KS;  // dwords of a row
   __shared__ uint32_t sTab8[32];
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63, sub = lane & 15;
   if (tid < 32) sTab8[tid] = tab8[tid].x;
   __syncthreads();
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + ((uint32_t)tid >> 6));
-  const uint32_t n_waves = gridDim.x * 4u;
+  const uint32_t grp = (blockIdx.x * 4u + ((uint32_t)tid >> 6)) * 4u + ((uint32_t)lane >> 4);
+  const uint32_t n_grp = gridDim.x * 16u;
   const uint32_t total = slice_off[nql];
-  for (uint32_t s = wave; s < total; s += n_waves) {
-    uint32_t lo = 0, hi = nql;  // largest ql with slice_off[ql] <= s
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (slice_off[mid] <= s) lo = mid; else hi = mid;
-    }
-    const uint32_t ql = lo, sl = s - slice_off[ql];
+  for (uint32_t s = grp; __any(s < total); s += n_grp) {
+    const bool have = s < total;
+    const uint32_t ql = have ? slice_ql[s] : 0u;
+    const uint32_t sl = have ? s - slice_off[ql] : 0u;
     const uint32_t q = ql / (uint32_t)L, l = ql % (uint32_t)L;
     const uint32_t start = qstart[ql] + sl * HS_SLICE;
-    const uint32_t cnt = min((uint32_t)HS_SLICE, qcount[ql] - sl * HS_SLICE);
-    const uint4* packed = tabs.t[l].packed;
+    const uint32_t cnt = have ? min((uint32_t)HS_SLICE, qcount[ql] - sl * HS_SLICE) : 0u;
+    const uint4* packed = packed_base + (uint64_t)l * n_entries * PW;
     const uint4* rec = rec_base + (uint64_t)l * n_entries;
-    // the query's row: K index = byte index (hs_qprep8_kernel); wave-uniform
+    // the query's row: K index = byte index (hs_qprep8_kernel); the same for the 16 lanes of a group
     const uint4* qrow = reinterpret_cast<const uint4*>(c8) + (uint64_t)q * (2 * KS);
     int B[NW];
 #pragma unroll
@@ -1096,11 +1099,11 @@ __global__ __launch_bounds__(256) void hs_thin8_kernel(hs_tables_dev tabs,
     qconst = __builtin_amdgcn_sdot4(0x7f7f7f7f, B[NW - 3], qconst, false);
     qconst = __builtin_amdgcn_sdot4(0x7f7f7f7f, B[NW - 2], qconst, false);
     qconst = __builtin_amdgcn_sdot4(0x017f7f7f, B[NW - 1], qconst, false);
-    const uint32_t iters = (cnt + 63u) / 64u;
-    for (uint32_t it = 0; it < iters; ++it) {
-      const uint32_t i = it * 64u + (uint32_t)lane;
+    const uint32_t iters = (cnt + 15u) / 16u;
+    for (uint32_t it = 0; __any(it < iters); ++it) {
+      const uint32_t i = it * 16u + (uint32_t)sub;
       const bool valid = i < cnt;
-      const uint64_t pos = (uint64_t)start + (valid ? i : cnt - 1);
+      const uint64_t pos = (uint64_t)start + (valid ? i : 0u);
       const uint4 pk = packed[pos * PW];
       uint4 pk1 = pk;
       if constexpr (PW == 2) pk1 = packed[pos * PW + 1];
@@ -1132,6 +1135,16 @@ __global__ __launch_bounds__(256) void hs_thin8_kernel(hs_tables_dev tabs,
       }
     }
   }
+}
+
+// slice_ql[slice_off[ql] + s] = ql for every slice s of every probe that kept slices
+__global__ __launch_bounds__(256) void hs_slice_map_kernel(const uint32_t* __restrict__ nslices,
+                                                           const uint32_t* __restrict__ slice_off, uint32_t nql,
+                                                           uint32_t* __restrict__ slice_ql) {
+  const uint32_t ql = blockIdx.x * 256 + threadIdx.x;
+  if (ql >= nql) return;
+  const uint32_t ns = nslices[ql], o = slice_off[ql];
+  for (uint32_t s = 0; s < ns; ++s) slice_ql[o + s] = ql;
 }
 
 // Survivors of the 4-column int8 bound, refined with all 8 columns before the exact fp64 decision:
@@ -1278,8 +1291,7 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
                             uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov,
                             uint32_t* d_item_counter, int n_blocks, hipStream_t s) {
   if (!n_items) return hipSuccess;
-  hipError_t e = hipMemsetAsync(d_item_counter, 0, 4, s);
-  if (e != hipSuccess) return e;
+  // (*d_item_counter is zeroed by the caller, with the batch's other counters)
   // chunk size: 8 items per counter access when there is plenty of work, fewer for small launches
   const uint32_t n_waves = (uint32_t)n_blocks * 4u;
   static const uint32_t g_max = getenv("HS_JOIN_CHUNK") ? (uint32_t)atoi(getenv("HS_JOIN_CHUNK")) : 8u;
@@ -1330,19 +1342,26 @@ hipError_t hs_launch_gather_rec8(const uint4* d_packed_all, const uint32_t* d_id
 
 hipError_t hs_launch_thin8(const hs_tables_dev& tabs, const uint4* d_rec_base, uint64_t n_entries,
                            const void* d_c8, const void* d_tab8, const uint32_t* d_qstart,
-                           const uint32_t* d_qcount, const uint32_t* d_slice_off, uint32_t nql, int L, int k,
-                           uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov, int n_blocks,
-                           hipStream_t s) {
+                           const uint32_t* d_qcount, const uint32_t* d_slice_off, const uint32_t* d_slice_ql,
+                           uint32_t nql, int L, int k, uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov,
+                           int n_blocks, hipStream_t s) {
   if (!nql) return hipSuccess;
 #define HS_T8(KS_)                                                                                      \
-  hs_thin8_kernel<KS_><<<n_blocks, 256, 0, s>>>(tabs, d_rec_base, n_entries, (const int8_t*)d_c8,       \
+  hs_thin8_kernel<KS_><<<n_blocks, 256, 0, s>>>(tabs.t[0].packed, d_rec_base, n_entries, (const int8_t*)d_c8, \
                                                 (const uint4*)d_tab8, d_qstart, d_qcount, d_slice_off,  \
-                                                nql, L, k, d_prov_count, prov_cap, d_prov)
+                                                d_slice_ql, nql, L, k, d_prov_count, prov_cap, d_prov)
   const int KS = ks_of(k);
   if (KS == 4) HS_T8(4);
   else if (KS == 6) HS_T8(6);
   else HS_T8(8);
 #undef HS_T8
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_slice_map(const uint32_t* d_nslices, const uint32_t* d_slice_off, uint32_t nql,
+                               uint32_t* d_slice_ql, hipStream_t s) {
+  if (!nql) return hipSuccess;
+  hs_slice_map_kernel<<<blocks_for(nql), 256, 0, s>>>(d_nslices, d_slice_off, nql, d_slice_ql);
   return hipGetLastError();
 }
 

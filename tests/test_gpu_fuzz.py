@@ -65,8 +65,17 @@ def _case(seed):
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("HS_FUZZ_CASES", "84"))))
 def test_random_configuration_matches_oracle(oracle, seed):
+    import os
     c = _case(seed)
-    eng = Engine(c["k"], c["K"], c["L"], c["W"], c["a"], c["b"], coords=c["table"])
+    # every third case with the thin-segment routing on (segments with < 3 probing queries or < 16
+    # members to the per-pair filters hs_thin8_kernel / hs_verify_kernel instead of the join)
+    thin = {"HS_JOIN_MIN_Q": "3", "HS_JOIN_MIN_M": "16"} if seed % 3 == 0 else {}
+    os.environ.update(thin)
+    try:
+        eng = Engine(c["k"], c["K"], c["L"], c["W"], c["a"], c["b"], coords=c["table"])
+    finally:
+        for key in thin:
+            del os.environ[key]
     info = eng.index_build(c["codes"])
     ix = oracle.Index(c["a"], c["b"], c["W"], c["pts"])
     try:

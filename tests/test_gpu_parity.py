@@ -144,10 +144,10 @@ def test_join_with_many_queries_per_bucket(oracle):
     _assert_hits_equal(got, oracle.search(a, b, W, R, oracle.embed_codes(codes), far))
     assert eng.profile()["join_batches"] == 0
     eng.close()
-    # every segment through the join (no routing of thin segments to the streaming kernel)
+    # thin segments (< 3 probing queries or < 16 members) routed to the per-pair filter instead
     import os
-    os.environ["HS_JOIN_MIN_Q"] = "1"
-    os.environ["HS_JOIN_MIN_M"] = "1"
+    os.environ["HS_JOIN_MIN_Q"] = "3"
+    os.environ["HS_JOIN_MIN_M"] = "16"
     try:
         eng = Engine(k, K, L, W, a, b)
     finally:
@@ -157,8 +157,16 @@ def test_join_with_many_queries_per_bucket(oracle):
     got = eng.query(centers, R)
     _assert_hits_equal(got, want)
     prof = eng.profile()
-    assert prof["join_pairs"] == prof["candidates"] == int(want["cand"].sum())
+    assert 0 < prof["join_pairs"] < prof["candidates"] == int(want["cand"].sum())   # some pairs took the thin path
     assert prof["join_pairs_issued"] >= prof["join_pairs"]
+    eng.close()
+    # the default routing: every segment through the join
+    eng = Engine(k, K, L, W, a, b)
+    eng.index_build(codes)
+    eng.set_verify_mode("join")
+    _assert_hits_equal(eng.query(centers, R), want)
+    prof = eng.profile()
+    assert prof["join_pairs"] == prof["candidates"] == int(want["cand"].sum())
     eng.close()
 
 
