@@ -1303,6 +1303,30 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   uint32_t* d_cnt = h->counters.as<uint32_t>();
   HS_HIP(h, hipMemsetAsync(d_cnt, 0, 256, h->stream));  // incl. the join's item counter (d_cnt + 32)
   HS_HIP(h, hipEventRecord(h->ev[0], h->stream));
+  // fp16 form: k <= 25 only; int8 form (hs_join8.hip): k <= 50 (6 or 8 k-steps for two packed words)
+  const bool can16 = h->join_tables_ok && k <= 25;
+  const bool can8 = h->join8_tables_ok && k <= 50 && h->verify_mode != 3;
+  bool use_join = !brute && h->verify_mode != 1 && r2 < 30000.0 && (can16 || can8);
+  // int8 form of the join filter unless forced to fp16 (mode 3) or not representable
+  bool use_i8 = use_join && can8;
+  // survivors of the int8 join's 4-column bound pass an 8-column int8 bound before the exact
+  // decision (hs_refine8_kernel); HS_NO_REFINE8 switches it off
+  const bool refine = use_i8 && !getenv("HS_NO_REFINE8");
+  uint32_t* d_unsafe = d_cnt + 8;
+  if (use_join) {
+    // the join filter's query rows depend on the centres only: quantised on the side stream while
+    // the main stream hashes and probes (both passes stream the same 8d bytes per query)
+    HS_HIP(h, h->c16.reserve((size_t)nq * 208 * 2));
+    if (refine) HS_HIP(h, h->c8b.reserve((size_t)nq * hs_join8_row_bytes(k)));
+    HS_HIP(h, hipEventRecord(h->evx[EV_FORK], h->stream));
+    HS_HIP(h, hipStreamWaitEvent(h->stream2, h->evx[EV_FORK], 0));
+    if (use_i8)
+      HS_HIP(h, hs_launch_qprep8(d_centers, nq, k, r2, h->jtab8.as<float>() + 128, h->c16.p, d_unsafe,
+                                 refine ? h->c8b.p : nullptr, h->stream2));
+    else
+      HS_HIP(h, hs_launch_qprep(d_centers, nq, k, r2, h->c16.p, d_unsafe, h->stream2));
+    HS_HIP(h, hipEventRecord(h->evx[EV_JOIN], h->stream2));
+  }
   if (!brute) {
     HS_HIP(h, h->qints.reserve((size_t)nq * h->LK * 4));
     HS_HIP(h, h->qstart.reserve((size_t)nql * 4));
@@ -1314,19 +1338,8 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_CHECK(hash_dispatch(h, nullptr, d_centers, nq, -1, h->qints.as<int32_t>(), h->LK, 2, h->stream));
   }
   HS_HIP(h, hipEventRecord(h->ev[1], h->stream));
-  // Bucket join (hs_join.hip) when fp16 can carry the data and a k-mer is one packed word; the
-  // streaming kernel otherwise (and for brute force).  With the join on, segments (bucket x its
-  // probing queries) with too few queries to fill MFMA columns still go to the streaming kernel:
-  // both kernels append survivors to the same list in front of the same exact decision.
-  // fp16 form: k <= 25 only; int8 form (hs_join8.hip): k <= 50 (6 or 8 k-steps for two packed words)
-  const bool can16 = h->join_tables_ok && k <= 25;
-  const bool can8 = h->join8_tables_ok && k <= 50 && h->verify_mode != 3;
-  bool use_join = !brute && h->verify_mode != 1 && r2 < 30000.0 && (can16 || can8);
-  // int8 form of the join filter unless forced to fp16 (mode 3) or not representable
-  bool use_i8 = use_join && can8;
-  // survivors of the int8 join's 4-column bound pass an 8-column int8 bound before the exact
-  // decision (hs_refine8_kernel); HS_NO_REFINE8 switches it off
-  const bool refine = use_i8 && !getenv("HS_NO_REFINE8");
+  // Bucket join when fp16 / int8 can carry the data (decided above); the streaming kernel otherwise
+  // (and for brute force).  Both append survivors to one list in front of the same exact decision.
   if (!brute) {
     // with a join ahead, the probe also numbers each probe's bucket and ranks it inside (the
     // grouping of the probes by bucket is then a counting sort: hs_launch_seg_group)
@@ -1346,13 +1359,11 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
                               h->probe_slow.as<uint32_t>(), h->dir_base.as<uint32_t>(), h->nb_total,
                               bucket_count, qbucket, qrank, h->stream));
   }
-  uint32_t* d_unsafe = d_cnt + 8;
   unsigned long long* d_jstats = reinterpret_cast<unsigned long long*>(d_cnt + 10);
   uint32_t n_items = 0, n_slices = 1, jm = HS_JM_BLOCK;
   const int seg_shift = seg_shift_of(h);
   if (use_join) {
     const size_t n1 = (size_t)nql + 1;
-    HS_HIP(h, h->c16.reserve((size_t)nq * 208 * 2));
     HS_HIP(h, h->c16s.reserve(((size_t)nql + 64) * 208 * 2));
     HS_HIP(h, h->seg_keys.reserve(n1 * 8));
     HS_HIP(h, h->seg_keys_sorted.reserve(n1 * 8));
@@ -1365,13 +1376,8 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, h->item_off.reserve(n1 * 4));
     HS_HIP(h, h->seg_n.reserve(64));
     HS_HIP(h, h->temp.reserve(std::max(hs_scan_u32_temp(n1), hs_scan_u32_temp((size_t)h->nb_total + 2)) + 256));
-    if (use_i8) {
-      if (refine) HS_HIP(h, h->c8b.reserve((size_t)nq * hs_join8_row_bytes(k)));
-      HS_HIP(h, hs_launch_qprep8(d_centers, nq, k, r2, h->jtab8.as<float>() + 128, h->c16.p, d_unsafe,
-                                 refine ? h->c8b.p : nullptr, h->stream));
-    }
-    else
-      HS_HIP(h, hs_launch_qprep(d_centers, nq, k, r2, h->c16.p, d_unsafe, h->stream));
+    // (the query rows of the join filter were quantised on the side stream, beside hash and probe)
+    HS_HIP(h, hipStreamWaitEvent(h->stream, h->evx[EV_JOIN], 0));
     HS_HIP(h, hipMemsetAsync(h->seg_cnt.p, 0, n1 * 4, h->stream));
     HS_HIP(h, hs_launch_seg_group(h->tabs, h->dir_base.as<uint32_t>(), L, seg_shift, h->nb_total,
                                   h->bucket_work.as<uint32_t>(),
