@@ -302,6 +302,7 @@ def main():
     join_ms = 0.0
     join_i8 = 0
     jstat = (0, 0, 0)
+    qproj = (0, 0)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -316,6 +317,7 @@ def main():
         join_ms += p["ms_join"]
         jstat = (p["join_items"], p["join_pairs"], p["join_pairs_issued"])
         join_i8 += p["join_i8_batches"]
+        qproj = (p["hash_values"], p["hash_flagged"])
         cand = p["candidates"]
         hits_local = nh
     fence()
@@ -407,6 +409,12 @@ def main():
             "hits_gathered": total_hits,
             "index": {"build_seconds": t_build, "build_kmers_per_s": args.n / t_build,
                       "device_ms": {f: build_prof[f] for f in ("ms_hash", "ms_sort", "ms_gather", "ms_total")},
+                      # LSH projection on the matrix cores (hs_proj.hip): values produced by the int8
+                      # MFMA pass / of which recomputed in the reference's fp64 order (within the
+                      # proven error bound of a bucket boundary)
+                      "projection": {"build_values": build_prof["hash_values"],
+                                     "build_recomputed": build_prof["hash_flagged"],
+                                     "query_values_per_step": qproj[0], "query_recomputed_per_step": qproj[1]},
                       "device_bytes": info["device_bytes"], "n_buckets": info["n_buckets"],
                       "max_bucket": info["max_bucket"]},
         }
