@@ -117,6 +117,9 @@ struct hs_handle {
   // persistent waves leave no room for a kernel beside it, and the per-pair filter run before it
   // cost 0.3 ms at C2 (a chain of dependent loads per probe) against 0.06 ms of extra join time
   uint32_t join_min_q = 1, join_min_m = 1;
+  // work items of the last joined batch x 1.25: with it the next batch sizes its descriptor array
+  // without asking the device (the kernels clamp to the real count; an overflow repeats the batch)
+  uint32_t item_cap_hint = 0;
   int join_blocks_per_cu = 2;                // resident workgroups of hs_join_kernel per CU
   DevBuf jtab, c16, seg_keys, seg_keys_sorted, seg_vals, sorted_ql, seg_key, seg_cnt, seg_qoff,
       seg_items, item_off, seg_n;
@@ -1294,7 +1297,8 @@ hs_status hs_index_info_get(const hs_handle* h, hs_index_info* out) {
 // ------------------------------------------------------------------------------------- query
 // Counters block (h->counters): [0] prov_count u32, [1] hit_count u32, [2..3] cand_total u64.
 static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq, uint32_t q_base,
-                             double R, bool brute, uint64_t* d_cand, uint32_t* n_batch_hits) {
+                             double R, bool brute, uint64_t* d_cand, uint32_t* n_batch_hits,
+                             bool allow_async = true) {
   const int K = (int)h->p.K, L = brute ? 1 : (int)h->p.L, k = (int)h->p.k;
   const uint32_t nql = nq * (uint32_t)L;
   const double r2 = R * R;  // motif_both_points.cpp:204
@@ -1361,6 +1365,8 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   }
   unsigned long long* d_jstats = reinterpret_cast<unsigned long long*>(d_cnt + 10);
   uint32_t n_items = 0, n_slices = 1, jm = HS_JM_BLOCK;
+  bool async_items = false;
+  uint32_t n_items_real = 0;
   const int seg_shift = seg_shift_of(h);
   if (use_join) {
     const size_t n1 = (size_t)nql + 1;
@@ -1400,16 +1406,26 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   if (!brute) {
     HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, h->nslices.as<uint32_t>(),
                                     h->slice_off.as<uint32_t>(), (size_t)nql + 1, h->stream));
-    // one host round trip: join legality, number of join items, number of streaming slices
+    // No host round trip when the int8 join takes every segment and the previous batch left a
+    // capacity hint: the item count stays on the device (item_off[nql]); join legality and the
+    // capacity are checked with the batch's final read-back, a violation repeats the batch the
+    // slow way.  Otherwise one round trip: join legality, item count, streaming slices.
+    async_items = allow_async && use_i8 && h->join_min_q == 1 && h->join_min_m == 1 && h->item_cap_hint &&
+                  !getenv("HS_SYNC_ITEMS");
     uint32_t unsafe = 0;
-    if (use_join) {
+    if (async_items) {
+      n_items = h->item_cap_hint;
+      n_slices = 0;
+    } else if (use_join) {
       HS_HIP(h, hipMemcpyAsync(&unsafe, d_unsafe, 4, hipMemcpyDeviceToHost, h->stream));
       HS_HIP(h, hipMemcpyAsync(&n_items, h->item_off.as<uint32_t>() + nql, 4, hipMemcpyDeviceToHost,
                                h->stream));
     }
-    HS_HIP(h, hipMemcpyAsync(&n_slices, h->slice_off.as<uint32_t>() + nql, 4, hipMemcpyDeviceToHost,
-                             h->stream));
-    HS_HIP(h, hipStreamSynchronize(h->stream));
+    if (!async_items) {
+      HS_HIP(h, hipMemcpyAsync(&n_slices, h->slice_off.as<uint32_t>() + nql, 4, hipMemcpyDeviceToHost,
+                               h->stream));
+      HS_HIP(h, hipStreamSynchronize(h->stream));
+    }
     if (use_i8 && unsafe && !can16) {
       // a query int8 cannot carry and no fp16 form for this k: the batch streams (below)
       use_i8 = false;
@@ -1449,8 +1465,9 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
       HS_HIP(h, hs_launch_item_desc(h->tabs, h->seg_key.as<uint64_t>(), h->seg_cnt.as<uint32_t>(),
                                     h->seg_qoff.as<uint32_t>(), h->item_off.as<uint32_t>(), nql,
                                     h->sorted_ql.as<uint32_t>(), h->qcount.as<uint32_t>(), n_items, jm,
-                                    seg_shift, h->seg_vals.as<uint32_t>(), h->PW, h->item_desc.as<uint4>(),
-                                    h->stream));
+                                    seg_shift, h->seg_vals.as<uint32_t>(), h->PW,
+                                    async_items ? h->item_off.as<uint32_t>() + nql : nullptr,
+                                    h->item_desc.as<uint4>(), h->stream));
     }
   }
   // ... with the int8 join, thin segments are filtered by the join's own integer bound on the
@@ -1515,7 +1532,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
         HS_HIP(h, hs_launch_join8w(h->item_desc.as<uint4>(), n_items, h->tabs.t[0].packed,
                                    h->t_rec8.as<uint4>(), h->c16s.p, h->jtab8.p, k, d_cnt, prov_cap,
                                    h->prov.as<uint2>(), d_cnt + 32, h->n_cu * h->join_blocks_per_cu,
-                                   h->stream));
+                                   async_items ? h->item_off.as<uint32_t>() + nql : nullptr, h->stream));
       else if (n_items)
         HS_HIP(h, hs_launch_join(h->item_desc.as<uint4>(), n_items, h->tabs.t[0].packed,
                                  h->sorted_ql.as<uint32_t>(),
@@ -1562,7 +1579,12 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, hipMemcpyAsync(host_cnt, d_cnt, 64, hipMemcpyDeviceToHost, h->stream));
     if (proj_stats)
       HS_HIP(h, hipMemcpyAsync(host_proj, h->proj_cnt.as<uint32_t>() + 4, 8, hipMemcpyDeviceToHost, h->stream));
+    if (async_items)
+      HS_HIP(h, hipMemcpyAsync(&n_items_real, h->item_off.as<uint32_t>() + nql, 4, hipMemcpyDeviceToHost,
+                               h->stream));
     HS_HIP(h, hipStreamSynchronize(h->stream));
+    if (async_items && (host_cnt[8] /* join legality */ || n_items_real > n_items))
+      return query_batch(h, d_centers, nq, q_base, R, brute, d_cand, n_batch_hits, false);
     ms_verify += ev_ms(h, 3, 4);
     if (!brute && n_items) ms_join += ev_ms(h, 11, 10);
     ms_final += ev_ms(h, 4, 5);
@@ -1591,7 +1613,9 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   h->prof.join_batches += n_items ? 1 : 0;
   h->prof.join_i8_batches += (n_items && use_i8) ? 1 : 0;
   h->prof.ms_join += ms_join;
+  if (async_items) n_items = n_items_real;
   h->prof.join_items += n_items;
+  if (use_i8 && n_items) h->item_cap_hint = n_items + n_items / 4 + 4096;
   if (use_join) {
     unsigned long long js[2] = {0, 0};
     memcpy(js, host_cnt + 10, 16);  // d_jstats = d_cnt + 10, read back with the counters

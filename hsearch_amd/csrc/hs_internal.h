@@ -291,8 +291,9 @@ hipError_t hs_launch_item_desc(const hs_tables_dev& tabs, const uint64_t* d_seg_
                                const uint32_t* d_seg_cnt,
                                const uint32_t* d_seg_qoff, const uint32_t* d_item_off, uint32_t n_max,
                                const uint32_t* d_sorted_ql, const uint32_t* d_qcount, uint32_t n_items,
-                               uint32_t jm, int shift, const uint32_t* d_order, int PW, uint4* d_desc,
-                               hipStream_t s);
+                               uint32_t jm, int shift, const uint32_t* d_order, int PW,
+                               const uint32_t* d_n_items /* null, or the device-side count: n_items is
+                               then the capacity */, uint4* d_desc, hipStream_t s);
 // item numbering order of the segments: many-query segments first (stable two-class partition):
 // d_big[n + 1] flags (last = 0) -> exclusive scan -> d_order[n], d_items_ordered[n]
 hipError_t hs_launch_seg_big(const uint32_t* d_seg_cnt, const uint32_t* d_items, uint32_t n,
@@ -346,7 +347,8 @@ hipError_t hs_launch_slice_map(const uint32_t* d_nslices, const uint32_t* d_slic
 hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* d_packed_base,
                             const uint4* d_rec_base, const void* d_c8t, const void* d_tab8, int k,
                             uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov,
-                            uint32_t* d_item_counter, int n_blocks, hipStream_t s);
+                            uint32_t* d_item_counter, int n_blocks, const uint32_t* d_n_items,
+                            hipStream_t s);
 // bucket-ordered packed copy of one table (k <= 25) + the per-entry 16-byte A-row tails of the
 // int8 join (d_out_rec[i] belongs to d_out_packed[i])
 hipError_t hs_launch_gather_rec8(const uint4* d_packed_all, const uint32_t* d_ids_sorted, uint32_t n,

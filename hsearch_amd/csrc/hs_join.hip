@@ -260,8 +260,10 @@ __global__ __launch_bounds__(256) void hs_item_desc_kernel(hs_tables_dev tabs,
                                                            const uint32_t* __restrict__ qcount,
                                                            uint32_t n_items, uint32_t jm, int shift,
                                                            const uint32_t* __restrict__ order, int PW,
+                                                           const uint32_t* __restrict__ n_items_dev,
                                                            uint4* __restrict__ desc) {
   const uint32_t item = blockIdx.x * 256 + threadIdx.x;
+  if (n_items_dev) n_items = min(n_items, *n_items_dev);  // n_items = capacity of desc then
   if (item >= n_items) return;
   uint32_t lo = 0, hi = n_max;  // largest j with item_off[j] <= item (zero-item segments share
   while (hi - lo > 1) {         // their successor's offset, so the last such j owns the item)
@@ -601,12 +603,12 @@ hipError_t hs_launch_item_desc(const hs_tables_dev& tabs, const uint64_t* d_seg_
                                const uint32_t* d_seg_cnt,
                                const uint32_t* d_seg_qoff, const uint32_t* d_item_off, uint32_t n_max,
                                const uint32_t* d_sorted_ql, const uint32_t* d_qcount, uint32_t n_items,
-                               uint32_t jm, int shift, const uint32_t* d_order, int PW, uint4* d_desc,
-                               hipStream_t s) {
+                               uint32_t jm, int shift, const uint32_t* d_order, int PW,
+                               const uint32_t* d_n_items, uint4* d_desc, hipStream_t s) {
   if (!n_items) return hipSuccess;
   hs_item_desc_kernel<<<blocks_for(n_items), 256, 0, s>>>(tabs, d_seg_key, d_seg_cnt, d_seg_qoff, d_item_off,
                                                           n_max, d_sorted_ql, d_qcount, n_items, jm, shift,
-                                                          d_order, PW, d_desc);
+                                                          d_order, PW, d_n_items, d_desc);
   return hipGetLastError();
 }
 

@@ -529,7 +529,11 @@ __global__ __launch_bounds__(256, 2) void hs_join8w_kernel(
     const uint4* __restrict__ desc, uint32_t n_items, const uint4* __restrict__ packed_base,
     const uint4* __restrict__ rec_base, const uint4* __restrict__ c8t,
     const uint4* __restrict__ tab8, uint32_t* __restrict__ prov_count, uint32_t prov_cap,
-    uint2* __restrict__ prov, uint32_t* __restrict__ item_counter, uint32_t G) {
+    uint2* __restrict__ prov, uint32_t* __restrict__ item_counter, uint32_t G,
+    const uint32_t* __restrict__ n_items_dev) {
+  // n_items = the capacity of desc; the real count may only be known on the device (no host round
+  // trip between cutting the items and joining them)
+  if (n_items_dev) n_items = min(n_items, __builtin_amdgcn_readfirstlane(*n_items_dev));
   static_assert(JT == 4 || JT == 2, "two accumulator groups of JT / 2 row tiles");
   static_assert(KS == 4 || KS == 6 || KS == 8, "k-steps of a row");
   constexpr int GT = JT / 2;
@@ -850,7 +854,9 @@ __global__ __launch_bounds__(256, 2) void hs_join8x_kernel(
     const uint4* __restrict__ desc, uint32_t n_items, const uint4* __restrict__ packed_base,
     const uint4* __restrict__ rec_base, const uint4* __restrict__ c8t,
     const uint4* __restrict__ tab8, uint32_t* __restrict__ prov_count, uint32_t prov_cap,
-    uint2* __restrict__ prov, uint32_t* __restrict__ item_counter, uint32_t G) {
+    uint2* __restrict__ prov, uint32_t* __restrict__ item_counter, uint32_t G,
+    const uint32_t* __restrict__ n_items_dev) {
+  if (n_items_dev) n_items = min(n_items, __builtin_amdgcn_readfirstlane(*n_items_dev));
   constexpr int RT = 8;  // row tiles of 16 members per wave
   __shared__ uint32_t sTab8[32];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1289,7 +1295,8 @@ hipError_t hs_launch_gather_c8t(const void* d_c8, const uint32_t* d_sorted_ql, c
 hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* d_packed_base,
                             const uint4* d_rec_base, const void* d_c8t, const void* d_tab8, int k,
                             uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov,
-                            uint32_t* d_item_counter, int n_blocks, hipStream_t s) {
+                            uint32_t* d_item_counter, int n_blocks, const uint32_t* d_n_items,
+                            hipStream_t s) {
   if (!n_items) return hipSuccess;
   // (*d_item_counter is zeroed by the caller, with the batch's other counters)
   // chunk size: 8 items per counter access when there is plenty of work, fewer for small launches
@@ -1303,14 +1310,15 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
 #define HS_J8(JT_, KS_)                                                                               \
   hs_join8w_kernel<JT_, KS_><<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_rec_base,     \
                                                       (const uint4*)d_c8t, (const uint4*)d_tab8,      \
-                                                      d_prov_count, prov_cap, d_prov, d_item_counter, G)
+                                                      d_prov_count, prov_cap, d_prov, d_item_counter, G, \
+                                                      d_n_items)
   const int KS = ks_of(k);
   // k <= 25: the 16x16x64 form by default (HS_JOIN_SHAPE=32 selects the 32x32x32 form)
   static const bool shape32 = getenv("HS_JOIN_SHAPE") && atoi(getenv("HS_JOIN_SHAPE")) == 32;
   if (KS == 4 && !shape32)
     hs_join8x_kernel<<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_rec_base, (const uint4*)d_c8t,
                                               (const uint4*)d_tab8, d_prov_count, prov_cap, d_prov,
-                                              d_item_counter, G);
+                                              d_item_counter, G, d_n_items);
   else if (KS == 4) HS_J8(4, 4);
   else if (KS == 6) HS_J8(2, 6);
   else HS_J8(2, 8);
