@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void hs_quant_points_kernel(const double* __re
 
 // ---------------------------------------------------------------------------------- fast pass
 template <int S, bool FROM_CODES>
-__global__ __launch_bounds__(256, 2) void hs_proj_kernel(
+__global__ __launch_bounds__(256, S > 10 ? 1 : 2) void hs_proj_kernel(
     const uint8_t* __restrict__ codes, const uint4* __restrict__ xq, const double* __restrict__ xmeta,
     uint64_t n, int k, const uint4* __restrict__ aq, const ProjFn* __restrict__ fn, int F,
     const hs_proj_table* __restrict__ tab, double invW, int32_t* __restrict__ out, int out_stride,
@@ -272,26 +272,72 @@ __global__ __launch_bounds__(256, 2) void hs_proj_kernel(
   const bool tab_unsafe = FROM_CODES && tab->unsafe != 0u;
   const uint64_t n_tiles = (n + 31) / 32;
   uint32_t res_base = 0, res_left = 0, flagged = 0;
-  for (uint64_t tile = (uint64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * 4) {
+  // Raw inputs of a point tile: the lane's residues (codes path: positions 4 s + 2 h, 4 s + 2 h + 1)
+  // or its digit fragments (points path).  The NEXT tile's are fetched before the current tile's
+  // epilogue (codes: before its MFMAs, into a second register set of 2 S dwords), so their latency
+  // is not exposed (a wave walks ~6 tiles for a query batch).  The number of loads per step never
+  // depends on the tile (a tile past the end re-reads the last).  Long rows (S > 7, points path)
+  // would not fit a whole tile's fragments in registers beside the planes: loaded step by step.
+  constexpr bool PF_POINTS = !FROM_CODES && S <= 7;
+  constexpr bool PF_CODES = FROM_CODES && S <= 10;  // S = 13: the second residue set would spill
+  constexpr int NRAW = PF_POINTS ? 2 * S : 1;
+  uint32_t c0[S], c1[S], c0n[PF_CODES ? S : 1], c1n[PF_CODES ? S : 1];
+  uint4 raw[NRAW];
+  const uint64_t tile0 = (uint64_t)blockIdx.x * 4 + wave, tstride = (uint64_t)gridDim.x * 4;
+  auto fetch = [&](uint64_t tile) {
+    const uint64_t t = tile < n_tiles ? tile : n_tiles - 1;
+    const uint64_t p = t * 32 + (uint64_t)r;
+    const bool pvalid = p < n;
+    if constexpr (FROM_CODES) {
+      const uint8_t* row = codes + (pvalid ? p : 0) * (uint64_t)k;
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const int q0 = 4 * s + 2 * h;
+        // positions past the k-mer (and rows past the end) read position 0 and are masked below
+        const uint32_t a0 = (uint32_t)row[q0 < k ? q0 : 0], a1 = (uint32_t)row[q0 + 1 < k ? q0 + 1 : 0];
+        if constexpr (PF_CODES) {
+          c0n[s] = a0;
+          c1n[s] = a1;
+        } else {
+          c0[s] = a0;
+          c1[s] = a1;
+        }
+      }
+    } else if constexpr (PF_POINTS) {
+      const uint4* xr = xq + (pvalid ? p : 0) * (uint64_t)S * 4 + 2 * h;
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        raw[2 * s] = xr[4 * s];
+        raw[2 * s + 1] = xr[4 * s + 1];
+      }
+    }
+  };
+  if (tile0 < n_tiles && (PF_CODES || PF_POINTS)) fetch(tile0);
+  for (uint64_t tile = tile0; tile < n_tiles; tile += tstride) {
     const uint64_t p = tile * 32 + (uint64_t)r;
     const bool pvalid = p < n;
     intx16 acc_hi, acc_mid, acc_lo;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc_hi[i] = acc_mid[i] = acc_lo[i] = 0;
     double x1 = 0.0;
-    if (FROM_CODES) {
-      // this lane's residues: positions 4 s + 2 h, 4 s + 2 h + 1 of point p (zero rows past k)
-      const uint8_t* row = codes + (pvalid ? p : 0) * (uint64_t)k;
-      uint32_t c0[S], c1[S];
+    if constexpr (FROM_CODES) {
+      const uint8_t* row_now = codes + (pvalid ? p : 0) * (uint64_t)k;
+      if constexpr (PF_CODES) {
 #pragma unroll
-      for (int s = 0; s < S; ++s) {
-        const int q0 = 4 * s + 2 * h;
-        c0[s] = (pvalid && q0 < k) ? (uint32_t)row[q0] : 0xffu;
-        c1[s] = (pvalid && q0 + 1 < k) ? (uint32_t)row[q0 + 1] : 0xffu;
+        for (int s = 0; s < S; ++s) {
+          c0[s] = c0n[s];
+          c1[s] = c1n[s];
+        }
+        fetch(tile + tstride);
       }
 #pragma unroll
       for (int s = 0; s < S; ++s) {
-        const bool v0 = c0[s] != 0xffu, v1 = c1[s] != 0xffu;
+        const int q0 = 4 * s + 2 * h;
+        const bool v0 = pvalid && q0 < k, v1 = pvalid && q0 + 1 < k;
+        if constexpr (!PF_CODES) {  // long rows: residues fetched step by step, no register arrays
+          c0[s] = (uint32_t)row_now[q0 < k ? q0 : 0];
+          c1[s] = (uint32_t)row_now[q0 + 1 < k ? q0 + 1 : 0];
+        }
         uint4 d0 = s_dig[c0[s] & 31u], d1 = s_dig[c1[s] & 31u];
         if (!v0) d0 = make_uint4(0u, 0u, 0u, 0u);
         if (!v1) d1 = make_uint4(0u, 0u, 0u, 0u);
@@ -309,7 +355,14 @@ __global__ __launch_bounds__(256, 2) void hs_proj_kernel(
       const uint4* xr = xq + (pvalid ? p : 0) * (uint64_t)S * 4 + 2 * h;
 #pragma unroll
       for (int s = 0; s < S; ++s) {
-        const uint4 v1 = xr[4 * s], v0 = xr[4 * s + 1];
+        uint4 v1, v0;
+        if constexpr (PF_POINTS) {
+          v1 = raw[2 * s];
+          v0 = raw[2 * s + 1];
+        } else {
+          v1 = xr[4 * s];
+          v0 = xr[4 * s + 1];
+        }
         const intx4 B1 = intx4{(int)v1.x, (int)v1.y, (int)v1.z, (int)v1.w};
         const intx4 B0 = intx4{(int)v0.x, (int)v0.y, (int)v0.z, (int)v0.w};
         acc_hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(Afr[s][0], B1, acc_hi, 0, 0, 0);
@@ -317,6 +370,7 @@ __global__ __launch_bounds__(256, 2) void hs_proj_kernel(
         acc_mid = __builtin_amdgcn_mfma_i32_32x32x32_i8(Afr[s][1], B1, acc_mid, 0, 0, 0);
         acc_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(Afr[s][1], B0, acc_lo, 0, 0, 0);
       }
+      fetch(tile + tstride);  // the registers just consumed take the next tile's fragments
     }
     double sx, dx;
     if (FROM_CODES) {
