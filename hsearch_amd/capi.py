@@ -56,7 +56,8 @@ _lib = None
 
 
 def lib_path():
-    return os.path.join(_HERE, "libhsearch_amd.so")
+    # HSEARCH_AMD_LIB: another build of the same library (A/B runs of two kernel versions on one box)
+    return os.environ.get("HSEARCH_AMD_LIB") or os.path.join(_HERE, "libhsearch_amd.so")
 
 
 def load():
