@@ -858,11 +858,13 @@ __global__ __launch_bounds__(256, 2) void hs_join8x_kernel(
     const uint32_t* __restrict__ n_items_dev) {
   if (n_items_dev) n_items = min(n_items, __builtin_amdgcn_readfirstlane(*n_items_dev));
   constexpr int RT = 8;  // row tiles of 16 members per wave
-  __shared__ uint32_t sTab8[32];
+  // x^ of TWO consecutive residues per lookup: entry (r1 << 5 | r0) = {x^(r0), x^(r1)} -- 8 KB of LDS,
+  // half the extractions and LDS reads of the operand build (4 ten-bit fields per row tile and lane)
+  __shared__ uint2 sPair[1024];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, q = lane >> 4, up = lane >> 5;
-  if (tid < 32) sTab8[tid] = tab8[tid].x;
+  for (int e = tid; e < 1024; e += 256) sPair[e] = make_uint2(tab8[e & 31].x, tab8[e >> 5].x);
   __syncthreads();  // the only one: the table is read-only from here on
   const uint32_t first_dynamic = gridDim.x * 4u * G;
   uint32_t item = (blockIdx.x * 4u + (uint32_t)wave) * G;
@@ -951,10 +953,11 @@ __global__ __launch_bounds__(256, 2) void hs_join8x_kernel(
       y = __funnelshift_r(y, z, bs);
       z = __funnelshift_r(z, w, bs);
       w = w >> bs;
-      A[t][0] = intx4{(int)sTab8[residue_at<0>(x, y, z, w)], (int)sTab8[residue_at<5>(x, y, z, w)],
-                      (int)sTab8[residue_at<10>(x, y, z, w)], (int)sTab8[residue_at<15>(x, y, z, w)]};
-      const intx4 lk = intx4{(int)sTab8[residue_at<80>(x, y, z, w)], (int)sTab8[residue_at<85>(x, y, z, w)],
-                             (int)sTab8[residue_at<90>(x, y, z, w)], (int)sTab8[residue_at<95>(x, y, z, w)]};
+      // ten-bit fields at bits 0, 10 (k-step 0) and 80, 90 (k-step 1: bits 16..25 / 26..35 of z:w)
+      const uint2 p0 = sPair[x & 1023u], p1 = sPair[(x >> 10) & 1023u];
+      const uint2 p2 = sPair[(z >> 16) & 1023u], p3 = sPair[__funnelshift_r(z, w, 26) & 1023u];
+      A[t][0] = intx4{(int)p0.x, (int)p0.y, (int)p1.x, (int)p1.y};
+      const intx4 lk = intx4{(int)p2.x, (int)p2.y, (int)p3.x, (int)p3.y};
       const intx4 rc = intx4{(int)rk.x, (int)rk.y, (int)rk.z, (int)rk.w};
       const intx4 cn = intx4{0x7f7f0000, 0x7f7f7f7f, 0x7f7f7f7f, 0x017f7f7f};
       A[t][1] = q < 2 ? lk : (q == 2 ? rc : cn);
