@@ -64,6 +64,16 @@ def load():
     """Load libhsearch_amd.so.  Raises (never falls back) when it has not been built."""
     global _lib
     if _lib is None:
+        # One ROCm runtime per process: PyTorch ships its own libamdhip64 / libhsa-runtime64 / librccl.
+        # If this library (linked against /opt/rocm's) is loaded BEFORE torch, the process ends up with
+        # /opt/rocm's HIP + HSA and, once torch is imported, torch's RCCL, whose dlopen of
+        # "libhsa-runtime64.so" then maps a second, uninitialised HSA copy (ncclCommInitAll: "no
+        # ROCm-capable device").  Importing torch first makes every later load resolve to its copies.
+        # (The C++ programs under hsearch_amd/host have no torch and use /opt/rocm's throughout.)
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         path = lib_path()
         if not os.path.exists(path):
             raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; "

@@ -109,7 +109,7 @@ struct hs_handle {
       counters, temp, io_centers, io_q, io_id, io_table, io_dist, io_cand, io_codes, io_misc;
   HostBuf sj_host;  // hs_self_join_range: hits of one chunk on their way to the edge lists
   // bucket-join workspace
-  DevBuf c16s, item_desc, probe_slow, jtab8, slice_ql;
+  DevBuf c16s, item_desc, probe_slow, jtab8, slice_ql, qhits;  // qhits: per-query hit counts, offsets, fill
   DevBuf c8b, prov2;  // survivor refinement: second int8 row per query, the refined survivor list
   bool join8_tables_ok = false;  // int8 can carry the coordinate table
   // segment routing thresholds (HS_JOIN_MIN_Q / _M): segments with fewer probing queries or members
@@ -461,7 +461,7 @@ void hs_destroy(hs_handle* h) {
                     &h->probe_slow, &h->jtab8, &h->c8b, &h->prov2, &h->t_packed, &h->t_rec8, &h->t_pos, &h->dir_base,
                     &h->bucket_work, &h->proj_aq_all, &h->proj_aq_tab, &h->proj_fn, &h->proj_tab, &h->proj_stats,
                     &h->proj_flags[0], &h->proj_flags[1], &h->proj_flags[2], &h->proj_cnt, &h->proj_xq,
-                    &h->proj_xmeta, &h->slice_ql};
+                    &h->proj_xmeta, &h->slice_ql, &h->qhits};
   for (DevBuf* bf : bufs) bf->release();
   h->sj_host.release();
   for (int l = 0; l < HS_MAX_L; ++l) {
@@ -1295,10 +1295,19 @@ hs_status hs_index_info_get(const hs_handle* h, hs_index_info* out) {
 }
 
 // ------------------------------------------------------------------------------------- query
+// Where a batch's ordered hits go (run_query's output arrays from its running total on) when the
+// batch orders them itself (hs_launch_hit_order); ordered = true on return if it did.
+struct BatchOut {
+  uint32_t *q = nullptr, *id = nullptr, *table = nullptr;
+  double* dist = nullptr;
+  uint64_t room = 0;   // entries left in the arrays
+  bool ordered = false;
+};
+
 // Counters block (h->counters): [0] prov_count u32, [1] hit_count u32, [2..3] cand_total u64.
 static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq, uint32_t q_base,
                              double R, bool brute, uint64_t* d_cand, uint32_t* n_batch_hits,
-                             bool allow_async = true) {
+                             BatchOut* bout = nullptr, bool allow_async = true) {
   const int K = (int)h->p.K, L = brute ? 1 : (int)h->p.L, k = (int)h->p.k;
   const uint32_t nql = nq * (uint32_t)L;
   const double r2 = R * R;  // motif_both_points.cpp:204
@@ -1492,7 +1501,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   HS_HIP(h, hipEventRecord(h->ev[2], h->stream));
   bool tables_done = !side;
   uint32_t prov_cap = (uint32_t)std::max<size_t>(h->prov.cap / 8, std::max<size_t>(1u << 20, 16ull * nq));
-  uint32_t host_cnt[16] = {0};  // [0] survivors [1] hits [2..3] candidates ... [10..13] join statistics
+  uint32_t host_cnt[24] = {0};  // [0] survivors [1] hits [2..3] candidates ... [10..13] join statistics [20] order fallback
   uint32_t host_proj[2] = {0, 0};  // MFMA projection of the queries: {slots reserved, values flagged}
   const bool proj_stats = !brute && use_projection(h);
   double ms_verify = 0, ms_final = 0, ms_join = 0;
@@ -1503,6 +1512,21 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, h->hit_key.reserve((size_t)hit_cap * 8));
     HS_HIP(h, h->hit_val.reserve((size_t)hit_cap * 8));
     HS_HIP(h, hipMemsetAsync(d_cnt, 0, 8, h->stream));
+    // the batch orders its hits itself (bucket by query, no sort, no host count) unless brute force
+    const bool order_here = bout && !brute && !getenv("HS_SORT_HITS");
+    uint32_t *qcnt = nullptr, *qoff = nullptr, *qfill = nullptr;
+    if (order_here) {
+      const size_t n1q = (size_t)nq + 1;
+      HS_HIP(h, h->qhits.reserve(3 * n1q * 4));
+      qcnt = h->qhits.as<uint32_t>();
+      qoff = qcnt + n1q;
+      qfill = qoff + n1q;
+      HS_HIP(h, hipMemsetAsync(qcnt, 0, 3 * n1q * 4, h->stream));
+      if (launches) HS_HIP(h, hipMemsetAsync(d_cnt + 20, 0, 4, h->stream));  // retry: the "too many hits" flag
+      HS_HIP(h, h->hit_key2.reserve((size_t)hit_cap * 8));
+      HS_HIP(h, h->hit_val2.reserve((size_t)hit_cap * 8));
+      HS_HIP(h, h->temp.reserve(hs_scan_u32_temp(n1q) + 256));
+    }
     HS_HIP(h, hipEventRecord(h->ev[3], h->stream));
     if (launches) HS_HIP(h, hipMemsetAsync(d_cnt + 32, 0, 4, h->stream));  // retry: the item counter again
     if (thin8)
@@ -1572,11 +1596,18 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
                                    h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
                                    fin_list, fin_count, prov_cap, h->sorted_ql.as<uint32_t>(),
                                    k, L, r2, h->sqrt_test ? R : (double)NAN, q_base, h->self_first, d_cnt + 1,
-                                   hit_cap, h->hit_key.as<uint64_t>(), h->hit_val.as<uint64_t>(),
+                                   hit_cap, h->hit_key.as<uint64_t>(), h->hit_val.as<uint64_t>(), qcnt,
                                    h->stream));
+      if (order_here) {
+        HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, qcnt, qoff, (size_t)nq + 1, h->stream));
+        HS_HIP(h, hs_launch_hit_order(h->hit_key.as<uint64_t>(), h->hit_val.as<uint64_t>(), d_cnt + 1, hit_cap,
+                                      q_base, nq, qoff, qfill, h->hit_key2.as<uint64_t>(),
+                                      h->hit_val2.as<uint64_t>(), d_cnt + 20, bout->q, bout->id, bout->table,
+                                      bout->dist, bout->room, h->stream));
+      }
     }
     HS_HIP(h, hipEventRecord(h->ev[5], h->stream));
-    HS_HIP(h, hipMemcpyAsync(host_cnt, d_cnt, 64, hipMemcpyDeviceToHost, h->stream));
+    HS_HIP(h, hipMemcpyAsync(host_cnt, d_cnt, 96, hipMemcpyDeviceToHost, h->stream));
     if (proj_stats)
       HS_HIP(h, hipMemcpyAsync(host_proj, h->proj_cnt.as<uint32_t>() + 4, 8, hipMemcpyDeviceToHost, h->stream));
     if (async_items)
@@ -1584,7 +1615,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
                                h->stream));
     HS_HIP(h, hipStreamSynchronize(h->stream));
     if (async_items && (host_cnt[8] /* join legality */ || n_items_real > n_items))
-      return query_batch(h, d_centers, nq, q_base, R, brute, d_cand, n_batch_hits, false);
+      return query_batch(h, d_centers, nq, q_base, R, brute, d_cand, n_batch_hits, bout, false);
     ms_verify += ev_ms(h, 3, 4);
     if (!brute && n_items) ms_join += ev_ms(h, 11, 10);
     ms_final += ev_ms(h, 4, 5);
@@ -1595,6 +1626,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
       prov_cap = host_cnt[0] + host_cnt[0] / 8 + 1024;
       continue;
     }
+    if (bout) bout->ordered = order_here && !host_cnt[20];
     break;  // hit_count <= prov_count <= prov_cap <= hit_cap
   }
   h->prof.ms_hash += ev_ms(h, 0, 1);
@@ -1649,11 +1681,19 @@ static hs_status run_query(hs_handle* h, const double* d_centers, uint64_t nq, d
     for (uint64_t q0 = 0; q0 < nq; q0 += QB) {
       const uint32_t nqb = (uint32_t)std::min<uint64_t>(QB, nq - q0);
       uint32_t nh = 0;
+      BatchOut bout;
+      const uint64_t at = std::min<uint64_t>(total, cap);
+      bout.q = d_hit_q + at;
+      bout.id = d_hit_id + at;
+      bout.table = d_hit_table ? d_hit_table + at : nullptr;
+      bout.dist = d_hit_dist + at;
+      bout.room = cap - at;
       st = query_batch(h, d_centers + q0 * h->d, nqb, (uint32_t)q0, R, brute,
-                       d_cand ? d_cand + q0 * h->p.L : nullptr, &nh);
+                       d_cand ? d_cand + q0 * h->p.L : nullptr, &nh, cap ? &bout : nullptr);
       if (st) return st;
-      if (nh) {
-        // order of the reference's output: query, table of first sight, ascending id
+      if (nh && !bout.ordered) {
+        // (brute force, a query with very many hits, HS_SORT_HITS) order of the reference's output
+        // by a radix sort on (query, table of first sight, id)
         HS_HIP(h, h->hit_key2.reserve((size_t)nh * 8));
         HS_HIP(h, h->hit_val2.reserve((size_t)nh * 8));
         HS_HIP(h, h->temp.reserve(hs_sort_pairs_u64_u64_temp(nh) + 256));

@@ -262,7 +262,16 @@ hipError_t hs_launch_finalize(const hs_tables_dev& tabs, const uint8_t* d_codes,
                               const uint2* d_prov, const uint32_t* d_prov_count, uint32_t prov_cap,
                               const uint32_t* d_sorted_ql, int k, int L, double r2, double r_sqrt,
                               uint32_t q_base, uint32_t self_first, uint32_t* d_hit_count,
-                              uint32_t hit_cap, uint64_t* d_hit_key, uint64_t* d_hit_val, hipStream_t s);
+                              uint32_t hit_cap, uint64_t* d_hit_key, uint64_t* d_hit_val,
+                              uint32_t* d_qcnt /* [nq] hits per query, or null */, hipStream_t s);
+// the batch's hits in the reference's order without a sort: bucket by query (d_qoff = exclusive
+// scan of the per-query counts), order every query's few hits, unpack to the outputs (at most
+// out_room of them); *d_big is set when a query has too many hits for that (caller: radix sort)
+hipError_t hs_launch_hit_order(const uint64_t* d_key, const uint64_t* d_val, const uint32_t* d_hit_count,
+                               uint32_t hit_cap, uint32_t q_base, uint32_t nq, const uint32_t* d_qoff,
+                               uint32_t* d_qfill, uint64_t* d_key2, uint64_t* d_val2, uint32_t* d_big,
+                               uint32_t* d_q, uint32_t* d_id, uint32_t* d_table, double* d_dist,
+                               uint64_t out_room, hipStream_t s);
 // self_first: the queries are the indexed k-mers self_first, self_first + 1, ... themselves (the
 // self-join): the pair of a k-mer with itself is not a hit; HS_NO_SELF otherwise
 #define HS_NO_SELF 0xffffffffu

@@ -717,7 +717,8 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
                                                           uint32_t* __restrict__ hit_count,
                                                           uint32_t hit_cap,
                                                           uint64_t* __restrict__ hit_key,
-                                                          uint64_t* __restrict__ hit_val) {
+                                                          uint64_t* __restrict__ hit_val,
+                                                          uint32_t* __restrict__ qcnt) {
   // One wave = 64 survivors, one per lane.  The exact d2 is a serial fp64 chain per survivor, but
   // its inputs -- 8k doubles of the query's centre row -- are fetched by the WAVE: per position,
   // the 64 rows' 64-byte pieces go through LDS (4 lanes x 16 B per row: every byte fetched is
@@ -829,6 +830,7 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
         hit_key[idx] = ((uint64_t)(q_base + q) << 37) | ((uint64_t)l << 32) | id;
         hit_val[idx] = (uint64_t)__double_as_longlong(__dsqrt_rn(d2));
       }
+      if (hit && qcnt) atomicAdd(&qcnt[q], 1u);  // hits per query: the ordering pass buckets by query
     }
   }
 }
@@ -999,6 +1001,73 @@ __global__ __launch_bounds__(256) void hs_bf_finalize_kernel(const uint8_t* __re
         hit_val[idx] = (uint64_t)__double_as_longlong(dis);
       }
     }
+  }
+}
+
+// Ordering of a batch's hits without a sort and without the host knowing their number: hits are
+// bucketed by query (qoff = exclusive scan of the per-query counts hs_finalize_kernel kept), then
+// every query orders its own few hits by (table of first sight, id) and writes them out -- the
+// reference's file order (motif_both_points.cpp:224-245).  A query with more than HS_ORDER_MAX hits
+// raises *big instead (the caller then falls back to the radix sort over the whole list).
+#define HS_ORDER_MAX 48u
+__global__ __launch_bounds__(256) void hs_hit_place_kernel(const uint64_t* __restrict__ key,
+                                                           const uint64_t* __restrict__ val,
+                                                           const uint32_t* __restrict__ hit_count,
+                                                           uint32_t hit_cap, uint32_t q_base,
+                                                           const uint32_t* __restrict__ qoff,
+                                                           uint32_t* __restrict__ qfill,
+                                                           uint64_t* __restrict__ key2,
+                                                           uint64_t* __restrict__ val2) {
+  const uint32_t n = min(*hit_count, hit_cap);
+  for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    const uint64_t kk = key[e];
+    const uint32_t q = (uint32_t)(kk >> 37) - q_base;
+    const uint32_t slot = qoff[q] + atomicAdd(&qfill[q], 1u);
+    if (slot < hit_cap) {
+      key2[slot] = kk;
+      val2[slot] = val[e];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void hs_hit_order_kernel(const uint32_t* __restrict__ qoff, uint32_t nq,
+                                                           const uint32_t* __restrict__ hit_count,
+                                                           uint32_t hit_cap, uint64_t* __restrict__ key2,
+                                                           uint64_t* __restrict__ val2,
+                                                           uint32_t* __restrict__ big,
+                                                           uint32_t* __restrict__ out_q,
+                                                           uint32_t* __restrict__ out_id,
+                                                           uint32_t* __restrict__ out_table,
+                                                           double* __restrict__ out_dist, uint64_t out_room) {
+  const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nq) return;
+  if (*hit_count > hit_cap) return;  // the batch is repeated with larger buffers anyway
+  const uint32_t lo = qoff[q], m = qoff[q + 1] - lo;
+  if (!m) return;
+  if (m > HS_ORDER_MAX) {
+    atomicOr(big, 1u);
+    return;
+  }
+  // insertion sort of the query's hits by key (distinct: (table, id) is unique per query)
+  for (uint32_t i = 1; i < m; ++i) {
+    const uint64_t kk = key2[lo + i], vv = val2[lo + i];
+    uint32_t j = i;
+    while (j > 0 && key2[lo + j - 1] > kk) {
+      key2[lo + j] = key2[lo + j - 1];
+      val2[lo + j] = val2[lo + j - 1];
+      --j;
+    }
+    key2[lo + j] = kk;
+    val2[lo + j] = vv;
+  }
+  for (uint32_t i = 0; i < m; ++i) {
+    const uint64_t o = (uint64_t)lo + i;
+    if (o >= out_room) break;
+    const uint64_t kk = key2[lo + i];
+    out_q[o] = (uint32_t)(kk >> 37);
+    if (out_table) out_table[o] = (uint32_t)((kk >> 32) & 31u);
+    out_id[o] = (uint32_t)kk;
+    out_dist[o] = __longlong_as_double((long long)val2[lo + i]);
   }
 }
 
@@ -1216,11 +1285,24 @@ hipError_t hs_launch_finalize(const hs_tables_dev& tabs, const uint8_t* d_codes,
                               const uint2* d_prov, const uint32_t* d_prov_count, uint32_t prov_cap,
                               const uint32_t* d_sorted_ql, int k, int L, double r2, double r_sqrt,
                               uint32_t q_base, uint32_t self_first, uint32_t* d_hit_count,
-                              uint32_t hit_cap, uint64_t* d_hit_key, uint64_t* d_hit_val, hipStream_t s) {
+                              uint32_t hit_cap, uint64_t* d_hit_key, uint64_t* d_hit_val, uint32_t* d_qcnt, hipStream_t s) {
   hs_finalize_kernel<<<1024, 256, 0, s>>>(tabs, d_codes, d_centers, d_coords, d_qstart, d_qcount,
                                           d_prov, d_prov_count, prov_cap, d_sorted_ql, k, L, r2,
                                           r_sqrt, q_base, self_first,
-                                          d_hit_count, hit_cap, d_hit_key, d_hit_val);
+                                          d_hit_count, hit_cap, d_hit_key, d_hit_val, d_qcnt);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_hit_order(const uint64_t* d_key, const uint64_t* d_val, const uint32_t* d_hit_count,
+                               uint32_t hit_cap, uint32_t q_base, uint32_t nq, const uint32_t* d_qoff,
+                               uint32_t* d_qfill, uint64_t* d_key2, uint64_t* d_val2, uint32_t* d_big,
+                               uint32_t* d_q, uint32_t* d_id, uint32_t* d_table, double* d_dist,
+                               uint64_t out_room, hipStream_t s) {
+  if (!nq) return hipSuccess;
+  hs_hit_place_kernel<<<256, 256, 0, s>>>(d_key, d_val, d_hit_count, hit_cap, q_base, d_qoff, d_qfill, d_key2,
+                                          d_val2);
+  hs_hit_order_kernel<<<blocks_for(nq), 256, 0, s>>>(d_qoff, nq, d_hit_count, hit_cap, d_key2, d_val2, d_big, d_q,
+                                                    d_id, d_table, d_dist, out_room);
   return hipGetLastError();
 }
 
