@@ -866,6 +866,10 @@ __global__ __launch_bounds__(256, 2) void hs_join8x_kernel(
   const int n = lane & 15, q = lane >> 4, up = lane >> 5;
   for (int e = tid; e < 1024; e += 256) sPair[e] = make_uint2(tab8[e & 31].x, tab8[e >> 5].x);
   __syncthreads();  // the only one: the table is read-only from here on
+#ifdef HS_JOIN_TIMING
+  uint64_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+  const uint64_t tstart = tlast;
+#endif
   const uint32_t first_dynamic = gridDim.x * 4u * G;
   uint32_t item = (blockIdx.x * 4u + (uint32_t)wave) * G;
   if (item >= n_items) return;
@@ -921,12 +925,14 @@ __global__ __launch_bounds__(256, 2) void hs_join8x_kernel(
     const uint32_t wbase = mt * 128u;
     const bool has_next = next_item < n_items;
     HS_ADVANCE_PF()  // pf_item = the item after next
+    HS_T(0)
     uint4 nnd0 = nd0, nnd1 = nd1;
     if (pf_item < n_items) {
       nnd0 = uniform4(desc[2 * (uint64_t)pf_item]);
       nnd1 = uniform4(desc[2 * (uint64_t)pf_item + 1]);
     }
     // ---- A operands of the item's 128 members
+    HS_TD(6, mk[0].x ^ mk[7].w)   // wait for the members
     intx4 A[RT][2];
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
@@ -962,7 +968,9 @@ __global__ __launch_bounds__(256, 2) void hs_join8x_kernel(
       const intx4 cn = intx4{0x7f7f0000, 0x7f7f7f7f, 0x7f7f7f7f, 0x017f7f7f};
       A[t][1] = q < 2 ? lk : (q == 2 ? rc : cn);
     }
+    HS_TD(1, __builtin_amdgcn_readfirstlane(A[0][0][0] ^ A[7][1][3] ^ A[3][1][0]))
     HS_LOAD_MEMBERS(nd0)
+    HS_T(2)
     intx4 accX[4][2], accY[4][2];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -1028,13 +1036,16 @@ __global__ __launch_bounds__(256, 2) void hs_join8x_kernel(
       qc0 = nq0;
     };
     do_group(0);
+    HS_T(3)
     for (uint32_t gi = 1; gi < n_groups; ++gi) do_group(gi);
+    HS_T(4)
     {  // the item's last Y group
       const uint32_t sY = and_tree_x(accY);
       if (__ballot((int)sY >= 0))
         emit_survivors_x(accY, 4, prev_qc, qoff, q_end, wbase, M, mstart, lane, res_base, res_used,
                          prov_count, prov_cap, prov);
     }
+    HS_T(5)
     if (!has_next) break;
     item = next_item;
     next_item = pf_item;
@@ -1050,6 +1061,12 @@ __global__ __launch_bounds__(256, 2) void hs_join8x_kernel(
 #undef HS_FIRST_Q
   if (res_used < JRES && lane >= (int)res_used && res_base + lane < prov_cap)
     prov[res_base + lane] = make_uint2(0xffffffffu, 0u);
+#ifdef HS_JOIN_TIMING
+  if (lane == 0) {
+    for (int i = 0; i < 7; ++i) atomicAdd(&g_join8_timing[i], (unsigned long long)tacc[i]);
+    atomicMax(&g_join8_timing[7], (unsigned long long)(tlast - tstart));
+  }
+#endif
 }
 
 // Thin segments (too few probing queries or members for MFMA tiles) with the int8 join on: the SAME
@@ -1331,7 +1348,7 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
     unsigned long long t[8];
     (void)hipStreamSynchronize(s);
     (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_join8_timing), sizeof(t));
-    fprintf(stderr, "join8w timing (wave-cycles): chunk %llu build(+member wait) %llu next-desc+issue %llu first group %llu other groups %llu flush %llu tail %llu | longest wave %llu, mean wave %llu\n",
+    fprintf(stderr, "join8 timing (wave-cycles): chunk %llu build %llu next-desc+issue %llu first group %llu other groups %llu flush %llu member-wait %llu | longest wave %llu, mean wave %llu\n",
             t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7],
             (t[0] + t[1] + t[2] + t[3] + t[4] + t[5] + t[6]) / (unsigned long long)(n_blocks * 4));
     memset(t, 0, sizeof(t));
