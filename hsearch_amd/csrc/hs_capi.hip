@@ -181,6 +181,41 @@ hs_status ensure_device(hs_handle* h) {
 }
 
 
+// The device code of the library's kernels -- rocPRIM's sort / scan / run-length kernels in
+// particular -- is loaded lazily, at first launch: measured 57 ms of host time inside the first
+// table's sort of the first index build of a process (rocprofv3 timeline).  One launch of each
+// on a few elements at handle creation moves that out of hs_index_build and out of the first query.
+hs_status warm_up_device_code(hs_handle* h) {
+  static bool done = false;  // per process
+  if (done) return HS_OK;
+  const size_t n = 64;
+  DevBuf k0, k1, v0, v1, cnt, tmp;
+  struct G {
+    DevBuf* b[6];
+    ~G() { for (DevBuf* x : b) x->release(); }
+  } g = {{&k0, &k1, &v0, &v1, &cnt, &tmp}};
+  HS_HIP(h, k0.reserve(n * 8));
+  HS_HIP(h, k1.reserve(n * 8));
+  HS_HIP(h, v0.reserve(n * 8));
+  HS_HIP(h, v1.reserve(n * 8));
+  HS_HIP(h, cnt.reserve((n + 2) * 4));
+  const size_t tb = std::max(std::max(hs_sort_pairs_u64_u32_temp(n), hs_sort_pairs_u64_u64_temp(n)),
+                             std::max(hs_rle_u64_temp(n), hs_scan_u32_temp(n))) + 256;
+  HS_HIP(h, tmp.reserve(tb));
+  HS_HIP(h, hipMemsetAsync(k0.p, 0, n * 8, h->stream));
+  HS_HIP(h, hipMemsetAsync(v0.p, 0, n * 8, h->stream));
+  HS_HIP(h, hs_sort_pairs_u64_u32(tmp.p, tmp.cap, k0.as<uint64_t>(), k1.as<uint64_t>(), v0.as<uint32_t>(),
+                                  v1.as<uint32_t>(), n, 64, h->stream));
+  HS_HIP(h, hs_sort_pairs_u64_u64(tmp.p, tmp.cap, k0.as<uint64_t>(), k1.as<uint64_t>(), v0.as<uint64_t>(),
+                                  v1.as<uint64_t>(), n, 64, h->stream));
+  HS_HIP(h, hs_rle_u64(tmp.p, tmp.cap, k1.as<uint64_t>(), k0.as<uint64_t>(), v0.as<uint32_t>(),
+                       cnt.as<uint32_t>(), n, h->stream));
+  HS_HIP(h, hs_exclusive_scan_u32(tmp.p, tmp.cap, v0.as<uint32_t>(), v1.as<uint32_t>(), n, h->stream));
+  HS_HIP(h, hipStreamSynchronize(h->stream));
+  done = true;
+  return HS_OK;
+}
+
 // (Re)quantise the handle's planes -- and, the first time, its coordinate table -- for the MFMA
 // projection, and decide whether the auto mode uses it: the bound's typical half-width, in bucket
 // units, is est = (da k max|row|_1 + dx max|a^|_1) / W; about 2 est of all values are recomputed.
@@ -402,6 +437,7 @@ hs_status hs_create(const hs_params* params, const double* a, const double* b, c
     if (!strcmp(m, "mfma")) h->hash_mode = 2;
   }
   HS_CHECK(setup_projection(h, true));
+  HS_CHECK(warm_up_device_code(h));
   if (const char* m = getenv("HS_VERIFY_MODE")) {
     if (!strcmp(m, "stream")) h->verify_mode = 1;
     if (!strcmp(m, "join")) h->verify_mode = 2;
