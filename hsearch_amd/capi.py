@@ -19,7 +19,7 @@ EXPORTS = ["hs_create", "hs_destroy", "hs_last_error", "hs_get_profile", "hs_get
            "hs_clustering_begin", "hs_clustering_table_edges", "hs_clustering_table_apply",
            "hs_clustering_end",
            "hs_embed_codes", "hs_hash_codes", "hs_hash_points", "hs_key_string", "hs_key_fingerprint",
-           "hs_key_strings_equal", "hs_index_build", "hs_index_build_windows", "hs_index_save", "hs_index_load", "hs_index_file_check", "hs_klsh_draw_planes", "hs_klsh_codes",
+           "hs_key_strings_equal", "hs_index_build", "hs_index_build_subset", "hs_index_build_windows", "hs_index_save", "hs_index_load", "hs_index_file_check", "hs_klsh_draw_planes", "hs_klsh_codes",
            "hs_index_info_get", "hs_query", "hs_query_dev", "hs_bruteforce", "hs_bruteforce_topk"]
 
 
@@ -279,6 +279,18 @@ class Engine:
         n = codes.shape[0]
         assert codes.ndim == 2 and codes.shape[1] == self.k
         self._check(self._lib.hs_index_build(self._h, _vp(codes), C.c_uint64(n)))
+        return self.index_info()
+
+    def index_build_subset(self, codes_all, subset):
+        """Index over rows `subset` (uint32, or None for all) of a code array kept on the device across
+        calls (hs_index_build_subset); the array must stay alive and unchanged between calls."""
+        assert codes_all.dtype == np.uint8 and codes_all.flags["C_CONTIGUOUS"] and codes_all.shape[1] == self.k
+        n_all = codes_all.shape[0]
+        sub = None if subset is None else np.ascontiguousarray(subset, dtype=np.uint32)
+        n_sub = n_all if sub is None else len(sub)
+        self._check(self._lib.hs_index_build_subset(self._h, _vp(codes_all), C.c_uint64(n_all),
+                                                    _vp(sub) if sub is not None else C.c_void_p(0),
+                                                    C.c_uint64(n_sub)))
         return self.index_info()
 
     def index_build_windows(self, residues, seq_start):

@@ -109,9 +109,16 @@ struct hs_handle {
       counters, temp, io_centers, io_q, io_id, io_table, io_dist, io_cand, io_codes, io_misc;
   HostBuf sj_host;  // hs_self_join_range: hits of one chunk on their way to the edge lists
   // bucket-join workspace
+  // hs_index_build_subset: the caller's whole code array, kept on the device across calls
+  DevBuf all_codes, subset_ids;
+  const uint8_t* all_codes_key = nullptr;
+  uint64_t all_codes_n = 0;
+  DevBuf bs_ints2[2], bs_keys2[2], bs_iota2[2], bs_keys_sorted, bs_rle_unique, bs_rle_counts, bs_small,
+      bs_sort_temp, bs_slow_q;  // index-build scratch (build_tables)
   DevBuf c16s, item_desc, probe_slow, jtab8, slice_ql, qhits;  // qhits: per-query hit counts, offsets, fill
   DevBuf c8b, prov2;  // survivor refinement: second int8 row per query, the refined survivor list
   bool join8_tables_ok = false;  // int8 can carry the coordinate table
+  double join8_scale = 0.0;      // its quantisation scale s (scale[0] of jtab8)
   // segment routing thresholds (HS_JOIN_MIN_Q / _M): segments with fewer probing queries or members
   // go to the per-pair filters instead of the join.  1 / 1 = everything through the join: its
   // persistent waves leave no room for a kernel beside it, and the per-pair filter run before it
@@ -429,9 +436,12 @@ hs_status hs_create(const hs_params* params, const double* a, const double* b, c
                                reinterpret_cast<uint32_t*>(h->jtab8.as<char>() + 640),
                                h->jtab8.as<char>() + 1024, h->stream));
   uint32_t unsafe8 = 1;
+  float scale8 = 0.f;
   HS_HIP(h, hipMemcpyAsync(&unsafe8, h->jtab8.as<char>() + 640, 4, hipMemcpyDeviceToHost, h->stream));
+  HS_HIP(h, hipMemcpyAsync(&scale8, h->jtab8.as<char>() + 512, 4, hipMemcpyDeviceToHost, h->stream));
   HS_HIP(h, hipStreamSynchronize(h->stream));
   h->join8_tables_ok = (unsafe8 == 0);
+  h->join8_scale = (double)scale8;
   if (const char* m = getenv("HS_HASH_MODE")) {
     if (!strcmp(m, "exact")) h->hash_mode = 1;
     if (!strcmp(m, "mfma")) h->hash_mode = 2;
@@ -497,7 +507,10 @@ void hs_destroy(hs_handle* h) {
                     &h->probe_slow, &h->jtab8, &h->c8b, &h->prov2, &h->t_packed, &h->t_rec8, &h->t_pos, &h->dir_base,
                     &h->bucket_work, &h->proj_aq_all, &h->proj_aq_tab, &h->proj_fn, &h->proj_tab, &h->proj_stats,
                     &h->proj_flags[0], &h->proj_flags[1], &h->proj_flags[2], &h->proj_cnt, &h->proj_xq,
-                    &h->proj_xmeta, &h->slice_ql, &h->qhits};
+                    &h->proj_xmeta, &h->slice_ql, &h->qhits, &h->bs_ints2[0], &h->bs_ints2[1], &h->bs_keys2[0],
+                    &h->bs_keys2[1], &h->bs_iota2[0], &h->bs_iota2[1], &h->bs_keys_sorted, &h->bs_rle_unique,
+                    &h->bs_rle_counts, &h->bs_small, &h->bs_sort_temp, &h->bs_slow_q, &h->all_codes,
+                    &h->subset_ids};
   for (DevBuf* bf : bufs) bf->release();
   h->sj_host.release();
   for (int l = 0; l < HS_MAX_L; ++l) {
@@ -625,7 +638,12 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
   // scratch shared by all tables.  Hashing (fp64 vector ALU) and grouping (radix sort: memory) of
   // consecutive tables overlap: table l + 1 is hashed on the side stream into the other half of
   // the double-buffered ints / keys / iota while table l is sorted on the main stream.
-  DevBuf ints2[2], keys2[2], iota2[2], keys_sorted, rle_unique, rle_counts, small, sort_temp, slow_q;
+  // (the scratch lives in the handle: Clustering() rebuilds a 10^6-k-mer index per table, and twelve
+  // hipMalloc / hipFree pairs per build cost more than the build's kernels; released after the build
+  // only when it is large)
+  DevBuf(&ints2)[2] = h->bs_ints2, (&keys2)[2] = h->bs_keys2, (&iota2)[2] = h->bs_iota2;
+  DevBuf &keys_sorted = h->bs_keys_sorted, &rle_unique = h->bs_rle_unique, &rle_counts = h->bs_rle_counts,
+         &small = h->bs_small, &sort_temp = h->bs_sort_temp, &slow_q = h->bs_slow_q;
   hipEvent_t ev_hashed[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_t[4] = {};
   // The hash runs on the handle's side stream (lowest priority: the sort's many small kernels get
   // the CUs they ask for, the hash fills the rest).  Measured at 10 M x 8 tables, repeated builds:
@@ -650,7 +668,10 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
       for (int g = 0; g < 3; ++g)
         for (int i = 0; i < ne[g]; ++i)
           if (e[g][i]) (void)hipEventDestroy(e[g][i]);
-      for (DevBuf* x : b) x->release();
+      size_t held = 0;
+      for (DevBuf* x : b) held += x->cap;
+      if (held > ((size_t)1 << 30))  // keep up to 1 GB of build scratch for the next build
+        for (DevBuf* x : b) x->release();
     }
   } guard = {h, &hash_stream, own_hash_stream, {ev_hashed, ev_free, ev_t}, {2, 2, 4},
              {&ints2[0], &ints2[1], &keys2[0], &keys2[1], &iota2[0], &iota2[1], &keys_sorted, &rle_unique,
@@ -870,6 +891,42 @@ hs_status hs_index_build(hs_handle* h, const uint8_t* codes, uint64_t n) {
   HS_HIP(h, hipEventRecord(h->ev[8], h->stream));
   if (n) HS_HIP(h, hipMemcpyAsync(h->codes.p, codes, (size_t)n * k, hipMemcpyHostToDevice, h->stream));
   return index_build_resident(h, n);
+}
+
+hs_status hs_index_build_subset(hs_handle* h, const uint8_t* codes_all, uint64_t n_all,
+                                const uint32_t* subset, uint64_t n_subset) {
+  if (!h || (n_all && !codes_all) || (!subset && n_subset != n_all)) return HS_ERR_INVALID;
+  if (n_all >= (1ull << 31) || n_subset > n_all)
+    return fail(h, HS_ERR_INVALID, "n must be < 2^31 and the subset no larger than the array");
+  hs_status st = ensure_device(h);
+  if (st) return st;
+  if (subset)
+    for (uint64_t i = 0; i < n_subset; ++i)
+      if (subset[i] >= n_all) return fail(h, HS_ERR_INVALID, "subset index outside the code array");
+  const int k = (int)h->p.k;
+  h->built = false;
+  h->n = n_subset;
+  memset(&h->prof, 0, sizeof(h->prof));
+  memset(&h->info, 0, sizeof(h->info));
+  HS_HIP(h, h->counters.reserve(256));
+  HS_HIP(h, hipEventRecord(h->ev[8], h->stream));
+  if (h->all_codes_key != codes_all || h->all_codes_n != n_all) {
+    h->all_codes_key = nullptr;
+    HS_HIP(h, h->all_codes.reserve(std::max<size_t>(16, (size_t)n_all * k)));
+    if (n_all) HS_HIP(h, hipMemcpyAsync(h->all_codes.p, codes_all, (size_t)n_all * k, hipMemcpyHostToDevice, h->stream));
+    h->all_codes_key = codes_all;
+    h->all_codes_n = n_all;
+  }
+  HS_HIP(h, h->codes.reserve(std::max<size_t>(16, (size_t)n_subset * k)));
+  const uint32_t* d_sub = nullptr;
+  if (subset && n_subset) {
+    HS_HIP(h, h->subset_ids.reserve((size_t)n_subset * 4));
+    HS_HIP(h, hipMemcpyAsync(h->subset_ids.p, subset, (size_t)n_subset * 4, hipMemcpyHostToDevice, h->stream));
+    d_sub = h->subset_ids.as<uint32_t>();
+  }
+  HS_HIP(h, hs_launch_gather_rows(h->all_codes.as<uint8_t>(), d_sub, n_subset, k, h->codes.as<uint8_t>(), h->stream));
+  HS_HIP(h, hipStreamSynchronize(h->stream));  // `subset` is the caller's again
+  return index_build_resident(h, n_subset);
 }
 
 // DB = every length-k window of every sequence of a concatenated residue buffer (kmer_search.cpp:
@@ -1341,6 +1398,19 @@ struct BatchOut {
 };
 
 // Counters block (h->counters): [0] prov_count u32, [1] hit_count u32, [2..3] cand_total u64.
+// May a self-join at radius R run from the residue codes alone (query_batch's self_codes)?  Only when
+// nothing on its way can need the embedded centres: the int8 join and its thin-segment filter must
+// apply, and no query row may be unrepresentable -- for a k-mer of the coordinate table the one way
+// is -gamma overflowing its 13 base-127 digits, bounded here from R and the scale alone.
+static bool self_codes_ok(const hs_handle* h, double R) {
+  const double r2 = R * R, s = h->join8_scale, k = (double)h->p.k;
+  if (!h->join8_tables_ok || h->p.k > 50 || h->verify_mode == 1 || h->verify_mode == 3 || !(r2 < 30000.0))
+    return false;
+  if (getenv("HS_NO_THIN8") || getenv("HS_NO_SELF_CODES")) return false;
+  // -gamma <= s^2 R^2 / 2 + L1(c^)/2 + 3, L1(c^) <= 127 * 4 k
+  return s > 0.0 && 0.5 * s * s * r2 + 254.0 * k + 3.0 < 127.0 * 127.0 * 13.0;
+}
+
 static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq, uint32_t q_base,
                              double R, bool brute, uint64_t* d_cand, uint32_t* n_batch_hits,
                              BatchOut* bout = nullptr, bool allow_async = true) {
@@ -1362,6 +1432,13 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   // decision (hs_refine8_kernel); HS_NO_REFINE8 switches it off
   const bool refine = use_i8 && !getenv("HS_NO_REFINE8");
   uint32_t* d_unsafe = d_cnt + 8;
+  // Self-join (the queries are the indexed k-mers self_first + q_base ..): every per-query quantity
+  // comes from the residue codes and the tables -- no embedded centres, no hashing, no directory
+  // search (a k-mer probes the bucket it sits in).  Needs the int8 join with its thin-segment filter,
+  // the only filters that work without per-query distance tables.
+  const bool self_codes = h->self_first != HS_NO_SELF && !brute && use_i8 && self_codes_ok(h, R);
+  const uint8_t* d_qcodes =
+      self_codes ? h->codes.as<uint8_t>() + ((uint64_t)h->self_first + q_base) * k : nullptr;
   if (use_join) {
     // the join filter's query rows depend on the centres only: quantised on the side stream while
     // the main stream hashes and probes (both passes stream the same 8d bytes per query)
@@ -1369,7 +1446,11 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     if (refine) HS_HIP(h, h->c8b.reserve((size_t)nq * hs_join8_row_bytes(k)));
     HS_HIP(h, hipEventRecord(h->evx[EV_FORK], h->stream));
     HS_HIP(h, hipStreamWaitEvent(h->stream2, h->evx[EV_FORK], 0));
-    if (use_i8)
+    if (self_codes)
+      HS_HIP(h, hs_launch_qprep8_codes(d_qcodes, nq, k, r2, h->coords.as<double>(), h->jtab8.p,
+                                       h->jtab8.as<char>() + 1024, h->jtab8.as<float>() + 128, h->c16.p,
+                                       refine ? h->c8b.p : nullptr, h->stream2));
+    else if (use_i8)
       HS_HIP(h, hs_launch_qprep8(d_centers, nq, k, r2, h->jtab8.as<float>() + 128, h->c16.p, d_unsafe,
                                  refine ? h->c8b.p : nullptr, h->stream2));
     else
@@ -1384,7 +1465,8 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, h->probe_slow.reserve(((size_t)nql + 1) * 4));
     HS_HIP(h, h->slice_off.reserve(((size_t)nql + 1) * 4));
     HS_HIP(h, h->temp.reserve(hs_scan_u32_temp((size_t)nql + 1) + 256));
-    HS_CHECK(hash_dispatch(h, nullptr, d_centers, nq, -1, h->qints.as<int32_t>(), h->LK, 2, h->stream));
+    if (!self_codes)
+      HS_CHECK(hash_dispatch(h, nullptr, d_centers, nq, -1, h->qints.as<int32_t>(), h->LK, 2, h->stream));
   }
   HS_HIP(h, hipEventRecord(h->ev[1], h->stream));
   // Bucket join when fp16 / int8 can carry the data (decided above); the streaming kernel otherwise
@@ -1401,12 +1483,19 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
       qrank = qbucket + ((size_t)nql + 1);
     }
     HS_HIP(h, hs_launch_set_u32(h->nslices.as<uint32_t>() + nql, 0u, h->stream));
-    HS_HIP(h, hs_launch_probe(h->tabs, h->qints.as<int32_t>(), nq, K, L, h->key_seed,
-                              h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
-                              h->nslices.as<uint32_t>(), d_cand,
-                              reinterpret_cast<unsigned long long*>(d_cnt + 2),
-                              h->probe_slow.as<uint32_t>(), h->dir_base.as<uint32_t>(), h->nb_total,
-                              bucket_count, qbucket, qrank, h->stream));
+    if (self_codes)
+      HS_HIP(h, hs_launch_self_probe(h->tabs, h->self_first + q_base, nq, L, h->qstart.as<uint32_t>(),
+                                     h->qcount.as<uint32_t>(), h->nslices.as<uint32_t>(), d_cand,
+                                     reinterpret_cast<unsigned long long*>(d_cnt + 2),
+                                     h->dir_base.as<uint32_t>(), h->nb_total, bucket_count, qbucket, qrank,
+                                     h->stream));
+    else
+      HS_HIP(h, hs_launch_probe(h->tabs, h->qints.as<int32_t>(), nq, K, L, h->key_seed,
+                                h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
+                                h->nslices.as<uint32_t>(), d_cand,
+                                reinterpret_cast<unsigned long long*>(d_cnt + 2),
+                                h->probe_slow.as<uint32_t>(), h->dir_base.as<uint32_t>(), h->nb_total,
+                                bucket_count, qbucket, qrank, h->stream));
   }
   unsigned long long* d_jstats = reinterpret_cast<unsigned long long*>(d_cnt + 10);
   uint32_t n_items = 0, n_slices = 1, jm = HS_JM_BLOCK;
@@ -1471,6 +1560,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
                                h->stream));
       HS_HIP(h, hipStreamSynchronize(h->stream));
     }
+    if (self_codes && unsafe) return fail(h, HS_ERR_STATE, "self-join from codes: a query row marked unsafe");
     if (use_i8 && unsafe && !can16) {
       // a query int8 cannot carry and no fp16 form for this k: the batch streams (below)
       use_i8 = false;
@@ -1520,7 +1610,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   // stream: the join's persistent waves take every register of every SIMD, so nothing runs beside
   // it anyway -- a kernel launched on a side stream first only delays the join's start (and one
   // launched later waits for the join's tail)
-  const bool thin8 = !brute && n_items && n_slices && use_i8 && !getenv("HS_NO_THIN8");
+  const bool thin8 = !brute && (n_items || self_codes) && n_slices && use_i8 && !getenv("HS_NO_THIN8");
   // without it (fp16 join, HS_NO_THIN8) the streaming filter and its tables go to the side stream
   const bool side = !brute && n_items && n_slices && !thin8;
   if (thin8) {
@@ -1539,7 +1629,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   uint32_t prov_cap = (uint32_t)std::max<size_t>(h->prov.cap / 8, std::max<size_t>(1u << 20, 16ull * nq));
   uint32_t host_cnt[24] = {0};  // [0] survivors [1] hits [2..3] candidates ... [10..13] join statistics [20] order fallback
   uint32_t host_proj[2] = {0, 0};  // MFMA projection of the queries: {slots reserved, values flagged}
-  const bool proj_stats = !brute && use_projection(h);
+  const bool proj_stats = !brute && !self_codes && use_projection(h);
   double ms_verify = 0, ms_final = 0, ms_join = 0;
   uint32_t launches = 0;
   for (;;) {  // retried only when a workspace capacity was exceeded
@@ -1628,7 +1718,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
         fin_list = h->prov2.as<uint2>();
         fin_count = d_cnt + 4;
       }
-      HS_HIP(h, hs_launch_finalize(h->tabs, h->codes.as<uint8_t>(), d_centers, h->coords.as<double>(),
+      HS_HIP(h, hs_launch_finalize(h->tabs, h->codes.as<uint8_t>(), d_centers, d_qcodes, h->coords.as<double>(),
                                    h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
                                    fin_list, fin_count, prov_cap, h->sorted_ql.as<uint32_t>(),
                                    k, L, r2, h->sqrt_test ? R : (double)NAN, q_base, h->self_first, d_cnt + 1,
@@ -1701,7 +1791,8 @@ static hs_status run_query(hs_handle* h, const double* d_centers, uint64_t nq, d
   *n_hits = 0;
   if (!h->built) return fail(h, HS_ERR_STATE, "hs_index_build has not been called");
   if (nq >= (1ull << 27)) return fail(h, HS_ERR_INVALID, "nq must be < 2^27 per call");
-  if (nq && !d_centers) return HS_ERR_INVALID;
+  // (a self-join that runs from the residue codes passes no centres)
+  if (nq && !d_centers && !(h->self_first != HS_NO_SELF && self_codes_ok(h, R))) return HS_ERR_INVALID;
   if (cap && (!d_hit_q || !d_hit_id || !d_hit_dist)) return HS_ERR_INVALID;
   if (!(R == R)) return fail(h, HS_ERR_INVALID, "R is NaN");
   hs_status st = ensure_device(h);
@@ -1724,7 +1815,7 @@ static hs_status run_query(hs_handle* h, const double* d_centers, uint64_t nq, d
       bout.table = d_hit_table ? d_hit_table + at : nullptr;
       bout.dist = d_hit_dist + at;
       bout.room = cap - at;
-      st = query_batch(h, d_centers + q0 * h->d, nqb, (uint32_t)q0, R, brute,
+      st = query_batch(h, d_centers ? d_centers + q0 * h->d : nullptr, nqb, (uint32_t)q0, R, brute,
                        d_cand ? d_cand + q0 * h->p.L : nullptr, &nh, cap ? &bout : nullptr);
       if (st) return st;
       if (nh && !bout.ordered) {
@@ -1848,10 +1939,15 @@ hs_status hs_self_join_range(hs_handle* h, uint64_t first, uint64_t count, doubl
   };
   for (uint64_t q0 = first; q0 < n; q0 += CH) {
     const uint64_t nq = std::min<uint64_t>(CH, n - q0);
-    HS_HIP(h, centers.reserve((size_t)nq * h->d * 8));
-    sj_lap("centers");
-    HS_HIP(h, hs_launch_embed(h->codes.as<uint8_t>() + q0 * h->p.k, nq, (int)h->p.k,
-                              h->coords.as<double>(), centers.as<double>(), h->stream));
+    // from the residue codes when every filter on the way can (query_batch's self_codes); embedded
+    // centres as for any other query otherwise
+    const bool from_codes = self_codes_ok(h, R);
+    if (!from_codes) {
+      HS_HIP(h, centers.reserve((size_t)nq * h->d * 8));
+      sj_lap("centers");
+      HS_HIP(h, hs_launch_embed(h->codes.as<uint8_t>() + q0 * h->p.k, nq, (int)h->p.k,
+                                h->coords.as<double>(), centers.as<double>(), h->stream));
+    }
     uint64_t hcap = std::max<uint64_t>(dq.cap / 4, 3 * nq + 1024), nh = 0;
     for (;;) {
       HS_HIP(h, dq.reserve(hcap * 4));
@@ -1860,7 +1956,7 @@ hs_status hs_self_join_range(hs_handle* h, uint64_t first, uint64_t count, doubl
       HS_HIP(h, dd.reserve(hcap * 8));
       h->sqrt_test = sqrt_test != 0;
       h->self_first = (uint32_t)q0;  // the pair of a k-mer with itself is dropped on the device
-      st = run_query(h, centers.as<double>(), nq, R, false, dq.as<uint32_t>(), did.as<uint32_t>(),
+      st = run_query(h, from_codes ? nullptr : centers.as<double>(), nq, R, false, dq.as<uint32_t>(), did.as<uint32_t>(),
                      dt.as<uint32_t>(), dd.as<double>(), hcap, &nh, nullptr);
       h->sqrt_test = false;
       h->self_first = HS_NO_SELF;

@@ -46,7 +46,6 @@ struct hs_cluster_state {
   // one L = 1 handle serves every table: new planes + rebuild (buffers, streams and events stay)
   hs_handle* h = nullptr;
   uint32_t built_table = 0xffffffffu;  // table h's index currently holds
-  std::vector<uint8_t> act_codes;
 };
 
 namespace {
@@ -135,17 +134,11 @@ extern "C" hs_status hs_clustering_table_edges(hs_cluster_state* st, uint32_t l,
   hs_handle* h = st->h;
   if (st->built_table != l) {  // a capacity retry of the same table finds its index still there
     st->built_table = 0xffffffffu;
-    const uint8_t* act = st->codes;  // nothing absorbed yet: the caller's array as it is
-    if (na != st->n) {
-      st->act_codes.resize(na * (size_t)k);
-      for (size_t t = 0; t < na; ++t)
-        memcpy(&st->act_codes[t * k], st->codes + (size_t)st->active[t] * k, k);
-      act = st->act_codes.data();
-    }
-    pt.lap("gather codes");
     rc = hs_set_planes(h, a_l, b_l);
     pt.lap("set planes");
-    if (rc == HS_OK) rc = hs_index_build(h, act, na);
+    // the k-mer codes stay on the device across tables; the active rows are gathered there
+    if (rc == HS_OK)
+      rc = hs_index_build_subset(h, st->codes, st->n, na != st->n ? st->active.data() : nullptr, na);
     pt.lap("index build");
     if (rc == HS_OK) st->built_table = l;
   }

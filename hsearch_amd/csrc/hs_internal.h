@@ -221,6 +221,8 @@ hipError_t hs_launch_klsh(const uint8_t* d_classes, const uint64_t* d_seq_start,
                           uint64_t* d_codes, uint64_t* d_uncertain, hipStream_t s);
 // d_out[d_perm[i]] = i
 hipError_t hs_launch_invert_perm(const uint32_t* d_perm, uint32_t n, uint32_t* d_out, hipStream_t s);
+hipError_t hs_launch_gather_rows(const uint8_t* d_all, const uint32_t* d_subset, uint64_t n_sub, int k,
+                                 uint8_t* d_out, hipStream_t s);
 // hs_index_load: checks of a table read from a file (see hs_validate_*_kernel); writes the inverse
 // permutation into d_pos_of, ORs failure bits into *d_flag, atomicMax of the bucket sizes into
 // *d_max_bucket
@@ -250,14 +252,22 @@ hipError_t hs_launch_seg_group(const hs_tables_dev& tabs, const uint32_t* d_dir_
                                size_t temp_bytes, const uint32_t* d_qbucket, const uint32_t* d_qrank,
                                uint32_t nql, uint32_t* d_sorted_ql, uint64_t* d_seg_key,
                                uint32_t* d_seg_cnt, uint32_t* d_n_seg, hipStream_t s);
+// self-join: query q = indexed k-mer first_id + q probes the bucket it sits in (no hash, no directory
+// search); outputs as hs_launch_probe
+hipError_t hs_launch_self_probe(const hs_tables_dev& tabs, uint32_t first_id, uint32_t nq, int L,
+                                uint32_t* d_qstart, uint32_t* d_qcount, uint32_t* d_nslices,
+                                uint64_t* d_cand_out, unsigned long long* d_cand_total,
+                                const uint32_t* d_dir_base, uint32_t nb_total, uint32_t* d_bucket_count,
+                                uint32_t* d_qbucket, uint32_t* d_qrank, hipStream_t s);
 hipError_t hs_launch_qtables(const double* d_centers, uint32_t nq, int k, const double* d_coords,
                              int alphabet, float* d_tq, hipStream_t s);
 hipError_t hs_launch_verify(const hs_tables_dev& tabs, const uint32_t* d_qstart,
                             const uint32_t* d_qcount, const uint32_t* d_slice_off, uint32_t nql,
                             const float* d_tq, int k, int L, float r2_hi, uint32_t* d_prov_count,
                             uint32_t prov_cap, uint2* d_prov, int n_blocks, hipStream_t s);
+// d_qcodes != null: the queries are indexed k-mers given as codes [nq][k] (self-join), d_centers unused
 hipError_t hs_launch_finalize(const hs_tables_dev& tabs, const uint8_t* d_codes,
-                              const double* d_centers, const double* d_coords,
+                              const double* d_centers, const uint8_t* d_qcodes, const double* d_coords,
                               const uint32_t* d_qstart, const uint32_t* d_qcount,
                               const uint2* d_prov, const uint32_t* d_prov_count, uint32_t prov_cap,
                               const uint32_t* d_sorted_ql, int k, int L, double r2, double r_sqrt,
@@ -328,6 +338,10 @@ hipError_t hs_launch_join(const uint4* d_desc, uint32_t n_items, const uint4* d_
 hipError_t hs_launch_jtables8(const double* d_coords, int alphabet, void* d_tab8, float* d_scale,
                               uint32_t* d_unsafe, void* d_tabR, hipStream_t s);
 // d_c8b (may be null): the second row per query (columns 4..7 + the refinement's scalars)
+// the same rows for queries that are k-mers given as codes (self-join): x^ from the tables, no doubles
+hipError_t hs_launch_qprep8_codes(const uint8_t* d_qcodes, uint32_t nq, int k, double r2, const double* d_coords,
+                                  const void* d_tab8, const void* d_tabR, const float* d_scale, void* d_c8,
+                                  void* d_c8b, hipStream_t s);
 hipError_t hs_launch_qprep8(const double* d_centers, uint32_t nq, int k, double r2,
                             const float* d_scale, void* d_c8, uint32_t* d_unsafe, void* d_c8b,
                             hipStream_t s);

@@ -249,6 +249,75 @@ __global__ __launch_bounds__(256) void hs_qprep8_kernel(const double* __restrict
   }
 }
 
+// The same two rows for a query that IS a k-mer of the coordinate table (self-join), from its codes:
+// x^ = the table's quantised rows (what the members carry), no saturation, norms from the table's
+// doubles.  One thread per query.
+__global__ __launch_bounds__(256) void hs_qprep8_codes_kernel(const uint8_t* __restrict__ qcodes, uint32_t nq,
+                                                              int k, double r2,
+                                                              const double* __restrict__ coords,
+                                                              const uint4* __restrict__ tab8,
+                                                              const uint4* __restrict__ tabR,
+                                                              const float* __restrict__ scale,
+                                                              int8_t* __restrict__ c8, int8_t* __restrict__ c8b) {
+  __shared__ uint32_t sA[32], sB[32], sL1[32];
+  __shared__ double sNA[32], sNB[32];
+  if (threadIdx.x < 32) {
+    const int aa = threadIdx.x;
+    sA[aa] = tab8[aa].x;
+    sB[aa] = tabR[aa].y;
+    sL1[aa] = tabR[aa].w;  // L1(x^ 0..3) | L1(x^ 4..7) << 16
+    double na = 0.0, nb = 0.0;
+    for (int j = 0; j < 8; ++j) {
+      const double v = coords[aa * 8 + j];
+      if (j < QD) na += v * v; else nb += v * v;
+    }
+    sNA[aa] = na;
+    sNB[aa] = nb;
+  }
+  __syncthreads();
+  const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nq) return;
+  const int ROW = 32 * ks_of(k), TAIL = ROW - 28;
+  const uint8_t* code = qcodes + (uint64_t)q * k;
+  uint32_t* outA = reinterpret_cast<uint32_t*>(c8 + (uint64_t)q * ROW);
+  uint32_t* outB = c8b ? reinterpret_cast<uint32_t*>(c8b + (uint64_t)q * ROW) : nullptr;
+  double ncA = 0.0, ncB = 0.0;
+  uint32_t l1A = 0, l1B = 0;
+  for (int p = 0; p < TAIL / 4; ++p) {
+    uint32_t a = 0u, b = 0u;
+    if (p < k) {
+      const uint32_t c = code[p] & 31u;
+      a = sA[c];
+      b = sB[c];
+      ncA += sNA[c];
+      ncB += sNB[c];
+      l1A += sL1[c] & 0xffffu;
+      l1B += sL1[c] >> 16;
+    }
+    outA[p] = a;
+    if (outB) outB[p] = b;
+  }
+  const double sAs = (double)scale[0];
+  // gamma as in hs_qprep8_kernel (no saturation penalty: table values quantise inside +-127)
+  const double g = floor(0.5 * sAs * sAs * (ncA - r2) - 0.5 * (double)l1A - 2.0);
+  int d[DIG + 1];
+  bool too_high = false;
+  digits127<DIG>(-(int)g, d, &too_high);  // a k-mer of the table never overflows (hs_qprep8_kernel's
+                                          // range checks are for arbitrary points); clamped if it did
+  int8_t* tail = c8 + (uint64_t)q * ROW + TAIL;
+  for (int i = 0; i < 28; ++i) tail[i] = i < RDIG ? (int8_t)-127 : i == RDIG ? (int8_t)-1 : i < 14 ? (int8_t)0 : (int8_t)d[i - 14];
+  if (outB) {
+    int8_t* tb = c8b + (uint64_t)q * ROW;
+    *reinterpret_cast<uint32_t*>(tb + ROW - 28) = 0u;
+    *reinterpret_cast<double*>(tb + ROW - 24) = (ncA + ncB) - r2;
+    const bool okB = scale[3] > 0.f && !too_high;
+    const float inf = __builtin_inff();
+    *reinterpret_cast<float*>(tb + ROW - 16) = okB ? __double2float_ru(0.5 * (double)l1A + 2.0) : inf;
+    *reinterpret_cast<float*>(tb + ROW - 12) = okB ? __double2float_ru(0.5 * (double)l1B + 2.0) : inf;
+    *reinterpret_cast<uint64_t*>(tb + ROW - 8) = 0ull;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ join
 template <int BIT>
 __device__ __forceinline__ uint32_t residue_at(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
@@ -1298,6 +1367,16 @@ hipError_t hs_launch_qprep8(const double* d_centers, uint32_t nq, int k, double 
   if (!nq) return hipSuccess;
   hs_qprep8_kernel<<<blocks_for(nq, 4), 256, 0, s>>>(d_centers, nq, k, r2, d_scale, (int8_t*)d_c8,
                                                      d_unsafe, (int8_t*)d_c8b);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_qprep8_codes(const uint8_t* d_qcodes, uint32_t nq, int k, double r2, const double* d_coords,
+                                  const void* d_tab8, const void* d_tabR, const float* d_scale, void* d_c8,
+                                  void* d_c8b, hipStream_t s) {
+  if (!nq) return hipSuccess;
+  hs_qprep8_codes_kernel<<<blocks_for(nq), 256, 0, s>>>(d_qcodes, nq, k, r2, d_coords, (const uint4*)d_tab8,
+                                                        (const uint4*)d_tabR, d_scale, (int8_t*)d_c8,
+                                                        (int8_t*)d_c8b);
   return hipGetLastError();
 }
 

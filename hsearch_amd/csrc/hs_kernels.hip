@@ -432,6 +432,54 @@ __global__ __launch_bounds__(256) void hs_probe_kernel(hs_tables_dev tabs,
   }
 }
 
+// Self-join: query q IS the indexed k-mer first_id + q, so the bucket it probes in table l is the
+// bucket it sits in -- found from its sorted position (pos_of) by a binary search over the bucket
+// boundaries, no hashing and no directory lookup.  Same outputs as hs_probe_kernel.
+__global__ __launch_bounds__(256) void hs_self_probe_kernel(hs_tables_dev tabs, uint32_t first_id, uint32_t nq,
+                                                            int L, uint32_t* __restrict__ qstart,
+                                                            uint32_t* __restrict__ qcount,
+                                                            uint32_t* __restrict__ nslices,
+                                                            uint64_t* __restrict__ cand_out,
+                                                            unsigned long long* __restrict__ cand_total,
+                                                            const uint32_t* __restrict__ dir_base,
+                                                            uint32_t* __restrict__ bucket_count,
+                                                            uint32_t* __restrict__ qbucket,
+                                                            uint32_t* __restrict__ qrank) {
+  const uint32_t ql = blockIdx.x * 256 + threadIdx.x;
+  uint32_t count = 0;
+  if (ql < nq * (uint32_t)L) {
+    const uint32_t q = ql / (uint32_t)L;
+    const int l = (int)(ql % (uint32_t)L);
+    const hs_table_dev& tb = tabs.t[l];
+    const uint32_t p = tb.pos_of[first_id + q];
+    uint32_t lo = 0, hi = tb.nb;  // largest b with dir_start[b] <= p
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (tb.dir_start[mid] <= p) lo = mid; else hi = mid;
+    }
+    const uint32_t start = tb.dir_start[lo];
+    count = tb.dir_start[lo + 1] - start;
+    qstart[ql] = start;
+    qcount[ql] = count;
+    nslices[ql] = (count + HS_SLICE - 1) / HS_SLICE;
+    if (cand_out) cand_out[ql] = count;
+    if (bucket_count) {
+      const uint32_t gb = dir_base[l] + lo;
+      qbucket[ql] = gb;
+      qrank[ql] = atomicAdd(&bucket_count[gb], 1u);
+    }
+  }
+  unsigned long long c = count;
+  for (int off = 32; off; off >>= 1) c += __shfl_xor(c, off);
+  __shared__ unsigned long long s_c[4];
+  if (lane_id() == 0) s_c[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long t = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+    if (t) atomicAdd(cand_total, t);
+  }
+}
+
 // Rare path: HashKey STRING equality (lsh.hpp:51-59) between the query's tuple and the tuple of
 // the bucket with the same fingerprint.
 __global__ __launch_bounds__(256) void hs_probe_slow_kernel(hs_tables_dev tabs,
@@ -701,9 +749,14 @@ __device__ __forceinline__ double exact_dist2(const uint8_t* __restrict__ row,
 // ascending inside a bucket, so membership in an earlier table's bucket is a binary search;
 // (2) exact fp64 d2 and the reference's test d2 <= R*R (:239); (3) emit (q, table, id) key +
 // sqrt(d2) (:241) for the ordering pass.
+// SELF: the queries are indexed k-mers themselves (the self-join of Clustering()): their centre rows
+// are rows of the coordinate table, taken from qcodes [nq][k] -- the same doubles an embedded centre
+// row would hold, in the same operation order -- instead of a materialised [nq][8k] array.
+template <bool SELF>
 __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
                                                           const uint8_t* __restrict__ codes,
                                                           const double* __restrict__ centers,
+                                                          const uint8_t* __restrict__ qcodes,
                                                           const double* __restrict__ coords,
                                                           const uint32_t* __restrict__ qstart,
                                                           const uint32_t* __restrict__ qcount,
@@ -750,24 +803,44 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
       const uint8_t* code = codes + (uint64_t)id * k;
       uint8_t* dst = &s_code[wave][lane * 76];
       for (int p = 0; p < k; ++p) dst[p] = code[p];
+      if constexpr (SELF) {
+        const uint8_t* qc = qcodes + (uint64_t)q * k;
+        uint8_t* qd = stage + lane * 76;  // SELF: no centre rows to stage, the area holds the queries' codes
+        for (int p = 0; p < k; ++p) qd[p] = qc[p];
+      }
     }
     // piece = 16 B: lane fetches pieces lane, lane + 64, ... of the wave's 64 x 64-byte block
     const int row0 = lane >> 2, part = lane & 3;
-    const double2* src0 = reinterpret_cast<const double2*>(centers + (uint64_t)s_q[wave][row0] * 8 * k) + part;
-    const double2* src1 = reinterpret_cast<const double2*>(centers + (uint64_t)s_q[wave][row0 + 16] * 8 * k) + part;
-    const double2* src2 = reinterpret_cast<const double2*>(centers + (uint64_t)s_q[wave][row0 + 32] * 8 * k) + part;
-    const double2* src3 = reinterpret_cast<const double2*>(centers + (uint64_t)s_q[wave][row0 + 48] * 8 * k) + part;
+    const double* cbase = SELF ? s_coords : centers;  // SELF: no centre rows to stage (addresses unused)
+    const uint64_t rs = SELF ? 0 : (uint64_t)8 * k;
+    const double2* src0 = reinterpret_cast<const double2*>(cbase + (uint64_t)s_q[wave][row0] * rs) + part;
+    const double2* src1 = reinterpret_cast<const double2*>(cbase + (uint64_t)s_q[wave][row0 + 16] * rs) + part;
+    const double2* src2 = reinterpret_cast<const double2*>(cbase + (uint64_t)s_q[wave][row0 + 32] * rs) + part;
+    const double2* src3 = reinterpret_cast<const double2*>(cbase + (uint64_t)s_q[wave][row0 + 48] * rs) + part;
     double2* const st0 = reinterpret_cast<double2*>(&stage[row0 * ROWB + part * 16]);
     double2* const st1 = reinterpret_cast<double2*>(&stage[(row0 + 16) * ROWB + part * 16]);
     double2* const st2 = reinterpret_cast<double2*>(&stage[(row0 + 32) * ROWB + part * 16]);
     double2* const st3 = reinterpret_cast<double2*>(&stage[(row0 + 48) * ROWB + part * 16]);
     // two positions in flight ahead of the one being summed (4 double2 per position of a row;
     // positions past the end re-read the last one: loads stay unconditional)
+    double d2 = 0.0;
+    if constexpr (SELF) {
+      __builtin_amdgcn_wave_barrier();
+      for (int p = 0; p < k; ++p) {
+        // exact left-to-right fp64, one rounding per operation (PairwiseDistance hclust2.cpp:64-71)
+        const double* xc = s_coords + (int)s_code[wave][lane * 76 + p] * 8;
+        const double* cc = s_coords + (int)stage[lane * 76 + p] * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const double r = __dsub_rn(xc[j], cc[j]);
+          d2 = __dadd_rn(d2, __dmul_rn(r, r));
+        }
+      }
+    } else {
     const int last = 4 * (k - 1);
     double2 n0 = src0[0], n1 = src1[0], n2 = src2[0], n3 = src3[0];
     const int o1 = min(4, last);
     double2 m0 = src0[o1], m1 = src1[o1], m2 = src2[o1], m3 = src3[o1];
-    double d2 = 0.0;
     for (int p = 0; p < k; ++p) {
       *st0 = n0;
       *st1 = n1;
@@ -798,6 +871,7 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
         const double r = __dsub_rn(xc[j], c[j]);
         d2 = __dadd_rn(d2, __dmul_rn(r, r));
       }
+    }
     }
     // Search(): d2 <= R*R (motif_both_points.cpp:239); Clustering(): sqrt(d2) <= R
     // (hclust2.cpp:64-71,119-120), selected by a non-NaN r_sqrt.
@@ -1009,7 +1083,7 @@ __global__ __launch_bounds__(256) void hs_bf_finalize_kernel(const uint8_t* __re
 // every query orders its own few hits by (table of first sight, id) and writes them out -- the
 // reference's file order (motif_both_points.cpp:224-245).  A query with more than HS_ORDER_MAX hits
 // raises *big instead (the caller then falls back to the radix sort over the whole list).
-#define HS_ORDER_MAX 48u
+#define HS_ORDER_MAX 128u
 __global__ __launch_bounds__(256) void hs_hit_place_kernel(const uint64_t* __restrict__ key,
                                                            const uint64_t* __restrict__ val,
                                                            const uint32_t* __restrict__ hit_count,
@@ -1234,6 +1308,23 @@ hipError_t hs_launch_probe(const hs_tables_dev& tabs, const int32_t* d_qints, ui
   return hipGetLastError();
 }
 
+hipError_t hs_launch_self_probe(const hs_tables_dev& tabs, uint32_t first_id, uint32_t nq, int L,
+                                uint32_t* d_qstart, uint32_t* d_qcount, uint32_t* d_nslices,
+                                uint64_t* d_cand_out, unsigned long long* d_cand_total,
+                                const uint32_t* d_dir_base, uint32_t nb_total, uint32_t* d_bucket_count,
+                                uint32_t* d_qbucket, uint32_t* d_qrank, hipStream_t s) {
+  if (!nq) return hipSuccess;
+  if (d_bucket_count) {
+    hipError_t e = hipMemsetAsync(d_bucket_count, 0, ((size_t)nb_total + 2) * 4, s);
+    if (e != hipSuccess) return e;
+  }
+  hs_self_probe_kernel<<<blocks_for((uint64_t)nq * L), 256, 0, s>>>(tabs, first_id, nq, L, d_qstart, d_qcount,
+                                                                    d_nslices, d_cand_out, d_cand_total,
+                                                                    d_dir_base, d_bucket_count, d_qbucket,
+                                                                    d_qrank);
+  return hipGetLastError();
+}
+
 hipError_t hs_launch_qtables(const double* d_centers, uint32_t nq, int k, const double* d_coords,
                              int alphabet, float* d_tq, hipStream_t s) {
   if (!nq) return hipSuccess;
@@ -1280,19 +1371,25 @@ hipError_t hs_launch_bruteforce(const uint4* d_packed_all, uint32_t n, const flo
 }
 
 hipError_t hs_launch_finalize(const hs_tables_dev& tabs, const uint8_t* d_codes,
-                              const double* d_centers, const double* d_coords,
+                              const double* d_centers, const uint8_t* d_qcodes, const double* d_coords,
                               const uint32_t* d_qstart, const uint32_t* d_qcount,
                               const uint2* d_prov, const uint32_t* d_prov_count, uint32_t prov_cap,
                               const uint32_t* d_sorted_ql, int k, int L, double r2, double r_sqrt,
                               uint32_t q_base, uint32_t self_first, uint32_t* d_hit_count,
-                              uint32_t hit_cap, uint64_t* d_hit_key, uint64_t* d_hit_val, uint32_t* d_qcnt, hipStream_t s) {
-  hs_finalize_kernel<<<1024, 256, 0, s>>>(tabs, d_codes, d_centers, d_coords, d_qstart, d_qcount,
-                                          d_prov, d_prov_count, prov_cap, d_sorted_ql, k, L, r2,
-                                          r_sqrt, q_base, self_first,
-                                          d_hit_count, hit_cap, d_hit_key, d_hit_val, d_qcnt);
+                              uint32_t hit_cap, uint64_t* d_hit_key, uint64_t* d_hit_val, uint32_t* d_qcnt,
+                              hipStream_t s) {
+  if (d_qcodes)  // the queries are indexed k-mers: centre rows from the coordinate table
+    hs_finalize_kernel<true><<<1024, 256, 0, s>>>(tabs, d_codes, nullptr, d_qcodes, d_coords, d_qstart, d_qcount,
+                                                  d_prov, d_prov_count, prov_cap, d_sorted_ql, k, L, r2,
+                                                  r_sqrt, q_base, self_first, d_hit_count, hit_cap,
+                                                  d_hit_key, d_hit_val, d_qcnt);
+  else
+    hs_finalize_kernel<false><<<1024, 256, 0, s>>>(tabs, d_codes, d_centers, nullptr, d_coords, d_qstart,
+                                                   d_qcount, d_prov, d_prov_count, prov_cap, d_sorted_ql, k, L,
+                                                   r2, r_sqrt, q_base, self_first, d_hit_count, hit_cap,
+                                                   d_hit_key, d_hit_val, d_qcnt);
   return hipGetLastError();
 }
-
 hipError_t hs_launch_hit_order(const uint64_t* d_key, const uint64_t* d_val, const uint32_t* d_hit_count,
                                uint32_t hit_cap, uint32_t q_base, uint32_t nq, const uint32_t* d_qoff,
                                uint32_t* d_qfill, uint64_t* d_key2, uint64_t* d_val2, uint32_t* d_big,
@@ -1334,6 +1431,23 @@ hipError_t hs_launch_dir_jump(const uint64_t* d_dir_key, uint32_t nb, uint32_t s
 hipError_t hs_launch_invert_perm(const uint32_t* d_perm, uint32_t n, uint32_t* d_out, hipStream_t s) {
   if (!n) return hipSuccess;
   hs_invert_perm_kernel<<<blocks_for(n), 256, 0, s>>>(d_perm, n, d_out);
+  return hipGetLastError();
+}
+
+// out[i][0..k) = all[subset[i]][0..k)  (subset == null: identity); one thread per byte
+__global__ __launch_bounds__(256) void hs_gather_rows_kernel(const uint8_t* __restrict__ all,
+                                                             const uint32_t* __restrict__ subset, uint64_t n_sub,
+                                                             int k, uint8_t* __restrict__ out) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_sub * (uint64_t)k) return;
+  const uint64_t i = t / (uint64_t)k;
+  const int p = (int)(t - i * (uint64_t)k);
+  out[t] = all[(uint64_t)(subset ? subset[i] : (uint32_t)i) * k + p];
+}
+hipError_t hs_launch_gather_rows(const uint8_t* d_all, const uint32_t* d_subset, uint64_t n_sub, int k,
+                                 uint8_t* d_out, hipStream_t s) {
+  if (!n_sub) return hipSuccess;
+  hs_gather_rows_kernel<<<blocks_for(n_sub * (uint64_t)k), 256, 0, s>>>(d_all, d_subset, n_sub, k, d_out);
   return hipGetLastError();
 }
 

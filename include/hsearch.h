@@ -153,6 +153,15 @@ HS_API int hs_key_strings_equal(const int32_t* x, const int32_t* y, uint32_t K);
  * The DB is kept as residue codes (k bytes per k-mer), never as 8k doubles. */
 HS_API hs_status hs_index_build(hs_handle* h, const uint8_t* codes, uint64_t n);
 
+/* Index over a SUBSET of a code array that stays the same across calls -- what BuildLSHTalbe does
+ * per table inside Clustering() (hclust2.cpp:74-84: the k-mers with merged != 2).  codes_all
+ * [n_all][k] crosses PCIe on the first call with this (pointer, n_all) and is kept on the device
+ * (the caller must not change it while it keeps calling; a call with another pointer or n_all
+ * replaces the copy); every call gathers the rows subset[0 .. n_subset) on the device -- DB id i of
+ * the new index = row subset[i]; subset == NULL means all rows in order -- and builds the index. */
+HS_API hs_status hs_index_build_subset(hs_handle* h, const uint8_t* codes_all, uint64_t n_all,
+                                       const uint32_t* subset, uint64_t n_subset);
+
 /* SURVEY 8(f) row 1 -- k-mer enumeration on the device.  The DB is every length-k window of every
  * sequence of one concatenated residue-code buffer: sequence s occupies residues[seq_start[s] ..
  * seq_start[s+1]), seq_start has n_seq + 1 ascending entries ending at n_residues.  Windows are

@@ -1,7 +1,8 @@
 """hs_clustering at config 4, twice (the second run is the warm one); for rocprofv3."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hsearch_amd
 from hsearch_amd import synth
 k, K, L, W, R, n = 25, 16, 8, 200.0, 40.0, 1_000_000
