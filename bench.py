@@ -12,9 +12,9 @@ the queries already resident in HBM.  N > 1: one process per GPU, index replicat
 sharded (weak scaling: 100 k queries per GPU), hits all-gathered.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel over its HIP-event time
-(events on the library's stream): with the bucket join on (the default) that is hs_join8w_kernel,
-an int8 MFMA GEMM of depth 128 per (bucket member, probing query) pair, against the dense int8 MFMA
-peak; with --verify-mode stream (and wherever no join runs) it is hs_verify_kernel, priced by the
+(events on the library's stream): with the bucket join on (the default) that is hs_join8x_kernel
+(k = 21..25; hs_join8w_kernel for k <= 20 and k = 26..50), an int8 MFMA GEMM of depth 128 (192 for
+k <= 20 and 26..41, 256 for k <= 50) per (bucket member, probing query) pair, against the dense int8 MFMA peak; with --verify-mode stream (and wherever no join runs) it is hs_verify_kernel, priced by the
 ALGORITHMIC bytes of SURVEY.md 8(d) against 8 TB/s.  `roofline.traffic` = measured HBM bytes per
 launch from profiles/traffic_latest.json, reported only while that file's recorded kernel source
 hash equals the hash of the kernel source this run was built from.  `cpu_baseline` times the
@@ -39,7 +39,29 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 JOIN_K = 112.0     # GEMM depth of hs_join_kernel (fp16)
-JOIN_K_I8 = 128.0  # GEMM depth of hs_join8w_kernel (int8)
+
+
+def wide_rows(k):
+    """Short k-mers: int8 rows over all 8 coordinate columns (hs_capi.hip: HS_WIDE_MAX_K, default 20)."""
+    return k <= min(20, int(os.environ.get("HS_WIDE_MAX_K", "20")))
+
+
+def join_i8_depth(k):
+    """GEMM depth of the int8 join (hs_join8.hip ks_of): 32-byte k-steps x 4 / 6 / 8."""
+    if wide_rows(k):
+        return 192.0
+    return 128.0 if k <= 25 else 192.0 if k <= 41 else 256.0
+
+
+def join_i8_kernel(k):
+    """Which int8 join kernel hs_launch_join8w starts (hs_join8.hip)."""
+    if wide_rows(k):
+        return "hs_join8w_kernel<2,6,wide>"
+    if k > 25:
+        return "hs_join8w_kernel<2,%d>" % (6 if k <= 41 else 8)
+    return "hs_join8w_kernel<4,4>" if os.environ.get("HS_JOIN_SHAPE") == "32" else "hs_join8x_kernel"
+
+
 MFMA_I8_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md: I8 MFMA = 2x the BF16 rate per clock
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
 
@@ -362,16 +384,17 @@ def main():
                 traffic = None
         if join_batches:
             # dominant kernel = the bucket join: an int8 MFMA GEMM of depth 128 (25 positions x 4
-            # coordinates + 28 threshold-digit slots; hs_join8.hip) -- or, when a batch had to fall
+            # coordinates + 28 threshold-digit slots; 192 / 256 for k = 26..41 / 42..50;
+            # hs_join8.hip) -- or, when a batch had to fall
             # back, the fp16 form of depth 112 (hs_join.hip) -- per (bucket member, probing query)
             # pair: 2 * depth operations per pair.
             j_ms = join_ms / steps
             i8 = join_i8 > 0
-            jk = JOIN_K_I8 if i8 else JOIN_K
+            jk = join_i8_depth(k) if i8 else JOIN_K
             peak = MFMA_I8_PEAK_TOPS if i8 else MFMA_F16_PEAK_TFLOPS
             flop = jstat[1] * 2.0 * jk          # real (member, query) pairs routed to the join
             tf = flop / (j_ms * 1e-3) / 1e12 if j_ms > 0 else 0.0
-            roofline = {"bound": "mfma", "kernel": "hs_join8w_kernel" if i8 else "hs_join_kernel",
+            roofline = {"bound": "mfma", "kernel": join_i8_kernel(k) if i8 else "hs_join_kernel",
                         "mfma_dtype": "i8" if i8 else "f16", "gemm_depth": jk, "achieved": tf,
                         "peak": peak, "unit": "TOP/s" if i8 else "TFLOP/s",
                         "frac": tf / peak, "traffic": traffic, "traffic_source": traffic_src,

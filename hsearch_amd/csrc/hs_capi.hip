@@ -118,7 +118,9 @@ struct hs_handle {
   DevBuf c16s, item_desc, probe_slow, jtab8, slice_ql, qhits;  // qhits: per-query hit counts, offsets, fill
   DevBuf c8b, prov2;  // survivor refinement: second int8 row per query, the refined survivor list
   bool join8_tables_ok = false;  // int8 can carry the coordinate table
-  double join8_scale = 0.0;      // its quantisation scale s (scale[0] of jtab8)
+  double join8_scale = 0.0;      // its quantisation scale s (scale[0] of jtab8; scale[4] with wide rows)
+  uint32_t test_split_above = 0; // HS_TEST_SPLIT_ABOVE (tests): batches above this size report a survivor overflow
+  bool wide8 = false;            // short k-mers: int8 rows over all 8 coordinate columns (hs_join8.hip)
   // segment routing thresholds (HS_JOIN_MIN_Q / _M): segments with fewer probing queries or members
   // go to the per-pair filters instead of the join.  1 / 1 = everything through the join: its
   // persistent waves leave no room for a kernel beside it, and the per-pair filter run before it
@@ -432,16 +434,23 @@ hs_status hs_create(const hs_params* params, const double* a, const double* b, c
   // ... refinement table {x^ 0..3, x^ 4..7, |x|^2, L1s} x 32 at bytes 1024..1535, scale[2..3] = its s, ok
   HS_HIP(h, h->jtab8.reserve(2048));
   HS_HIP(h, hipMemsetAsync(h->jtab8.p, 0, 2048, h->stream));
+  // ... the 8-column one-scale table of the wide rows (short k-mers) at bytes 1536..2047, scale[4..6]
   HS_HIP(h, hs_launch_jtables8(h->coords.as<double>(), h->alphabet, h->jtab8.p, h->jtab8.as<float>() + 128,
                                reinterpret_cast<uint32_t*>(h->jtab8.as<char>() + 640),
-                               h->jtab8.as<char>() + 1024, h->stream));
+                               h->jtab8.as<char>() + 1024, h->jtab8.as<char>() + 1536, h->stream));
   uint32_t unsafe8 = 1;
-  float scale8 = 0.f;
+  float scale8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   HS_HIP(h, hipMemcpyAsync(&unsafe8, h->jtab8.as<char>() + 640, 4, hipMemcpyDeviceToHost, h->stream));
-  HS_HIP(h, hipMemcpyAsync(&scale8, h->jtab8.as<char>() + 512, 4, hipMemcpyDeviceToHost, h->stream));
+  HS_HIP(h, hipMemcpyAsync(scale8, h->jtab8.as<char>() + 512, 32, hipMemcpyDeviceToHost, h->stream));
   HS_HIP(h, hipStreamSynchronize(h->stream));
   h->join8_tables_ok = (unsafe8 == 0);
-  h->join8_scale = (double)scale8;
+  // Short k-mers: R^2 is not far below the 4-column distance of bucket mates any more (k = 15: the
+  // 4-column bound passes 4 % of random pairs), so their rows carry all 8 columns (hs_join8.hip)
+  int wide_max_k = 20;
+  if (const char* m = getenv("HS_WIDE_MAX_K")) wide_max_k = std::min(20, atoi(m));
+  if (const char* m = getenv("HS_TEST_SPLIT_ABOVE")) h->test_split_above = (uint32_t)std::max(0, atoi(m));
+  h->wide8 = h->join8_tables_ok && scale8[6] > 0.f && (int)h->p.k <= wide_max_k;
+  h->join8_scale = (double)scale8[h->wide8 ? 4 : 0];
   if (const char* m = getenv("HS_HASH_MODE")) {
     if (!strcmp(m, "exact")) h->hash_mode = 1;
     if (!strcmp(m, "mfma")) h->hash_mode = 2;
@@ -773,7 +782,8 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
     HS_HIP(h, hipEventRecord(h->ev[2], h->stream));
     if (with_rec8)
       HS_HIP(h, hs_launch_gather_rec8(h->packed_all.as<uint4>(), h->t_ids[l].as<uint32_t>(), (uint32_t)n,
-                                      k, h->jtab8.p, h->jtab8.as<float>() + 128, tab_packed,
+                                      k, h->wide8, h->jtab8.p, h->jtab8.as<char>() + 1536,
+                                      h->jtab8.as<float>() + 128, tab_packed,
                                       h->t_rec8.as<uint4>() + (size_t)l * n, h->stream));
     else
       HS_HIP(h, hs_launch_gather_packed(h->packed_all.as<uint4>(), h->t_ids[l].as<uint32_t>(), n, PW,
@@ -1275,7 +1285,8 @@ hs_status hs_index_load(hs_handle* h, const char* path) {
     }
     if (with_rec8)
       HS_HIP(h, hs_launch_gather_rec8(h->packed_all.as<uint4>(), h->t_ids[l].as<uint32_t>(), (uint32_t)n,
-                                      k, h->jtab8.p, h->jtab8.as<float>() + 128, tab_packed,
+                                      k, h->wide8, h->jtab8.p, h->jtab8.as<char>() + 1536,
+                                      h->jtab8.as<float>() + 128, tab_packed,
                                       h->t_rec8.as<uint4>() + (size_t)l * n, h->stream));
     else
       HS_HIP(h, hs_launch_gather_packed(h->packed_all.as<uint4>(), h->t_ids[l].as<uint32_t>(), n, PW,
@@ -1397,7 +1408,10 @@ struct BatchOut {
   bool ordered = false;
 };
 
-// Counters block (h->counters): [0] prov_count u32, [1] hit_count u32, [2..3] cand_total u64.
+// Counters block (h->counters): [0] prov_count u32, [1] hit_count u32, [2..3] cand_total u64, ...,
+// [20] hits not ordered on the device, [21] HS_CNT_SURVIVOR_OVERFLOW, [32] the join's item counter.
+// Internal status: the batch's filters passed more pairs than the 32-bit survivor counter holds.
+static const hs_status HS_SPLIT_BATCH = (hs_status)1000;
 // May a self-join at radius R run from the residue codes alone (query_batch's self_codes)?  Only when
 // nothing on its way can need the embedded centres: the int8 join and its thin-segment filter must
 // apply, and no query row may be unrepresentable -- for a k-mer of the coordinate table the one way
@@ -1407,8 +1421,8 @@ static bool self_codes_ok(const hs_handle* h, double R) {
   if (!h->join8_tables_ok || h->p.k > 50 || h->verify_mode == 1 || h->verify_mode == 3 || !(r2 < 30000.0))
     return false;
   if (getenv("HS_NO_THIN8") || getenv("HS_NO_SELF_CODES")) return false;
-  // -gamma <= s^2 R^2 / 2 + L1(c^)/2 + 3, L1(c^) <= 127 * 4 k
-  return s > 0.0 && 0.5 * s * s * r2 + 254.0 * k + 3.0 < 127.0 * 127.0 * 13.0;
+  // -gamma <= s^2 R^2 / 2 + L1(c^)/2 + 3, L1(c^) <= 127 * 4 k (127 * 8 k with wide rows)
+  return s > 0.0 && 0.5 * s * s * r2 + (h->wide8 ? 508.0 : 254.0) * k + 3.0 < 127.0 * 127.0 * 13.0;
 }
 
 static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq, uint32_t q_base,
@@ -1430,7 +1444,10 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   bool use_i8 = use_join && can8;
   // survivors of the int8 join's 4-column bound pass an 8-column int8 bound before the exact
   // decision (hs_refine8_kernel); HS_NO_REFINE8 switches it off
-  const bool refine = use_i8 && !getenv("HS_NO_REFINE8");
+  // (wide rows already hold all 8 columns: nothing to refine)
+  const int wide = h->wide8 ? 1 : 0;
+  const void* const jtab_rows = wide ? (const void*)(h->jtab8.as<char>() + 1536) : (const void*)h->jtab8.p;
+  const bool refine = use_i8 && !wide && !getenv("HS_NO_REFINE8");
   uint32_t* d_unsafe = d_cnt + 8;
   // Self-join (the queries are the indexed k-mers self_first + q_base ..): every per-query quantity
   // comes from the residue codes and the tables -- no embedded centres, no hashing, no directory
@@ -1443,15 +1460,16 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     // the join filter's query rows depend on the centres only: quantised on the side stream while
     // the main stream hashes and probes (both passes stream the same 8d bytes per query)
     HS_HIP(h, h->c16.reserve((size_t)nq * 208 * 2));
-    if (refine) HS_HIP(h, h->c8b.reserve((size_t)nq * hs_join8_row_bytes(k)));
+    if (refine) HS_HIP(h, h->c8b.reserve((size_t)nq * hs_join8_row_bytes(k, wide)));
     HS_HIP(h, hipEventRecord(h->evx[EV_FORK], h->stream));
     HS_HIP(h, hipStreamWaitEvent(h->stream2, h->evx[EV_FORK], 0));
     if (self_codes)
-      HS_HIP(h, hs_launch_qprep8_codes(d_qcodes, nq, k, r2, h->coords.as<double>(), h->jtab8.p,
-                                       h->jtab8.as<char>() + 1024, h->jtab8.as<float>() + 128, h->c16.p,
-                                       refine ? h->c8b.p : nullptr, h->stream2));
+      HS_HIP(h, hs_launch_qprep8_codes(d_qcodes, nq, k, wide, r2, h->coords.as<double>(), h->jtab8.p,
+                                       h->jtab8.as<char>() + 1024, h->jtab8.as<char>() + 1536,
+                                       h->jtab8.as<float>() + 128, h->c16.p, refine ? h->c8b.p : nullptr,
+                                       h->stream2));
     else if (use_i8)
-      HS_HIP(h, hs_launch_qprep8(d_centers, nq, k, r2, h->jtab8.as<float>() + 128, h->c16.p, d_unsafe,
+      HS_HIP(h, hs_launch_qprep8(d_centers, nq, k, wide, r2, h->jtab8.as<float>() + 128, h->c16.p, d_unsafe,
                                  refine ? h->c8b.p : nullptr, h->stream2));
     else
       HS_HIP(h, hs_launch_qprep(d_centers, nq, k, r2, h->c16.p, d_unsafe, h->stream2));
@@ -1529,11 +1547,11 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, h->seg_cnt.as<uint32_t>(),
                                     h->seg_qoff.as<uint32_t>(), n1, h->stream));
     // work items: one wave's 128 members for the wave-independent int8 join, 512 otherwise
-    jm = use_i8 ? hs_join8_members_per_item(k) : HS_JM_BLOCK;
+    jm = use_i8 ? hs_join8_members_per_item(k, wide) : HS_JM_BLOCK;
     HS_CHECK(cut_items(h, nql, jm, d_jstats));
     if (use_i8)
       HS_HIP(h, hs_launch_gather_c8t(h->c16.p, h->sorted_ql.as<uint32_t>(), h->seg_qoff.as<uint32_t>(),
-                                     nql, L, k, h->c16s.p, h->stream));
+                                     nql, L, k, wide, h->c16s.p, h->stream));
     else
       HS_HIP(h, hs_launch_gather_c16(h->c16.p, h->sorted_ql.as<uint32_t>(), nql, L, h->c16s.p, h->stream));
   }
@@ -1656,9 +1674,9 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, hipEventRecord(h->ev[3], h->stream));
     if (launches) HS_HIP(h, hipMemsetAsync(d_cnt + 32, 0, 4, h->stream));  // retry: the item counter again
     if (thin8)
-      HS_HIP(h, hs_launch_thin8(h->tabs, h->t_rec8.as<uint4>(), h->n, h->c16.p, h->jtab8.p,
+      HS_HIP(h, hs_launch_thin8(h->tabs, h->t_rec8.as<uint4>(), h->n, h->c16.p, jtab_rows,
                                 h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
-                                h->slice_off.as<uint32_t>(), h->slice_ql.as<uint32_t>(), nql, L, k, d_cnt,
+                                h->slice_off.as<uint32_t>(), h->slice_ql.as<uint32_t>(), nql, L, k, wide, d_cnt,
                                 prov_cap, h->prov.as<uint2>(), n_blocks, h->stream));
     if (side) {
       HS_HIP(h, hipEventRecord(h->evx[EV_FORK], h->stream));
@@ -1680,7 +1698,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
       HS_HIP(h, hipEventRecord(h->ev[11], h->stream));  // the join kernel alone: ev[11] .. ev[10]
       if (n_items && use_i8)
         HS_HIP(h, hs_launch_join8w(h->item_desc.as<uint4>(), n_items, h->tabs.t[0].packed,
-                                   h->t_rec8.as<uint4>(), h->c16s.p, h->jtab8.p, k, d_cnt, prov_cap,
+                                   h->t_rec8.as<uint4>(), h->c16s.p, jtab_rows, k, wide, d_cnt, prov_cap,
                                    h->prov.as<uint2>(), d_cnt + 32, h->n_cu * h->join_blocks_per_cu,
                                    async_items ? h->item_off.as<uint32_t>() + nql : nullptr, h->stream));
       else if (n_items)
@@ -1740,6 +1758,10 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
       HS_HIP(h, hipMemcpyAsync(&n_items_real, h->item_off.as<uint32_t>() + nql, 4, hipMemcpyDeviceToHost,
                                h->stream));
     HS_HIP(h, hipStreamSynchronize(h->stream));
+    // > ~4e9 survivors: run_query halves the batch (HS_TEST_SPLIT_ABOVE=n: as if every batch of more
+    // than n queries had overflowed -- the tests' handle on the splitting logic)
+    if (host_cnt[HS_CNT_SURVIVOR_OVERFLOW] || (h->test_split_above && nq > h->test_split_above))
+      return HS_SPLIT_BATCH;
     if (async_items && (host_cnt[8] /* join legality */ || n_items_real > n_items))
       return query_batch(h, d_centers, nq, q_base, R, brute, d_cand, n_batch_hits, bout, false);
     ms_verify += ev_ms(h, 3, 4);
@@ -1804,9 +1826,11 @@ static hs_status run_query(hs_handle* h, const double* d_centers, uint64_t nq, d
   if (nq && h->n && !(brute && R < 0)) {
     // queries per batch: bounds the workspace, which grows with nq * L (2^17 at L >= 8; with few
     // tables -- the one-table indexes of Clustering() -- larger batches, fewer fixed costs)
-    const uint32_t QB = std::max(1u << 17, std::min(1u << 20, (1u << 20) / h->p.L));
-    for (uint64_t q0 = 0; q0 < nq; q0 += QB) {
-      const uint32_t nqb = (uint32_t)std::min<uint64_t>(QB, nq - q0);
+    uint32_t QB = std::max(1u << 17, std::min(1u << 20, (1u << 20) / h->p.L));
+    if (const char* m = getenv("HS_QUERY_BATCH")) QB = (uint32_t)std::max(1, atoi(m));  // tests
+    uint32_t nqb = 0;
+    for (uint64_t q0 = 0; q0 < nq; q0 += nqb) {
+      nqb = (uint32_t)std::min<uint64_t>(QB, nq - q0);
       uint32_t nh = 0;
       BatchOut bout;
       const uint64_t at = std::min<uint64_t>(total, cap);
@@ -1817,6 +1841,14 @@ static hs_status run_query(hs_handle* h, const double* d_centers, uint64_t nq, d
       bout.room = cap - at;
       st = query_batch(h, d_centers ? d_centers + q0 * h->d : nullptr, nqb, (uint32_t)q0, R, brute,
                        d_cand ? d_cand + q0 * h->p.L : nullptr, &nh, cap ? &bout : nullptr);
+      if (st == HS_SPLIT_BATCH) {
+        // more filter survivors than the 32-bit list counter holds (a radius near the typical
+        // distance of bucket mates): the same queries again in batches half the size
+        if (nqb == 1) return fail(h, HS_ERR_CAPACITY, "the filter survivors of one query exceed 2^32");
+        QB = (nqb + 1) / 2;
+        nqb = 0;
+        continue;
+      }
       if (st) return st;
       if (nh && !bout.ordered) {
         // (brute force, a query with very many hits, HS_SORT_HITS) order of the reference's output

@@ -107,6 +107,20 @@ __host__ __device__ inline bool hs_key_equal(const int32_t* x, const int32_t* y,
 }
 
 // ---- device view of one hash table --------------------------------------------------------------
+// The survivor list's counter is 32 bits (the batch's counters block, word 0).  A batch whose filters
+// pass more than ~4e9 pairs (a radius close to the typical distance of bucket mates) would wrap it
+// silently: every reservation that lands in the last 2^28 slots raises HS_CNT_SURVIVOR_OVERFLOW in
+// the same block -- reservations are <= 64 slots, so one does before the counter wraps -- and the
+// host repeats the batch in halves (hs_capi.hip run_query).
+#define HS_CNT_SURVIVOR_OVERFLOW 21
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t hs_reserve_survivors(uint32_t* prov_count, uint32_t n) {
+  const uint32_t base = atomicAdd(prov_count, n);
+  if (base >= 0xF0000000u) atomicOr(prov_count + HS_CNT_SURVIVOR_OVERFLOW, 1u);
+  return base;
+}
+#endif
+
 struct hs_table_dev {
   const uint64_t* dir_key;   // [nb] sorted fingerprints of the distinct keys
   const uint32_t* dir_start; // [nb+1] first sorted position of each bucket
@@ -335,14 +349,17 @@ hipError_t hs_launch_join(const uint4* d_desc, uint32_t n_items, const uint4* d_
                           const float* d_rownorm, int k, uint32_t* d_prov_count, uint32_t prov_cap,
                           uint2* d_prov, int n_blocks, hipStream_t s);
 // int8 form of the join filter (hs_join8.hip)
+// `wide` below: rows of short k-mers (k <= 20) carry all 8 coordinates on one scale (6 k-steps, table
+// d_tabW, scale[4..6]); the launchers that take d_tab8 expect d_tabW in its place then
 hipError_t hs_launch_jtables8(const double* d_coords, int alphabet, void* d_tab8, float* d_scale,
-                              uint32_t* d_unsafe, void* d_tabR, hipStream_t s);
+                              uint32_t* d_unsafe, void* d_tabR, void* d_tabW, hipStream_t s);
 // d_c8b (may be null): the second row per query (columns 4..7 + the refinement's scalars)
 // the same rows for queries that are k-mers given as codes (self-join): x^ from the tables, no doubles
-hipError_t hs_launch_qprep8_codes(const uint8_t* d_qcodes, uint32_t nq, int k, double r2, const double* d_coords,
-                                  const void* d_tab8, const void* d_tabR, const float* d_scale, void* d_c8,
-                                  void* d_c8b, hipStream_t s);
-hipError_t hs_launch_qprep8(const double* d_centers, uint32_t nq, int k, double r2,
+hipError_t hs_launch_qprep8_codes(const uint8_t* d_qcodes, uint32_t nq, int k, int wide, double r2,
+                                  const double* d_coords, const void* d_tab8, const void* d_tabR,
+                                  const void* d_tabW, const float* d_scale, void* d_c8, void* d_c8b,
+                                  hipStream_t s);
+hipError_t hs_launch_qprep8(const double* d_centers, uint32_t nq, int k, int wide, double r2,
                             const float* d_scale, void* d_c8, uint32_t* d_unsafe, void* d_c8b,
                             hipStream_t s);
 // survivors of the 4-column bound -> those that also pass the 8-column bound (compacted, direct form)
@@ -352,31 +369,31 @@ hipError_t hs_launch_refine8(const hs_tables_dev& tabs, const uint2* d_prov, con
                              const uint32_t* d_qstart, const uint32_t* d_qcount,
                              uint2* d_out, uint32_t* d_out_count, hipStream_t s);
 hipError_t hs_launch_gather_c8t(const void* d_c8, const uint32_t* d_sorted_ql, const uint32_t* d_seg_qoff,
-                                uint32_t nql, int L, int k, void* d_out, hipStream_t s);
-// bytes of a quantised int8 row (32 per k-step: 128 for k <= 25, 192 for k <= 41, 256 for k <= 50) and
-// the members of one work item of the wave-independent int8 join (128 / 64)
-int hs_join8_row_bytes(int k);
-uint32_t hs_join8_members_per_item(int k);
+                                uint32_t nql, int L, int k, int wide, void* d_out, hipStream_t s);
+// bytes of a quantised int8 row (32 per k-step: 128 for k <= 25, 192 for k <= 41 and for wide rows,
+// 256 for k <= 50) and the members of one work item of the wave-independent int8 join (128 / 64)
+int hs_join8_row_bytes(int k, int wide);
+uint32_t hs_join8_members_per_item(int k, int wide);
 // thin segments with the int8 join on: the join's filter value per (probe, member) pair on the
 // vector ALU (v_dot4_i32_i8), work items = the streaming kernel's (probe, slice) list
 hipError_t hs_launch_thin8(const hs_tables_dev& tabs, const uint4* d_rec_base, uint64_t n_entries,
                            const void* d_c8, const void* d_tab8, const uint32_t* d_qstart,
                            const uint32_t* d_qcount, const uint32_t* d_slice_off, const uint32_t* d_slice_ql,
-                           uint32_t nql, int L, int k, uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov,
-                           int n_blocks, hipStream_t s);
+                           uint32_t nql, int L, int k, int wide, uint32_t* d_prov_count, uint32_t prov_cap,
+                           uint2* d_prov, int n_blocks, hipStream_t s);
 // d_slice_ql[d_slice_off[ql] + s] = ql: the probe of every (probe, slice) work item
 hipError_t hs_launch_slice_map(const uint32_t* d_nslices, const uint32_t* d_slice_off, uint32_t nql,
                                uint32_t* d_slice_ql, hipStream_t s);
 hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* d_packed_base,
-                            const uint4* d_rec_base, const void* d_c8t, const void* d_tab8, int k,
+                            const uint4* d_rec_base, const void* d_c8t, const void* d_tab8, int k, int wide,
                             uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov,
                             uint32_t* d_item_counter, int n_blocks, const uint32_t* d_n_items,
                             hipStream_t s);
 // bucket-ordered packed copy of one table (k <= 25) + the per-entry 16-byte A-row tails of the
 // int8 join (d_out_rec[i] belongs to d_out_packed[i])
 hipError_t hs_launch_gather_rec8(const uint4* d_packed_all, const uint32_t* d_ids_sorted, uint32_t n,
-                                 int k, const void* d_tab8, const float* d_scale, uint4* d_out_packed,
-                                 uint4* d_out_rec, hipStream_t s);
+                                 int k, int wide, const void* d_tab8, const void* d_tabW, const float* d_scale,
+                                 uint4* d_out_packed, uint4* d_out_rec, hipStream_t s);
 hipError_t hs_launch_kth_min(const float* d_slice_min, uint32_t nq, uint32_t per_q, uint32_t topk,
                              float* d_thr, hipStream_t s);
 hipError_t hs_launch_topk_exact(const uint8_t* d_codes, const double* d_centers,

@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256, 2) void hs_join_kernel(
                 if (res_used < JRES && lane >= (int)res_used && res_base + lane < prov_cap)
                   prov[res_base + lane] = make_uint2(0xffffffffu, 0u);  // unused tail: skipped later
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(prov_count, (uint32_t)JRES);
+                if (lane == 0) base = hs_reserve_survivors(prov_count, (uint32_t)JRES);
                 res_base = __builtin_amdgcn_readfirstlane(base);
                 res_used = 0;
               }

@@ -30,6 +30,13 @@
 // slots).  Such work items are 64 members (two row tiles) per wave: the A operands of 128 members
 // over 6 or 8 k-steps would not leave room for the query tiles in flight.
 //
+// Short k-mers (k <= 20, "wide" rows): R^2 is no longer far below the typical 4-coordinate distance of
+// bucket mates (k = 15: the 4-column bound passes 4 % of random pairs, the 8-column bound 0.03 %), so
+// the row carries ALL 8 coordinates, quantised with one scale: byte 8p + j = coordinate j of
+// position p, 6 k-steps (160 coordinate bytes + 4 spare + 28 digit slots), rho and gamma over all
+// 8 columns with dims = 8k, 64 members per work item like the other 6-k-step rows; there is nothing
+// left for hs_refine8_kernel to add, so it does not run.
+//
 // rho depends on the member only, so it is evaluated ONCE, at index build: hs_gather_rec8_kernel
 // writes, next to the bucket-ordered packed copy, a 16-byte record per entry = bytes 96..111 of the
 // member's A row (x^ of position 24, then the 12 rho slots).  The join kernel then builds a member's
@@ -49,7 +56,10 @@ typedef int intx16 __attribute__((ext_vector_type(16)));
 
 constexpr int QD = 4;        // table columns used
 // k-steps of 32 bytes in a row: 4 (k <= 25), 6 (k <= 41), 8 (k <= 50); row = 32 KS bytes = 2 KS pieces
-__host__ __device__ constexpr int ks_of(int k) { return k <= 25 ? 4 : k <= 41 ? 6 : 8; }
+// wide rows (all 8 coordinates, k <= 20): 6
+__host__ __device__ constexpr int ks_of(int k, bool wide = false) {
+  return wide ? 6 : k <= 25 ? 4 : k <= 41 ? 6 : 8;
+}
 constexpr uint32_t JRES = 64;  // survivor slots a wave reserves per counter access
 constexpr int DIG = 13;      // base-127 digits (+1 remainder slot) of -gamma
 constexpr int RDIG = 11;     // base-127 digits (+1 remainder slot) of rho
@@ -91,9 +101,12 @@ __device__ __forceinline__ void digits127(int v, int (&d)[ND + 1], bool* overflo
 // tabR[aa] = { packed x^ of columns 0..3, packed x^ of columns 4..7 (own scale), |x|^2 over all 8
 // columns as float bits, L1(x^ 0..3) | L1(x^ 4..7) << 16 } for the survivor refinement;
 // scale[2] = s of columns 4..7, scale[3] = 1 when that table is usable
+// tabW[aa] = { packed x^ of columns 0..3, of columns 4..7 (ONE scale over all 8 columns), |x|^2 over
+// all 8 as float bits, L1(x^) over all 8 } for the wide rows; scale[4] = that s, scale[5] = s^2/2
 __global__ void hs_jtables8_kernel(const double* __restrict__ coords, int alphabet,
                                    uint4* __restrict__ tab8, float* __restrict__ scale,
-                                   uint32_t* __restrict__ unsafe, uint4* __restrict__ tabR) {
+                                   uint32_t* __restrict__ unsafe, uint4* __restrict__ tabR,
+                                   uint4* __restrict__ tabW) {
   __shared__ double smax[32];
   const int aa = threadIdx.x;
   if (aa >= 32) return;
@@ -133,6 +146,7 @@ __global__ void hs_jtables8_kernel(const double* __restrict__ coords, int alphab
   double mm2 = 0.0;
   for (int i = 0; i < 32; ++i) mm2 = fmax(mm2, smax[i]);
   const bool ok2 = mm2 < 1e6;          // NaN or huge: no refinement
+  const double mm2_raw = mm2;
   if (!(mm2 > 0.0) || !ok2) mm2 = 127.0;  // all-zero columns: any scale does
   const float s2f = (float)(127.0 / mm2);
   const double s2 = (double)s2f;
@@ -152,11 +166,31 @@ __global__ void hs_jtables8_kernel(const double* __restrict__ coords, int alphab
     scale[2] = s2f;
     scale[3] = ok2 ? 1.0f : 0.0f;
   }
+  // all 8 columns on one scale (an unusable table was flagged above: mm covers columns 0..3, mm2
+  // columns 4..7)
+  const double mw = ok2 ? fmax(mm, mm2_raw) : mm;
+  const double sw = 127.0 / mw;
+  uint32_t pw[2] = {0u, 0u};
+  int l1w = 0;
+  for (int j = 0; j < 8; ++j) {
+    const double v = aa < alphabet ? coords[aa * 8 + j] : 0.0;
+    int q = (int)rint(sw * v);
+    q = max(-127, min(127, q));
+    pw[j >> 2] |= ((uint32_t)(q & 0xff)) << (8 * (j & 3));
+    l1w += abs(q);
+  }
+  tabW[aa] = make_uint4(pw[0], pw[1], __float_as_uint((float)n8), (uint32_t)l1w);
+  if (aa == 0) {
+    scale[4] = (float)sw;
+    scale[5] = (float)(0.5 * sw * sw);
+    scale[6] = ok2 ? 1.0f : 0.0f;
+  }
 }
 
 // ---------------------------------------------------------------------------------- query prep
 // c8[q] (ROW = 32 KS bytes): byte 4p + j = c^ of coordinate j (< 4) of position p (< k), zeros up to
 // byte ROW - 29; the last 28 bytes: (-127 x11, -1), 0, 0, then the 14 digits of -gamma.
+template <bool WIDE>
 __global__ __launch_bounds__(256) void hs_qprep8_kernel(const double* __restrict__ centers, uint32_t nq,
                                                         int k, double r2, const float* __restrict__ scale,
                                                         int8_t* __restrict__ c8,
@@ -165,8 +199,9 @@ __global__ __launch_bounds__(256) void hs_qprep8_kernel(const double* __restrict
   const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= nq) return;
   const int lane = lane_id();
-  const int ROW = 32 * ks_of(k), TAIL = ROW - 28;
-  const double sA = (double)scale[0], sB = (double)scale[2];
+  const int ROW = 32 * ks_of(k, WIDE), TAIL = ROW - 28;
+  // WIDE: one row, all 8 columns on one scale, byte 8 pos + j
+  const double sA = (double)scale[WIDE ? 4 : 0], sB = (double)scale[WIDE ? 4 : 2];
   const double* c = centers + (uint64_t)q * 8 * k;
   int8_t* outA = c8 + (uint64_t)q * ROW;
   int8_t* outB = c8b ? c8b + (uint64_t)q * ROW : nullptr;
@@ -176,9 +211,9 @@ __global__ __launch_bounds__(256) void hs_qprep8_kernel(const double* __restrict
   double ncA = 0.0, penA = 0.0, ncB = 0.0, penB = 0.0;
   int l1A = 0, l1B = 0;
   bool badA = false, badB = !(scale[3] > 0.f);
-  for (int i = lane; i < 2 * TAIL; i += 64) {
+  for (int i = lane; i < (WIDE ? TAIL : 2 * TAIL); i += 64) {
     const int pos = i >> 3, j = i & 7;
-    const bool second = j >= QD;
+    const bool second = !WIDE && j >= QD;
     int qv = 0;
     if (pos < k) {
       const double v = c[i];
@@ -200,7 +235,8 @@ __global__ __launch_bounds__(256) void hs_qprep8_kernel(const double* __restrict
         badA = badA || bad;
       }
     }
-    if (!second) outA[4 * pos + j] = (int8_t)qv;
+    if (WIDE) outA[i] = (int8_t)qv;
+    else if (!second) outA[4 * pos + j] = (int8_t)qv;
     else if (outB) outB[4 * pos + j - QD] = (int8_t)qv;
   }
   for (int off = 32; off; off >>= 1) {
@@ -252,20 +288,23 @@ __global__ __launch_bounds__(256) void hs_qprep8_kernel(const double* __restrict
 // The same two rows for a query that IS a k-mer of the coordinate table (self-join), from its codes:
 // x^ = the table's quantised rows (what the members carry), no saturation, norms from the table's
 // doubles.  One thread per query.
+template <bool WIDE>
 __global__ __launch_bounds__(256) void hs_qprep8_codes_kernel(const uint8_t* __restrict__ qcodes, uint32_t nq,
                                                               int k, double r2,
                                                               const double* __restrict__ coords,
                                                               const uint4* __restrict__ tab8,
                                                               const uint4* __restrict__ tabR,
+                                                              const uint4* __restrict__ tabW,
                                                               const float* __restrict__ scale,
                                                               int8_t* __restrict__ c8, int8_t* __restrict__ c8b) {
   __shared__ uint32_t sA[32], sB[32], sL1[32];
   __shared__ double sNA[32], sNB[32];
   if (threadIdx.x < 32) {
     const int aa = threadIdx.x;
-    sA[aa] = tab8[aa].x;
-    sB[aa] = tabR[aa].y;
-    sL1[aa] = tabR[aa].w;  // L1(x^ 0..3) | L1(x^ 4..7) << 16
+    // WIDE: both halves of a position's 8 bytes go to the one row; the L1 over all 8 counts as "A"
+    sA[aa] = WIDE ? tabW[aa].x : tab8[aa].x;
+    sB[aa] = WIDE ? tabW[aa].y : tabR[aa].y;
+    sL1[aa] = WIDE ? tabW[aa].w : tabR[aa].w;  // L1(x^ 0..3) | L1(x^ 4..7) << 16
     double na = 0.0, nb = 0.0;
     for (int j = 0; j < 8; ++j) {
       const double v = coords[aa * 8 + j];
@@ -277,12 +316,27 @@ __global__ __launch_bounds__(256) void hs_qprep8_codes_kernel(const uint8_t* __r
   __syncthreads();
   const uint32_t q = blockIdx.x * 256 + threadIdx.x;
   if (q >= nq) return;
-  const int ROW = 32 * ks_of(k), TAIL = ROW - 28;
+  const int ROW = 32 * ks_of(k, WIDE), TAIL = ROW - 28;
   const uint8_t* code = qcodes + (uint64_t)q * k;
   uint32_t* outA = reinterpret_cast<uint32_t*>(c8 + (uint64_t)q * ROW);
-  uint32_t* outB = c8b ? reinterpret_cast<uint32_t*>(c8b + (uint64_t)q * ROW) : nullptr;
+  uint32_t* outB = (c8b && !WIDE) ? reinterpret_cast<uint32_t*>(c8b + (uint64_t)q * ROW) : nullptr;
   double ncA = 0.0, ncB = 0.0;
   uint32_t l1A = 0, l1B = 0;
+  if constexpr (WIDE) {
+    for (int p = 0; p < TAIL / 8; ++p) {
+      uint32_t a = 0u, b = 0u;
+      if (p < k) {
+        const uint32_t c = code[p] & 31u;
+        a = sA[c];
+        b = sB[c];
+        ncA += sNA[c] + sNB[c];
+        l1A += sL1[c];
+      }
+      outA[2 * p] = a;
+      outA[2 * p + 1] = b;
+    }
+    outA[TAIL / 4 - 1] = 0u;  // bytes 160..163
+  } else
   for (int p = 0; p < TAIL / 4; ++p) {
     uint32_t a = 0u, b = 0u;
     if (p < k) {
@@ -297,7 +351,7 @@ __global__ __launch_bounds__(256) void hs_qprep8_codes_kernel(const uint8_t* __r
     outA[p] = a;
     if (outB) outB[p] = b;
   }
-  const double sAs = (double)scale[0];
+  const double sAs = (double)scale[WIDE ? 4 : 0];
   // gamma as in hs_qprep8_kernel (no saturation penalty: table values quantise inside +-127)
   const double g = floor(0.5 * sAs * sAs * (ncA - r2) - 0.5 * (double)l1A - 2.0);
   int d[DIG + 1];
@@ -406,20 +460,46 @@ __device__ __forceinline__ void build_afrags8(const uint4 pk, const uint4 pk1, c
   A[KS - 1][3] = h ? 0x017f7f7f : (int)rec.w;          // last byte = 1 (remainder slot of -gamma)
 }
 
+// Wide rows (6 k-steps, all 8 coordinates): k-step s < 5 carries positions 4 s + 2 h + {0, 1}, 8 bytes
+// each, by one 8-byte lookup per position; the last k-step as above.
+__device__ __forceinline__ void build_afrags8_wide(const uint4 pk, const uint4 rec, int h, const uint2* sTabW,
+                                                   intx4 (&A)[6]) {
+  const uint32_t sh = 10u * (uint32_t)h;  // the upper half's positions are two further on
+  const uint32_t x = __funnelshift_r(pk.x, pk.y, sh), y = __funnelshift_r(pk.y, pk.z, sh),
+                 z = __funnelshift_r(pk.z, pk.w, sh), w = pk.w >> sh;
+#define HS_AW(S)                                                          \
+  {                                                                       \
+    const uint2 p0_ = sTabW[residue_at<20 * (S)>(x, y, z, w)];            \
+    const uint2 p1_ = sTabW[residue_at<20 * (S) + 5>(x, y, z, w)];        \
+    A[S] = intx4{(int)p0_.x, (int)p0_.y, (int)p1_.x, (int)p1_.y};         \
+  }
+  HS_AW(0) HS_AW(1) HS_AW(2) HS_AW(3) HS_AW(4)
+#undef HS_AW
+  constexpr uint32_t C127 = 0x7f7f7f7fu;
+  A[5][0] = h ? 0x7f7f0000 : (int)rec.x;
+  A[5][1] = h ? (int)C127 : (int)rec.y;
+  A[5][2] = h ? (int)C127 : (int)rec.z;
+  A[5][3] = h ? 0x017f7f7f : (int)rec.w;
+}
+
 // index build: bucket-ordered packed copy of one table + the 16-byte A-row tail of every entry
 __global__ __launch_bounds__(256) void hs_gather_rec8_kernel(const uint4* __restrict__ packed_all,
                                                              const uint32_t* __restrict__ ids,
-                                                             uint32_t n, int k, int PW,
+                                                             uint32_t n, int k, int PW, int wide,
                                                              const uint4* __restrict__ tab8,
+                                                             const uint4* __restrict__ tabW,
                                                              const float* __restrict__ scale,
                                                              uint4* __restrict__ out_packed,
                                                              uint4* __restrict__ out_rec) {
+  // rows {x^, |x|^2 (float bits), L1(x^)}: of the 4 filter columns, or (wide) of all 8
   __shared__ uint4 sTab[32];
-  if (threadIdx.x < 32) sTab[threadIdx.x] = tab8[threadIdx.x];
+  if (threadIdx.x < 32)
+    sTab[threadIdx.x] = wide ? make_uint4(0u, tabW[threadIdx.x].z, tabW[threadIdx.x].w, 0u) : tab8[threadIdx.x];
   __syncthreads();
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t >= n) return;
-  const int plast = 8 * ks_of(k) - 8;  // the position whose x^ opens the record (if the k-mer has it)
+  // the position whose x^ opens the record (if the k-mer has it; never with wide rows)
+  const int plast = wide ? 1 << 20 : 8 * ks_of(k) - 8;
   double nx = 0.0;
   int l1 = 0;
   uint32_t xlast = 0;
@@ -443,7 +523,8 @@ __global__ __launch_bounds__(256) void hs_gather_rec8_kernel(const uint4* __rest
   }
   // rho = floor(s^2 |x1|^2 / 2 - L1(x^)/2 - dims/4 - 2); the 2 absorbs the fp32 roundings of
   // scale[1] and of the table's squared norms
-  const double rho = floor((double)scale[1] * nx - 0.5 * (double)l1 - 0.25 * (double)(QD * k) - 2.0);
+  const double rho = floor((double)scale[wide ? 5 : 1] * nx - 0.5 * (double)l1 -
+                           0.25 * (double)((wide ? 8 : QD) * k) - 2.0);
   int d[RDIG + 1];
   digits127<RDIG>((int)rho, d, nullptr);  // too large -> clamped down: more permissive, never less
   out_rec[t] = make_uint4(xlast, pack4(d[0], d[1], d[2], d[3]), pack4(d[4], d[5], d[6], d[7]),
@@ -558,7 +639,7 @@ __device__ __forceinline__ void emit_survivors(const intx16 (&acc)[GT], int T0, 
           if (res_used < JRES && lane >= (int)res_used && res_base + lane < prov_cap)
             prov[res_base + lane] = make_uint2(0xffffffffu, 0u);
           uint32_t base = 0;
-          if (lane == 0) base = atomicAdd(prov_count, (uint32_t)JRES);
+          if (lane == 0) base = hs_reserve_survivors(prov_count, (uint32_t)JRES);
           res_base = __builtin_amdgcn_readfirstlane(base);
           res_used = 0;
         }
@@ -593,7 +674,7 @@ __device__ __forceinline__ uint4 uniform4(const uint4 v) {
 // query tile: 8 MFMAs into X while the sign test of Y (previous query tile) issues in their gaps,
 // then 8 MFMAs into Y beside the sign test of X -- the vector instructions of the epilogue never
 // stand between two MFMAs of the same wave.
-template <int JT, int KS>
+template <int JT, int KS, bool WIDE = false>
 __global__ __launch_bounds__(256, 2) void hs_join8w_kernel(
     const uint4* __restrict__ desc, uint32_t n_items, const uint4* __restrict__ packed_base,
     const uint4* __restrict__ rec_base, const uint4* __restrict__ c8t,
@@ -605,9 +686,11 @@ __global__ __launch_bounds__(256, 2) void hs_join8w_kernel(
   if (n_items_dev) n_items = min(n_items, __builtin_amdgcn_readfirstlane(*n_items_dev));
   static_assert(JT == 4 || JT == 2, "two accumulator groups of JT / 2 row tiles");
   static_assert(KS == 4 || KS == 6 || KS == 8, "k-steps of a row");
+  static_assert(!WIDE || KS == 6, "wide rows have 6 k-steps");
   constexpr int GT = JT / 2;
-  constexpr int PW = KS == 4 ? 1 : 2;  // packed words per member
+  constexpr int PW = (KS == 4 || WIDE) ? 1 : 2;  // packed words per member
   __shared__ uint32_t sTab8[32];
+  __shared__ uint2 sTabW[WIDE ? 32 : 1];
   const int tid = threadIdx.x, lane = tid & 63;
   // wave-uniform by construction: say so, or every per-item quantity derived from it (descriptor
   // addresses, loop bounds) is computed per lane and the descriptor loads become vector loads
@@ -617,7 +700,10 @@ __global__ __launch_bounds__(256, 2) void hs_join8w_kernel(
   uint64_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
   const uint64_t tstart = tlast;
 #endif
-  if (tid < 32) sTab8[tid] = tab8[tid].x;
+  if (tid < 32) {
+    sTab8[tid] = tab8[tid].x;
+    if constexpr (WIDE) sTabW[tid] = make_uint2(tab8[tid].x, tab8[tid].y);  // (the caller passes tabW)
+  }
   __syncthreads();  // the only one: the table is read-only from here on
   // Items come in chunks of G consecutive ones (same-address atomics are slow: one per chunk): the
   // first chunk by position, every further one from the counter, requested a whole chunk ahead.
@@ -711,7 +797,8 @@ __global__ __launch_bounds__(256, 2) void hs_join8w_kernel(
 #undef HS_SWAP
       uint4 pk1 = pk;
       if constexpr (PW == 2) pk1 = mk1[t];
-      build_afrags8<KS, PW>(pk, pk1, rk, h, sTab8, A[t]);
+      if constexpr (WIDE) build_afrags8_wide(pk, rk, h, sTabW, A[t]);
+      else build_afrags8<KS, PW>(pk, pk1, rk, h, sTab8, A[t]);
     }
     HS_TD(1, __builtin_amdgcn_readfirstlane(A[0][0][0] ^ A[JT - 1][3][3] ^ A[JT - 1][2][0] ^ A[1][1][1]))
     HS_LOAD_MEMBERS(nd0)
@@ -905,7 +992,7 @@ __device__ __forceinline__ void emit_survivors_x(const intx4 (&acc)[4][2], int T
             if (res_used < JRES && lane >= (int)res_used && res_base + lane < prov_cap)
               prov[res_base + lane] = make_uint2(0xffffffffu, 0u);
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(prov_count, (uint32_t)JRES);
+            if (lane == 0) base = hs_reserve_survivors(prov_count, (uint32_t)JRES);
             res_base = __builtin_amdgcn_readfirstlane(base);
             res_used = 0;
           }
@@ -1143,7 +1230,7 @@ __global__ __launch_bounds__(256, 2) void hs_join8x_kernel(
 // query's row, v_dot4_i32_i8 instead of MFMA -- one member per lane, work item = one (probe, slice
 // of <= HS_SLICE bucket entries) per wave as in the streaming kernel.  Needs no per-query distance
 // tables: with this kernel the side stream's work beside the join is a few tens of microseconds.
-template <int KS>
+template <int KS, bool WIDE = false>
 __global__ __launch_bounds__(256) void hs_thin8_kernel(const uint4* __restrict__ packed_base,
                                                        const uint4* __restrict__ rec_base, uint64_t n_entries,
                                                        const int8_t* __restrict__ c8,
@@ -1160,11 +1247,15 @@ __global__ __launch_bounds__(256) void hs_thin8_kernel(const uint4* __restrict__
   // probed by one or two queries; an item is a chain of dependent loads (probe -> bucket range ->
   // query row -> members), so the kernel's time is that latency times the items per wave -- four
   // chains per wave in flight instead of one.
-  constexpr int PW = KS == 4 ? 1 : 2;
+  constexpr int PW = (KS == 4 || WIDE) ? 1 : 2;
   constexpr int NW = 8 * KS;  // dwords of a row
   __shared__ uint32_t sTab8[32];
+  __shared__ uint32_t sTabY[WIDE ? 32 : 1];  // WIDE (tab8 = the 8-column table): columns 4..7
   const int tid = threadIdx.x, lane = tid & 63, sub = lane & 15;
-  if (tid < 32) sTab8[tid] = tab8[tid].x;
+  if (tid < 32) {
+    sTab8[tid] = tab8[tid].x;
+    if constexpr (WIDE) sTabY[tid] = tab8[tid].y;
+  }
   __syncthreads();
   const uint32_t grp = (blockIdx.x * 4u + ((uint32_t)tid >> 6)) * 4u + ((uint32_t)lane >> 4);
   const uint32_t n_grp = gridDim.x * 16u;
@@ -1208,9 +1299,22 @@ __global__ __launch_bounds__(256) void hs_thin8_kernel(const uint4* __restrict__
       // positions 0 .. 8 KS - 9 by table lookup (those past the k-mer meet zero query bytes)
 #define HS_P(P) if ((P) < NW - 8 && (P) < k) acc = __builtin_amdgcn_sdot4((int)sTab8[stream_at<5 * (P)>(st)], B[(P) < NW ? (P) : 0], acc, false);
 #define HS_P8(P) HS_P(P) HS_P(P + 1) HS_P(P + 2) HS_P(P + 3) HS_P(P + 4) HS_P(P + 5) HS_P(P + 6) HS_P(P + 7)
+      if constexpr (WIDE) {
+        // position P = dwords 2 P (columns 0..3) and 2 P + 1 (columns 4..7) of the row; P < 20
+#define HS_PW(P)                                                                           \
+  if ((P) < k) {                                                                           \
+    const uint32_t r_ = stream_at<5 * (P)>(st);                                            \
+    acc = __builtin_amdgcn_sdot4((int)sTab8[r_], B[2 * (P)], acc, false);                  \
+    acc = __builtin_amdgcn_sdot4((int)sTabY[r_], B[2 * (P) + 1], acc, false);              \
+  }
+        HS_PW(0) HS_PW(1) HS_PW(2) HS_PW(3) HS_PW(4) HS_PW(5) HS_PW(6) HS_PW(7) HS_PW(8) HS_PW(9)
+        HS_PW(10) HS_PW(11) HS_PW(12) HS_PW(13) HS_PW(14) HS_PW(15) HS_PW(16) HS_PW(17) HS_PW(18) HS_PW(19)
+#undef HS_PW
+      } else {
       HS_P8(0) HS_P8(8) HS_P8(16)
       if constexpr (KS > 4) { HS_P8(24) HS_P8(32) }
       if constexpr (KS > 6) { HS_P8(40) HS_P8(48) }
+      }
 #undef HS_P8
 #undef HS_P
       acc = __builtin_amdgcn_sdot4((int)rc.x, B[NW - 8], acc, false);  // position 8 KS - 8 + the rho digits
@@ -1221,7 +1325,7 @@ __global__ __launch_bounds__(256) void hs_thin8_kernel(const uint4* __restrict__
       const unsigned long long m = __ballot(pass);
       if (m) {
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(prov_count, (uint32_t)__popcll(m));
+        if (lane == 0) base = hs_reserve_survivors(prov_count, (uint32_t)__popcll(m));
         base = __builtin_amdgcn_readfirstlane(base);
         if (pass) {
           const uint32_t idx = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -1356,43 +1460,54 @@ inline unsigned blocks_for(uint64_t n, unsigned per = 256) { return (unsigned)((
 }  // namespace
 
 hipError_t hs_launch_jtables8(const double* d_coords, int alphabet, void* d_tab8, float* d_scale,
-                              uint32_t* d_unsafe, void* d_tabR, hipStream_t s) {
-  hs_jtables8_kernel<<<1, 32, 0, s>>>(d_coords, alphabet, (uint4*)d_tab8, d_scale, d_unsafe, (uint4*)d_tabR);
+                              uint32_t* d_unsafe, void* d_tabR, void* d_tabW, hipStream_t s) {
+  hs_jtables8_kernel<<<1, 32, 0, s>>>(d_coords, alphabet, (uint4*)d_tab8, d_scale, d_unsafe, (uint4*)d_tabR,
+                                      (uint4*)d_tabW);
   return hipGetLastError();
 }
 
-hipError_t hs_launch_qprep8(const double* d_centers, uint32_t nq, int k, double r2,
+hipError_t hs_launch_qprep8(const double* d_centers, uint32_t nq, int k, int wide, double r2,
                             const float* d_scale, void* d_c8, uint32_t* d_unsafe, void* d_c8b,
                             hipStream_t s) {
   if (!nq) return hipSuccess;
-  hs_qprep8_kernel<<<blocks_for(nq, 4), 256, 0, s>>>(d_centers, nq, k, r2, d_scale, (int8_t*)d_c8,
-                                                     d_unsafe, (int8_t*)d_c8b);
+  if (wide)
+    hs_qprep8_kernel<true><<<blocks_for(nq, 4), 256, 0, s>>>(d_centers, nq, k, r2, d_scale, (int8_t*)d_c8,
+                                                             d_unsafe, nullptr);
+  else
+    hs_qprep8_kernel<false><<<blocks_for(nq, 4), 256, 0, s>>>(d_centers, nq, k, r2, d_scale, (int8_t*)d_c8,
+                                                              d_unsafe, (int8_t*)d_c8b);
   return hipGetLastError();
 }
 
-hipError_t hs_launch_qprep8_codes(const uint8_t* d_qcodes, uint32_t nq, int k, double r2, const double* d_coords,
-                                  const void* d_tab8, const void* d_tabR, const float* d_scale, void* d_c8,
-                                  void* d_c8b, hipStream_t s) {
+hipError_t hs_launch_qprep8_codes(const uint8_t* d_qcodes, uint32_t nq, int k, int wide, double r2,
+                                  const double* d_coords, const void* d_tab8, const void* d_tabR,
+                                  const void* d_tabW, const float* d_scale, void* d_c8, void* d_c8b,
+                                  hipStream_t s) {
   if (!nq) return hipSuccess;
-  hs_qprep8_codes_kernel<<<blocks_for(nq), 256, 0, s>>>(d_qcodes, nq, k, r2, d_coords, (const uint4*)d_tab8,
-                                                        (const uint4*)d_tabR, d_scale, (int8_t*)d_c8,
-                                                        (int8_t*)d_c8b);
+  if (wide)
+    hs_qprep8_codes_kernel<true><<<blocks_for(nq), 256, 0, s>>>(d_qcodes, nq, k, r2, d_coords, (const uint4*)d_tab8,
+                                                                (const uint4*)d_tabR, (const uint4*)d_tabW,
+                                                                d_scale, (int8_t*)d_c8, nullptr);
+  else
+    hs_qprep8_codes_kernel<false><<<blocks_for(nq), 256, 0, s>>>(d_qcodes, nq, k, r2, d_coords, (const uint4*)d_tab8,
+                                                                 (const uint4*)d_tabR, (const uint4*)d_tabW,
+                                                                 d_scale, (int8_t*)d_c8, (int8_t*)d_c8b);
   return hipGetLastError();
 }
 
-int hs_join8_row_bytes(int k) { return 32 * ks_of(k); }
-uint32_t hs_join8_members_per_item(int k) { return k <= 25 ? 128u : 64u; }
+int hs_join8_row_bytes(int k, int wide) { return 32 * ks_of(k, wide != 0); }
+uint32_t hs_join8_members_per_item(int k, int wide) { return ks_of(k, wide != 0) == 4 ? 128u : 64u; }
 
 hipError_t hs_launch_gather_c8t(const void* d_c8, const uint32_t* d_sorted_ql, const uint32_t* d_seg_qoff,
-                                uint32_t nql, int L, int k, void* d_out, hipStream_t s) {
+                                uint32_t nql, int L, int k, int wide, void* d_out, hipStream_t s) {
   if (!nql) return hipSuccess;
   hs_gather_c8t_kernel<<<blocks_for(nql), 256, 0, s>>>((const int8_t*)d_c8, d_sorted_ql, d_seg_qoff, nql,
-                                                       L, 2 * ks_of(k), (uint4*)d_out);
+                                                       L, 2 * ks_of(k, wide != 0), (uint4*)d_out);
   return hipGetLastError();
 }
 
 hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* d_packed_base,
-                            const uint4* d_rec_base, const void* d_c8t, const void* d_tab8, int k,
+                            const uint4* d_rec_base, const void* d_c8t, const void* d_tab8, int k, int wide,
                             uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov,
                             uint32_t* d_item_counter, int n_blocks, const uint32_t* d_n_items,
                             hipStream_t s) {
@@ -1411,10 +1526,14 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
                                                       (const uint4*)d_c8t, (const uint4*)d_tab8,      \
                                                       d_prov_count, prov_cap, d_prov, d_item_counter, G, \
                                                       d_n_items)
-  const int KS = ks_of(k);
+  const int KS = ks_of(k, wide != 0);
   // k <= 25: the 16x16x64 form by default (HS_JOIN_SHAPE=32 selects the 32x32x32 form)
   static const bool shape32 = getenv("HS_JOIN_SHAPE") && atoi(getenv("HS_JOIN_SHAPE")) == 32;
-  if (KS == 4 && !shape32)
+  if (wide)  // d_tab8 = the 8-column table here
+    hs_join8w_kernel<2, 6, true><<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_rec_base,
+                                                          (const uint4*)d_c8t, (const uint4*)d_tab8, d_prov_count,
+                                                          prov_cap, d_prov, d_item_counter, G, d_n_items);
+  else if (KS == 4 && !shape32)
     hs_join8x_kernel<<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_rec_base, (const uint4*)d_c8t,
                                               (const uint4*)d_tab8, d_prov_count, prov_cap, d_prov,
                                               d_item_counter, G, d_n_items);
@@ -1438,21 +1557,27 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
 }
 
 hipError_t hs_launch_gather_rec8(const uint4* d_packed_all, const uint32_t* d_ids_sorted, uint32_t n,
-                                 int k, const void* d_tab8, const float* d_scale, uint4* d_out_packed,
-                                 uint4* d_out_rec, hipStream_t s) {
+                                 int k, int wide, const void* d_tab8, const void* d_tabW, const float* d_scale,
+                                 uint4* d_out_packed, uint4* d_out_rec, hipStream_t s) {
   if (!n) return hipSuccess;
-  hs_gather_rec8_kernel<<<blocks_for(n), 256, 0, s>>>(d_packed_all, d_ids_sorted, n, k, hs_packed_words(k),
-                                                      (const uint4*)d_tab8, d_scale, d_out_packed,
-                                                      d_out_rec);
+  hs_gather_rec8_kernel<<<blocks_for(n), 256, 0, s>>>(d_packed_all, d_ids_sorted, n, k, hs_packed_words(k), wide,
+                                                      (const uint4*)d_tab8, (const uint4*)d_tabW, d_scale,
+                                                      d_out_packed, d_out_rec);
   return hipGetLastError();
 }
 
 hipError_t hs_launch_thin8(const hs_tables_dev& tabs, const uint4* d_rec_base, uint64_t n_entries,
                            const void* d_c8, const void* d_tab8, const uint32_t* d_qstart,
                            const uint32_t* d_qcount, const uint32_t* d_slice_off, const uint32_t* d_slice_ql,
-                           uint32_t nql, int L, int k, uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov,
-                           int n_blocks, hipStream_t s) {
+                           uint32_t nql, int L, int k, int wide, uint32_t* d_prov_count, uint32_t prov_cap,
+                           uint2* d_prov, int n_blocks, hipStream_t s) {
   if (!nql) return hipSuccess;
+  if (wide) {  // d_tab8 = the 8-column table
+    hs_thin8_kernel<6, true><<<n_blocks, 256, 0, s>>>(tabs.t[0].packed, d_rec_base, n_entries, (const int8_t*)d_c8,
+                                                      (const uint4*)d_tab8, d_qstart, d_qcount, d_slice_off,
+                                                      d_slice_ql, nql, L, k, d_prov_count, prov_cap, d_prov);
+    return hipGetLastError();
+  }
 #define HS_T8(KS_)                                                                                      \
   hs_thin8_kernel<KS_><<<n_blocks, 256, 0, s>>>(tabs.t[0].packed, d_rec_base, n_entries, (const int8_t*)d_c8, \
                                                 (const uint4*)d_tab8, d_qstart, d_qcount, d_slice_off,  \

@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256) void hs_verify_kernel(hs_tables_dev tabs,
       const unsigned long long m = __ballot(pass);
       if (m) {
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(prov_count, (uint32_t)__popcll(m));
+        if (lane == 0) base = hs_reserve_survivors(prov_count, (uint32_t)__popcll(m));
         base = __builtin_amdgcn_readfirstlane(base);
         if (pass) {
           const uint32_t idx = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));

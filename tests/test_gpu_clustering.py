@@ -125,3 +125,36 @@ def test_self_join_edges_match_bruteforce_within_buckets(oracle):
     got = list(zip(e["i"].tolist(), e["table"].tolist(), e["j"].tolist(), e["dist"].tolist()))
     assert got == want and len(want) > 1000
     eng.close()
+
+
+@pytest.mark.parametrize("k,K,L,W,R", [(25, 4, 3, 120.0, 50.0), (39, 6, 4, 200.0, 60.0), (12, 3, 2, 90.0, 30.0),
+                                      (25, 4, 3, 120.0, 171.0)])
+def test_self_join_from_codes_equals_embedded_queries(monkeypatch, k, K, L, W, R):
+    """The self-join's two routes -- per-query rows from the residue codes (no centres, no hashing, no
+    directory search) and the ordinary query path over embedded centres -- give the same edges, in
+    the same order, with the same distances.  R = 171 is past what the int8 filter's digits carry
+    (R^2 < 30000 still): that call must take the embedded route by itself."""
+    rng = np.random.default_rng(k + int(R))
+    codes = np.concatenate([_families(rng, k, 40, 30), synth.make_db(3000, k, seed=4)])
+    a, b = synth.make_planes(k, K, L, W, seed=3)
+    out = []
+    for route in ("codes", "centres", "codes-min"):
+        monkeypatch.delenv("HS_NO_SELF_CODES", raising=False)
+        monkeypatch.delenv("HS_JOIN_MIN_Q", raising=False)
+        monkeypatch.delenv("HS_JOIN_MIN_M", raising=False)
+        if route == "centres":
+            monkeypatch.setenv("HS_NO_SELF_CODES", "1")
+        if route == "codes-min":  # thin segments leave the join: the int8 thin filter serves them
+            monkeypatch.setenv("HS_JOIN_MIN_Q", "3")
+            monkeypatch.setenv("HS_JOIN_MIN_M", "16")
+        eng = Engine(k, K, L, W, a, b)
+        eng.index_build(codes)
+        for sq in (False, True):
+            out.append((route, sq, eng.self_join(R, sqrt_test=sq), eng.self_join(R, first=100, count=2345, sqrt_test=sq)))
+        eng.close()
+    ref = {(sq): (full, part) for route, sq, full, part in out if route == "centres"}
+    assert len(ref[False][0]["i"]) > 1000
+    for route, sq, full, part in out:
+        for got, want in zip((full, part), ref[sq]):
+            for key in ("i", "j", "table", "dist"):
+                assert np.array_equal(got[key], want[key]), (route, sq, key)

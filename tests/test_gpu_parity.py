@@ -112,6 +112,88 @@ def test_long_kmers_through_the_int8_join(oracle, k):
     eng.close()
 
 
+@pytest.mark.parametrize("k,R", [(5, 20.0), (8, 30.0), (12, 36.0), (15, 40.0), (20, 40.0)])
+def test_short_kmers_through_the_wide_int8_join(oracle, monkeypatch, k, R):
+    """k <= 20 (configs[4]'s k = 15): R^2 is no longer far below the 4-column distance of bucket mates,
+    so the int8 rows carry all 8 coordinate columns (6 k-steps, 64-member work items, no refinement
+    pass).  Hits, order and distances equal the oracle's in every verify mode, with the thin-segment
+    filter in play (HS_JOIN_MIN_Q/_M) and with the 4-column rows forced (HS_WIDE_MAX_K=0); the wide
+    rows leave far fewer survivors to the exact decision than the 4-column ones."""
+    K, L, W, n, nq = 3, 3, 260.0, 20011, 1203
+    a, b = synth.make_planes(k, K, L, W, seed=25)
+    codes = synth.make_db(n, k, seed=26)
+    centers, _ = synth.make_queries(codes, nq, seed=27, jitter=0.2)
+    want = oracle.search(a, b, W, R, oracle.embed_codes(codes), centers)
+    assert len(want["q"]) > 200
+    survivors = {}
+    for rows in ("wide", "wide-thin", "narrow"):
+        monkeypatch.delenv("HS_WIDE_MAX_K", raising=False)
+        monkeypatch.delenv("HS_JOIN_MIN_Q", raising=False)
+        monkeypatch.delenv("HS_JOIN_MIN_M", raising=False)
+        if rows == "narrow":
+            monkeypatch.setenv("HS_WIDE_MAX_K", "0")
+        if rows == "wide-thin":
+            monkeypatch.setenv("HS_JOIN_MIN_Q", "3")
+            monkeypatch.setenv("HS_JOIN_MIN_M", "16")
+        eng = Engine(k, K, L, W, a, b)
+        info = eng.index_build(codes)
+        assert max(info["max_bucket"]) > 1000
+        for mode in ("join", "auto", "join16", "stream"):
+            eng.set_verify_mode(mode)
+            got = eng.query(centers, R)
+            assert np.array_equal(got["cand"], want["cand"])
+            _assert_hits_equal(got, want)
+            prof = eng.profile()
+            if mode == "join":
+                assert prof["join_i8_batches"] > 0 and prof["join_pairs"] > 0.5 * prof["candidates"]
+                survivors[rows] = prof["provisional"]
+        # a query far outside the table's range: int8 cannot carry it, the fp16 form takes the batch
+        far = centers[:64].copy()
+        far[:8, ::8] += 9.0
+        eng.set_verify_mode("join")
+        _assert_hits_equal(eng.query(far, R), oracle.search(a, b, W, R, oracle.embed_codes(codes), far))
+        eng.close()
+    assert survivors["wide"] <= survivors["narrow"]
+    if 12 <= k <= 15:
+        assert survivors["wide"] * 3 < survivors["narrow"]
+
+
+def test_batches_split_when_the_survivor_counter_would_overflow(oracle, monkeypatch):
+    """A batch whose filters pass more pairs than the 32-bit survivor counter holds is repeated in
+    halves (hs_capi.hip run_query).  HS_TEST_SPLIT_ABOVE makes every batch above 150 queries report
+    that overflow: hits, order, candidates and the self-join's edges are those of the unsplit run."""
+    k, K, L, W, R, n, nq = 25, 4, 5, 150.0, 45.0, 20011, 1203
+    a, b = synth.make_planes(k, K, L, W, seed=35)
+    codes = synth.make_db(n, k, seed=36)
+    centers, _ = synth.make_queries(codes, nq, seed=37, jitter=0.2)
+    want = oracle.search(a, b, W, R, oracle.embed_codes(codes), centers)
+    eng = Engine(k, K, L, W, a, b)
+    eng.index_build(codes)
+    plain = eng.self_join(R, sqrt_test=True)
+    eng.close()
+    monkeypatch.setenv("HS_TEST_SPLIT_ABOVE", "150")
+    eng = Engine(k, K, L, W, a, b)
+    eng.index_build(codes)
+    for mode in ("auto", "stream"):
+        eng.set_verify_mode(mode)
+        got = eng.query(centers, R)
+        assert np.array_equal(got["cand"], want["cand"])
+        _assert_hits_equal(got, want)
+    assert eng.profile()["verify_launches"] >= nq // 150
+    bf = eng.bruteforce(centers[:400], R)
+    split = eng.self_join(R, sqrt_test=True)
+    eng.close()
+    monkeypatch.delenv("HS_TEST_SPLIT_ABOVE")
+    eng = Engine(k, K, L, W, a, b)
+    eng.index_build(codes)
+    bf0 = eng.bruteforce(centers[:400], R)
+    eng.close()
+    for key in ("q", "id", "dist"):
+        assert np.array_equal(bf[key], bf0[key])
+    for key in ("i", "j", "table", "dist"):
+        assert np.array_equal(split[key], plain[key])
+
+
 def test_join_with_many_queries_per_bucket(oracle):
     """Coarse keys (K=2, large W): a handful of huge buckets, each probed by hundreds of queries --
     multi-chunk, multi-tile work items of the bucket join, plus ragged tile/chunk remainders."""
