@@ -98,6 +98,10 @@ struct hs_handle {
   // bucket-ordered packed copies of all tables in ONE allocation ([L][n][PW]), and the int8 join's
   // per-entry records ([L][n], k <= 50 only) at the same entry numbers
   DevBuf t_packed, t_rec8;
+  // member records of the wide rows for k = 21..25 (built when a call's radius first asks for them)
+  DevBuf t_rec8w;
+  bool rec8w_ready = false;
+  double pair4_mean = 0.0, pair4_var = 0.0;  // 4-column squared distance of two random residues
   DevBuf t_pos;  // [L][n] sorted position of every DB id in every table (first-seen dedupe)
   DevBuf dir_base;       // [L + 1] first global bucket number of every table; [L] = nb_total
   uint32_t nb_total = 0;  // buckets of all tables
@@ -118,7 +122,8 @@ struct hs_handle {
   DevBuf c16s, item_desc, probe_slow, jtab8, slice_ql, qhits;  // qhits: per-query hit counts, offsets, fill
   DevBuf c8b, prov2;  // survivor refinement: second int8 row per query, the refined survivor list
   bool join8_tables_ok = false;  // int8 can carry the coordinate table
-  double join8_scale = 0.0;      // its quantisation scale s (scale[0] of jtab8; scale[4] with wide rows)
+  double join8_scale = 0.0, join8_scale_w = 0.0;  // quantisation scales: 4-column rows, wide rows
+  bool wide8_ok = false;         // the 8-column table is usable (wide rows on demand for k = 21..25)
   uint32_t test_split_above = 0; // HS_TEST_SPLIT_ABOVE (tests): batches above this size report a survivor overflow
   bool wide8 = false;            // short k-mers: int8 rows over all 8 coordinate columns (hs_join8.hip)
   // segment routing thresholds (HS_JOIN_MIN_Q / _M): segments with fewer probing queries or members
@@ -449,8 +454,24 @@ hs_status hs_create(const hs_params* params, const double* a, const double* b, c
   int wide_max_k = 20;
   if (const char* m = getenv("HS_WIDE_MAX_K")) wide_max_k = std::min(20, atoi(m));
   if (const char* m = getenv("HS_TEST_SPLIT_ABOVE")) h->test_split_above = (uint32_t)std::max(0, atoi(m));
-  h->wide8 = h->join8_tables_ok && scale8[6] > 0.f && (int)h->p.k <= wide_max_k;
-  h->join8_scale = (double)scale8[h->wide8 ? 4 : 0];
+  h->wide8_ok = h->join8_tables_ok && scale8[6] > 0.f;
+  h->wide8 = h->wide8_ok && (int)h->p.k <= wide_max_k;
+  h->join8_scale = (double)scale8[0];
+  h->join8_scale_w = (double)scale8[4];
+  {  // mean and variance of the 4-column squared distance of two uniformly drawn residues (want_wide)
+    const double* ct = coords ? coords : &HS_AA_COORDS[0][0];
+    const int A = h->alphabet;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < A; ++i)
+      for (int j = 0; j < A; ++j) {
+        double d = 0.0;
+        for (int c = 0; c < 4; ++c) d += (ct[i * 8 + c] - ct[j * 8 + c]) * (ct[i * 8 + c] - ct[j * 8 + c]);
+        s1 += d;
+        s2 += d * d;
+      }
+    h->pair4_mean = s1 / ((double)A * A);
+    h->pair4_var = std::max(0.0, s2 / ((double)A * A) - h->pair4_mean * h->pair4_mean);
+  }
   if (const char* m = getenv("HS_HASH_MODE")) {
     if (!strcmp(m, "exact")) h->hash_mode = 1;
     if (!strcmp(m, "mfma")) h->hash_mode = 2;
@@ -472,7 +493,7 @@ hs_status hs_set_planes(hs_handle* h, const double* a, const double* b) {
   if (!h || !a || !b) return HS_ERR_INVALID;
   hs_status st = ensure_device(h);
   if (st) return st;
-  h->built = false;  // the tables were keyed by the old family
+  h->built = false, h->rec8w_ready = false;  // the tables were keyed by the old family
   const size_t na = (size_t)h->LK * h->d;
   // the previous family may still be read by work queued on the stream: order the copies after it
   HS_HIP(h, hipMemcpyAsync(h->a.p, a, na * 8, hipMemcpyHostToDevice, h->stream));
@@ -513,7 +534,7 @@ void hs_destroy(hs_handle* h) {
                     &h->io_codes, &h->io_misc, &h->jtab, &h->c16, &h->seg_keys, &h->seg_keys_sorted,
                     &h->seg_vals, &h->sorted_ql, &h->seg_key, &h->seg_cnt, &h->seg_qoff,
                     &h->seg_items, &h->item_off, &h->seg_n, &h->c16s, &h->item_desc,
-                    &h->probe_slow, &h->jtab8, &h->c8b, &h->prov2, &h->t_packed, &h->t_rec8, &h->t_pos, &h->dir_base,
+                    &h->probe_slow, &h->jtab8, &h->c8b, &h->prov2, &h->t_packed, &h->t_rec8, &h->t_rec8w, &h->t_pos, &h->dir_base,
                     &h->bucket_work, &h->proj_aq_all, &h->proj_aq_tab, &h->proj_fn, &h->proj_tab, &h->proj_stats,
                     &h->proj_flags[0], &h->proj_flags[1], &h->proj_flags[2], &h->proj_cnt, &h->proj_xq,
                     &h->proj_xmeta, &h->slice_ql, &h->qhits, &h->bs_ints2[0], &h->bs_ints2[1], &h->bs_keys2[0],
@@ -847,7 +868,7 @@ static hs_status finish_index(hs_handle* h) {
     h->tabs.t[l].jump_shift = 64 - J;
   }
   HS_HIP(h, hipStreamSynchronize(h->stream));
-  uint64_t bytes = h->codes.cap + h->packed_all.cap + h->t_packed.cap + h->t_rec8.cap + h->t_pos.cap;
+  uint64_t bytes = h->codes.cap + h->packed_all.cap + h->t_packed.cap + h->t_rec8.cap + h->t_rec8w.cap + h->t_pos.cap;
   for (uint32_t l = 0; l < h->p.L; ++l)
     bytes += h->t_dirkey[l].cap + h->t_dirstart[l].cap + h->t_dirtuple[l].cap + h->t_ids[l].cap +
              h->t_dirjump[l].cap;
@@ -891,7 +912,7 @@ hs_status hs_index_build(hs_handle* h, const uint8_t* codes, uint64_t n) {
   if (n >= (1ull << 31)) return fail(h, HS_ERR_INVALID, "n must be < 2^31 (ids are 32-bit, as in the reference)");
   hs_status st = ensure_device(h);
   if (st) return st;
-  h->built = false;
+  h->built = false, h->rec8w_ready = false;
   h->n = n;
   memset(&h->prof, 0, sizeof(h->prof));
   memset(&h->info, 0, sizeof(h->info));
@@ -914,7 +935,7 @@ hs_status hs_index_build_subset(hs_handle* h, const uint8_t* codes_all, uint64_t
     for (uint64_t i = 0; i < n_subset; ++i)
       if (subset[i] >= n_all) return fail(h, HS_ERR_INVALID, "subset index outside the code array");
   const int k = (int)h->p.k;
-  h->built = false;
+  h->built = false, h->rec8w_ready = false;
   h->n = n_subset;
   memset(&h->prof, 0, sizeof(h->prof));
   memset(&h->info, 0, sizeof(h->info));
@@ -966,7 +987,7 @@ hs_status hs_index_build_windows(hs_handle* h, const uint8_t* residues, uint64_t
   }
   starts[n_seq] = (uint32_t)(n_seq ? seq_start[n_seq] : 0);
   win_off[n_seq] = (uint32_t)n;
-  h->built = false;
+  h->built = false, h->rec8w_ready = false;
   h->n = n;
   memset(&h->prof, 0, sizeof(h->prof));
   memset(&h->info, 0, sizeof(h->info));
@@ -1216,7 +1237,7 @@ hs_status hs_index_load(hs_handle* h, const char* path) {
       hd.W != h->p.W)
     return fail(h, HS_ERR_IO, "index file written for other parameters (k, K, L, W, alphabet)");
   if (hd.payload_bytes != payload_size(hd)) return fail(h, HS_ERR_IO, "index file inconsistent (payload length)");
-  h->built = false;
+  h->built = false, h->rec8w_ready = false;
   memset(&h->prof, 0, sizeof(h->prof));
   memset(&h->info, 0, sizeof(h->info));
   HS_HIP(h, hipStreamSynchronize(h->stream));
@@ -1412,17 +1433,45 @@ struct BatchOut {
 // [20] hits not ordered on the device, [21] HS_CNT_SURVIVOR_OVERFLOW, [32] the join's item counter.
 // Internal status: the batch's filters passed more pairs than the 32-bit survivor counter holds.
 static const hs_status HS_SPLIT_BATCH = (hs_status)1000;
+// Wide int8 rows (all 8 coordinate columns) for this call?  Always for short k-mers (the index's
+// member records are wide then).  For k = 21..25 when the radius is large for the k-mer length: the
+// 4-column squared distance of two random k-mers is ~ N(k m, k v) (m, v: one residue pair), and once
+// R^2 comes within 3 standard deviations of its mean the 4-column bound passes > 1e-3 of the bucket
+// mates -- the survivor path, not the matrix pipe, then sets the pace (k = 25, R = 50: 1 % pass).
+static bool want_wide(const hs_handle* h, double R) {
+  if (h->wide8) return true;
+  if (!h->wide8_ok || h->p.k > 25 || getenv("HS_NO_WIDE_BY_RADIUS")) return false;
+  if (getenv("HS_FORCE_WIDE")) return true;
+  const double k = (double)h->p.k, sd = sqrt(k * h->pair4_var);
+  return R * R > k * h->pair4_mean - 3.0 * sd;
+}
+
+// The wide rows' member records for k = 21..25 (16 bytes per entry and table), built on first use
+static hs_status ensure_rec8w(hs_handle* h) {
+  if (h->wide8 || h->rec8w_ready) return HS_OK;
+  const size_t n = h->n;
+  const int L = (int)h->p.L;
+  HS_HIP(h, h->t_rec8w.reserve(std::max<size_t>(16, (size_t)L * n * 16)));
+  for (int l = 0; l < L; ++l)
+    HS_HIP(h, hs_launch_gather_rec8(h->packed_all.as<uint4>(), h->tabs.t[l].ids, (uint32_t)n, (int)h->p.k, 1,
+                                    h->jtab8.p, h->jtab8.as<char>() + 1536, h->jtab8.as<float>() + 128,
+                                    nullptr, h->t_rec8w.as<uint4>() + (size_t)l * n, h->stream));
+  h->rec8w_ready = true;
+  return HS_OK;
+}
+
 // May a self-join at radius R run from the residue codes alone (query_batch's self_codes)?  Only when
 // nothing on its way can need the embedded centres: the int8 join and its thin-segment filter must
 // apply, and no query row may be unrepresentable -- for a k-mer of the coordinate table the one way
 // is -gamma overflowing its 13 base-127 digits, bounded here from R and the scale alone.
 static bool self_codes_ok(const hs_handle* h, double R) {
-  const double r2 = R * R, s = h->join8_scale, k = (double)h->p.k;
+  const bool wide = want_wide(h, R);
+  const double r2 = R * R, s = wide ? h->join8_scale_w : h->join8_scale, k = (double)h->p.k;
   if (!h->join8_tables_ok || h->p.k > 50 || h->verify_mode == 1 || h->verify_mode == 3 || !(r2 < 30000.0))
     return false;
   if (getenv("HS_NO_THIN8") || getenv("HS_NO_SELF_CODES")) return false;
   // -gamma <= s^2 R^2 / 2 + L1(c^)/2 + 3, L1(c^) <= 127 * 4 k (127 * 8 k with wide rows)
-  return s > 0.0 && 0.5 * s * s * r2 + (h->wide8 ? 508.0 : 254.0) * k + 3.0 < 127.0 * 127.0 * 13.0;
+  return s > 0.0 && 0.5 * s * s * r2 + (wide ? 508.0 : 254.0) * k + 3.0 < 127.0 * 127.0 * 13.0;
 }
 
 static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq, uint32_t q_base,
@@ -1445,7 +1494,9 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   // survivors of the int8 join's 4-column bound pass an 8-column int8 bound before the exact
   // decision (hs_refine8_kernel); HS_NO_REFINE8 switches it off
   // (wide rows already hold all 8 columns: nothing to refine)
-  const int wide = h->wide8 ? 1 : 0;
+  const int wide = (use_i8 && want_wide(h, R)) ? 1 : 0;
+  if (wide) HS_CHECK(ensure_rec8w(h));
+  const uint4* const rec8 = (wide && !h->wide8) ? h->t_rec8w.as<uint4>() : h->t_rec8.as<uint4>();
   const void* const jtab_rows = wide ? (const void*)(h->jtab8.as<char>() + 1536) : (const void*)h->jtab8.p;
   const bool refine = use_i8 && !wide && !getenv("HS_NO_REFINE8");
   uint32_t* d_unsafe = d_cnt + 8;
@@ -1674,7 +1725,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, hipEventRecord(h->ev[3], h->stream));
     if (launches) HS_HIP(h, hipMemsetAsync(d_cnt + 32, 0, 4, h->stream));  // retry: the item counter again
     if (thin8)
-      HS_HIP(h, hs_launch_thin8(h->tabs, h->t_rec8.as<uint4>(), h->n, h->c16.p, jtab_rows,
+      HS_HIP(h, hs_launch_thin8(h->tabs, rec8, h->n, h->c16.p, jtab_rows,
                                 h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
                                 h->slice_off.as<uint32_t>(), h->slice_ql.as<uint32_t>(), nql, L, k, wide, d_cnt,
                                 prov_cap, h->prov.as<uint2>(), n_blocks, h->stream));
@@ -1698,7 +1749,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
       HS_HIP(h, hipEventRecord(h->ev[11], h->stream));  // the join kernel alone: ev[11] .. ev[10]
       if (n_items && use_i8)
         HS_HIP(h, hs_launch_join8w(h->item_desc.as<uint4>(), n_items, h->tabs.t[0].packed,
-                                   h->t_rec8.as<uint4>(), h->c16s.p, jtab_rows, k, wide, d_cnt, prov_cap,
+                                   rec8, h->c16s.p, jtab_rows, k, wide, d_cnt, prov_cap,
                                    h->prov.as<uint2>(), d_cnt + 32, h->n_cu * h->join_blocks_per_cu,
                                    async_items ? h->item_off.as<uint32_t>() + nql : nullptr, h->stream));
       else if (n_items)

@@ -35,7 +35,9 @@
 // the row carries ALL 8 coordinates, quantised with one scale: byte 8p + j = coordinate j of
 // position p, 6 k-steps (160 coordinate bytes + 4 spare + 28 digit slots), rho and gamma over all
 // 8 columns with dims = 8k, 64 members per work item like the other 6-k-step rows; there is nothing
-// left for hs_refine8_kernel to add, so it does not run.
+// left for hs_refine8_kernel to add, so it does not run.  The same rows with 8 k-steps (k = 21..25)
+// serve calls whose radius is large for the k-mer length (hs_capi.hip want_wide): their member
+// records are built the first time such a radius is asked for.
 //
 // rho depends on the member only, so it is evaluated ONCE, at index build: hs_gather_rec8_kernel
 // writes, next to the bucket-ordered packed copy, a 16-byte record per entry = bytes 96..111 of the
@@ -56,9 +58,9 @@ typedef int intx16 __attribute__((ext_vector_type(16)));
 
 constexpr int QD = 4;        // table columns used
 // k-steps of 32 bytes in a row: 4 (k <= 25), 6 (k <= 41), 8 (k <= 50); row = 32 KS bytes = 2 KS pieces
-// wide rows (all 8 coordinates, k <= 20): 6
+// wide rows (all 8 coordinates): 6 (k <= 20) or 8 (k <= 25)
 __host__ __device__ constexpr int ks_of(int k, bool wide = false) {
-  return wide ? 6 : k <= 25 ? 4 : k <= 41 ? 6 : 8;
+  return wide ? (k <= 20 ? 6 : 8) : k <= 25 ? 4 : k <= 41 ? 6 : 8;
 }
 constexpr uint32_t JRES = 64;  // survivor slots a wave reserves per counter access
 constexpr int DIG = 13;      // base-127 digits (+1 remainder slot) of -gamma
@@ -460,26 +462,29 @@ __device__ __forceinline__ void build_afrags8(const uint4 pk, const uint4 pk1, c
   A[KS - 1][3] = h ? 0x017f7f7f : (int)rec.w;          // last byte = 1 (remainder slot of -gamma)
 }
 
-// Wide rows (6 k-steps, all 8 coordinates): k-step s < 5 carries positions 4 s + 2 h + {0, 1}, 8 bytes
-// each, by one 8-byte lookup per position; the last k-step as above.
+// Wide rows (6 or 8 k-steps, all 8 coordinates): k-step s < KS - 1 carries positions 4 s + 2 h + {0, 1},
+// 8 bytes each, by one 8-byte lookup per position (positions past the k-mer meet zero query bytes);
+// the last k-step as above.
+template <int KS>
 __device__ __forceinline__ void build_afrags8_wide(const uint4 pk, const uint4 rec, int h, const uint2* sTabW,
-                                                   intx4 (&A)[6]) {
+                                                   intx4 (&A)[KS]) {
   const uint32_t sh = 10u * (uint32_t)h;  // the upper half's positions are two further on
   const uint32_t x = __funnelshift_r(pk.x, pk.y, sh), y = __funnelshift_r(pk.y, pk.z, sh),
                  z = __funnelshift_r(pk.z, pk.w, sh), w = pk.w >> sh;
 #define HS_AW(S)                                                          \
   {                                                                       \
     const uint2 p0_ = sTabW[residue_at<20 * (S)>(x, y, z, w)];            \
-    const uint2 p1_ = sTabW[residue_at<20 * (S) + 5>(x, y, z, w)];        \
+    const uint2 p1_ = sTabW[residue_at<(20 * (S) + 5 < 124 ? 20 * (S) + 5 : 123)>(x, y, z, w)]; \
     A[S] = intx4{(int)p0_.x, (int)p0_.y, (int)p1_.x, (int)p1_.y};         \
   }
   HS_AW(0) HS_AW(1) HS_AW(2) HS_AW(3) HS_AW(4)
+  if constexpr (KS == 8) { HS_AW(5) HS_AW(6) }
 #undef HS_AW
   constexpr uint32_t C127 = 0x7f7f7f7fu;
-  A[5][0] = h ? 0x7f7f0000 : (int)rec.x;
-  A[5][1] = h ? (int)C127 : (int)rec.y;
-  A[5][2] = h ? (int)C127 : (int)rec.z;
-  A[5][3] = h ? 0x017f7f7f : (int)rec.w;
+  A[KS - 1][0] = h ? 0x7f7f0000 : (int)rec.x;
+  A[KS - 1][1] = h ? (int)C127 : (int)rec.y;
+  A[KS - 1][2] = h ? (int)C127 : (int)rec.z;
+  A[KS - 1][3] = h ? 0x017f7f7f : (int)rec.w;
 }
 
 // index build: bucket-ordered packed copy of one table + the 16-byte A-row tail of every entry
@@ -505,7 +510,7 @@ __global__ __launch_bounds__(256) void hs_gather_rec8_kernel(const uint4* __rest
   uint32_t xlast = 0;
   for (int wd = 0; wd < PW; ++wd) {
     const uint4 pk = packed_all[(uint64_t)ids[t] * PW + wd];
-    out_packed[(uint64_t)t * PW + wd] = pk;
+    if (out_packed) out_packed[(uint64_t)t * PW + wd] = pk;  // (null: records only)
     const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
 #pragma unroll
     for (int r = 0; r < 25; ++r) {
@@ -686,7 +691,7 @@ __global__ __launch_bounds__(256, 2) void hs_join8w_kernel(
   if (n_items_dev) n_items = min(n_items, __builtin_amdgcn_readfirstlane(*n_items_dev));
   static_assert(JT == 4 || JT == 2, "two accumulator groups of JT / 2 row tiles");
   static_assert(KS == 4 || KS == 6 || KS == 8, "k-steps of a row");
-  static_assert(!WIDE || KS == 6, "wide rows have 6 k-steps");
+  static_assert(!WIDE || KS == 6 || KS == 8, "wide rows have 6 or 8 k-steps");
   constexpr int GT = JT / 2;
   constexpr int PW = (KS == 4 || WIDE) ? 1 : 2;  // packed words per member
   __shared__ uint32_t sTab8[32];
@@ -797,7 +802,7 @@ __global__ __launch_bounds__(256, 2) void hs_join8w_kernel(
 #undef HS_SWAP
       uint4 pk1 = pk;
       if constexpr (PW == 2) pk1 = mk1[t];
-      if constexpr (WIDE) build_afrags8_wide(pk, rk, h, sTabW, A[t]);
+      if constexpr (WIDE) build_afrags8_wide<KS>(pk, rk, h, sTabW, A[t]);
       else build_afrags8<KS, PW>(pk, pk1, rk, h, sTab8, A[t]);
     }
     HS_TD(1, __builtin_amdgcn_readfirstlane(A[0][0][0] ^ A[JT - 1][3][3] ^ A[JT - 1][2][0] ^ A[1][1][1]))
@@ -1300,7 +1305,7 @@ __global__ __launch_bounds__(256) void hs_thin8_kernel(const uint4* __restrict__
 #define HS_P(P) if ((P) < NW - 8 && (P) < k) acc = __builtin_amdgcn_sdot4((int)sTab8[stream_at<5 * (P)>(st)], B[(P) < NW ? (P) : 0], acc, false);
 #define HS_P8(P) HS_P(P) HS_P(P + 1) HS_P(P + 2) HS_P(P + 3) HS_P(P + 4) HS_P(P + 5) HS_P(P + 6) HS_P(P + 7)
       if constexpr (WIDE) {
-        // position P = dwords 2 P (columns 0..3) and 2 P + 1 (columns 4..7) of the row; P < 20
+        // position P = dwords 2 P (columns 0..3) and 2 P + 1 (columns 4..7) of the row; P < 20 / 25
 #define HS_PW(P)                                                                           \
   if ((P) < k) {                                                                           \
     const uint32_t r_ = stream_at<5 * (P)>(st);                                            \
@@ -1309,6 +1314,7 @@ __global__ __launch_bounds__(256) void hs_thin8_kernel(const uint4* __restrict__
   }
         HS_PW(0) HS_PW(1) HS_PW(2) HS_PW(3) HS_PW(4) HS_PW(5) HS_PW(6) HS_PW(7) HS_PW(8) HS_PW(9)
         HS_PW(10) HS_PW(11) HS_PW(12) HS_PW(13) HS_PW(14) HS_PW(15) HS_PW(16) HS_PW(17) HS_PW(18) HS_PW(19)
+        if constexpr (KS == 8) { HS_PW(20) HS_PW(21) HS_PW(22) HS_PW(23) HS_PW(24) }
 #undef HS_PW
       } else {
       HS_P8(0) HS_P8(8) HS_P8(16)
@@ -1529,8 +1535,12 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
   const int KS = ks_of(k, wide != 0);
   // k <= 25: the 16x16x64 form by default (HS_JOIN_SHAPE=32 selects the 32x32x32 form)
   static const bool shape32 = getenv("HS_JOIN_SHAPE") && atoi(getenv("HS_JOIN_SHAPE")) == 32;
-  if (wide)  // d_tab8 = the 8-column table here
+  if (wide && KS == 6)  // d_tab8 = the 8-column table here
     hs_join8w_kernel<2, 6, true><<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_rec_base,
+                                                          (const uint4*)d_c8t, (const uint4*)d_tab8, d_prov_count,
+                                                          prov_cap, d_prov, d_item_counter, G, d_n_items);
+  else if (wide)
+    hs_join8w_kernel<2, 8, true><<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_rec_base,
                                                           (const uint4*)d_c8t, (const uint4*)d_tab8, d_prov_count,
                                                           prov_cap, d_prov, d_item_counter, G, d_n_items);
   else if (KS == 4 && !shape32)
@@ -1573,9 +1583,14 @@ hipError_t hs_launch_thin8(const hs_tables_dev& tabs, const uint4* d_rec_base, u
                            uint2* d_prov, int n_blocks, hipStream_t s) {
   if (!nql) return hipSuccess;
   if (wide) {  // d_tab8 = the 8-column table
-    hs_thin8_kernel<6, true><<<n_blocks, 256, 0, s>>>(tabs.t[0].packed, d_rec_base, n_entries, (const int8_t*)d_c8,
-                                                      (const uint4*)d_tab8, d_qstart, d_qcount, d_slice_off,
-                                                      d_slice_ql, nql, L, k, d_prov_count, prov_cap, d_prov);
+    if (ks_of(k, true) == 6)
+      hs_thin8_kernel<6, true><<<n_blocks, 256, 0, s>>>(tabs.t[0].packed, d_rec_base, n_entries, (const int8_t*)d_c8,
+                                                        (const uint4*)d_tab8, d_qstart, d_qcount, d_slice_off,
+                                                        d_slice_ql, nql, L, k, d_prov_count, prov_cap, d_prov);
+    else
+      hs_thin8_kernel<8, true><<<n_blocks, 256, 0, s>>>(tabs.t[0].packed, d_rec_base, n_entries, (const int8_t*)d_c8,
+                                                        (const uint4*)d_tab8, d_qstart, d_qcount, d_slice_off,
+                                                        d_slice_ql, nql, L, k, d_prov_count, prov_cap, d_prov);
     return hipGetLastError();
   }
 #define HS_T8(KS_)                                                                                      \

