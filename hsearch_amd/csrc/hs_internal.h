@@ -144,7 +144,7 @@ static inline int hs_packed_words(int k) { return (k + 24) / 25; }
 size_t hs_sort_pairs_u64_u32_temp(size_t n);
 // keys ordered by their bits [0, end_bit) only
 hipError_t hs_sort_pairs_u64_u32(void* temp, size_t temp_bytes, const uint64_t* kin, uint64_t* kout,
-                                 const uint32_t* vin, uint32_t* vout, size_t n, int end_bit,
+                                 const uint32_t* vin, uint32_t* vout, size_t n, int begin_bit, int end_bit,
                                  hipStream_t s);
 size_t hs_sort_pairs_u64_u64_temp(size_t n);
 hipError_t hs_sort_pairs_u64_u64(void* temp, size_t temp_bytes, const uint64_t* kin, uint64_t* kout,
@@ -214,7 +214,7 @@ hipError_t hs_launch_keys(const int32_t* d_ints, uint64_t n, int stride, int K, 
 // case the caller repeats the call with exhaustive = true (every neighbour pair compared as strings)
 hipError_t hs_launch_check_runs(const uint64_t* d_keys_sorted, const uint32_t* d_ids_sorted,
                                 const int32_t* d_ints, uint64_t n, int K, uint32_t* d_flag,
-                                uint32_t* d_slow, uint32_t slow_cap, bool exhaustive,
+                                uint32_t* d_slow, uint32_t slow_cap, bool exhaustive, int sorted_from_bit,
                                 hipStream_t s);
 hipError_t hs_launch_dir_tuples(const uint32_t* d_dir_start, const uint32_t* d_ids_sorted,
                                 const int32_t* d_ints, uint32_t nb, int K, int32_t* d_dir_tuple,

@@ -177,10 +177,16 @@ __global__ __launch_bounds__(256) void hs_check_runs_kernel(const uint64_t* __re
                                                             const int32_t* __restrict__ ints,
                                                             uint64_t n, int K,
                                                             uint32_t* __restrict__ slow,
-                                                            uint32_t slow_cap) {
+                                                            uint32_t slow_cap, int sorted_from_bit,
+                                                            uint32_t* __restrict__ flag) {
   const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x + 1;
   if (p >= n) return;
-  if (keys[p] != keys[p - 1]) return;
+  if (keys[p] != keys[p - 1]) {
+    // the sort looked at bits [sorted_from_bit, 64) only: two fingerprints that agree there may have
+    // interleaved -- flag 4, the caller sorts this table again on all 64 bits
+    if (sorted_from_bit && (keys[p] >> sorted_from_bit) == (keys[p - 1] >> sorted_from_bit)) atomicOr(flag, 4u);
+    return;
+  }
   const int32_t* px = ints + (uint64_t)ids[p] * K;
   const int32_t* py = ints + (uint64_t)ids[p - 1] * K;
   bool same = true;
@@ -1232,7 +1238,7 @@ hipError_t hs_launch_keys(const int32_t* d_ints, uint64_t n, int stride, int K, 
 
 hipError_t hs_launch_check_runs(const uint64_t* d_keys_sorted, const uint32_t* d_ids_sorted,
                                 const int32_t* d_ints, uint64_t n, int K, uint32_t* d_flag,
-                                uint32_t* d_slow, uint32_t slow_cap, bool exhaustive,
+                                uint32_t* d_slow, uint32_t slow_cap, bool exhaustive, int sorted_from_bit,
                                 hipStream_t s) {
   if (n < 2) return hipSuccess;
   if (exhaustive) {
@@ -1243,7 +1249,7 @@ hipError_t hs_launch_check_runs(const uint64_t* d_keys_sorted, const uint32_t* d
   hipError_t e = hipMemsetAsync(d_slow, 0, 4, s);
   if (e != hipSuccess) return e;
   hs_check_runs_kernel<<<blocks_for(n - 1), 256, 0, s>>>(d_keys_sorted, d_ids_sorted, d_ints, n, K,
-                                                         d_slow, slow_cap);
+                                                         d_slow, slow_cap, sorted_from_bit, d_flag);
   hs_check_runs_slow_kernel<<<64, 256, 0, s>>>(d_ids_sorted, d_ints, K, d_slow, slow_cap, 0,
                                                d_keys_sorted, d_flag);
   return hipGetLastError();

@@ -17,9 +17,9 @@ size_t hs_sort_pairs_u64_u32_temp(size_t n) {
   return bytes;
 }
 hipError_t hs_sort_pairs_u64_u32(void* temp, size_t temp_bytes, const uint64_t* kin, uint64_t* kout,
-                                 const uint32_t* vin, uint32_t* vout, size_t n, int end_bit,
+                                 const uint32_t* vin, uint32_t* vout, size_t n, int begin_bit, int end_bit,
                                  hipStream_t s) {
-  return rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, n, 0, end_bit, s);
+  return rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, n, begin_bit, end_bit, s);
 }
 
 size_t hs_sort_pairs_u64_u64_temp(size_t n) {

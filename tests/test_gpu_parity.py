@@ -613,3 +613,29 @@ def test_set_planes_rebuild_equals_fresh_handle(oracle):
     assert np.array_equal(got["cand"], want["cand"])
     assert not np.array_equal(first["cand"], got["cand"])
     eng.close()
+
+
+def test_build_sorts_again_when_partial_fingerprints_interleave(monkeypatch):
+    """From 2^20 k-mers on, the build's radix sort looks at the fingerprints' top 48 bits only; distinct
+    fingerprints that agree there would interleave, which hs_check_runs_kernel reports and a second
+    sort on all bits repairs.  HS_SORT_FROM_BIT=56 (8 bits) makes that certain: the index and the hits
+    must be those of the one-pass form (=0) and of the default."""
+    k, K, L, W, R, n, nq = 25, 8, 3, 150.0, 45.0, (1 << 20) + 77, 2003
+    a, b = synth.make_planes(k, K, L, W, seed=55)
+    codes = synth.make_db(n, k, seed=56)
+    centers, _ = synth.make_queries(codes, nq, seed=57, jitter=0.2)
+    res = {}
+    for from_bit in ("0", "56", None):
+        monkeypatch.delenv("HS_SORT_FROM_BIT", raising=False)
+        if from_bit is not None:
+            monkeypatch.setenv("HS_SORT_FROM_BIT", from_bit)
+        eng = Engine(k, K, L, W, a, b)
+        info = eng.index_build(codes)
+        assert min(info["n_buckets"]) > 300          # far more buckets than 8 bits tell apart
+        res[from_bit] = (info["n_buckets"], info["max_bucket"], eng.query(centers, R))
+        eng.close()
+    assert len(res["0"][2]["q"]) > 1000
+    for other in ("56", None):
+        assert res[other][0] == res["0"][0] and res[other][1] == res["0"][1]
+        for key in ("q", "id", "table", "dist", "cand"):
+            assert np.array_equal(res[other][2][key], res["0"][2][key])
