@@ -197,13 +197,33 @@ __global__ __launch_bounds__(256) void hs_quant_points_kernel(const double* __re
   if (p >= n) return;
   const int lane = threadIdx.x & 63;
   const double* row = pts + p * (uint64_t)d;
+  // a lane owns 4 consecutive coordinates (two sets of them for rows of more than 256): the row is
+  // read once, 32 bytes per lane, and the digits leave as one dword of high and one of low bytes
+  const int nv = 32 * S;
+  double v[2][4];
   double m = 0.0, l1 = 0.0;
   bool ok = true;
-  for (int i = lane; i < d; i += 64) {
-    const double v = row[i];
-    if (!(fabs(v) < 1e300)) ok = false;
-    m = fmax(m, fabs(v));
-    l1 += fabs(v);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int base = 4 * (lane + 64 * it);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[it][e] = 0.0;
+    if (base + 3 < d) {
+      const double2 a = *reinterpret_cast<const double2*>(row + base);
+      const double2 b = *reinterpret_cast<const double2*>(row + base + 2);
+      v[it][0] = a.x; v[it][1] = a.y; v[it][2] = b.x; v[it][3] = b.y;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (base + e < d) v[it][e] = row[base + e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const double a = fabs(v[it][e]);
+      if (!(a < 1e300)) ok = false;
+      m = fmax(m, a);
+      l1 += a;
+    }
   }
   for (int off = 32; off; off >>= 1) {
     m = fmax(m, __shfl_xor(m, off));
@@ -215,14 +235,22 @@ __global__ __launch_bounds__(256) void hs_quant_points_kernel(const double* __re
   ok = __ballot(!ok) == 0;
   if (!ok) ex = 0;
   char* out = reinterpret_cast<char*>(xq) + p * (uint64_t)S * 64;
-  for (int i = lane; i < 32 * S; i += 64) {
-    const double v = (ok && i < d) ? row[i] : 0.0;
-    const int X = (int)rint(ldexp(v, ex));
-    int hi, lo;
-    split_digits(X, &hi, &lo);
-    const int s = i >> 5, h = (i >> 4) & 1, j = i & 15;
-    out[s * 64 + h * 32 + j] = (char)hi;
-    out[s * 64 + h * 32 + 16 + j] = (char)lo;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int base = 4 * (lane + 64 * it);
+    if (base >= nv) continue;
+    uint32_t whi = 0, wlo = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int X = (int)rint(ldexp(ok ? v[it][e] : 0.0, ex));
+      int hi, lo;
+      split_digits(X, &hi, &lo);
+      whi |= ((uint32_t)hi & 0xffu) << (8 * e);
+      wlo |= ((uint32_t)lo & 0xffu) << (8 * e);
+    }
+    const int s = base >> 5, h = (base >> 4) & 1, j = base & 15;
+    *reinterpret_cast<uint32_t*>(out + s * 64 + h * 32 + j) = whi;
+    *reinterpret_cast<uint32_t*>(out + s * 64 + h * 32 + 16 + j) = wlo;
   }
   if (lane == 0) {
     // the wave sums |x_i| in a tree: <= d roundings, relative error < d 2^-53
@@ -271,6 +299,8 @@ __global__ __launch_bounds__(256, S > 10 ? 1 : 2) void hs_proj_kernel(
   const double sx_tab = FROM_CODES ? tab->sx : 0.0, dx_tab = FROM_CODES ? tab->dx : 0.0;
   const bool tab_unsafe = FROM_CODES && tab->unsafe != 0u;
   const uint64_t n_tiles = (n + 31) / 32;
+  // 16-byte stores of the bucket ints need rows that start on 16 bytes
+  const bool aligned16 = (out_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
   uint32_t res_base = 0, res_left = 0, flagged = 0;
   // Raw inputs of a point tile: the lane's residues (codes path: positions 4 s + 2 h, 4 s + 2 h + 1)
   // or its digit fragments (points path).  The NEXT tile's are fetched before the current tile's
@@ -385,10 +415,12 @@ __global__ __launch_bounds__(256, S > 10 ? 1 : 2) void hs_proj_kernel(
     }
     // ---- epilogue: T~, its bound, the certain floor or a flag
     uint32_t fmask = 0;
+    int32_t fv[16];
     int32_t* orow = out + (pvalid ? p : 0) * (uint64_t)out_stride + 32 * ft;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int frow = (i & 3) + 8 * (i >> 2) + 4 * h;
+      fv[i] = 0;
       if (32 * ft + 8 * (i >> 2) >= F) continue;  // wave-uniform: this group of rows is padding
       const ProjFn c = s_fn[frow];
       const double N = fma((double)acc_hi[i], 65536.0, fma((double)acc_mid[i], 256.0, (double)acc_lo[i]));
@@ -399,9 +431,22 @@ __global__ __launch_bounds__(256, S > 10 ? 1 : 2) void hs_proj_kernel(
       const double E = fma(x1, c.alpha, fma(dx, c.beta, fma(fabs(T), 0x1p-49, 0x1p-40)));
       const bool certain = (frac >= E) && ((1.0 - frac) > E);  // false for NaN / infinite bounds
       const bool real = pvalid && 32 * ft + frow < F;
-      if (real) {
-        orow[frow] = (int32_t)fl;
-        if (!certain) fmask |= 1u << i;
+      fv[i] = (int32_t)fl;
+      if (real && !certain) fmask |= 1u << i;
+    }
+    // the lane's values are 4 groups of 4 consecutive functions (8 j + 4 h + {0..3}): one 16-byte store
+    // per group where the whole group is real (F is a multiple of 4 for every K the reference uses)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int f0 = 32 * ft + 8 * j + 4 * h;
+      if (!pvalid || f0 >= F) continue;
+      int32_t* dst = orow + 8 * j + 4 * h;
+      if (f0 + 3 < F && aligned16) {
+        *reinterpret_cast<int4*>(dst) = make_int4(fv[4 * j], fv[4 * j + 1], fv[4 * j + 2], fv[4 * j + 3]);
+      } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          if (f0 + m < F) dst[m] = fv[4 * j + m];
       }
     }
     if (__ballot(fmask != 0)) {
