@@ -124,6 +124,7 @@ struct hs_handle {
   bool join8_tables_ok = false;  // int8 can carry the coordinate table
   double join8_scale = 0.0, join8_scale_w = 0.0;  // quantisation scales: 4-column rows, wide rows
   bool wide8_ok = false;         // the 8-column table is usable (wide rows on demand for k = 21..25)
+  double pairs_per_item = 0.0;   // average of the previous batch's join work items (0: none yet)
   uint32_t test_split_above = 0; // HS_TEST_SPLIT_ABOVE (tests): batches above this size report a survivor overflow
   bool wide8 = false;            // short k-mers: int8 rows over all 8 coordinate columns (hs_join8.hip)
   // segment routing thresholds (HS_JOIN_MIN_Q / _M): segments with fewer probing queries or members
@@ -1778,7 +1779,8 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
         HS_HIP(h, hs_launch_join8w(h->item_desc.as<uint4>(), n_items, h->tabs.t[0].packed,
                                    rec8, h->c16s.p, jtab_rows, k, wide, d_cnt, prov_cap,
                                    h->prov.as<uint2>(), d_cnt + 32, h->n_cu * h->join_blocks_per_cu,
-                                   async_items ? h->item_off.as<uint32_t>() + nql : nullptr, h->stream));
+                                   async_items ? h->item_off.as<uint32_t>() + nql : nullptr,
+                                   h->pairs_per_item, h->stream));
       else if (n_items)
         HS_HIP(h, hs_launch_join(h->item_desc.as<uint4>(), n_items, h->tabs.t[0].packed,
                                  h->sorted_ql.as<uint32_t>(),
@@ -1874,6 +1876,11 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   if (async_items) n_items = n_items_real;
   h->prof.join_items += n_items;
   if (use_i8 && n_items) h->item_cap_hint = n_items + n_items / 4 + 4096;
+  if (use_i8 && n_items) {  // sizes the next batch's counter chunks (hs_launch_join8w)
+    unsigned long long issued = 0;
+    memcpy(&issued, host_cnt + 10, 8);
+    h->pairs_per_item = (double)issued / (double)n_items;
+  }
   if (use_join) {
     unsigned long long js[2] = {0, 0};
     memcpy(js, host_cnt + 10, 16);  // d_jstats = d_cnt + 10, read back with the counters

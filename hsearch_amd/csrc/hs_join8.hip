@@ -57,6 +57,7 @@ typedef int intx4 __attribute__((ext_vector_type(4)));
 typedef int intx16 __attribute__((ext_vector_type(16)));
 
 constexpr int QD = 4;        // table columns used
+constexpr int HS_J8_CONST_AT = 48;  // uint4 index in the int8 table block of the gamma slots' constant factors
 // k-steps of 32 bytes in a row: 4 (k <= 25), 6 (k <= 41), 8 (k <= 50); row = 32 KS bytes = 2 KS pieces
 // wide rows (all 8 coordinates): 6 (k <= 20) or 8 (k <= 25)
 __host__ __device__ constexpr int ks_of(int k, bool wide = false) {
@@ -138,6 +139,9 @@ __global__ void hs_jtables8_kernel(const double* __restrict__ coords, int alphab
   if (aa == 0) {
     scale[0] = (float)s;
     scale[1] = (float)(0.5 * s * s);
+    // the constant factors of the gamma slots (last 16 bytes of a member's row) as data, at byte 768
+    // of the table block: hs_join8x_kernel's lanes of the fourth quarter LOAD them in place of a record
+    tab8[HS_J8_CONST_AT] = make_uint4(0x7f7f0000u, 0x7f7f7f7fu, 0x7f7f7f7fu, 0x017f7f7fu);
   }
   // the other four columns, for hs_refine8_kernel
   __syncthreads();
@@ -1055,15 +1059,24 @@ __global__ __launch_bounds__(256, 2) void hs_join8x_kernel(
     nd0 = uniform4(desc[2 * (uint64_t)next_item]);
     nd1 = uniform4(desc[2 * (uint64_t)next_item + 1]);
   }
-  uint4 mk[RT];                  // lanes 0..31: packed member 16 t + n, lanes 32..63: its record
+  // lanes 0..31: packed member 16 t + n; lanes 32..47: its record; lanes 48..63: the constant factors
+  // of the gamma slots (one 16-byte block for everybody: their index is pinned to the segment's last
+  // entry and their base moved back by as much, so the same clamped-index load serves all lanes)
+  uint4 mk[RT];
   constexpr int NB = 3;          // B tiles in flight per wave: the one in use + two prefetched
   constexpr uint32_t GQ = 32 * NB;
   intx4 Bq[NB][2][2];
+  const uint4* const cn_src = tab8 + HS_J8_CONST_AT;
+  const uint32_t low_half = up ? 0u : 0xffffffffu;
 #define HS_LOAD_MEMBERS(D0)                                                              \
   {                                                                                      \
     const int64_t off_ = (int64_t)(((uint64_t)(D0).y << 32) | (uint64_t)(D0).x);         \
     const uint4* src_ = (up ? rec_base : packed_base) + off_;                            \
-    const uint32_t idx_ = (D0).w * 128u + (uint32_t)n;                                   \
+    uint32_t idx_ = (D0).w * 128u + (uint32_t)n;                                         \
+    if (q == 3) {                                                                        \
+      src_ = cn_src - ((D0).z - 1u);                                                     \
+      idx_ = 0x7fffff00u;                                                                \
+    }                                                                                    \
     _Pragma("unroll") for (int t = 0; t < RT; ++t)                                       \
       mk[t] = src_[min(idx_ + 16 * t, (D0).z - 1)];                                      \
   }
@@ -1097,46 +1110,37 @@ __global__ __launch_bounds__(256, 2) void hs_join8x_kernel(
     intx4 A[RT][2];
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
-      uint4 pk, rk;  // after the swap: pk = the lower half's value, rk = the upper half's, in all lanes
-#define HS_SWAP(C)                                                                        \
-  {                                                                                       \
-    const auto sw_ = __builtin_amdgcn_permlane32_swap(mk[t].C, mk[t].C, false, false);    \
-    pk.C = sw_[0];                                                                        \
-    rk.C = sw_[1];                                                                        \
-  }
-      HS_SWAP(x) HS_SWAP(y) HS_SWAP(z) HS_SWAP(w)
-#undef HS_SWAP
-      // positions 4 q + m (k-step 0) and 16 + 4 q + m (k-step 1, q < 2): the word shifted down by
-      // 20 q bits has them at bits 5 m and 80 + 5 m
-      uint32_t x = pk.x, y = pk.y, z = pk.z, w = pk.w;
-      if (q >= 2) {
-        x = y;
-        y = z;
-        z = w;
-        w = 0u;
-      }
+      // Every lane needs the member's packed word shifted down by 20 q bits (positions 4 q + m of
+      // k-step 0 at bits 5 m, 16 + 4 q + m of k-step 1 at bits 80 + 5 m).  The upper half-wave gets
+      // it from the lower one already moved down by one dword: v_permlane32_swap(a, b) exchanges the
+      // upper half of a with the lower half of b, so swap(x, y) leaves {own x | the lower lane's y},
+      // and so on -- three swaps and one mask instead of four swaps and four selects.  The upper
+      // half's own registers (record / constants) are not touched.
+      const uint32_t x0 = __builtin_amdgcn_permlane32_swap(mk[t].x, mk[t].y, false, false)[0];
+      const uint32_t y0 = __builtin_amdgcn_permlane32_swap(mk[t].y, mk[t].z, false, false)[0];
+      const uint32_t z0 = __builtin_amdgcn_permlane32_swap(mk[t].z, mk[t].w, false, false)[0];
+      const uint32_t w0 = mk[t].w & low_half;
       const uint32_t bs = (20u * (uint32_t)q) & 31u;  // 0, 20, 8, 28
-      x = __funnelshift_r(x, y, bs);
-      y = __funnelshift_r(y, z, bs);
-      z = __funnelshift_r(z, w, bs);
-      w = w >> bs;
+      const uint32_t x = __funnelshift_r(x0, y0, bs), z = __funnelshift_r(z0, w0, bs), w = w0 >> bs;
       // ten-bit fields at bits 0, 10 (k-step 0) and 80, 90 (k-step 1: bits 16..25 / 26..35 of z:w)
       const uint2 p0 = sPair[x & 1023u], p1 = sPair[(x >> 10) & 1023u];
       const uint2 p2 = sPair[(z >> 16) & 1023u], p3 = sPair[__funnelshift_r(z, w, 26) & 1023u];
       A[t][0] = intx4{(int)p0.x, (int)p0.y, (int)p1.x, (int)p1.y};
       const intx4 lk = intx4{(int)p2.x, (int)p2.y, (int)p3.x, (int)p3.y};
-      const intx4 rc = intx4{(int)rk.x, (int)rk.y, (int)rk.z, (int)rk.w};
-      const intx4 cn = intx4{0x7f7f0000, 0x7f7f7f7f, 0x7f7f7f7f, 0x017f7f7f};
-      A[t][1] = q < 2 ? lk : (q == 2 ? rc : cn);
+      const intx4 own = intx4{(int)mk[t].x, (int)mk[t].y, (int)mk[t].z, (int)mk[t].w};
+      A[t][1] = up ? own : lk;  // q = 2: the member's record, q = 3: the constants it loaded
     }
     HS_TD(1, __builtin_amdgcn_readfirstlane(A[0][0][0] ^ A[7][1][3] ^ A[3][1][0]))
     HS_LOAD_MEMBERS(nd0)
     HS_T(2)
     intx4 accX[4][2], accY[4][2];
+    // Y has no previous query tile at the item's first one: its sign test runs on whatever the
+    // registers hold (no 32 moves per item to preset them) and y_live says not to believe it
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int c = 0; c < 2; ++c) accY[t][c] = intx4{-1, -1, -1, -1};  // "no survivor" for the first Y test
+      for (int c = 0; c < 2; ++c) accY[t][c] = __builtin_nondeterministic_value(accY[t][c]);
+    bool y_live = false;
     uint32_t prev_qc = q_begin;
     const uint32_t n_groups = HS_N_GROUPS(d1);
     uint32_t qc0 = HS_FIRST_Q(d1);
@@ -1168,9 +1172,10 @@ __global__ __launch_bounds__(256, 2) void hs_join8x_kernel(
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
           }
-          if (__ballot((int)sY >= 0))
+          if (y_live && __ballot((int)sY >= 0))
             emit_survivors_x(accY, 4, prev_qc, qoff, q_end, wbase, M, mstart, lane, res_base, res_used,
                              prov_count, prov_cap, prov);
+          y_live = true;
           // ---- phase 2: Y <- row tiles 4..7 x B, beside the sign test of X
 #pragma unroll
           for (int s = 0; s < 2; ++s)
@@ -1516,13 +1521,24 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
                             const uint4* d_rec_base, const void* d_c8t, const void* d_tab8, int k, int wide,
                             uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov,
                             uint32_t* d_item_counter, int n_blocks, const uint32_t* d_n_items,
-                            hipStream_t s) {
+                            double pairs_per_item, hipStream_t s) {
   if (!n_items) return hipSuccess;
   // (*d_item_counter is zeroed by the caller, with the batch's other counters)
-  // chunk size: 8 items per counter access when there is plenty of work, fewer for small launches
+  // Chunk size = items per access to the global counter.  Same-address atomics complete at only
+  // ~ 90 per microsecond on this part, so a chunk has to be worth ~ 100 us of a wave's time: 8 items
+  // at C2 (79 k pairs per item), 32-48 where items are small (C3 shape at W = 160: 3.5 k pairs per
+  // item, 1.7e7 items -- with chunks of 8 the counter alone took 2.1e6 / 88 = 24 ms of a 26 ms
+  // kernel); bigger chunks than that cost balance at the end.  pairs_per_item = the previous
+  // batch's average (0: unknown).  Fewer for small launches.
   const uint32_t n_waves = (uint32_t)n_blocks * 4u;
-  static const uint32_t g_max = getenv("HS_JOIN_CHUNK") ? (uint32_t)atoi(getenv("HS_JOIN_CHUNK")) : 8u;
-  const uint32_t G = std::max(2u, std::min(g_max, n_items / (n_waves * 8u)));
+  static const uint32_t g_env = getenv("HS_JOIN_CHUNK") ? (uint32_t)atoi(getenv("HS_JOIN_CHUNK")) : 0u;
+  uint32_t g_max = 8u;
+  if (pairs_per_item > 0.0) g_max = (uint32_t)std::max(8.0, std::min(48.0, 7.0e5 / pairs_per_item));
+  if (g_env) g_max = g_env;
+  // up to 8: at least 8 chunks per wave; beyond: at least 64 (the balance at the end is paid in
+  // chunks: k = 39 at the C2 sizes, 576 items per wave, lost 3 % with chunks of 18)
+  const uint32_t g_small = std::min(8u, n_items / (n_waves * 8u));
+  const uint32_t G = std::max(2u, std::min(g_max, std::max(g_small, n_items / (n_waves * 64u))));
   // k <= 25: JT = 4 row tiles per wave (128 members), 4 k-steps, 2 waves per SIMD.  (JT = 2 at 4
   // waves per SIMD, with work items of 64 members, was measured 1.7x slower there: twice the B-tile
   // traffic and per-item work.)  k > 25: 64 members per wave over 6 or 8 k-steps -- the operands of
