@@ -796,6 +796,7 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
       nb = host_small[0];
       flag = host_small[1];
       if ((flag & 4u) && from_bit) {  // interleaved fingerprints: once more, on every bit
+        if (getenv("HS_BUILD_DEBUG")) fprintf(stderr, "table %d: %u buckets, second sort on all bits\n", l, nb);
         HS_HIP(h, hipMemsetAsync(d_small, 0, 64, h->stream));
         continue;
       }
