@@ -1533,6 +1533,10 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   // comes from the residue codes and the tables -- no embedded centres, no hashing, no directory
   // search (a k-mer probes the bucket it sits in).  Needs the int8 join with its thin-segment filter,
   // the only filters that work without per-query distance tables.
+  // how the probes are grouped by bucket in front of the join: a counting sort over the bucket slots,
+  // or -- when those far outnumber the probes -- a sort of the probes (HS_SEG_MODE=dense|sparse forces one)
+  bool seg_sparse = (uint64_t)h->nb_total > 4ull * nql;
+  if (const char* m = getenv("HS_SEG_MODE")) seg_sparse = !strcmp(m, "sparse") ? true : !strcmp(m, "dense") ? false : seg_sparse;
   const bool self_codes = h->self_first != HS_NO_SELF && !brute && use_i8 && self_codes_ok(h, R);
   const uint8_t* d_qcodes =
       self_codes ? h->codes.as<uint8_t>() + ((uint64_t)h->self_first + q_base) * k : nullptr;
@@ -1574,11 +1578,17 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     // grouping of the probes by bucket is then a counting sort: hs_launch_seg_group)
     uint32_t *bucket_count = nullptr, *qbucket = nullptr, *qrank = nullptr;
     if (use_join) {
-      HS_HIP(h, h->bucket_work.reserve(4 * ((size_t)h->nb_total + 2) * 4));
       HS_HIP(h, h->seg_keys.reserve(((size_t)nql + 1) * 8));
-      bucket_count = h->bucket_work.as<uint32_t>();
       qbucket = h->seg_keys.as<uint32_t>();
-      qrank = qbucket + ((size_t)nql + 1);
+      if (seg_sparse) {
+        // buckets far outnumber probes: the probes are sorted on their bucket number instead (no
+        // ranks, no pass over the bucket slots: hs_launch_seg_group_sparse)
+        HS_HIP(h, h->bucket_work.reserve(4 * ((size_t)nql + 1) * 4));
+      } else {
+        HS_HIP(h, h->bucket_work.reserve(4 * ((size_t)h->nb_total + 2) * 4));
+        bucket_count = h->bucket_work.as<uint32_t>();
+        qrank = qbucket + ((size_t)nql + 1);
+      }
     }
     HS_HIP(h, hs_launch_set_u32(h->nslices.as<uint32_t>() + nql, 0u, h->stream));
     if (self_codes)
@@ -1617,6 +1627,15 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     // (the query rows of the join filter were quantised on the side stream, beside hash and probe)
     HS_HIP(h, hipStreamWaitEvent(h->stream, h->evx[EV_JOIN], 0));
     HS_HIP(h, hipMemsetAsync(h->seg_cnt.p, 0, n1 * 4, h->stream));
+    if (seg_sparse) {
+      HS_HIP(h, h->temp.reserve(std::max(hs_sort_pairs_u32_u32_temp(nql), hs_scan_u32_temp(n1)) + 256));
+      HS_HIP(h, hs_launch_seg_group_sparse(h->tabs, h->dir_base.as<uint32_t>(), L, seg_shift, h->nb_total,
+                                           h->temp.p, h->temp.cap, h->seg_keys.as<uint32_t>(),
+                                           h->seg_keys.as<uint32_t>() + n1, h->seg_vals.as<uint32_t>(),
+                                           h->bucket_work.as<uint32_t>(), nql, h->sorted_ql.as<uint32_t>(),
+                                           h->seg_key.as<uint64_t>(), h->seg_cnt.as<uint32_t>(),
+                                           h->seg_n.as<uint32_t>(), h->stream));
+    } else
     HS_HIP(h, hs_launch_seg_group(h->tabs, h->dir_base.as<uint32_t>(), L, seg_shift, h->nb_total,
                                   h->bucket_work.as<uint32_t>(),
                                   h->bucket_work.as<uint32_t>() + ((size_t)h->nb_total + 2), h->temp.p,

@@ -146,6 +146,9 @@ size_t hs_sort_pairs_u64_u32_temp(size_t n);
 hipError_t hs_sort_pairs_u64_u32(void* temp, size_t temp_bytes, const uint64_t* kin, uint64_t* kout,
                                  const uint32_t* vin, uint32_t* vout, size_t n, int begin_bit, int end_bit,
                                  hipStream_t s);
+size_t hs_sort_pairs_u32_u32_temp(size_t n);
+hipError_t hs_sort_pairs_u32_u32(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout,
+                                 const uint32_t* vin, uint32_t* vout, size_t n, int end_bit, hipStream_t s);
 size_t hs_sort_pairs_u64_u64_temp(size_t n);
 hipError_t hs_sort_pairs_u64_u64(void* temp, size_t temp_bytes, const uint64_t* kin, uint64_t* kout,
                                  const uint64_t* vin, uint64_t* vout, size_t n, int end_bit,
@@ -260,6 +263,16 @@ hipError_t hs_launch_probe(const hs_tables_dev& tabs, const int32_t* d_qints, ui
 // of probes that found none) and d_qrank[ql] = arrival rank inside it (d_bucket_count[nb_total + 2]).
 // hs_launch_seg_group turns that into sorted_ql / seg_key / seg_cnt / n_seg (a counting sort: the
 // segments come out in bucket-number order, the pseudo-bucket last).
+// The same outputs when buckets far outnumber probes (the counting sort's passes over every bucket
+// slot would dominate: C3 shape at W = 160, 1.3e8 slots for 4e6 probes): the probes are radix-sorted
+// on their bucket number (d_qbucket from the probe kernels, which then take no ranks), segment
+// heads found by comparing neighbours.  d_work: 4 (nql + 1) words; d_iota / d_keys_sorted: nql words.
+hipError_t hs_launch_seg_group_sparse(const hs_tables_dev& tabs, const uint32_t* d_dir_base, int L, int shift,
+                                      uint32_t nb_total, void* d_temp, size_t temp_bytes,
+                                      const uint32_t* d_qbucket, uint32_t* d_keys_sorted, uint32_t* d_iota,
+                                      uint32_t* d_work, uint32_t nql, uint32_t* d_sorted_ql,
+                                      uint64_t* d_seg_key, uint32_t* d_seg_cnt, uint32_t* d_n_seg,
+                                      hipStream_t s);
 hipError_t hs_launch_seg_group(const hs_tables_dev& tabs, const uint32_t* d_dir_base, int L, int shift,
                                uint32_t nb_total, const uint32_t* d_bucket_count,
                                uint32_t* d_bucket_work /* 3 x (nb_total + 2) */, void* d_temp,

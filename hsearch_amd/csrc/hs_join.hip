@@ -156,6 +156,47 @@ __global__ __launch_bounds__(256) void hs_seg_emit_kernel(hs_tables_dev tabs,
   seg_cnt[j] = c;
 }
 
+// ---- the same grouping by a sort of the probes (hs_launch_seg_group_sparse)
+__global__ __launch_bounds__(256) void hs_iota_kernel(uint32_t n, uint32_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = i;
+}
+// head[p] = 1 where a new bucket starts in the sorted probe list; head[n] = 0 closes the scan
+__global__ __launch_bounds__(256) void hs_seg_heads_kernel(const uint32_t* __restrict__ gb, uint32_t n,
+                                                           uint32_t* __restrict__ head) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p <= n) head[p] = (p < n && (p == 0 || gb[p] != gb[p - 1])) ? 1u : 0u;
+}
+// per head: the segment's key (table, first member position) and where its probes start
+__global__ __launch_bounds__(256) void hs_seg_emit_sparse_kernel(hs_tables_dev tabs,
+                                                                 const uint32_t* __restrict__ dir_base, int L,
+                                                                 int shift, const uint32_t* __restrict__ gb,
+                                                                 const uint32_t* __restrict__ head,
+                                                                 const uint32_t* __restrict__ head_pos,
+                                                                 uint32_t n, uint64_t* __restrict__ seg_key,
+                                                                 uint32_t* __restrict__ seg_start,
+                                                                 uint32_t* __restrict__ n_seg) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p == 0) {
+    *n_seg = head_pos[n];
+    seg_start[head_pos[n]] = n;
+  }
+  if (p >= n || !head[p]) return;
+  const uint32_t g = gb[p];
+  int l = 0;
+  while (l < L && g >= dir_base[l + 1]) ++l;  // dir_base[L] = the pseudo-bucket: l = L
+  const uint32_t mstart = l < L ? tabs.t[l].dir_start[g - dir_base[l]] : 0u;
+  const uint32_t j = head_pos[p];
+  seg_key[j] = ((uint64_t)(uint32_t)l << shift) | mstart;
+  seg_start[j] = p;
+}
+__global__ __launch_bounds__(256) void hs_seg_counts_kernel(const uint32_t* __restrict__ seg_start,
+                                                            const uint32_t* __restrict__ n_seg,
+                                                            uint32_t* __restrict__ seg_cnt) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j < *n_seg) seg_cnt[j] = seg_start[j + 1] - seg_start[j];
+}
+
 // Routing: a segment (bucket x its probing queries) goes to the MFMA join when enough queries share
 // it, otherwise its queries stay with the streaming kernel (one wavefront per query and slice).
 // items[j] = member tiles x query groups for joined segments, 0 otherwise / past the end.
@@ -571,6 +612,31 @@ hipError_t hs_launch_seg_group(const hs_tables_dev& tabs, const uint32_t* d_dir_
   if (e != hipSuccess) return e;
   hs_seg_emit_kernel<<<blocks_for(n), 256, 0, s>>>(tabs, d_dir_base, L, shift, d_bucket_count, flag_pos,
                                                    n, d_seg_key, d_seg_cnt, d_n_seg);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_seg_group_sparse(const hs_tables_dev& tabs, const uint32_t* d_dir_base, int L, int shift,
+                                      uint32_t nb_total, void* d_temp, size_t temp_bytes,
+                                      const uint32_t* d_qbucket, uint32_t* d_keys_sorted, uint32_t* d_iota,
+                                      uint32_t* d_work, uint32_t nql, uint32_t* d_sorted_ql,
+                                      uint64_t* d_seg_key, uint32_t* d_seg_cnt, uint32_t* d_n_seg,
+                                      hipStream_t s) {
+  if (!nql) return hipSuccess;
+  uint32_t* head = d_work;
+  uint32_t* head_pos = d_work + ((size_t)nql + 1);
+  uint32_t* seg_start = d_work + 2 * ((size_t)nql + 1);
+  int bits = 1;
+  while (bits < 32 && (nb_total >> bits)) ++bits;  // bucket numbers are <= nb_total
+  hs_iota_kernel<<<blocks_for(nql), 256, 0, s>>>(nql, d_iota);
+  hipError_t e = hs_sort_pairs_u32_u32(d_temp, temp_bytes, d_qbucket, d_keys_sorted, d_iota, d_sorted_ql, nql,
+                                       bits, s);
+  if (e != hipSuccess) return e;
+  hs_seg_heads_kernel<<<blocks_for((uint64_t)nql + 1), 256, 0, s>>>(d_keys_sorted, nql, head);
+  e = hs_exclusive_scan_u32(d_temp, temp_bytes, head, head_pos, (size_t)nql + 1, s);
+  if (e != hipSuccess) return e;
+  hs_seg_emit_sparse_kernel<<<blocks_for(nql), 256, 0, s>>>(tabs, d_dir_base, L, shift, d_keys_sorted, head,
+                                                            head_pos, nql, d_seg_key, seg_start, d_n_seg);
+  hs_seg_counts_kernel<<<blocks_for(nql), 256, 0, s>>>(seg_start, d_n_seg, d_seg_cnt);
   return hipGetLastError();
 }
 

@@ -406,6 +406,9 @@ __global__ __launch_bounds__(256) void hs_probe_kernel(hs_tables_dev tabs,
     nslices[ql] = (count + HS_SLICE - 1) / HS_SLICE;
     if (cand_out) cand_out[ql] = count;
   }
+  // (bucket_count == null with qbucket set: the caller groups the probes by sorting them on their
+  // bucket number -- hs_launch_seg_group_sparse -- and needs no ranks)
+  if (!bucket_count && qbucket && ranked) qbucket[ql] = gb;
   if (bucket_count) {
     const bool pseudo = ranked && gb == nb_total;
     // one counter access per BLOCK for the pseudo-bucket (same-address atomics are slow): ranks
@@ -473,6 +476,8 @@ __global__ __launch_bounds__(256) void hs_self_probe_kernel(hs_tables_dev tabs, 
       const uint32_t gb = dir_base[l] + lo;
       qbucket[ql] = gb;
       qrank[ql] = atomicAdd(&bucket_count[gb], 1u);
+    } else if (qbucket) {
+      qbucket[ql] = dir_base[l] + lo;
     }
   }
   unsigned long long c = count;
@@ -531,6 +536,8 @@ __global__ __launch_bounds__(256) void hs_probe_slow_kernel(hs_tables_dev tabs,
     if (bucket_count) {
       qbucket[ql] = gb;
       qrank[ql] = atomicAdd(&bucket_count[gb], 1u);
+    } else if (qbucket) {
+      qbucket[ql] = gb;
     }
   }
 }

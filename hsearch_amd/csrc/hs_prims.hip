@@ -22,6 +22,17 @@ hipError_t hs_sort_pairs_u64_u32(void* temp, size_t temp_bytes, const uint64_t* 
   return rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, n, begin_bit, end_bit, s);
 }
 
+size_t hs_sort_pairs_u32_u32_temp(size_t n) {
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                  (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 32, 0);
+  return bytes;
+}
+hipError_t hs_sort_pairs_u32_u32(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout,
+                                 const uint32_t* vin, uint32_t* vout, size_t n, int end_bit, hipStream_t s) {
+  return rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, n, 0, end_bit, s);
+}
+
 size_t hs_sort_pairs_u64_u64_temp(size_t n) {
   size_t bytes = 0;
   (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,

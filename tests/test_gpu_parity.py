@@ -639,3 +639,47 @@ def test_build_sorts_again_when_partial_fingerprints_interleave(monkeypatch):
         assert res[other][0] == res["0"][0] and res[other][1] == res["0"][1]
         for key in ("q", "id", "table", "dist", "cand"):
             assert np.array_equal(res[other][2][key], res["0"][2][key])
+
+
+@pytest.mark.parametrize("k,K,L,W,R", [(25, 6, 5, 120.0, 45.0), (25, 2, 3, 400.0, 42.0), (15, 5, 4, 90.0, 32.0),
+                                      (39, 6, 3, 260.0, 50.0)])
+def test_probe_grouping_by_counting_sort_and_by_probe_sort(oracle, monkeypatch, k, K, L, W, R):
+    """The probes are grouped by bucket in front of the join either by a counting sort over the bucket
+    slots or, when buckets far outnumber probes (C3 shape: 1.3e8 slots for 4e6 probes), by a radix sort
+    of the probes on their bucket number.  Both forms, forced in turn, give the oracle's hits -- for
+    searches, with thin segments routed away from the join, and for the self-join from codes."""
+    n, nq = 20011, 1203
+    a, b = synth.make_planes(k, K, L, W, seed=65)
+    base = synth.make_db(n // 2, k, seed=66)
+    near = base.copy()                      # every k-mer once more with one substitution: self-join edges
+    rng = np.random.default_rng(68)
+    near[np.arange(len(near)), rng.integers(0, k, size=len(near))] = rng.integers(0, 20, size=len(near), dtype=np.uint8)
+    codes = np.concatenate([base, near])
+    centers, _ = synth.make_queries(codes, nq, seed=67, jitter=0.2)
+    want = oracle.search(a, b, W, R, oracle.embed_codes(codes), centers)
+    assert len(want["q"]) > 100
+    edges = {}
+    for mode in ("dense", "sparse"):
+        for thin in (False, True):
+            monkeypatch.setenv("HS_SEG_MODE", mode)
+            monkeypatch.delenv("HS_JOIN_MIN_Q", raising=False)
+            monkeypatch.delenv("HS_JOIN_MIN_M", raising=False)
+            if thin:
+                monkeypatch.setenv("HS_JOIN_MIN_Q", "3")
+                monkeypatch.setenv("HS_JOIN_MIN_M", "16")
+            eng = Engine(k, K, L, W, a, b)
+            eng.index_build(codes)
+            for vm in ("join", "join16") if k <= 25 else ("join",):
+                eng.set_verify_mode(vm)
+                got = eng.query(centers, R)
+                assert np.array_equal(got["cand"], want["cand"])
+                _assert_hits_equal(got, want)
+                assert eng.profile()["join_batches"] > 0
+            eng.set_verify_mode("auto")
+            edges[(mode, thin)] = eng.self_join(R, sqrt_test=True)
+            eng.close()
+    ref = edges[("dense", False)]
+    assert len(ref["i"]) > 100
+    for e in edges.values():
+        for key in ("i", "j", "table", "dist"):
+            assert np.array_equal(e[key], ref[key])
