@@ -683,3 +683,38 @@ def test_probe_grouping_by_counting_sort_and_by_probe_sort(oracle, monkeypatch, 
     for e in edges.values():
         for key in ("i", "j", "table", "dist"):
             assert np.array_equal(e[key], ref[key])
+
+
+def test_hit_ordering_paths_with_many_hits_per_query(oracle, monkeypatch):
+    """Output order = (query, table of first sight, id) (motif_both_points.cpp:224-245).  Up to 128 hits per
+    query are ordered inside a kernel (hits bucketed by query, no sort); a batch in which some query has
+    more -- and any batch under HS_SORT_HITS=1 -- is radix-sorted on the full key.  A DB with a family
+    of 700 near-identical k-mers (some queries get ~700 hits, most a few) through both against the
+    oracle.  (A segmented sort of the bucketed hits was tried for the hit-heavy case: k = 15 at the C2
+    sizes, 545 hits per query, 38.0 ms against 32.2 for the full-key sort.)"""
+    k, K, L, W, R, n, nq = 25, 4, 5, 150.0, 40.0, 20011, 903
+    a, b = synth.make_planes(k, K, L, W, seed=75)
+    codes = synth.make_db(n, k, seed=76)
+    rng = np.random.default_rng(77)
+    fam = np.repeat(codes[:1], 700, axis=0)
+    fam[np.arange(700), rng.integers(0, k, size=700)] = rng.integers(0, 20, size=700, dtype=np.uint8)
+    codes[1000:1700] = fam
+    centers, _ = synth.make_queries(codes, nq, seed=78, jitter=0.2)
+    centers[:40] = synth.embed(fam[:40])            # 40 queries inside the family
+    want = oracle.search(a, b, W, R, oracle.embed_codes(codes), centers)
+    per_q = np.bincount(want["q"], minlength=nq)
+    assert per_q.max() > 500 and np.median(per_q) < 20
+    eng = Engine(k, K, L, W, a, b)
+    eng.index_build(codes)
+    for sort_all in (False, True):
+        monkeypatch.delenv("HS_SORT_HITS", raising=False)
+        if sort_all:
+            monkeypatch.setenv("HS_SORT_HITS", "1")
+        for mode in ("auto", "stream"):
+            eng.set_verify_mode(mode)
+            _assert_hits_equal(eng.query(centers, R), want)
+        # without the family queries every query stays under 128 hits: the in-kernel ordering
+        few = eng.query(centers[40:], R)
+        want_few = oracle.search(a, b, W, R, oracle.embed_codes(codes), centers[40:])
+        _assert_hits_equal(few, want_few)
+    eng.close()
