@@ -125,6 +125,8 @@ struct hs_handle {
   double join8_scale = 0.0, join8_scale_w = 0.0;  // quantisation scales: 4-column rows, wide rows
   bool wide8_ok = false;         // the 8-column table is usable (wide rows on demand for k = 21..25)
   double pairs_per_item = 0.0;   // average of the previous batch's join work items (0: none yet)
+  bool order_failed = false;     // the last batch that ordered its hits itself had to fall back to the sort
+  double order_failed_R = 0.0;   // ... at this radius
   uint32_t test_split_above = 0; // HS_TEST_SPLIT_ABOVE (tests): batches above this size report a survivor overflow
   bool wide8 = false;            // short k-mers: int8 rows over all 8 coordinate columns (hs_join8.hip)
   // segment routing thresholds (HS_JOIN_MIN_Q / _M): segments with fewer probing queries or members
@@ -506,7 +508,7 @@ hs_status hs_set_planes(hs_handle* h, const double* a, const double* b) {
   if (!h || !a || !b) return HS_ERR_INVALID;
   hs_status st = ensure_device(h);
   if (st) return st;
-  h->built = false, h->rec8w_ready = false;  // the tables were keyed by the old family
+  h->built = false, h->rec8w_ready = false, h->order_failed = false;  // the tables were keyed by the old family
   const size_t na = (size_t)h->LK * h->d;
   // the previous family may still be read by work queued on the stream: order the copies after it
   HS_HIP(h, hipMemcpyAsync(h->a.p, a, na * 8, hipMemcpyHostToDevice, h->stream));
@@ -941,7 +943,7 @@ hs_status hs_index_build(hs_handle* h, const uint8_t* codes, uint64_t n) {
   if (n >= (1ull << 31)) return fail(h, HS_ERR_INVALID, "n must be < 2^31 (ids are 32-bit, as in the reference)");
   hs_status st = ensure_device(h);
   if (st) return st;
-  h->built = false, h->rec8w_ready = false;
+  h->built = false, h->rec8w_ready = false, h->order_failed = false;
   h->n = n;
   memset(&h->prof, 0, sizeof(h->prof));
   memset(&h->info, 0, sizeof(h->info));
@@ -964,7 +966,7 @@ hs_status hs_index_build_subset(hs_handle* h, const uint8_t* codes_all, uint64_t
     for (uint64_t i = 0; i < n_subset; ++i)
       if (subset[i] >= n_all) return fail(h, HS_ERR_INVALID, "subset index outside the code array");
   const int k = (int)h->p.k;
-  h->built = false, h->rec8w_ready = false;
+  h->built = false, h->rec8w_ready = false, h->order_failed = false;
   h->n = n_subset;
   memset(&h->prof, 0, sizeof(h->prof));
   memset(&h->info, 0, sizeof(h->info));
@@ -1016,7 +1018,7 @@ hs_status hs_index_build_windows(hs_handle* h, const uint8_t* residues, uint64_t
   }
   starts[n_seq] = (uint32_t)(n_seq ? seq_start[n_seq] : 0);
   win_off[n_seq] = (uint32_t)n;
-  h->built = false, h->rec8w_ready = false;
+  h->built = false, h->rec8w_ready = false, h->order_failed = false;
   h->n = n;
   memset(&h->prof, 0, sizeof(h->prof));
   memset(&h->info, 0, sizeof(h->info));
@@ -1266,7 +1268,7 @@ hs_status hs_index_load(hs_handle* h, const char* path) {
       hd.W != h->p.W)
     return fail(h, HS_ERR_IO, "index file written for other parameters (k, K, L, W, alphabet)");
   if (hd.payload_bytes != payload_size(hd)) return fail(h, HS_ERR_IO, "index file inconsistent (payload length)");
-  h->built = false, h->rec8w_ready = false;
+  h->built = false, h->rec8w_ready = false, h->order_failed = false;
   memset(&h->prof, 0, sizeof(h->prof));
   memset(&h->info, 0, sizeof(h->info));
   HS_HIP(h, hipStreamSynchronize(h->stream));
@@ -1756,7 +1758,9 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, h->hit_val.reserve((size_t)hit_cap * 8));
     HS_HIP(h, hipMemsetAsync(d_cnt, 0, 8, h->stream));
     // the batch orders its hits itself (bucket by query, no sort, no host count) unless brute force
-    const bool order_here = bout && !brute && !getenv("HS_SORT_HITS");
+    // (not tried again at a radius at which the previous batch had a query with too many hits for it:
+    // the attempt costs 10 % of such a batch -- k = 15 at the C2 sizes, 545 hits per query)
+    const bool order_here = bout && !brute && !getenv("HS_SORT_HITS") && !(h->order_failed && h->order_failed_R == R);
     uint32_t *qcnt = nullptr, *qoff = nullptr, *qfill = nullptr;
     if (order_here) {
       const size_t n1q = (size_t)nq + 1;
@@ -1875,6 +1879,10 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
       continue;
     }
     if (bout) bout->ordered = order_here && !host_cnt[20];
+    if (order_here) {
+      h->order_failed = host_cnt[20] != 0;
+      h->order_failed_R = R;
+    }
     break;  // hit_count <= prov_count <= prov_cap <= hit_cap
   }
   h->prof.ms_hash += ev_ms(h, 0, 1);
