@@ -137,6 +137,13 @@ def cpu_baseline(args, a, b, codes, centers):
     t0 = time.perf_counter()
     res = ix.query(cq, args.R)               # Search() query loop, :224-245
     t_query = time.perf_counter() - t0
+    # EXTENSION: the same query loop over every host core of the box (the reference is
+    # single-threaded; `value` stays the single-thread rate).  More queries so that each thread has some.
+    n_thr = max(1, len(os.sched_getaffinity(0)))
+    q_mt = min(centers.shape[0], max(q_s, 32 * n_thr))
+    t0 = time.perf_counter()
+    res_mt = ix.query_mt(centers[:q_mt], args.R, n_thr)
+    t_mt = time.perf_counter() - t0
     ix.close()
     qps_sample = q_s / t_query
     out = {
@@ -157,6 +164,12 @@ def cpu_baseline(args, a, b, codes, centers):
         "build_kmers_per_s": n_s / t_build,
         "sample_hits": int(len(res["q"])),
         "sample_seconds": t_build + t_query,
+        "all_cores_extension": {
+            "what": "the same query loop (oracle hso_index_query_mt) over all host threads of the box; not "
+                    "something the single-threaded reference does; the index build stays single-threaded",
+            "threads": n_thr, "sample_nq": int(q_mt), "measured_qps_at_sample": q_mt / t_mt,
+            "value_scaled_to_bench_n": q_mt / t_mt * n_s / codes.shape[0],
+            "hits": int(len(res_mt["q"])), "seconds": t_mt},
     }
     if O.have_ref() and args.cpu_ref_n > 0:
         # the real compiled reference (oracle/_ref) on a smaller sample (its Search() is monolithic:

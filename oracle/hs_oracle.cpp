@@ -19,6 +19,7 @@
 #include <random>
 #include <string>
 #include <unordered_map>
+#include <thread>
 #include <vector>
 
 #include "../include/hs_tables.h"
@@ -174,6 +175,56 @@ uint64_t hso_index_query(hso_index* ix, const double* centers, uint64_t nq, doub
       }
     }
   }
+  return n_hits;
+}
+
+// EXTENSION (not in the reference, which is single-threaded): the same query loop with the queries
+// split into contiguous blocks over `threads` host threads, each with its own label[] array; hits
+// are concatenated in block order, i.e. in the single-threaded order.  For the CPU baseline's
+// "all host cores" figure only; results are identical to hso_index_query.
+uint64_t hso_index_query_mt(hso_index* ix, const double* centers, uint64_t nq, double R, uint32_t threads,
+                            uint32_t* hit_q, uint32_t* hit_id, uint32_t* hit_table, double* hit_dist,
+                            uint64_t cap) {
+  const uint32_t d = ix->d, K = ix->K, L = ix->L;
+  const double R2 = R * R;
+  if (threads < 1) threads = 1;
+  struct Hit { uint32_t q, id, table; double dist; };
+  std::vector<std::vector<Hit>> part(threads);
+  std::vector<std::thread> pool;
+  for (uint32_t t = 0; t < threads; ++t)
+    pool.emplace_back([&, t]() {
+      const uint64_t lo = nq * t / threads, hi = nq * (t + 1) / threads;
+      std::vector<int> label(ix->points.size(), 0);
+      std::string key;
+      for (uint64_t q = lo; q < hi; ++q) {
+        const double* c = centers + q * d;
+        if (!label.empty()) memset(&label[0], 0, sizeof(int) * label.size());  // :225
+        for (uint32_t l = 0; l < L; ++l) {
+          key_of(c, &ix->a[(size_t)l * K * d], &ix->b[(size_t)l * K], d, K, ix->W, key);
+          Table::const_iterator it = ix->tables[l].find(key);
+          if (it == ix->tables[l].end()) continue;
+          const std::vector<uint32_t>& ids = it->second;
+          for (size_t j = 0; j < ids.size(); ++j) {
+            if (label[ids[j]] != 0) continue;
+            const double d2 = dist2_sequential(ix->points[ids[j]].data(), c, d);
+            label[ids[j]] = 1;
+            if (d2 <= R2) part[t].push_back(Hit{(uint32_t)q, ids[j], l, sqrt(d2)});
+          }
+        }
+      }
+    });
+  for (auto& th : pool) th.join();
+  uint64_t n_hits = 0;
+  for (uint32_t t = 0; t < threads; ++t)
+    for (const Hit& hh : part[t]) {
+      if (n_hits < cap) {
+        hit_q[n_hits] = hh.q;
+        hit_id[n_hits] = hh.id;
+        hit_table[n_hits] = hh.table;
+        hit_dist[n_hits] = hh.dist;
+      }
+      ++n_hits;
+    }
   return n_hits;
 }
 

@@ -47,6 +47,11 @@ uint64_t hso_index_table_size(const hso_index* ix, uint32_t l);
 uint64_t hso_index_query(hso_index* ix, const double* centers, uint64_t nq, double R,
                          uint32_t* hit_q, uint32_t* hit_id, uint32_t* hit_table, double* hit_dist,
                          uint64_t cap, uint64_t* cand_out);
+/* EXTENSION (the reference is single-threaded): the same loop over `threads` host threads, identical
+ * results in identical order; for the CPU baseline's all-cores figure only. */
+uint64_t hso_index_query_mt(hso_index* ix, const double* centers, uint64_t nq, double R, uint32_t threads,
+                            uint32_t* hit_q, uint32_t* hit_id, uint32_t* hit_table, double* hit_dist,
+                            uint64_t cap);
 
 /* a10 hits writer motif_both_points.cpp:240-241: "<qname> <dbname> <dist>\n", dist with ostream
  * default formatting (6 significant digits).  names may be NULL -> decimal indices. */

@@ -131,6 +131,26 @@ class Index:
             cap = n
         return dict(q=hq[:n], id=hid[:n], table=ht[:n], dist=hd[:n], cand=cand)
 
+    def query_mt(self, centers, R, threads, cap=None):
+        """EXTENSION: Search()'s query loop over `threads` host threads (the reference is single-threaded);
+        same hits in the same order.  For bench.py's all-cores CPU figure."""
+        centers = _f64(centers)
+        nq = centers.shape[0]
+        cap = int(cap) if cap is not None else max(1024, 64 * nq)
+        f = lib().hso_index_query_mt
+        f.restype = C.c_uint64
+        while True:
+            hq = np.empty(cap, dtype=np.uint32)
+            hid = np.empty(cap, dtype=np.uint32)
+            ht = np.empty(cap, dtype=np.uint32)
+            hd = np.empty(cap, dtype=np.float64)
+            n = int(f(self._h, _ptr(centers, _dp), C.c_uint64(nq), C.c_double(R), C.c_uint32(int(threads)),
+                      _ptr(hq, _u32p), _ptr(hid, _u32p), _ptr(ht, _u32p), _ptr(hd, _dp), C.c_uint64(cap)))
+            if n <= cap:
+                break
+            cap = n
+        return dict(q=hq[:n], id=hid[:n], table=ht[:n], dist=hd[:n])
+
     def close(self):
         if self._h:
             lib().hso_index_free(self._h)

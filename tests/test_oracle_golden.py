@@ -162,3 +162,23 @@ def test_tools_center_sampling(oracle, golden_dir):
         rand = open(pr).read()
         assert rand.split("\n")[:8] == t["random_head"] and rand.split("\n")[-9:-1] == t["random_tail"]
         assert rand.count("\n") == t["random_lines"] and _sha(rand) == t["random_sha256"]
+
+
+def test_multithreaded_query_extension_equals_the_single_threaded_loop():
+    """hso_index_query_mt (bench.py's all-cores CPU figure; not in the reference) returns the hits of
+    hso_index_query in the same order, whatever the thread count."""
+    import numpy as np
+    from oracle import pyoracle as O
+    from hsearch_amd import synth
+    k, K, L, W, R = 25, 4, 4, 120.0, 45.0
+    a, b = synth.make_planes(k, K, L, W, seed=3)
+    codes = synth.make_db(4000, k, seed=4)
+    centers, _ = synth.make_queries(codes, 257, seed=5, jitter=0.2)
+    ix = O.Index(a, b, W, O.embed_codes(codes))
+    one = ix.query(centers, R)
+    assert len(one["q"]) > 50
+    for threads in (1, 3, 8, 300):
+        mt = ix.query_mt(centers, R, threads)
+        for key in ("q", "id", "table", "dist"):
+            assert np.array_equal(mt[key], one[key])
+    ix.close()
