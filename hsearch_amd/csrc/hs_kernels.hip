@@ -794,12 +794,30 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
   __shared__ __attribute__((aligned(16))) unsigned char s_stage[4][64 * ROWB];
   __shared__ uint32_t s_q[4][64];
   __shared__ uint8_t s_code[4][64 * 76];  // the survivors' residue codes, row stride 76 (k <= 75)
+  constexpr uint32_t HBUF = 128;          // hits a wave collects before it asks for global slots
+  __shared__ uint64_t s_hk[4][HBUF], s_hv[4][HBUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int t = tid; t < HS_ALPHABET_PAD * 8; t += 256) s_coords[t] = coords[t];
   __syncthreads();
   const uint32_t n = min(*prov_count, prov_cap);
   unsigned char* stage = s_stage[wave];
   const uint32_t wave_stride = gridDim.x * 4u * 64u;
+  const int PW = (k + 24) / 25;  // packed words per k-mer (hs_packed_words)
+  uint32_t n_buf = 0;  // wave-uniform: entries in the wave's hit buffer
+  auto flush_hits = [&]() {
+    if (!n_buf) return;
+    uint32_t gbase = 0;
+    if (lane == 0) gbase = atomicAdd(hit_count, n_buf);
+    gbase = __shfl(gbase, 0);
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = (uint32_t)lane; i < n_buf; i += 64u)
+      if (gbase + i < hit_cap) {
+        hit_key[gbase + i] = s_hk[wave][i];
+        hit_val[gbase + i] = s_hv[wave][i];
+      }
+    __builtin_amdgcn_wave_barrier();
+    n_buf = 0;
+  };
   for (uint32_t base = (blockIdx.x * 4u + (uint32_t)wave) * 64u; base < n; base += wave_stride) {
     const uint32_t e = base + (uint32_t)lane;
     uint32_t ql = e < n ? prov[e].x : 0xffffffffu;
@@ -812,10 +830,23 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
     const uint32_t id = live ? tabs.t[l].ids[pos] : 0u;
     s_q[wave][lane] = q;
     __builtin_amdgcn_wave_barrier();
-    {  // residue codes of this lane's survivor into LDS (all byte loads in flight at once)
-      const uint8_t* code = codes + (uint64_t)id * k;
+    {  // residue codes of this lane's survivor into LDS: from the table's bucket-ordered PACKED copy
+       // (one 16-byte load per 25 residues at the survivor's position) rather than k byte loads from
+       // the code array -- each of those touched 64 different cache lines per wave instruction
       uint8_t* dst = &s_code[wave][lane * 76];
-      for (int p = 0; p < k; ++p) dst[p] = code[p];
+      const uint4* pkp = tabs.t[l].packed + (uint64_t)pos * PW;
+      for (int wd = 0; wd < PW; ++wd) {
+        const uint4 pk = pkp[wd];
+        const uint32_t w[5] = {pk.x, pk.y, pk.z, pk.w, 0u};
+#pragma unroll
+        for (int r = 0; r < 25; ++r) {
+          const int bit = 5 * r, wi = bit >> 5, sh = bit & 31;
+          uint32_t c = w[wi] >> sh;
+          if (sh > 27) c |= w[wi + 1] << (32 - sh);
+          const int p = 25 * wd + r;
+          if (p < k) dst[p] = (uint8_t)(c & 31u);
+        }
+      }
       if constexpr (SELF) {
         const uint8_t* qc = qcodes + (uint64_t)q * k;
         uint8_t* qd = stage + lane * 76;  // SELF: no centre rows to stage, the area holds the queries' codes
@@ -850,41 +881,61 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
         }
       }
     } else {
+    // FOUR positions in flight ahead of the one being summed (the kernel is latency-bound: with two,
+    // a wave spent ~ 23 k cycles on its 64 survivors at k = 15): four register sets, the loop unrolled
+    // by four so that each set is a fixed group of registers; positions past the end re-read the last
+    // one (loads stay unconditional) and are not summed.
     const int last = 4 * (k - 1);
-    double2 n0 = src0[0], n1 = src1[0], n2 = src2[0], n3 = src3[0];
-    const int o1 = min(4, last);
-    double2 m0 = src0[o1], m1 = src1[o1], m2 = src2[o1], m3 = src3[o1];
-    for (int p = 0; p < k; ++p) {
-      *st0 = n0;
-      *st1 = n1;
-      *st2 = n2;
-      *st3 = n3;
-      n0 = m0;
-      n1 = m1;
-      n2 = m2;
-      n3 = m3;
-      const int o2 = min(4 * (p + 2), last);
-      m0 = src0[o2];
-      m1 = src1[o2];
-      m2 = src2[o2];
-      m3 = src3[o2];
-      __builtin_amdgcn_wave_barrier();
-      double c[8];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const double2 v = *reinterpret_cast<const double2*>(&stage[lane * ROWB + j * 16]);
-        c[2 * j] = v.x;
-        c[2 * j + 1] = v.y;
-      }
-      __builtin_amdgcn_wave_barrier();
-      // exact left-to-right fp64, one rounding per operation (PairwiseDistance_square :176-183)
-      const double* xc = s_coords + (int)s_code[wave][lane * 76 + p] * 8;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const double r = __dsub_rn(xc[j], c[j]);
-        d2 = __dadd_rn(d2, __dmul_rn(r, r));
-      }
+#define HS_FIN_LOAD(A, B, C, D, O) \
+  {                                \
+    const int o_ = min((O), last); \
+    A = src0[o_];                  \
+    B = src1[o_];                  \
+    C = src2[o_];                  \
+    D = src3[o_];                  \
+  }
+    double2 a0, a1, a2, a3, b0, b1, b2, b3, e0, e1, e2, e3, g0, g1, g2, g3;
+    HS_FIN_LOAD(a0, a1, a2, a3, 0)
+    HS_FIN_LOAD(b0, b1, b2, b3, 4)
+    HS_FIN_LOAD(e0, e1, e2, e3, 8)
+    HS_FIN_LOAD(g0, g1, g2, g3, 12)
+    // one position: stage this set's pieces, refill the set with the position four further on, sum
+#define HS_FIN_STEP(A, B, C, D, P)                                                               \
+  {                                                                                              \
+    const int p = (P);                                                                           \
+    *st0 = A;                                                                                    \
+    *st1 = B;                                                                                    \
+    *st2 = C;                                                                                    \
+    *st3 = D;                                                                                    \
+    HS_FIN_LOAD(A, B, C, D, 4 * (p + 4))                                                         \
+    __builtin_amdgcn_wave_barrier();                                                             \
+    double c[8];                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                              \
+      const double2 v = *reinterpret_cast<const double2*>(&stage[lane * ROWB + j * 16]);         \
+      c[2 * j] = v.x;                                                                            \
+      c[2 * j + 1] = v.y;                                                                        \
+    }                                                                                            \
+    __builtin_amdgcn_wave_barrier();                                                             \
+    if (p < k) { /* wave-uniform; exact left-to-right fp64, one rounding per operation           \
+                    (PairwiseDistance_square :176-183) */                                        \
+      const double* xc = s_coords + (int)s_code[wave][lane * 76 + p] * 8;                        \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                            \
+        const double r = __dsub_rn(xc[j], c[j]);                                                 \
+        d2 = __dadd_rn(d2, __dmul_rn(r, r));                                                     \
+      }                                                                                          \
+    }                                                                                            \
+  }
+    // FOUR positions in flight ahead of the one being summed (the kernel is latency-bound: with two,
+    // a wave spent ~ 23 k cycles on its 64 survivors at k = 15): four register sets, the loop unrolled
+    // by four; positions past the end re-read the last one (loads stay unconditional), not summed
+    for (int p0 = 0; p0 < k; p0 += 4) {
+      HS_FIN_STEP(a0, a1, a2, a3, p0)
+      HS_FIN_STEP(b0, b1, b2, b3, p0 + 1)
+      HS_FIN_STEP(e0, e1, e2, e3, p0 + 2)
+      HS_FIN_STEP(g0, g1, g2, g3, p0 + 3)
     }
+#undef HS_FIN_STEP
+#undef HS_FIN_LOAD
     }
     // Search(): d2 <= R*R (motif_both_points.cpp:239); Clustering(): sqrt(d2) <= R
     // (hclust2.cpp:64-71,119-120), selected by a non-NaN r_sqrt.
@@ -905,21 +956,24 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
       }
       hit = !dup;
     }
-    // one counter access per wave (same-address atomics are slow): hits take consecutive slots
+    // Hits go through a per-wave LDS buffer of HBUF entries and take their global slots when it
+    // fills: same-address atomics complete at ~ 90 per microsecond on this part, and with hundreds of
+    // hits per query (k = 15 at the C2 sizes: 3.3e6 wave iterations with hits) one counter access
+    // per iteration WAS the kernel's time (37 of ~ 50 ms).
     const unsigned long long hm = __ballot(hit);
     if (hm) {
-      const int leader = __ffsll((long long)hm) - 1;
-      uint32_t base = 0;
-      if (lane == leader) base = atomicAdd(hit_count, (uint32_t)__popcll(hm));
-      base = __shfl(base, leader);
-      const uint32_t idx = base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
-      if (hit && idx < hit_cap) {
-        hit_key[idx] = ((uint64_t)(q_base + q) << 37) | ((uint64_t)l << 32) | id;
-        hit_val[idx] = (uint64_t)__double_as_longlong(__dsqrt_rn(d2));
+      const uint32_t cnt = (uint32_t)__popcll(hm);
+      if (n_buf + cnt > HBUF) flush_hits();
+      const uint32_t idx = n_buf + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+      if (hit) {
+        s_hk[wave][idx] = ((uint64_t)(q_base + q) << 37) | ((uint64_t)l << 32) | id;
+        s_hv[wave][idx] = (uint64_t)__double_as_longlong(__dsqrt_rn(d2));
       }
+      n_buf += cnt;
       if (hit && qcnt) atomicAdd(&qcnt[q], 1u);  // hits per query: the ordering pass buckets by query
     }
   }
+  flush_hits();
 }
 
 // One thread per residue position: the position starts a window iff k residues of its own
