@@ -63,7 +63,16 @@ constexpr int HS_J8_CONST_AT = 48;  // uint4 index in the int8 table block of th
 __host__ __device__ constexpr int ks_of(int k, bool wide = false) {
   return wide ? (k <= 20 ? 6 : 8) : k <= 25 ? 4 : k <= 41 ? 6 : 8;
 }
-constexpr uint32_t JRES = 64;  // survivor slots a wave reserves per counter access
+// survivor slots a wave reserves per counter access: same-address atomics complete at ~ 90 per
+// microsecond, and a hit-heavy launch (k = 15 at the C2 sizes: 1.4e8 survivors in 25 ms) asked for
+// 2.2e6 blocks of 64 -- the counter's whole capacity; 256 leaves it at a quarter
+constexpr uint32_t JRES = 256;
+// the unused tail of a wave's reserved block, marked so that the consumers skip it
+__device__ __forceinline__ void close_reservation(uint2* __restrict__ prov, uint32_t res_base, uint32_t res_used,
+                                                  uint32_t prov_cap, int lane) {
+  for (uint32_t i = res_used + (uint32_t)lane; i < JRES; i += 64u)
+    if (res_base + i < prov_cap) prov[res_base + i] = make_uint2(0xffffffffu, 0u);
+}
 constexpr int DIG = 13;      // base-127 digits (+1 remainder slot) of -gamma
 constexpr int RDIG = 11;     // base-127 digits (+1 remainder slot) of rho
 
@@ -645,8 +654,7 @@ __device__ __forceinline__ void emit_survivors(const intx16 (&acc)[GT], int T0, 
       if (m) {
         const uint32_t cnt = (uint32_t)__popcll(m);
         if (res_used + cnt > JRES) {
-          if (res_used < JRES && lane >= (int)res_used && res_base + lane < prov_cap)
-            prov[res_base + lane] = make_uint2(0xffffffffu, 0u);
+          close_reservation(prov, res_base, res_used, prov_cap, lane);
           uint32_t base = 0;
           if (lane == 0) base = hs_reserve_survivors(prov_count, (uint32_t)JRES);
           res_base = __builtin_amdgcn_readfirstlane(base);
@@ -906,8 +914,7 @@ __global__ __launch_bounds__(256, 2) void hs_join8w_kernel(
 #undef HS_N_GROUPS
 #undef HS_LOAD_MEMBERS
 #undef HS_FIRST_Q
-  if (res_used < JRES && lane >= (int)res_used && res_base + lane < prov_cap)
-    prov[res_base + lane] = make_uint2(0xffffffffu, 0u);
+  close_reservation(prov, res_base, res_used, prov_cap, lane);
 #ifdef HS_JOIN_TIMING
   HS_T(6)
   if (lane == 0) {
@@ -998,8 +1005,7 @@ __device__ __forceinline__ void emit_survivors_x(const intx4 (&acc)[4][2], int T
         if (m) {
           const uint32_t cnt = (uint32_t)__popcll(m);
           if (res_used + cnt > JRES) {
-            if (res_used < JRES && lane >= (int)res_used && res_base + lane < prov_cap)
-              prov[res_base + lane] = make_uint2(0xffffffffu, 0u);
+            close_reservation(prov, res_base, res_used, prov_cap, lane);
             uint32_t base = 0;
             if (lane == 0) base = hs_reserve_survivors(prov_count, (uint32_t)JRES);
             res_base = __builtin_amdgcn_readfirstlane(base);
@@ -1225,8 +1231,7 @@ __global__ __launch_bounds__(256, 2) void hs_join8x_kernel(
 #undef HS_N_GROUPS
 #undef HS_LOAD_MEMBERS
 #undef HS_FIRST_Q
-  if (res_used < JRES && lane >= (int)res_used && res_base + lane < prov_cap)
-    prov[res_base + lane] = make_uint2(0xffffffffu, 0u);
+  close_reservation(prov, res_base, res_used, prov_cap, lane);
 #ifdef HS_JOIN_TIMING
   if (lane == 0) {
     for (int i = 0; i < 7; ++i) atomicAdd(&g_join8_timing[i], (unsigned long long)tacc[i]);
