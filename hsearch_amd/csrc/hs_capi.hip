@@ -124,6 +124,8 @@ struct hs_handle {
   bool join8_tables_ok = false;  // int8 can carry the coordinate table
   double join8_scale = 0.0, join8_scale_w = 0.0;  // quantisation scales: 4-column rows, wide rows
   bool wide8_ok = false;         // the 8-column table is usable (wide rows on demand for k = 21..25)
+  uint32_t* pin_cnt = nullptr;   // 64 pinned words: where a batch's counters land (three small device ->
+                                 // host copies into PAGEABLE memory cost ~ 50 us of host staging per batch)
   double pairs_per_item = 0.0;   // average of the previous batch's join work items (0: none yet)
   bool order_failed = false;     // the last batch that ordered its hits itself had to fall back to the sort
   double order_failed_R = 0.0;   // ... at this radius
@@ -565,6 +567,7 @@ void hs_destroy(hs_handle* h) {
     h->t_dirtuple[l].release();
     h->t_ids[l].release();
   }
+  if (h->pin_cnt) (void)hipHostFree(h->pin_cnt);
   if (h->ev_ok)
     for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(h->ev[i]);
   if (h->evx_ok)
@@ -1610,7 +1613,6 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   unsigned long long* d_jstats = reinterpret_cast<unsigned long long*>(d_cnt + 10);
   uint32_t n_items = 0, n_slices = 1, jm = HS_JM_BLOCK;
   bool async_items = false;
-  uint32_t n_items_real = 0;
   const int seg_shift = seg_shift_of(h);
   if (use_join) {
     const size_t n1 = (size_t)nql + 1;
@@ -1746,8 +1748,15 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   HS_HIP(h, hipEventRecord(h->ev[2], h->stream));
   bool tables_done = !side;
   uint32_t prov_cap = (uint32_t)std::max<size_t>(h->prov.cap / 8, std::max<size_t>(1u << 20, 16ull * nq));
-  uint32_t host_cnt[24] = {0};  // [0] survivors [1] hits [2..3] candidates ... [10..13] join statistics [20] order fallback
-  uint32_t host_proj[2] = {0, 0};  // MFMA projection of the queries: {slots reserved, values flagged}
+  if (!h->pin_cnt) {
+    HS_HIP(h, hipHostMalloc(reinterpret_cast<void**>(&h->pin_cnt), 64 * 4, hipHostMallocDefault));
+    memset(h->pin_cnt, 0, 64 * 4);
+  }
+  // [0] survivors [1] hits [2..3] candidates ... [10..13] join statistics [20] order fallback
+  uint32_t* const host_cnt = h->pin_cnt;
+  uint32_t* const host_proj = h->pin_cnt + 32;  // MFMA projection of the queries: {slots reserved, values flagged}
+  uint32_t& n_items_real = h->pin_cnt[40];
+  memset(h->pin_cnt, 0, 64 * 4);
   const bool proj_stats = !brute && !self_codes && use_projection(h);
   double ms_verify = 0, ms_final = 0, ms_join = 0;
   uint32_t launches = 0;
