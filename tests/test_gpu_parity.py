@@ -117,7 +117,8 @@ def test_short_kmers_through_the_wide_int8_join(oracle, monkeypatch, k, R):
     """k <= 20 (configs[4]'s k = 15): R^2 is no longer far below the 4-column distance of bucket mates,
     so the int8 rows carry all 8 coordinate columns (6 k-steps, 64-member work items, no refinement
     pass).  Hits, order and distances equal the oracle's in every verify mode, with the thin-segment
-    filter in play (HS_JOIN_MIN_Q/_M) and with the 4-column rows forced (HS_WIDE_MAX_K=0).  (How many
+    filter in play (HS_JOIN_MIN_Q/_M) and with the 4-column rows forced (HS_WIDE_MAX_K=0 and
+    HS_NO_WIDE_BY_RADIUS=1).  (How many
     fewer survivors the wide rows leave at the bench's sizes: tools/regime_sweep.py.)"""
     K, L, W, n, nq = 3, 3, 260.0, 20011, 1203
     a, b = synth.make_planes(k, K, L, W, seed=25)
@@ -128,10 +129,12 @@ def test_short_kmers_through_the_wide_int8_join(oracle, monkeypatch, k, R):
     survivors = {}
     for rows in ("wide", "wide-thin", "narrow"):
         monkeypatch.delenv("HS_WIDE_MAX_K", raising=False)
+        monkeypatch.delenv("HS_NO_WIDE_BY_RADIUS", raising=False)
         monkeypatch.delenv("HS_JOIN_MIN_Q", raising=False)
         monkeypatch.delenv("HS_JOIN_MIN_M", raising=False)
-        if rows == "narrow":
+        if rows == "narrow":  # (without the second switch the radius rule would bring the wide rows back)
             monkeypatch.setenv("HS_WIDE_MAX_K", "0")
+            monkeypatch.setenv("HS_NO_WIDE_BY_RADIUS", "1")
         if rows == "wide-thin":
             monkeypatch.setenv("HS_JOIN_MIN_Q", "3")
             monkeypatch.setenv("HS_JOIN_MIN_M", "16")
