@@ -41,24 +41,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 JOIN_K = 112.0     # GEMM depth of hs_join_kernel (fp16)
 
 
-def wide_rows(k):
-    """Short k-mers: int8 rows over all 8 coordinate columns (hs_capi.hip: HS_WIDE_MAX_K, default 20)."""
-    return k <= min(20, int(os.environ.get("HS_WIDE_MAX_K", "20")))
-
-
-def join_i8_depth(k):
-    """GEMM depth of the int8 join (hs_join8.hip ks_of): 32-byte k-steps x 4 / 6 / 8."""
-    if wide_rows(k):
-        return 192.0
-    return 128.0 if k <= 25 else 192.0 if k <= 41 else 256.0
-
-
-def join_i8_kernel(k):
-    """Which int8 join kernel hs_launch_join8w starts (hs_join8.hip)."""
-    if wide_rows(k):
-        return "hs_join8w_kernel<2,6,wide>"
-    if k > 25:
-        return "hs_join8w_kernel<2,%d>" % (6 if k <= 41 else 8)
+def join_i8_kernel(row_bytes, wide):
+    """Which int8 join kernel hs_launch_join8w started, from what the library reports about the last
+    batch (hs_profile.join_row_bytes = GEMM depth, join_wide): hs_join8.hip."""
+    ks = row_bytes // 32
+    if wide:
+        return "hs_join8w_kernel<2,%d,wide>" % ks
+    if ks > 4:
+        return "hs_join8w_kernel<2,%d>" % ks
     return "hs_join8w_kernel<4,4>" if os.environ.get("HS_JOIN_SHAPE") == "32" else "hs_join8x_kernel"
 
 
@@ -336,6 +326,7 @@ def main():
     join_batches = 0
     join_ms = 0.0
     join_i8 = 0
+    join_rows = (128, 0)   # (row bytes = GEMM depth, wide) of the int8 join as the library reports them
     jstat = (0, 0, 0)
     qproj = (0, 0)
     fence()
@@ -352,6 +343,8 @@ def main():
         join_ms += p["ms_join"]
         jstat = (p["join_items"], p["join_pairs"], p["join_pairs_issued"])
         join_i8 += p["join_i8_batches"]
+        if p["join_i8_batches"]:
+            join_rows = (int(p["join_row_bytes"]), int(p["join_wide"]))
         qproj = (p["hash_values"], p["hash_flagged"])
         cand = p["candidates"]
         hits_local = nh
@@ -397,17 +390,18 @@ def main():
                 traffic = None
         if join_batches:
             # dominant kernel = the bucket join: an int8 MFMA GEMM of depth 128 (25 positions x 4
-            # coordinates + 28 threshold-digit slots; 192 / 256 for k = 26..41 / 42..50;
-            # hs_join8.hip) -- or, when a batch had to fall
+            # coordinates + 28 threshold-digit slots; 192 / 256 for longer rows: k = 26..50, and rows
+            # over all 8 columns for k <= 20 or large radii -- the library reports which:
+            # hs_profile.join_row_bytes / join_wide; hs_join8.hip) -- or, when a batch had to fall
             # back, the fp16 form of depth 112 (hs_join.hip) -- per (bucket member, probing query)
             # pair: 2 * depth operations per pair.
             j_ms = join_ms / steps
             i8 = join_i8 > 0
-            jk = join_i8_depth(k) if i8 else JOIN_K
+            jk = float(join_rows[0]) if i8 else JOIN_K
             peak = MFMA_I8_PEAK_TOPS if i8 else MFMA_F16_PEAK_TFLOPS
             flop = jstat[1] * 2.0 * jk          # real (member, query) pairs routed to the join
             tf = flop / (j_ms * 1e-3) / 1e12 if j_ms > 0 else 0.0
-            roofline = {"bound": "mfma", "kernel": join_i8_kernel(k) if i8 else "hs_join_kernel",
+            roofline = {"bound": "mfma", "kernel": join_i8_kernel(*join_rows) if i8 else "hs_join_kernel",
                         "mfma_dtype": "i8" if i8 else "f16", "gemm_depth": jk, "achieved": tf,
                         "peak": peak, "unit": "TOP/s" if i8 else "TFLOP/s",
                         "frac": tf / peak, "traffic": traffic, "traffic_source": traffic_src,

@@ -42,7 +42,8 @@ class _Profile(C.Structure):
                 ("hits", C.c_uint64), ("verify_launches", C.c_uint64), ("join_batches", C.c_uint64),
                 ("ms_join", C.c_double), ("join_items", C.c_uint64), ("join_pairs", C.c_uint64),
                 ("join_pairs_issued", C.c_uint64), ("join_i8_batches", C.c_uint64),
-                ("hash_values", C.c_uint64), ("hash_flagged", C.c_uint64)]
+                ("hash_values", C.c_uint64), ("hash_flagged", C.c_uint64),
+                ("join_row_bytes", C.c_uint32), ("join_wide", C.c_uint32)]
 
 
 class _IndexInfo(C.Structure):

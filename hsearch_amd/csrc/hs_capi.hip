@@ -1909,6 +1909,10 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   h->prof.provisional += host_cnt[0];
   h->prof.join_batches += n_items ? 1 : 0;
   h->prof.join_i8_batches += (n_items && use_i8) ? 1 : 0;
+  if (n_items && use_i8) {
+    h->prof.join_row_bytes = (uint32_t)hs_join8_row_bytes(k, wide);
+    h->prof.join_wide = (uint32_t)wide;
+  }
   h->prof.ms_join += ms_join;
   if (async_items) n_items = n_items_real;
   h->prof.join_items += n_items;

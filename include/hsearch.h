@@ -82,6 +82,10 @@ typedef struct hs_profile {
   uint64_t hash_values;       /* bucket ints produced by the MFMA projection pass (hs_proj_kernel) ... */
   uint64_t hash_flagged;      /* ... of which this many lay within the error bound of a bucket boundary
                                  and were recomputed in the reference's fp64 order (hs_proj_fix_kernel) */
+  uint32_t join_row_bytes;    /* int8 join of the last batch: bytes of a row = GEMM depth (128 / 192 / 256; 0:
+                                 it did not run) ... */
+  uint32_t join_wide;         /* ... and 1 if the rows carried all 8 coordinate columns (short k-mers, large
+                                 radii), 0 for the 4 filter columns */
 } hs_profile;
 
 typedef struct hs_index_info {
