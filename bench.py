@@ -79,6 +79,13 @@ def parse():
     ap.add_argument("--verify-mode", choices=["auto", "stream", "join", "join16"], default="auto")
     ap.add_argument("--cpu-ref-n", type=int, default=200_000,
                     help="DB sample on which the compiled reference (oracle/_ref) is timed beside the port")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the second block (configs[2]'s per-GPU shape: 10^8 25-mers, L=32, K=20)")
+    ap.add_argument("--secondary-W", type=float, default=160.0,
+                    help="W of the secondary block: profiles/r02_recall_sweep_c3_shape.json picks 152..160")
+    ap.add_argument("--secondary-steps", type=int, default=8)
+    ap.add_argument("--pcie-steps", type=int, default=5,
+                    help="steps of the PCIe-inclusive measurement of hs_query / hs_query_codes (0: skip)")
     return ap.parse_args()
 
 
@@ -237,6 +244,201 @@ def planted_family_recall(args, eng, codes, a, b, device):
             "true_neighbours_within_R": len(truth)}
 
 
+class Workload:
+    """One resident index + one resident query batch on this rank, and the timed loop over it."""
+
+    def __init__(self, args, dev_index, dev, rank, synth, Engine, torch, label):
+        self.args, self.dev, self.rank, self.torch, self.label = args, dev, rank, torch, label
+        k, K, L, W = args.k, args.K, args.L, args.W
+        self.a, self.b = synth.make_planes(k, K, L, W)
+        self.codes = synth.make_db(args.n, k)
+        self.qcodes, self.src = synth.make_query_codes(self.codes, args.nq, seed=synth.SEED_QUERIES + 1000 * rank)
+        self.centers = synth.embed(self.qcodes)
+        self.eng = Engine(k, K, L, W, self.a, self.b, device=dev_index)
+        self.eng.set_verify_mode(args.verify_mode)
+        t0 = time.perf_counter()
+        self.info = self.eng.index_build(self.codes)
+        self.t_build = time.perf_counter() - t0
+        self.build_prof = self.eng.profile()
+        self.d_centers = torch.from_numpy(self.centers).to(dev)
+        self.cap = 16 * args.nq + 4096
+        self.out = self.alloc(self.cap)
+
+    def alloc(self, c):
+        t, dev = self.torch, self.dev
+        return dict(q=t.empty(c, dtype=t.int32, device=dev), id=t.empty(c, dtype=t.int32, device=dev),
+                    table=t.empty(c, dtype=t.int32, device=dev), dist=t.empty(c, dtype=t.float64, device=dev))
+
+    def step(self, hdist, HsError, use_dist):
+        """One pass of the query hot path over the rank's resident batch (+ the hit all-gather)."""
+        args = self.args
+        while True:
+            o = self.out
+            try:
+                nh = self.eng.query_dev(self.d_centers.data_ptr(), args.nq, args.R, o["q"].data_ptr(),
+                                        o["id"].data_ptr(), o["table"].data_ptr(), o["dist"].data_ptr(), self.cap)
+                break
+            except HsError as e:
+                if getattr(e, "needed", 0) <= self.cap:
+                    raise
+                self.cap = int(e.needed * 1.25) + 1024
+                self.out = self.alloc(self.cap)
+        gathered = hdist.allgather_hits(o["q"], o["id"], o["table"], o["dist"], nh, q_offset=self.rank * args.nq,
+                                        force=use_dist)
+        return nh, gathered
+
+    def timed(self, steps, warmup, hdist, HsError, use_dist, fence, dist, backend):
+        """W untimed steps, then exactly `steps` steps between two fences; max over ranks."""
+        for _ in range(warmup):
+            self.step(hdist, HsError, use_dist)
+        acc = dict(verify_ms=0.0, hash_ms=0.0, probe_ms=0.0, fin_ms=0.0, join_ms=0.0, launches=0, join_batches=0,
+                   join_i8=0, retries=0)
+        jstat, qproj, join_rows, cand, hits_local = (0, 0, 0), (0, 0), (128, 0), 0, 0
+        gathered = None
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            nh, gathered = self.step(hdist, HsError, use_dist)
+            p = self.eng.profile()
+            acc["verify_ms"] += p["ms_verify"]
+            acc["hash_ms"] += p["ms_hash"]
+            acc["probe_ms"] += p["ms_probe"]
+            acc["fin_ms"] += p["ms_finalize"]
+            acc["launches"] += p["verify_launches"]
+            acc["join_batches"] += p["join_batches"]
+            acc["join_ms"] += p["ms_join"]
+            acc["join_i8"] += p["join_i8_batches"]
+            acc["retries"] += p["join_async_retries"]
+            jstat = (p["join_items"], p["join_pairs"], p["join_pairs_issued"])
+            if p["join_i8_batches"]:
+                join_rows = (int(p["join_row_bytes"]), int(p["join_wide"]))
+            qproj = (p["hash_values"], p["hash_flagged"])
+            cand = p["candidates"]
+            hits_local = nh
+        fence()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            t = self.torch.tensor([dt], dtype=self.torch.float64, device=self.dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        acc.update(dt=dt, jstat=jstat, qproj=qproj, join_rows=join_rows, cand=cand, hits_local=hits_local,
+                   total_hits=int(gathered[0].numel()) if gathered is not None else 0)
+        return acc
+
+    def roofline(self, m, steps, traffic=None, traffic_src=None):
+        """The dominant kernel of the timed loop priced against its roofline (module docstring)."""
+        args = self.args
+        k, L, d = args.k, args.L, 8 * args.k
+        steps = max(steps, 1)
+        cand, hits_local, jstat, join_rows = m["cand"], m["hits_local"], m["jstat"], m["join_rows"]
+        # ALGORITHMIC bytes of one step on this rank (SURVEY.md 8d): per scanned bucket entry one
+        # k-byte k-mer + one u32 id, + per query its vector (8d) + L bucket lookups (16 B) + 16 B per hit
+        algo_bytes = cand * (k + 4) + args.nq * (8 * d + 16 * L) + 16 * hits_local
+        v_ms = m["verify_ms"] / steps
+        achieved = algo_bytes / (v_ms * 1e-3) / 1e9 if v_ms > 0 else 0.0
+        if m["join_batches"]:
+            # dominant kernel = the bucket join: an int8 MFMA GEMM of depth 128 (25 positions x 4
+            # coordinates + 28 threshold-digit slots; 192 / 256 for longer rows: k = 26..50, and rows
+            # over all 8 columns for k <= 20 or large radii -- the library reports which:
+            # hs_profile.join_row_bytes / join_wide; hs_join8.hip) -- or, when a batch had to fall
+            # back, the fp16 form of depth 112 (hs_join.hip) -- per (bucket member, probing query)
+            # pair: 2 * depth operations per pair.
+            j_ms = m["join_ms"] / steps
+            i8 = m["join_i8"] > 0
+            jk = float(join_rows[0]) if i8 else JOIN_K
+            peak = MFMA_I8_PEAK_TOPS if i8 else MFMA_F16_PEAK_TFLOPS
+            flop = jstat[1] * 2.0 * jk          # real (member, query) pairs routed to the join
+            tf = flop / (j_ms * 1e-3) / 1e12 if j_ms > 0 else 0.0
+            return {"bound": "mfma", "kernel": join_i8_kernel(*join_rows) if i8 else "hs_join_kernel",
+                    "mfma_dtype": "i8" if i8 else "f16", "gemm_depth": jk, "achieved": tf,
+                    "peak": peak, "unit": "TOP/s" if i8 else "TFLOP/s",
+                    "frac": tf / peak, "traffic": traffic, "traffic_source": traffic_src,
+                    "flop_per_step": flop, "pairs_per_step": jstat[1],
+                    "pairs_issued_per_step": jstat[2], "work_items_per_step": jstat[0],
+                    "issued_over_useful": (jstat[2] / jstat[1]) if jstat[1] else None,
+                    "issued_tops": (jstat[2] * 2.0 * jk / (j_ms * 1e-3) / 1e12) if j_ms > 0 else 0.0,
+                    "kernel_ms_per_step": j_ms, "streaming_kernel_ms_per_step": v_ms - j_ms,
+                    "pairs_streamed_per_step": cand - jstat[1],
+                    "launches_per_step": m["launches"] / steps,
+                    "steps_with_a_repeated_join": m["retries"],
+                    # SURVEY 8(d)'s byte count for the same step, for reference only: the join
+                    # re-uses a bucket's rows across the queries probing it, so this is NOT a
+                    # physical rate (it exceeds the HBM peak) and no fraction of 8 TB/s is given
+                    "algorithmic_bytes_per_step": algo_bytes,
+                    "algorithmic_bytes_per_s_nonphysical": achieved * 1e9}
+        return {"bound": "hbm", "kernel": "hs_verify_kernel", "achieved": achieved,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_step": algo_bytes,
+                "kernel_ms_per_step": v_ms, "launches_per_step": m["launches"] / steps,
+                "packed_stream_bytes_per_step": cand * 16 * ((k + 24) // 25)}
+
+    def index_block(self):
+        """Index build of this workload, with its SURVEY 8(d) roofline: bytes per k-mer = k (codes in)
+        + 36 L (12 B (key, id) written, then one read + write pass to group them) + k L + 4 L (the
+        bucket-ordered copies), over the device time of the build (hs_profile.ms_total)."""
+        args, bp = self.args, self.build_prof
+        bpk = args.k + 36 * args.L + args.k * args.L + 4 * args.L
+        ms = bp["ms_total"]
+        gbs = args.n * bpk / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        return {"build_seconds": self.t_build, "build_kmers_per_s": args.n / self.t_build,
+                "device_ms": {f: bp[f] for f in ("ms_hash", "ms_sort", "ms_gather", "ms_total")},
+                "roofline": {"bound": "hbm", "bytes_per_kmer": bpk, "algorithmic_bytes": args.n * bpk,
+                             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                             "device_ms": ms},
+                # LSH projection on the matrix cores (hs_proj.hip): values produced by the int8
+                # MFMA pass / of which recomputed in the reference's fp64 order (within the
+                # proven error bound of a bucket boundary)
+                "projection": {"build_values": bp["hash_values"], "build_recomputed": bp["hash_flagged"]},
+                "device_bytes": self.info["device_bytes"], "n_buckets": self.info["n_buckets"],
+                "max_bucket": self.info["max_bucket"]}
+
+    def recall(self, nr):
+        """Radius recall and recall@10 on a query subsample; ground truth = the exhaustive scans on the
+        GPU (hs_bruteforce / hs_bruteforce_topk, themselves parity-tested against the oracle)."""
+        args, eng = self.args, self.eng
+        sub = self.centers[:nr]
+        bf = eng.bruteforce(sub, args.R)
+        lsh = eng.query(sub, args.R, want_cand=False)
+        truth = set(zip(bf["q"].tolist(), bf["id"].tolist()))
+        found = set(zip(lsh["q"].tolist(), lsh["id"].tolist()))
+        out = {"radius_recall": len(truth & found) / max(len(truth), 1), "recall_queries": nr,
+               "true_neighbours_in_sample": len(truth)}
+        # recall@10 (SURVEY 8d): |LSH hits of q  ∩  the 10 nearest DB k-mers of q| / 10, the
+        # nearest ones by (d2, id) from the exact exhaustive top-k scan (hs_bruteforce_topk)
+        nn, _ = eng.bruteforce_topk(sub, 10)
+        by_q = {}
+        for qq, ii in zip(lsh["q"].tolist(), lsh["id"].tolist()):
+            by_q.setdefault(qq, set()).add(ii)
+        out["recall_at_10"] = float(np.mean([len(by_q.get(qq, set()) & set(nn[qq].tolist())) / 10.0
+                                             for qq in range(nr)]))
+        return out
+
+    def pcie_inclusive(self, steps):
+        """The same step through the HOST-pointer entry points (queries cross PCIe inside the timed region,
+        hits come back to host arrays): hs_query (8d bytes per query) and hs_query_codes (k bytes).
+        Never part of `value`."""
+        args = self.args
+        cap = self.cap
+        hq, hid, ht = (np.empty(cap, np.uint32) for _ in range(3))
+        hd = np.empty(cap, np.float64)
+        out = {}
+        for name, arr, codes in (("hs_query", self.centers, False), ("hs_query_codes", self.qcodes, True)):
+            self.eng.query_into(arr, args.R, hq, hid, ht, hd, codes=codes)        # warm-up (staging buffers)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                nh = self.eng.query_into(arr, args.R, hq, hid, ht, hd, codes=codes)
+            dt = (time.perf_counter() - t0) / steps
+            out[name] = {"queries_per_s": args.nq / dt, "ms_per_step": dt * 1e3,
+                         "bytes_in_per_query": int(arr.shape[1] * arr.itemsize), "hits": nh}
+        return out
+
+    def close(self):
+        self.eng.close()
+        self.d_centers = None
+        self.out = None
+
+
 def main():
     args = parse()
     # stdout carries ONE line, the JSON result: libraries that print there (RCCL announces its
@@ -271,101 +473,17 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    k, K, L, W, R = args.k, args.K, args.L, args.W, args.R
-    d = 8 * k
-    a, b = synth.make_planes(k, K, L, W)
-    codes = synth.make_db(args.n, k)
-    centers, src = synth.make_queries(codes, args.nq, seed=synth.SEED_QUERIES + 1000 * rank)
-
-    eng = Engine(k, K, L, W, a, b, device=dev_index)
-    eng.set_verify_mode(args.verify_mode)
-    t0 = time.perf_counter()
-    info = eng.index_build(codes)
-    t_build = time.perf_counter() - t0
-    build_prof = eng.profile()
-
-    d_centers = torch.from_numpy(centers).to(dev)
-    cap = 16 * args.nq + 4096
-    out = None
-
-    def alloc(c):
-        return dict(q=torch.empty(c, dtype=torch.int32, device=dev),
-                    id=torch.empty(c, dtype=torch.int32, device=dev),
-                    table=torch.empty(c, dtype=torch.int32, device=dev),
-                    dist=torch.empty(c, dtype=torch.float64, device=dev))
-    out = alloc(cap)
-    q_lo = rank * args.nq
-    state = {"cap": cap, "out": out}
-
-    def step():
-        while True:
-            o = state["out"]
-            try:
-                nh = eng.query_dev(d_centers.data_ptr(), args.nq, R, o["q"].data_ptr(),
-                                   o["id"].data_ptr(), o["table"].data_ptr(), o["dist"].data_ptr(),
-                                   state["cap"])
-                break
-            except HsError as e:
-                if getattr(e, "needed", 0) <= state["cap"]:
-                    raise
-                state["cap"] = int(e.needed * 1.25) + 1024
-                state["out"] = alloc(state["cap"])
-        gathered = hdist.allgather_hits(o["q"], o["id"], o["table"], o["dist"], nh, q_offset=q_lo,
-                                        force=use_dist)
-        return nh, gathered
-
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    verify_ms, cand, hits_local, hash_ms, probe_ms, fin_ms = 0.0, 0, 0, 0.0, 0.0, 0.0
-    launches = 0
-    join_batches = 0
-    join_ms = 0.0
-    join_i8 = 0
-    join_rows = (128, 0)   # (row bytes = GEMM depth, wide) of the int8 join as the library reports them
-    jstat = (0, 0, 0)
-    qproj = (0, 0)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        nh, gathered = step()
-        p = eng.profile()
-        verify_ms += p["ms_verify"]
-        hash_ms += p["ms_hash"]
-        probe_ms += p["ms_probe"]
-        fin_ms += p["ms_finalize"]
-        launches += p["verify_launches"]
-        join_batches += p["join_batches"]
-        join_ms += p["ms_join"]
-        jstat = (p["join_items"], p["join_pairs"], p["join_pairs_issued"])
-        join_i8 += p["join_i8_batches"]
-        if p["join_i8_batches"]:
-            join_rows = (int(p["join_row_bytes"]), int(p["join_wide"]))
-        qproj = (p["hash_values"], p["hash_flagged"])
-        cand = p["candidates"]
-        hits_local = nh
-    fence()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    total_hits = int(gathered[0].numel())
-
+    k, K, L, W, R = args.k, args.K, args.L, args.W, args.R
+    wl = Workload(args, dev_index, dev, rank, synth, Engine, torch, workload_label(args))
+    m = wl.timed(args.steps, args.warmup, hdist, HsError, use_dist, fence, dist, backend)
+    line = None
     if rank == 0:
         steps = max(args.steps, 1)
-        ms_step = dt / steps * 1e3
-        value = world * args.nq * steps / dt
-        # ALGORITHMIC bytes of one step on this rank: per scanned bucket entry one
-        # k-byte k-mer + one u32 id, + per query its vector (8d) + L bucket lookups (16 B) +
-        # 16 B per hit.
-        algo_bytes = cand * (k + 4) + args.nq * (8 * d + 16 * L) + 16 * hits_local
-        v_ms = verify_ms / steps
-        achieved = algo_bytes / (v_ms * 1e-3) / 1e9 if v_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         # the PMC passes behind that file were taken on the default workload and kernel choice: the
@@ -388,88 +506,29 @@ def main():
                                    "current_hash": kernel_source_hash()}
             except Exception:
                 traffic = None
-        if join_batches:
-            # dominant kernel = the bucket join: an int8 MFMA GEMM of depth 128 (25 positions x 4
-            # coordinates + 28 threshold-digit slots; 192 / 256 for longer rows: k = 26..50, and rows
-            # over all 8 columns for k <= 20 or large radii -- the library reports which:
-            # hs_profile.join_row_bytes / join_wide; hs_join8.hip) -- or, when a batch had to fall
-            # back, the fp16 form of depth 112 (hs_join.hip) -- per (bucket member, probing query)
-            # pair: 2 * depth operations per pair.
-            j_ms = join_ms / steps
-            i8 = join_i8 > 0
-            jk = float(join_rows[0]) if i8 else JOIN_K
-            peak = MFMA_I8_PEAK_TOPS if i8 else MFMA_F16_PEAK_TFLOPS
-            flop = jstat[1] * 2.0 * jk          # real (member, query) pairs routed to the join
-            tf = flop / (j_ms * 1e-3) / 1e12 if j_ms > 0 else 0.0
-            roofline = {"bound": "mfma", "kernel": join_i8_kernel(*join_rows) if i8 else "hs_join_kernel",
-                        "mfma_dtype": "i8" if i8 else "f16", "gemm_depth": jk, "achieved": tf,
-                        "peak": peak, "unit": "TOP/s" if i8 else "TFLOP/s",
-                        "frac": tf / peak, "traffic": traffic, "traffic_source": traffic_src,
-                        "flop_per_step": flop, "pairs_per_step": jstat[1],
-                        "pairs_issued_per_step": jstat[2], "work_items_per_step": jstat[0],
-                        "issued_tops": (jstat[2] * 2.0 * jk / (j_ms * 1e-3) / 1e12) if j_ms > 0 else 0.0,
-                        "kernel_ms_per_step": j_ms, "streaming_kernel_ms_per_step": v_ms - j_ms,
-                        "pairs_streamed_per_step": cand - jstat[1],
-                        "launches_per_step": launches / steps,
-                        # SURVEY 8(d)'s byte count for the same step, for reference only: the join
-                        # re-uses a bucket's rows across the queries probing it, so this is NOT a
-                        # physical rate (it exceeds the HBM peak) and no fraction of 8 TB/s is given
-                        "algorithmic_bytes_per_step": algo_bytes,
-                        "algorithmic_bytes_per_s_nonphysical": achieved * 1e9}
-        else:
-            roofline = {"bound": "hbm", "kernel": "hs_verify_kernel", "achieved": achieved,
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": traffic, "traffic_source": traffic_src,
-                        "algorithmic_bytes_per_step": algo_bytes,
-                        "kernel_ms_per_step": v_ms, "launches_per_step": launches / steps,
-                        "packed_stream_bytes_per_step": cand * 16 * ((k + 24) // 25)}
+        index = wl.index_block()
+        index["projection"].update({"query_values_per_step": m["qproj"][0], "query_recomputed_per_step": m["qproj"][1]})
         line = {
             "metric": "motif queries/sec (LSH probe + verify, index resident in HBM)",
-            "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "value": world * args.nq * steps / m["dt"], "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": m["dt"] / steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload_label(args),
+            "config": {"workload": wl.label,
                        "db_kmers": args.n, "k": k, "L": L, "K": K, "W": W, "R": R,
                        "queries_per_gpu": args.nq, "parallelism": "query-sharded x%d" % world},
-            "roofline": roofline,
+            "roofline": wl.roofline(m, args.steps, traffic, traffic_src),
             "verify_mode": args.verify_mode,
-            "phases_ms_per_step": {"hash_queries": hash_ms / steps, "probe_segments": probe_ms / steps,
-                                   "verify": v_ms, "finalize_sort": fin_ms / steps},
-            "candidates_per_query": cand / args.nq, "hits_per_step_rank0": hits_local,
-            "hits_gathered": total_hits,
-            "index": {"build_seconds": t_build, "build_kmers_per_s": args.n / t_build,
-                      "device_ms": {f: build_prof[f] for f in ("ms_hash", "ms_sort", "ms_gather", "ms_total")},
-                      # LSH projection on the matrix cores (hs_proj.hip): values produced by the int8
-                      # MFMA pass / of which recomputed in the reference's fp64 order (within the
-                      # proven error bound of a bucket boundary)
-                      "projection": {"build_values": build_prof["hash_values"],
-                                     "build_recomputed": build_prof["hash_flagged"],
-                                     "query_values_per_step": qproj[0], "query_recomputed_per_step": qproj[1]},
-                      "device_bytes": info["device_bytes"], "n_buckets": info["n_buckets"],
-                      "max_bucket": info["max_bucket"]},
+            "phases_ms_per_step": {"hash_queries": m["hash_ms"] / steps, "probe_segments": m["probe_ms"] / steps,
+                                   "verify": m["verify_ms"] / steps, "finalize_sort": m["fin_ms"] / steps},
+            "candidates_per_query": m["cand"] / args.nq, "hits_per_step_rank0": m["hits_local"],
+            "hits_gathered": m["total_hits"],
+            "index": index,
         }
-        # radius recall on a query subsample, ground truth = exhaustive scan on the GPU
-        # (hs_bruteforce, itself parity-tested against the oracle)
         nr = min(args.recall_queries, args.nq)
         if nr > 0:
-            sub = centers[:nr]
-            bf = eng.bruteforce(sub, R)
-            lsh = eng.query(sub, R, want_cand=False)
-            truth = set(zip(bf["q"].tolist(), bf["id"].tolist()))
-            found = set(zip(lsh["q"].tolist(), lsh["id"].tolist()))
-            line["radius_recall"] = len(truth & found) / max(len(truth), 1)
-            line["recall_queries"] = nr
-            line["true_neighbours_in_sample"] = len(truth)
-            # recall@10: |LSH hits of q  ∩  the 10 nearest DB k-mers of q| / 10, the
-            # nearest ones by (d2, id) from the exact exhaustive top-k scan (hs_bruteforce_topk)
-            nn, _ = eng.bruteforce_topk(sub, 10)
-            by_q = {}
-            for qq, ii in zip(lsh["q"].tolist(), lsh["id"].tolist()):
-                by_q.setdefault(qq, set()).add(ii)
-            line["recall_at_10"] = float(np.mean([len(by_q.get(qq, set()) & set(nn[qq].tolist())) / 10.0
-                                                  for qq in range(nr)]))
+            line.update(wl.recall(nr))
         if nr > 0 and args.planted_members > 0:
-            line["planted_family_recall"] = planted_family_recall(args, eng, codes, a, b, dev_index)
+            line["planted_family_recall"] = planted_family_recall(args, wl.eng, wl.codes, wl.a, wl.b, dev_index)
         sweep = os.path.join(ROOT, "profiles", "r02_recall_sweep_c2_fine.json")
         if os.path.exists(sweep) and (args.n, args.k, args.K, args.L, args.R) == (10_000_000, 25, 16, 8, 40.0):
             sj = json.load(open(sweep))
@@ -478,10 +537,60 @@ def main():
                                     "points": [{"W": r["W"], "radius_recall": round(r["radius_recall"], 4),
                                                 "candidates_per_query": round(r["candidates_per_query"])}
                                                for r in sj["sweep"]]}
+        if world == 1 and args.pcie_steps > 0:
+            # the boundary's host-pointer entry points, PCIe inside the timed region; never `value`
+            line["value_pcie_inclusive"] = wl.pcie_inclusive(args.pcie_steps)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args, a, b, codes, centers)
+            line["cpu_baseline"] = cpu_baseline(args, wl.a, wl.b, wl.codes, wl.centers)
+    wl.close()
+    del wl
+
+    # ---- the north star's own target as a second block of the same line: BASELINE.json configs[2]'s
+    # per-GPU share (10^8 25-mers, L = 32, K = 20, 10^6 / 8 queries per GPU) at the W its recall sweep
+    # picks (profiles/r02_recall_sweep_c3_shape.json: the smallest W with radius recall >= 0.9 is
+    # 152..160), index replicated per GPU, same timing protocol (fences, max over ranks).  Run when the
+    # primary line is the default workload and the GPU has the room (index: 135 GB).
+    want_secondary = (not args.no_secondary and args.verify_mode == "auto" and
+                      (args.n, args.k, args.K, args.L) == (10_000_000, 25, 16, 8))
+    if want_secondary:
+        torch.cuda.empty_cache()
+        free_b, _total_b = torch.cuda.mem_get_info(dev_index)
+        ok = torch.tensor([1 if free_b >= 150 * (1 << 30) else 0], dtype=torch.int32,
+                          device=dev if (use_dist and backend == "nccl") else "cpu")
+        if use_dist:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank or none
+        if int(ok.item()):
+            a2 = argparse.Namespace(**vars(args))
+            a2.n, a2.L, a2.K, a2.W, a2.nq = 100_000_000, 32, 20, args.secondary_W, 125_000
+            t0 = time.perf_counter()
+            w2 = Workload(a2, dev_index, dev, rank, synth, Engine, torch, workload_label(a2))
+            m2 = w2.timed(args.secondary_steps, 2, hdist, HsError, use_dist, fence, dist, backend)
+            if rank == 0:
+                s2 = max(args.secondary_steps, 1)
+                sec = {"what": "BASELINE.json configs[2] (the north-star target: 100M x 25-mers, L=32, K=20), one "
+                               "GPU's share of the 10^6 queries per GPU, index replicated; W from "
+                               "profiles/r02_recall_sweep_c3_shape.json",
+                       "config": {"workload": w2.label, "db_kmers": a2.n, "k": a2.k, "L": a2.L, "K": a2.K,
+                                  "W": a2.W, "R": a2.R, "queries_per_gpu": a2.nq,
+                                  "parallelism": "query-sharded x%d" % world},
+                       "value": world * a2.nq * s2 / m2["dt"], "unit": "queries/s", "n_gpus": world,
+                       "steps": args.secondary_steps, "warmup": 2, "ms_per_step": m2["dt"] / s2 * 1e3,
+                       "roofline": w2.roofline(m2, args.secondary_steps),
+                       "phases_ms_per_step": {"hash_queries": m2["hash_ms"] / s2, "probe_segments": m2["probe_ms"] / s2,
+                                              "verify": m2["verify_ms"] / s2, "finalize_sort": m2["fin_ms"] / s2},
+                       "candidates_per_query": m2["cand"] / a2.nq, "hits_per_step_rank0": m2["hits_local"],
+                       "index": w2.index_block()}
+                nr2 = min(args.recall_queries, a2.nq)
+                if nr2 > 0:
+                    sec.update(w2.recall(nr2))
+                sec["wall_seconds_of_this_block"] = time.perf_counter() - t0
+                line["secondary"] = sec
+            w2.close()
+            del w2
+        elif rank == 0:
+            line["secondary"] = {"skipped": "less than 150 GB of HBM free on a rank (%.0f GB here)" % (free_b / 2**30)}
+    if rank == 0:
         print(json.dumps(line), file=result_out, flush=True)
-    eng.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -7,9 +7,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 HS_OK, HS_ERR_INVALID, HS_ERR_NO_DEVICE, HS_ERR_HIP, HS_ERR_CAPACITY, HS_ERR_STATE, \
-    HS_ERR_KEY_COLLISION, HS_ERR_NOMEM, HS_ERR_IO = range(9)
+    HS_ERR_KEY_COLLISION, HS_ERR_NOMEM, HS_ERR_IO, HS_ERR_PEER = range(10)
 _STATUS = ["HS_OK", "HS_ERR_INVALID", "HS_ERR_NO_DEVICE", "HS_ERR_HIP", "HS_ERR_CAPACITY",
-           "HS_ERR_STATE", "HS_ERR_KEY_COLLISION", "HS_ERR_NOMEM", "HS_ERR_IO"]
+           "HS_ERR_STATE", "HS_ERR_KEY_COLLISION", "HS_ERR_NOMEM", "HS_ERR_IO", "HS_ERR_PEER"]
 
 # Row order of the embedding table (include/hs_tables.h HS_CODE_TO_LETTER): BLOSUM order.
 _ALPHABET = "ARNDCQEGHILKMFPSTWYV"
@@ -20,7 +20,8 @@ EXPORTS = ["hs_create", "hs_destroy", "hs_last_error", "hs_get_profile", "hs_get
            "hs_clustering_end",
            "hs_embed_codes", "hs_hash_codes", "hs_hash_points", "hs_key_string", "hs_key_fingerprint",
            "hs_key_strings_equal", "hs_index_build", "hs_index_build_subset", "hs_index_build_windows", "hs_index_save", "hs_index_load", "hs_index_file_check", "hs_klsh_draw_planes", "hs_klsh_codes",
-           "hs_index_info_get", "hs_query", "hs_query_dev", "hs_bruteforce", "hs_bruteforce_topk"]
+           "hs_index_info_get", "hs_query", "hs_query_dev", "hs_query_codes", "hs_query_codes_dev", "hs_bruteforce",
+           "hs_bruteforce_topk"]
 
 
 class HsError(RuntimeError):
@@ -43,7 +44,7 @@ class _Profile(C.Structure):
                 ("ms_join", C.c_double), ("join_items", C.c_uint64), ("join_pairs", C.c_uint64),
                 ("join_pairs_issued", C.c_uint64), ("join_i8_batches", C.c_uint64),
                 ("hash_values", C.c_uint64), ("hash_flagged", C.c_uint64),
-                ("join_row_bytes", C.c_uint32), ("join_wide", C.c_uint32)]
+                ("join_row_bytes", C.c_uint32), ("join_wide", C.c_uint32), ("join_async_retries", C.c_uint64)]
 
 
 class _IndexInfo(C.Structure):
@@ -53,18 +54,21 @@ class _IndexInfo(C.Structure):
 
 profile_fields = [f[0] for f in _Profile._fields_]
 
-_lib = None
+_libs = {}
 
 
-def lib_path():
+def lib_path(hooks=False):
     # HSEARCH_AMD_LIB: another build of the same library (A/B runs of two kernel versions on one box)
+    if hooks:
+        return os.path.join(_HERE, "libhsearch_amd_hooks.so")
     return os.environ.get("HSEARCH_AMD_LIB") or os.path.join(_HERE, "libhsearch_amd.so")
 
 
-def load():
-    """Load libhsearch_amd.so.  Raises (never falls back) when it has not been built."""
-    global _lib
-    if _lib is None:
+def load(hooks=False):
+    """Load libhsearch_amd.so.  Raises (never falls back) when it has not been built.
+    hooks=True: the TEST build of the same library (libhsearch_amd_hooks.so: the same kernel objects
+    under a C-ABI layer compiled with -DHS_TEST_HOOKS = fault injection), for the tests that need it."""
+    if hooks not in _libs:
         # One ROCm runtime per process: PyTorch ships its own libamdhip64 / libhsa-runtime64 / librccl.
         # If this library (linked against /opt/rocm's) is loaded BEFORE torch, the process ends up with
         # /opt/rocm's HIP + HSA and, once torch is imported, torch's RCCL, whose dlopen of
@@ -75,7 +79,7 @@ def load():
             import torch  # noqa: F401
         except Exception:
             pass
-        path = lib_path()
+        path = lib_path(hooks)
         if not os.path.exists(path):
             raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; "
                               "g.build()'` (or make -C hsearch_amd/csrc)" % path)
@@ -88,8 +92,8 @@ def load():
         lib.hs_key_string.restype = C.c_uint32
         lib.hs_key_fingerprint.restype = C.c_uint64
         lib.hs_key_strings_equal.restype = C.c_int
-        _lib = lib
-    return _lib
+        _libs[hooks] = lib
+    return _libs[hooks]
 
 
 def alphabet():
@@ -182,8 +186,8 @@ class Engine:
     Search() build loop -> index_build; Search() query loop -> query; noLSH Search() -> bruteforce.
     """
 
-    def __init__(self, k, K, L, W, a, b, device=0, coords=None):
-        self._lib = load()
+    def __init__(self, k, K, L, W, a, b, device=0, coords=None, hooks=False):
+        self._lib = load(hooks)
         self.k, self.K, self.L, self.W = int(k), int(K), int(L), float(W)
         self.d = 8 * self.k
         a = np.ascontiguousarray(a, dtype=np.float64)
@@ -346,11 +350,51 @@ class Engine:
             n = int(n.value)
             return dict(q=hq[:n], id=hid[:n], table=ht[:n], dist=hd[:n], cand=cand)
 
-    def query_dev(self, d_centers_ptr, nq, R, d_q, d_id, d_table, d_dist, cap, d_cand=None):
-        """Raw device-pointer call (ints from torch .data_ptr()).  Returns the number of hits; raises
-        HsError(HS_ERR_CAPACITY) with the required size in .needed when cap is too small."""
+    def query_codes(self, qcodes, R, cap=None, want_cand=True):
+        """hs_query_codes: the queries are k-mers given as residue codes [nq][k] (uint8)."""
+        qcodes = np.ascontiguousarray(qcodes, dtype=np.uint8)
+        nq = qcodes.shape[0]
+        assert qcodes.shape == (nq, self.k)
+        cap = int(cap) if cap is not None else max(1024, 64 * nq)
+        while True:
+            hq = np.empty(cap, dtype=np.uint32)
+            hid = np.empty(cap, dtype=np.uint32)
+            ht = np.empty(cap, dtype=np.uint32)
+            hd = np.empty(cap, dtype=np.float64)
+            cand = np.zeros((nq, self.L), dtype=np.uint64) if want_cand else None
+            n = C.c_uint64(0)
+            st = self._lib.hs_query_codes(self._h, _vp(qcodes), C.c_uint64(nq), C.c_double(R), _vp(hq),
+                                          _vp(hid), _vp(ht), _vp(hd), C.c_uint64(cap), C.byref(n),
+                                          _vp(cand) if want_cand else None)
+            if st == HS_ERR_CAPACITY:
+                cap = int(n.value)
+                continue
+            self._check(st)
+            n = int(n.value)
+            return dict(q=hq[:n], id=hid[:n], table=ht[:n], dist=hd[:n], cand=cand)
+
+    def query_into(self, queries, R, hq, hid, ht, hd, codes=False):
+        """hs_query / hs_query_codes (HOST pointers, the PCIe-inclusive entry points) into caller-owned
+        numpy arrays -- no allocation per call, for timing.  Returns the number of hits."""
+        queries = np.ascontiguousarray(queries, dtype=np.uint8 if codes else np.float64)
         n = C.c_uint64(0)
-        st = self._lib.hs_query_dev(self._h, C.c_void_p(d_centers_ptr), C.c_uint64(nq), C.c_double(R),
+        fn = self._lib.hs_query_codes if codes else self._lib.hs_query
+        st = fn(self._h, _vp(queries), C.c_uint64(queries.shape[0]), C.c_double(R), _vp(hq), _vp(hid), _vp(ht),
+                _vp(hd), C.c_uint64(len(hq)), C.byref(n), None)
+        if st == HS_ERR_CAPACITY:
+            e = HsError(st, self._lib.hs_last_error(self._h).decode())
+            e.needed = int(n.value)
+            raise e
+        self._check(st)
+        return int(n.value)
+
+    def query_dev(self, d_centers_ptr, nq, R, d_q, d_id, d_table, d_dist, cap, d_cand=None, codes=False):
+        """Raw device-pointer call (ints from torch .data_ptr()).  Returns the number of hits; raises
+        HsError(HS_ERR_CAPACITY) with the required size in .needed when cap is too small.
+        codes=True: d_centers_ptr points at residue codes uint8 [nq][k] (hs_query_codes_dev)."""
+        n = C.c_uint64(0)
+        fn = self._lib.hs_query_codes_dev if codes else self._lib.hs_query_dev
+        st = fn(self._h, C.c_void_p(d_centers_ptr), C.c_uint64(nq), C.c_double(R),
                                     C.c_void_p(d_q), C.c_void_p(d_id), C.c_void_p(d_table),
                                     C.c_void_p(d_dist), C.c_uint64(cap), C.byref(n),
                                     C.c_void_p(d_cand) if d_cand else None)

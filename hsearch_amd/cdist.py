@@ -9,7 +9,8 @@ from . import capi
 
 RCCL_LOCAL, LOOPBACK = 0, 1
 EXPORTS = ["hs_comm_create", "hs_comm_unique_id", "hs_comm_create_rank", "hs_comm_destroy", "hs_comm_world",
-           "hs_comm_last_error", "hs_shard_bounds", "hs_allgather_hits", "hs_comm_barrier", "hs_comm_query"]
+           "hs_comm_last_error", "hs_shard_bounds", "hs_allgather_hits", "hs_comm_barrier", "hs_comm_query",
+           "hs_comm_query_codes"]
 
 _lib = None
 
@@ -76,6 +77,20 @@ class Comm:
         except Exception:
             pass
 
+    def last_error(self, rank):
+        return self._lib.hs_comm_last_error(self._h, C.c_uint32(rank)).decode()
+
+    def query_status(self, rank, engine, centers_block, q_offset, R, cap=1024):
+        """hs_comm_query's raw status (tests of the failure protocol); engine may be None."""
+        centers_block = np.ascontiguousarray(centers_block, dtype=np.float64)
+        hq = np.empty(cap, np.uint32); hid = np.empty(cap, np.uint32); ht = np.empty(cap, np.uint32)
+        hd = np.empty(cap, np.float64)
+        n_total = C.c_uint64(0)
+        return self._lib.hs_comm_query(self._h, C.c_uint32(rank), engine._h if engine is not None else None,
+                                       _p(centers_block), C.c_uint64(centers_block.shape[0]), C.c_uint32(q_offset),
+                                       C.c_double(R), _p(hq), _p(hid), _p(ht), _p(hd), C.c_uint64(cap),
+                                       C.byref(n_total))
+
     def allgather_hits(self, rank, q, id_, table, dist, n_local, q_offset, out_q, out_id, out_table, out_dist,
                        cap):
         """Raw call (pointers: numpy arrays = host, ints = device).  Returns (status, n_total)."""
@@ -104,19 +119,21 @@ class Comm:
                 raise capi.HsError(st, self._lib.hs_comm_last_error(self._h, C.c_uint32(rank)).decode())
             return {k: (v[:tot] if v is not None else None) for k, v in out.items()}
 
-    def query(self, rank, engine, centers_block, q_offset, R, cap=None):
+    def query(self, rank, engine, centers_block, q_offset, R, cap=None, codes=False):
         """hs_comm_query: this rank's block through `engine` (bound to the rank's GPU), all ranks'
-        hits back on the host."""
-        centers_block = np.ascontiguousarray(centers_block, dtype=np.float64)
+        hits back on the host.  codes=True: the block is residue codes uint8 [nq][k]
+        (hs_comm_query_codes)."""
+        centers_block = np.ascontiguousarray(centers_block, dtype=np.uint8 if codes else np.float64)
         nq = centers_block.shape[0]
         cap = int(cap) if cap else max(1024, 64 * nq)
         while True:
             hq = np.empty(cap, np.uint32); hid = np.empty(cap, np.uint32); ht = np.empty(cap, np.uint32)
             hd = np.empty(cap, np.float64)
             n_total = C.c_uint64(0)
-            st = self._lib.hs_comm_query(self._h, C.c_uint32(rank), engine._h, _p(centers_block), C.c_uint64(nq),
-                                         C.c_uint32(q_offset), C.c_double(R), _p(hq), _p(hid), _p(ht), _p(hd),
-                                         C.c_uint64(cap), C.byref(n_total))
+            fn = self._lib.hs_comm_query_codes if codes else self._lib.hs_comm_query
+            st = fn(self._h, C.c_uint32(rank), engine._h, _p(centers_block), C.c_uint64(nq),
+                    C.c_uint32(q_offset), C.c_double(R), _p(hq), _p(hid), _p(ht), _p(hd),
+                    C.c_uint64(cap), C.byref(n_total))
             if st == capi.HS_ERR_CAPACITY:
                 cap = n_total.value
                 continue

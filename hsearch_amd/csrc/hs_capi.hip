@@ -73,6 +73,31 @@ struct HostBuf {
 enum { EV_COUNT = 12 };
 enum { EV_FORK = 0, EV_JOIN = 1, EVX_COUNT = 2 };
 
+// Environment switches, read ONCE per handle (hs_create -> read_knobs).  None of them changes a result:
+// each forces one of several equivalent paths (the tests run both and compare), sizes a batch, or prints
+// a diagnostic.  HS_VERIFY_MODE / HS_HASH_MODE are the documented defaults of hs_set_verify_mode /
+// hs_set_hash_mode (include/hsearch.h).  Fault injection (HS_TEST_SPLIT_ABOVE) exists only in the test
+// build of the library (-DHS_TEST_HOOKS: libhsearch_amd_hooks.so), never in libhsearch_amd.so.
+struct Knobs {
+  bool build_serial = false;       // HS_BUILD_SERIAL: no hash / sort overlap in the build (measurement)
+  bool build_debug = false;        // HS_BUILD_DEBUG: say when a table is sorted a second time
+  bool cluster_timing = false;     // HS_CLUSTER_TIMING: phase times of hs_self_join_range on stderr
+  bool debug_refine = false;       // HS_DEBUG_REFINE: survivor counts per batch on stderr
+  bool force_wide = false;         // HS_FORCE_WIDE: 8-column rows whatever the radius (k <= 25)
+  bool no_wide_by_radius = false;  // HS_NO_WIDE_BY_RADIUS: never choose 8-column rows by radius
+  bool no_refine8 = false;         // HS_NO_REFINE8: no 8-column refinement of the join's survivors
+  bool no_self_codes = false;      // HS_NO_SELF_CODES: self-join from embedded centres, not from codes
+  bool no_thin8 = false;           // HS_NO_THIN8: thin segments through the streaming filter
+  bool sort_hits = false;          // HS_SORT_HITS: order hits by the radix sort, not per query
+  bool sync_items = false;         // HS_SYNC_ITEMS: read the join's item count back before launching it
+  int seg_mode = 0;                // HS_SEG_MODE=sparse|dense: 1 / 2; 0 = by the bucket : probe ratio
+  int sort_from_bit = 16;          // HS_SORT_FROM_BIT: lowest fingerprint bit the build's sort looks at
+  uint32_t query_batch = 0;        // HS_QUERY_BATCH: queries per batch (0: by L)
+#ifdef HS_TEST_HOOKS
+  uint32_t test_split_above = 0;   // HS_TEST_SPLIT_ABOVE: batches above this size report a survivor overflow
+#endif
+};
+
 }  // namespace
 
 struct hs_handle {
@@ -111,6 +136,8 @@ struct hs_handle {
   // query workspace (grown on demand, reused across calls)
   DevBuf qints, qstart, qcount, nslices, slice_off, tq, prov, hit_key, hit_val, hit_key2, hit_val2,
       counters, temp, io_centers, io_q, io_id, io_table, io_dist, io_cand, io_codes, io_misc;
+  DevBuf qcodes_buf, qembed;  // hs_query_codes: a batch's checked copy of the query codes; their embedding
+                              // when no from-codes path applies
   HostBuf sj_host;  // hs_self_join_range: hits of one chunk on their way to the edge lists
   // bucket-join workspace
   // hs_index_build_subset: the caller's whole code array, kept on the device across calls
@@ -129,7 +156,7 @@ struct hs_handle {
   double pairs_per_item = 0.0;   // average of the previous batch's join work items (0: none yet)
   bool order_failed = false;     // the last batch that ordered its hits itself had to fall back to the sort
   double order_failed_R = 0.0;   // ... at this radius
-  uint32_t test_split_above = 0; // HS_TEST_SPLIT_ABOVE (tests): batches above this size report a survivor overflow
+  Knobs knobs;
   bool wide8 = false;            // short k-mers: int8 rows over all 8 coordinate columns (hs_join8.hip)
   // segment routing thresholds (HS_JOIN_MIN_Q / _M): segments with fewer probing queries or members
   // go to the per-pair filters instead of the join.  1 / 1 = everything through the join: its
@@ -192,6 +219,18 @@ float filter_bound(double r2) {
   float f = (float)hi;
   if ((double)f < hi) f = nextafterf(f, INFINITY);
   return nextafterf(f, INFINITY);
+}
+
+// The index is about to change (or go): nothing learnt from batches against the old one may size or
+// steer batches against the new one (a stale capacity hint made the first batches after a rebuild to
+// another shape run their join twice: once with the stale capacity, then again the slow way).
+void drop_index(hs_handle* h) {
+  h->built = false;
+  h->rec8w_ready = false;
+  h->order_failed = false;
+  h->order_failed_R = 0.0;
+  h->item_cap_hint = 0;
+  h->pairs_per_item = 0.0;
 }
 
 hs_status ensure_device(hs_handle* h) {
@@ -297,6 +336,15 @@ hs_status hash_dispatch(hs_handle* h, const uint8_t* d_codes, const double* d_pt
                                       h->p.W, out, out_stride, s));
     return HS_OK;
   }
+  // the flag list's counter is 32 bits and every value may be flagged (an inflated bound, a table the
+  // fixed point cannot carry): at most 0xE0000000 / F points per pass
+  const uint64_t n_max = 0xE0000000ull / (uint64_t)F;
+  if (n > n_max) {
+    for (uint64_t i0 = 0; i0 < n; i0 += n_max)
+      HS_CHECK(hash_dispatch(h, d_codes ? d_codes + i0 * k : nullptr, d_pts ? d_pts + i0 * h->d : nullptr,
+                             std::min(n_max, n - i0), table, out + i0 * out_stride, out_stride, set, s));
+    return HS_OK;
+  }
   const int S = h->proj_S;
   const size_t tile = (size_t)S * 2 * 64;  // uint4 per function tile
   const uint4* aq = table >= 0 ? h->proj_aq_tab.as<uint4>() + (size_t)table * tile : h->proj_aq_all.as<uint4>();
@@ -333,12 +381,49 @@ hs_status hash_account(hs_handle* h, uint64_t n, int F, int set) {
   return HS_OK;
 }
 
+void read_knobs(hs_handle* h) {
+  Knobs& kn = h->knobs;
+  auto on = [](const char* name) { return getenv(name) != nullptr; };
+  kn.build_serial = on("HS_BUILD_SERIAL");
+  kn.build_debug = on("HS_BUILD_DEBUG");
+  kn.cluster_timing = on("HS_CLUSTER_TIMING");
+  kn.debug_refine = on("HS_DEBUG_REFINE");
+  kn.force_wide = on("HS_FORCE_WIDE");
+  kn.no_wide_by_radius = on("HS_NO_WIDE_BY_RADIUS");
+  kn.no_refine8 = on("HS_NO_REFINE8");
+  kn.no_self_codes = on("HS_NO_SELF_CODES");
+  kn.no_thin8 = on("HS_NO_THIN8");
+  kn.sort_hits = on("HS_SORT_HITS");
+  kn.sync_items = on("HS_SYNC_ITEMS");
+  if (const char* m = getenv("HS_SEG_MODE")) kn.seg_mode = !strcmp(m, "sparse") ? 1 : !strcmp(m, "dense") ? 2 : 0;
+  if (const char* m = getenv("HS_SORT_FROM_BIT")) kn.sort_from_bit = std::max(0, std::min(60, atoi(m)));
+  if (const char* m = getenv("HS_QUERY_BATCH")) kn.query_batch = (uint32_t)std::max(1, atoi(m));
+#ifdef HS_TEST_HOOKS
+  if (const char* m = getenv("HS_TEST_SPLIT_ABOVE")) kn.test_split_above = (uint32_t)std::max(0, atoi(m));
+#endif
+  if (const char* m = getenv("HS_HASH_MODE")) {
+    if (!strcmp(m, "exact")) h->hash_mode = 1;
+    if (!strcmp(m, "mfma")) h->hash_mode = 2;
+  }
+  if (const char* m = getenv("HS_VERIFY_MODE")) {
+    if (!strcmp(m, "stream")) h->verify_mode = 1;
+    if (!strcmp(m, "join")) h->verify_mode = 2;
+    if (!strcmp(m, "join16")) h->verify_mode = 3;
+  }
+  if (const char* m = getenv("HS_JOIN_MIN_Q")) h->join_min_q = (uint32_t)std::max(1, atoi(m));
+  if (const char* m = getenv("HS_JOIN_MIN_M")) h->join_min_m = (uint32_t)std::max(1, atoi(m));
+  if (const char* m = getenv("HS_JOIN_BLOCKS_PER_CU")) h->join_blocks_per_cu = std::max(1, atoi(m));
+}
+
 }  // namespace
 
 extern "C" {
 
-const char* hs_version(void) { return "hsearch_amd 0.1 (gfx950)"; }
-
+#ifdef HS_TEST_HOOKS
+const char* hs_version(void) { return "hsearch_amd 0.3 (gfx950, test hooks)"; }
+#else
+const char* hs_version(void) { return "hsearch_amd 0.3 (gfx950)"; }
+#endif
 const char* hs_last_error(const hs_handle* h) { return h ? h->err.c_str() : "null handle"; }
 
 hs_status hs_get_profile(const hs_handle* h, hs_profile* out) {
@@ -470,7 +555,6 @@ hs_status hs_create(const hs_params* params, const double* a, const double* b, c
   if (getenv("HS_BACKTRACE")) signal(SIGABRT, hs_abort_backtrace);
   int wide_max_k = 20;
   if (const char* m = getenv("HS_WIDE_MAX_K")) wide_max_k = std::min(20, atoi(m));
-  if (const char* m = getenv("HS_TEST_SPLIT_ABOVE")) h->test_split_above = (uint32_t)std::max(0, atoi(m));
   h->wide8_ok = h->join8_tables_ok && scale8[6] > 0.f;
   h->wide8 = h->wide8_ok && (int)h->p.k <= wide_max_k;
   h->join8_scale = (double)scale8[0];
@@ -489,20 +573,9 @@ hs_status hs_create(const hs_params* params, const double* a, const double* b, c
     h->pair4_mean = s1 / ((double)A * A);
     h->pair4_var = std::max(0.0, s2 / ((double)A * A) - h->pair4_mean * h->pair4_mean);
   }
-  if (const char* m = getenv("HS_HASH_MODE")) {
-    if (!strcmp(m, "exact")) h->hash_mode = 1;
-    if (!strcmp(m, "mfma")) h->hash_mode = 2;
-  }
+  read_knobs(h);
   HS_CHECK(setup_projection(h, true));
   HS_CHECK(warm_up_device_code(h));
-  if (const char* m = getenv("HS_VERIFY_MODE")) {
-    if (!strcmp(m, "stream")) h->verify_mode = 1;
-    if (!strcmp(m, "join")) h->verify_mode = 2;
-    if (!strcmp(m, "join16")) h->verify_mode = 3;
-  }
-  if (const char* m = getenv("HS_JOIN_MIN_Q")) h->join_min_q = (uint32_t)std::max(1, atoi(m));
-  if (const char* m = getenv("HS_JOIN_MIN_M")) h->join_min_m = (uint32_t)std::max(1, atoi(m));
-  if (const char* m = getenv("HS_JOIN_BLOCKS_PER_CU")) h->join_blocks_per_cu = std::max(1, atoi(m));
   return HS_OK;
 }
 
@@ -510,7 +583,7 @@ hs_status hs_set_planes(hs_handle* h, const double* a, const double* b) {
   if (!h || !a || !b) return HS_ERR_INVALID;
   hs_status st = ensure_device(h);
   if (st) return st;
-  h->built = false, h->rec8w_ready = false, h->order_failed = false;  // the tables were keyed by the old family
+  drop_index(h);  // the tables were keyed by the old family
   const size_t na = (size_t)h->LK * h->d;
   // the previous family may still be read by work queued on the stream: order the copies after it
   HS_HIP(h, hipMemcpyAsync(h->a.p, a, na * 8, hipMemcpyHostToDevice, h->stream));
@@ -557,7 +630,7 @@ void hs_destroy(hs_handle* h) {
                     &h->proj_xmeta, &h->slice_ql, &h->qhits, &h->bs_ints2[0], &h->bs_ints2[1], &h->bs_keys2[0],
                     &h->bs_keys2[1], &h->bs_iota2[0], &h->bs_iota2[1], &h->bs_keys_sorted, &h->bs_rle_unique,
                     &h->bs_rle_counts, &h->bs_small, &h->bs_sort_temp, &h->bs_slow_q, &h->all_codes,
-                    &h->subset_ids};
+                    &h->subset_ids, &h->qcodes_buf, &h->qembed};
   for (DevBuf* bf : bufs) bf->release();
   h->sj_host.release();
   for (int l = 0; l < HS_MAX_L; ++l) {
@@ -700,7 +773,7 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
   // a quarter of the CUs for the sort hung in the second build of a process and was dropped.
   hipStream_t hash_stream = h->stream2;
   const bool own_hash_stream = false;
-  const bool serial = getenv("HS_BUILD_SERIAL") != nullptr;  // measurement: no overlap
+  const bool serial = h->knobs.build_serial;  // measurement: no overlap
   struct Guard {
     hs_handle* h;
     hipStream_t* hs;
@@ -776,13 +849,12 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
     // The radix sort looks at the fingerprints' top 48 bits only (6 passes instead of 8): buckets are
     // far fewer than 2^24, so two DISTINCT fingerprints rarely agree there (~ nb^2 / 2^49 per table);
     // hs_check_runs_kernel sees it if they do (flag 4) and the table is sorted again on all 64 bits.
-    // Only where rocPRIM's onesweep passes do the sorting (n >= 2^20): below that its merge sort takes
-    // over, whose cost does not depend on the bits -- and which faulted on a bit range in this
-    // library's tests.  (HS_SORT_FROM_BIT: 0 = every bit at once; the tests pass 56 to see the second
-    // sort happen.)
-    const int from_bit_env =
-        getenv("HS_SORT_FROM_BIT") ? std::max(0, std::min(60, atoi(getenv("HS_SORT_FROM_BIT")))) : 16;
-    const int from_bit0 = n >= (1u << 20) ? from_bit_env : 0;
+    // Only where rocPRIM's onesweep passes do the sorting (hs_sort_partial_bits_ok: n above the library's
+    // merge_sort_limit, 2^20): up to that size its merge sort takes over, whose cost does not depend on
+    // the bits and whose comparator for a range ending at bit 64 is built from 1 << 64 (hs_prims.hip) --
+    // the memory fault of this sort's first draft.  (HS_SORT_FROM_BIT: 0 = every bit at once; the tests
+    // pass 56 to see the second sort happen.)
+    const int from_bit0 = hs_sort_partial_bits_ok((size_t)n) ? h->knobs.sort_from_bit : 0;
     for (int from_bit = from_bit0; n; from_bit = 0) {
       HS_HIP(h, hs_sort_pairs_u64_u32(sort_temp.p, sort_temp.cap, keys.as<uint64_t>(),
                                       keys_sorted.as<uint64_t>(), iota.as<uint32_t>(),
@@ -801,7 +873,7 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
       nb = host_small[0];
       flag = host_small[1];
       if ((flag & 4u) && from_bit) {  // interleaved fingerprints: once more, on every bit
-        if (getenv("HS_BUILD_DEBUG")) fprintf(stderr, "table %d: %u buckets, second sort on all bits\n", l, nb);
+        if (h->knobs.build_debug) fprintf(stderr, "table %d: %u buckets, second sort on all bits\n", l, nb);
         HS_HIP(h, hipMemsetAsync(d_small, 0, 64, h->stream));
         continue;
       }
@@ -946,7 +1018,7 @@ hs_status hs_index_build(hs_handle* h, const uint8_t* codes, uint64_t n) {
   if (n >= (1ull << 31)) return fail(h, HS_ERR_INVALID, "n must be < 2^31 (ids are 32-bit, as in the reference)");
   hs_status st = ensure_device(h);
   if (st) return st;
-  h->built = false, h->rec8w_ready = false, h->order_failed = false;
+  drop_index(h);
   h->n = n;
   memset(&h->prof, 0, sizeof(h->prof));
   memset(&h->info, 0, sizeof(h->info));
@@ -969,7 +1041,7 @@ hs_status hs_index_build_subset(hs_handle* h, const uint8_t* codes_all, uint64_t
     for (uint64_t i = 0; i < n_subset; ++i)
       if (subset[i] >= n_all) return fail(h, HS_ERR_INVALID, "subset index outside the code array");
   const int k = (int)h->p.k;
-  h->built = false, h->rec8w_ready = false, h->order_failed = false;
+  drop_index(h);
   h->n = n_subset;
   memset(&h->prof, 0, sizeof(h->prof));
   memset(&h->info, 0, sizeof(h->info));
@@ -1021,7 +1093,7 @@ hs_status hs_index_build_windows(hs_handle* h, const uint8_t* residues, uint64_t
   }
   starts[n_seq] = (uint32_t)(n_seq ? seq_start[n_seq] : 0);
   win_off[n_seq] = (uint32_t)n;
-  h->built = false, h->rec8w_ready = false, h->order_failed = false;
+  drop_index(h);
   h->n = n;
   memset(&h->prof, 0, sizeof(h->prof));
   memset(&h->info, 0, sizeof(h->info));
@@ -1271,7 +1343,7 @@ hs_status hs_index_load(hs_handle* h, const char* path) {
       hd.W != h->p.W)
     return fail(h, HS_ERR_IO, "index file written for other parameters (k, K, L, W, alphabet)");
   if (hd.payload_bytes != payload_size(hd)) return fail(h, HS_ERR_IO, "index file inconsistent (payload length)");
-  h->built = false, h->rec8w_ready = false, h->order_failed = false;
+  drop_index(h);
   memset(&h->prof, 0, sizeof(h->prof));
   memset(&h->info, 0, sizeof(h->info));
   HS_HIP(h, hipStreamSynchronize(h->stream));
@@ -1474,8 +1546,8 @@ static const hs_status HS_SPLIT_BATCH = (hs_status)1000;
 // mates -- the survivor path, not the matrix pipe, then sets the pace (k = 25, R = 50: 1 % pass).
 static bool want_wide(const hs_handle* h, double R) {
   if (h->wide8) return true;
-  if (!h->wide8_ok || h->p.k > 25 || getenv("HS_NO_WIDE_BY_RADIUS")) return false;
-  if (getenv("HS_FORCE_WIDE")) return true;
+  if (!h->wide8_ok || h->p.k > 25 || h->knobs.no_wide_by_radius) return false;
+  if (h->knobs.force_wide) return true;
   const double k = (double)h->p.k, sd = sqrt(k * h->pair4_var);
   return R * R > k * h->pair4_mean - 3.0 * sd;
 }
@@ -1503,13 +1575,15 @@ static bool self_codes_ok(const hs_handle* h, double R) {
   const double r2 = R * R, s = wide ? h->join8_scale_w : h->join8_scale, k = (double)h->p.k;
   if (!h->join8_tables_ok || h->p.k > 50 || h->verify_mode == 1 || h->verify_mode == 3 || !(r2 < 30000.0))
     return false;
-  if (getenv("HS_NO_THIN8") || getenv("HS_NO_SELF_CODES")) return false;
+  if (h->knobs.no_thin8 || h->knobs.no_self_codes) return false;
   // -gamma <= s^2 R^2 / 2 + L1(c^)/2 + 3, L1(c^) <= 127 * 4 k (127 * 8 k with wide rows)
   return s > 0.0 && 0.5 * s * s * r2 + (wide ? 508.0 : 254.0) * k + 3.0 < 127.0 * 127.0 * 13.0;
 }
 
-static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq, uint32_t q_base,
-                             double R, bool brute, uint64_t* d_cand, uint32_t* n_batch_hits,
+// d_qcodes_ext != null: the queries are k-mers given as residue codes [nq][k] (hs_query_codes) -- rows of
+// the coordinate table like the DB's -- and d_centers is unused.
+static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_t* d_qcodes_ext, uint32_t nq,
+                             uint32_t q_base, double R, bool brute, uint64_t* d_cand, uint32_t* n_batch_hits,
                              BatchOut* bout = nullptr, bool allow_async = true) {
   const int K = (int)h->p.K, L = brute ? 1 : (int)h->p.L, k = (int)h->p.k;
   const uint32_t nql = nq * (uint32_t)L;
@@ -1532,7 +1606,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   if (wide) HS_CHECK(ensure_rec8w(h));
   const uint4* const rec8 = (wide && !h->wide8) ? h->t_rec8w.as<uint4>() : h->t_rec8.as<uint4>();
   const void* const jtab_rows = wide ? (const void*)(h->jtab8.as<char>() + 1536) : (const void*)h->jtab8.p;
-  const bool refine = use_i8 && !wide && !getenv("HS_NO_REFINE8");
+  const bool refine = use_i8 && !wide && !h->knobs.no_refine8;
   uint32_t* d_unsafe = d_cnt + 8;
   // Self-join (the queries are the indexed k-mers self_first + q_base ..): every per-query quantity
   // comes from the residue codes and the tables -- no embedded centres, no hashing, no directory
@@ -1541,10 +1615,32 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   // how the probes are grouped by bucket in front of the join: a counting sort over the bucket slots,
   // or -- when those far outnumber the probes -- a sort of the probes (HS_SEG_MODE=dense|sparse forces one)
   bool seg_sparse = (uint64_t)h->nb_total > 4ull * nql;
-  if (const char* m = getenv("HS_SEG_MODE")) seg_sparse = !strcmp(m, "sparse") ? true : !strcmp(m, "dense") ? false : seg_sparse;
+  if (h->knobs.seg_mode) seg_sparse = h->knobs.seg_mode == 1;
   const bool self_codes = h->self_first != HS_NO_SELF && !brute && use_i8 && self_codes_ok(h, R);
   const uint8_t* d_qcodes =
       self_codes ? h->codes.as<uint8_t>() + ((uint64_t)h->self_first + q_base) * k : nullptr;
+  // Queries given as codes (hs_query_codes): a checked copy first (a code outside the alphabet is
+  // reported with the batch's counters and replaced by 0, so no kernel indexes a table with it).  When
+  // every filter on the way works from codes (self_codes_ok: the int8 join and its thin-segment filter)
+  // no embedded centre exists at any point: 25 bytes per query instead of 1600 -- hash, query rows and
+  // the exact decision all read the table rows the DB's k-mers read.  Otherwise the codes are embedded
+  // here, on the device, and the batch runs as for any other centres.
+  bool ext_codes = false;
+  if (d_qcodes_ext) {
+    HS_HIP(h, h->qcodes_buf.reserve(std::max<size_t>(16, (size_t)nq * k)));
+    HS_HIP(h, hs_launch_check_codes(d_qcodes_ext, (uint64_t)nq * k, h->alphabet, h->qcodes_buf.as<uint8_t>(),
+                                    d_cnt + HS_CNT_BAD_QUERY_CODE, h->stream));
+    if (!brute && use_i8 && self_codes_ok(h, R)) {
+      ext_codes = true;
+      d_qcodes = h->qcodes_buf.as<uint8_t>();
+    } else {
+      HS_HIP(h, h->qembed.reserve(std::max<size_t>(16, (size_t)nq * h->d * 8)));
+      HS_HIP(h, hs_launch_embed(h->qcodes_buf.as<uint8_t>(), nq, k, h->coords.as<double>(), h->qembed.as<double>(),
+                                h->stream));
+      d_centers = h->qembed.as<double>();
+    }
+  }
+  const bool from_codes = self_codes || ext_codes;  // no centres: every per-query quantity from the codes
   if (use_join) {
     // the join filter's query rows depend on the centres only: quantised on the side stream while
     // the main stream hashes and probes (both passes stream the same 8d bytes per query)
@@ -1552,7 +1648,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     if (refine) HS_HIP(h, h->c8b.reserve((size_t)nq * hs_join8_row_bytes(k, wide)));
     HS_HIP(h, hipEventRecord(h->evx[EV_FORK], h->stream));
     HS_HIP(h, hipStreamWaitEvent(h->stream2, h->evx[EV_FORK], 0));
-    if (self_codes)
+    if (from_codes)
       HS_HIP(h, hs_launch_qprep8_codes(d_qcodes, nq, k, wide, r2, h->coords.as<double>(), h->jtab8.p,
                                        h->jtab8.as<char>() + 1024, h->jtab8.as<char>() + 1536,
                                        h->jtab8.as<float>() + 128, h->c16.p, refine ? h->c8b.p : nullptr,
@@ -1572,7 +1668,9 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, h->probe_slow.reserve(((size_t)nql + 1) * 4));
     HS_HIP(h, h->slice_off.reserve(((size_t)nql + 1) * 4));
     HS_HIP(h, h->temp.reserve(hs_scan_u32_temp((size_t)nql + 1) + 256));
-    if (!self_codes)
+    if (ext_codes)
+      HS_CHECK(hash_dispatch(h, d_qcodes, nullptr, nq, -1, h->qints.as<int32_t>(), h->LK, 2, h->stream));
+    else if (!self_codes)
       HS_CHECK(hash_dispatch(h, nullptr, d_centers, nq, -1, h->qints.as<int32_t>(), h->LK, 2, h->stream));
   }
   HS_HIP(h, hipEventRecord(h->ev[1], h->stream));
@@ -1666,7 +1764,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     // capacity are checked with the batch's final read-back, a violation repeats the batch the
     // slow way.  Otherwise one round trip: join legality, item count, streaming slices.
     async_items = allow_async && use_i8 && h->join_min_q == 1 && h->join_min_m == 1 && h->item_cap_hint &&
-                  !getenv("HS_SYNC_ITEMS");
+                  !h->knobs.sync_items;
     uint32_t unsafe = 0;
     if (async_items) {
       n_items = h->item_cap_hint;
@@ -1681,7 +1779,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
                                h->stream));
       HS_HIP(h, hipStreamSynchronize(h->stream));
     }
-    if (self_codes && unsafe) return fail(h, HS_ERR_STATE, "self-join from codes: a query row marked unsafe");
+    if (from_codes && unsafe) return fail(h, HS_ERR_STATE, "queries from codes: a query row marked unsafe");
     if (use_i8 && unsafe && !can16) {
       // a query int8 cannot carry and no fp16 form for this k: the batch streams (below)
       use_i8 = false;
@@ -1731,7 +1829,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   // stream: the join's persistent waves take every register of every SIMD, so nothing runs beside
   // it anyway -- a kernel launched on a side stream first only delays the join's start (and one
   // launched later waits for the join's tail)
-  const bool thin8 = !brute && (n_items || self_codes) && n_slices && use_i8 && !getenv("HS_NO_THIN8");
+  const bool thin8 = !brute && (n_items || from_codes) && n_slices && use_i8 && !h->knobs.no_thin8;
   // without it (fp16 join, HS_NO_THIN8) the streaming filter and its tables go to the side stream
   const bool side = !brute && n_items && n_slices && !thin8;
   if (thin8) {
@@ -1769,7 +1867,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     // the batch orders its hits itself (bucket by query, no sort, no host count) unless brute force
     // (not tried again at a radius at which the previous batch had a query with too many hits for it:
     // the attempt costs 10 % of such a batch -- k = 15 at the C2 sizes, 545 hits per query)
-    const bool order_here = bout && !brute && !getenv("HS_SORT_HITS") && !(h->order_failed && h->order_failed_R == R);
+    const bool order_here = bout && !brute && !h->knobs.sort_hits && !(h->order_failed && h->order_failed_R == R);
     uint32_t *qcnt = nullptr, *qoff = nullptr, *qfill = nullptr;
     if (order_here) {
       const size_t n1q = (size_t)nq + 1;
@@ -1873,18 +1971,41 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
     HS_HIP(h, hipStreamSynchronize(h->stream));
     // > ~4e9 survivors: run_query halves the batch (HS_TEST_SPLIT_ABOVE=n: as if every batch of more
     // than n queries had overflowed -- the tests' handle on the splitting logic)
-    if (host_cnt[HS_CNT_SURVIVOR_OVERFLOW] || (h->test_split_above && nq > h->test_split_above))
-      return HS_SPLIT_BATCH;
-    if (async_items && (host_cnt[8] /* join legality */ || n_items_real > n_items))
-      return query_batch(h, d_centers, nq, q_base, R, brute, d_cand, n_batch_hits, bout, false);
+    if (host_cnt[HS_CNT_SURVIVOR_OVERFLOW]) return HS_SPLIT_BATCH;
+#ifdef HS_TEST_HOOKS
+    if (h->knobs.test_split_above && nq > h->knobs.test_split_above) return HS_SPLIT_BATCH;
+#endif
+    if (host_cnt[HS_CNT_BAD_QUERY_CODE])
+      return fail(h, HS_ERR_INVALID, "residue code outside the alphabet in the queries");
+    if (async_items && (host_cnt[8] /* join legality */ || n_items_real > n_items)) {
+      ++h->prof.join_async_retries;  // (measurements can exclude such a call: its join ran twice)
+      return query_batch(h, d_centers, d_qcodes_ext, nq, q_base, R, brute, d_cand, n_batch_hits, bout, false);
+    }
     ms_verify += ev_ms(h, 3, 4);
     if (!brute && n_items) ms_join += ev_ms(h, 11, 10);
     ms_final += ev_ms(h, 4, 5);
     ++launches;
-    if (getenv("HS_DEBUG_REFINE"))
+    if (h->knobs.debug_refine)
       fprintf(stderr, "survivors %u -> refined %u -> hits %u\n", host_cnt[0], host_cnt[4], host_cnt[1]);
     if (host_cnt[0] > prov_cap) {
-      prov_cap = host_cnt[0] + host_cnt[0] / 8 + 1024;
+      // the survivor list was too short: once more with room for what the filters reported (64-bit
+      // arithmetic: the count may sit just under the overflow flag's 0xF0000000).  The six lists of the
+      // exact pass are sized from it -- 48 bytes per entry -- so beyond 2^30 entries, or when the device
+      // has no room for them, the batch is cut in halves like a counter overflow instead.
+      const uint64_t need = (uint64_t)host_cnt[0] + host_cnt[0] / 8 + 1024;
+      if (need > (1ull << 30) && nq > 1) return HS_SPLIT_BATCH;
+      if (need > 0xffffffffull) return fail(h, HS_ERR_CAPACITY, "the filter survivors of one query exceed the survivor list");
+      const uint64_t have = prov_cap;
+      prov_cap = (uint32_t)need;
+      if (nq > 1) {  // can the lists grow?  (a failed reserve keeps the old buffer's size at 0: re-reserved below)
+        const size_t bytes = (size_t)prov_cap * 8;
+        if (h->prov.reserve(bytes) != hipSuccess || h->hit_key.reserve(bytes) != hipSuccess ||
+            h->hit_val.reserve(bytes) != hipSuccess) {
+          (void)hipGetLastError();
+          prov_cap = (uint32_t)have;
+          return HS_SPLIT_BATCH;
+        }
+      }
       continue;
     }
     if (bout) bout->ordered = order_here && !host_cnt[20];
@@ -1932,7 +2053,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, uint32_t nq,
   return HS_OK;
 }
 
-static hs_status run_query(hs_handle* h, const double* d_centers, uint64_t nq, double R, bool brute,
+static hs_status run_query(hs_handle* h, const double* d_centers, const uint8_t* d_qcodes, uint64_t nq, double R, bool brute,
                            uint32_t* d_hit_q, uint32_t* d_hit_id, uint32_t* d_hit_table,
                            double* d_hit_dist, uint64_t cap, uint64_t* n_hits, uint64_t* d_cand) {
   if (!h || !n_hits) return HS_ERR_INVALID;
@@ -1940,7 +2061,7 @@ static hs_status run_query(hs_handle* h, const double* d_centers, uint64_t nq, d
   if (!h->built) return fail(h, HS_ERR_STATE, "hs_index_build has not been called");
   if (nq >= (1ull << 27)) return fail(h, HS_ERR_INVALID, "nq must be < 2^27 per call");
   // (a self-join that runs from the residue codes passes no centres)
-  if (nq && !d_centers && !(h->self_first != HS_NO_SELF && self_codes_ok(h, R))) return HS_ERR_INVALID;
+  if (nq && !d_centers && !d_qcodes && !(h->self_first != HS_NO_SELF && self_codes_ok(h, R))) return HS_ERR_INVALID;
   if (cap && (!d_hit_q || !d_hit_id || !d_hit_dist)) return HS_ERR_INVALID;
   if (!(R == R)) return fail(h, HS_ERR_INVALID, "R is NaN");
   hs_status st = ensure_device(h);
@@ -1953,7 +2074,7 @@ static hs_status run_query(hs_handle* h, const double* d_centers, uint64_t nq, d
     // queries per batch: bounds the workspace, which grows with nq * L (2^17 at L >= 8; with few
     // tables -- the one-table indexes of Clustering() -- larger batches, fewer fixed costs)
     uint32_t QB = std::max(1u << 17, std::min(1u << 20, (1u << 20) / h->p.L));
-    if (const char* m = getenv("HS_QUERY_BATCH")) QB = (uint32_t)std::max(1, atoi(m));  // tests
+    if (h->knobs.query_batch) QB = h->knobs.query_batch;  // tests
     uint32_t nqb = 0;
     for (uint64_t q0 = 0; q0 < nq; q0 += nqb) {
       nqb = (uint32_t)std::min<uint64_t>(QB, nq - q0);
@@ -1965,7 +2086,8 @@ static hs_status run_query(hs_handle* h, const double* d_centers, uint64_t nq, d
       bout.table = d_hit_table ? d_hit_table + at : nullptr;
       bout.dist = d_hit_dist + at;
       bout.room = cap - at;
-      st = query_batch(h, d_centers ? d_centers + q0 * h->d : nullptr, nqb, (uint32_t)q0, R, brute,
+      st = query_batch(h, d_centers ? d_centers + q0 * h->d : nullptr, d_qcodes ? d_qcodes + q0 * h->p.k : nullptr,
+                       nqb, (uint32_t)q0, R, brute,
                        d_cand ? d_cand + q0 * h->p.L : nullptr, &nh, cap ? &bout : nullptr);
       if (st == HS_SPLIT_BATCH) {
         // more filter survivors than the 32-bit list counter holds (a radius near the typical
@@ -2013,26 +2135,38 @@ static hs_status run_query(hs_handle* h, const double* d_centers, uint64_t nq, d
 hs_status hs_query_dev(hs_handle* h, const double* d_centers, uint64_t nq, double R,
                        uint32_t* d_hit_q, uint32_t* d_hit_id, uint32_t* d_hit_table,
                        double* d_hit_dist, uint64_t cap, uint64_t* n_hits, uint64_t* d_cand) {
-  return run_query(h, d_centers, nq, R, false, d_hit_q, d_hit_id, d_hit_table, d_hit_dist, cap,
+  return run_query(h, d_centers, nullptr, nq, R, false, d_hit_q, d_hit_id, d_hit_table, d_hit_dist, cap,
                    n_hits, d_cand);
 }
 
-static hs_status host_query(hs_handle* h, const double* centers, uint64_t nq, double R, bool brute,
-                            uint32_t* hit_q, uint32_t* hit_id, uint32_t* hit_table, double* hit_dist,
+hs_status hs_query_codes_dev(hs_handle* h, const uint8_t* d_qcodes, uint64_t nq, double R,
+                             uint32_t* d_hit_q, uint32_t* d_hit_id, uint32_t* d_hit_table,
+                             double* d_hit_dist, uint64_t cap, uint64_t* n_hits, uint64_t* d_cand) {
+  if (nq && !d_qcodes) return HS_ERR_INVALID;
+  return run_query(h, nullptr, d_qcodes, nq, R, false, d_hit_q, d_hit_id, d_hit_table, d_hit_dist, cap,
+                   n_hits, d_cand);
+}
+
+static hs_status host_query(hs_handle* h, const double* centers, const uint8_t* qcodes, uint64_t nq, double R,
+                            bool brute, uint32_t* hit_q, uint32_t* hit_id, uint32_t* hit_table, double* hit_dist,
                             uint64_t cap, uint64_t* n_hits, uint64_t* cand) {
   if (!h || !n_hits) return HS_ERR_INVALID;
-  if (nq && !centers) return HS_ERR_INVALID;
+  if (nq && !centers && !qcodes) return HS_ERR_INVALID;
   hs_status st = ensure_device(h);
   if (st) return st;
-  const size_t cbytes = (size_t)nq * h->d * 8;
+  // centres: 8d bytes per query over PCIe; codes: k bytes
+  const size_t cbytes = qcodes ? 0 : (size_t)nq * h->d * 8, kbytes = qcodes ? (size_t)nq * h->p.k : 0;
   HS_HIP(h, h->io_centers.reserve(std::max<size_t>(16, cbytes)));
+  HS_HIP(h, h->io_codes.reserve(std::max<size_t>(16, kbytes)));
   HS_HIP(h, h->io_q.reserve(std::max<size_t>(16, cap * 4)));
   HS_HIP(h, h->io_id.reserve(std::max<size_t>(16, cap * 4)));
   HS_HIP(h, h->io_table.reserve(std::max<size_t>(16, cap * 4)));
   HS_HIP(h, h->io_dist.reserve(std::max<size_t>(16, cap * 8)));
   if (cand) HS_HIP(h, h->io_cand.reserve(std::max<size_t>(16, (size_t)nq * h->p.L * 8)));
   if (cbytes) HS_HIP(h, hipMemcpyAsync(h->io_centers.p, centers, cbytes, hipMemcpyHostToDevice, h->stream));
-  st = run_query(h, h->io_centers.as<double>(), nq, R, brute, h->io_q.as<uint32_t>(),
+  if (kbytes) HS_HIP(h, hipMemcpyAsync(h->io_codes.p, qcodes, kbytes, hipMemcpyHostToDevice, h->stream));
+  st = run_query(h, qcodes ? nullptr : h->io_centers.as<double>(), qcodes ? h->io_codes.as<uint8_t>() : nullptr, nq,
+                 R, brute, h->io_q.as<uint32_t>(),
                  h->io_id.as<uint32_t>(), h->io_table.as<uint32_t>(), h->io_dist.as<double>(), cap,
                  n_hits, cand ? h->io_cand.as<uint64_t>() : nullptr);
   if (st != HS_OK) return st;
@@ -2053,12 +2187,19 @@ static hs_status host_query(hs_handle* h, const double* centers, uint64_t nq, do
 hs_status hs_query(hs_handle* h, const double* centers, uint64_t nq, double R, uint32_t* hit_q,
                    uint32_t* hit_id, uint32_t* hit_table, double* hit_dist, uint64_t cap,
                    uint64_t* n_hits, uint64_t* cand) {
-  return host_query(h, centers, nq, R, false, hit_q, hit_id, hit_table, hit_dist, cap, n_hits, cand);
+  return host_query(h, centers, nullptr, nq, R, false, hit_q, hit_id, hit_table, hit_dist, cap, n_hits, cand);
+}
+
+hs_status hs_query_codes(hs_handle* h, const uint8_t* qcodes, uint64_t nq, double R, uint32_t* hit_q,
+                         uint32_t* hit_id, uint32_t* hit_table, double* hit_dist, uint64_t cap,
+                         uint64_t* n_hits, uint64_t* cand) {
+  if (nq && !qcodes) return HS_ERR_INVALID;
+  return host_query(h, nullptr, qcodes, nq, R, false, hit_q, hit_id, hit_table, hit_dist, cap, n_hits, cand);
 }
 
 hs_status hs_bruteforce(hs_handle* h, const double* centers, uint64_t nq, double R, uint32_t* hit_q,
                         uint32_t* hit_id, double* hit_dist, uint64_t cap, uint64_t* n_hits) {
-  return host_query(h, centers, nq, R, true, hit_q, hit_id, nullptr, hit_dist, cap, n_hits, nullptr);
+  return host_query(h, centers, nullptr, nq, R, true, hit_q, hit_id, nullptr, hit_dist, cap, n_hits, nullptr);
 }
 
 hs_status hs_self_join(hs_handle* h, double R, int sqrt_test, uint32_t* edge_i, uint32_t* edge_j,
@@ -2087,7 +2228,7 @@ hs_status hs_self_join_range(hs_handle* h, uint64_t first, uint64_t count, doubl
   // area: Clustering() calls this once per table, reallocating 1.6 GB of centres and faulting in
   // fresh host vectors every time cost more than the join itself
   DevBuf &centers = h->io_centers, &dq = h->io_q, &did = h->io_id, &dt = h->io_table, &dd = h->io_dist;
-  const bool sj_timing = getenv("HS_CLUSTER_TIMING") != nullptr;
+  const bool sj_timing = h->knobs.cluster_timing;
   auto sj_t0 = std::chrono::steady_clock::now();
   auto sj_lap = [&](const char* what) {
     if (!sj_timing) return;
@@ -2114,7 +2255,7 @@ hs_status hs_self_join_range(hs_handle* h, uint64_t first, uint64_t count, doubl
       HS_HIP(h, dd.reserve(hcap * 8));
       h->sqrt_test = sqrt_test != 0;
       h->self_first = (uint32_t)q0;  // the pair of a k-mer with itself is dropped on the device
-      st = run_query(h, from_codes ? nullptr : centers.as<double>(), nq, R, false, dq.as<uint32_t>(), did.as<uint32_t>(),
+      st = run_query(h, from_codes ? nullptr : centers.as<double>(), nullptr, nq, R, false, dq.as<uint32_t>(), did.as<uint32_t>(),
                      dt.as<uint32_t>(), dd.as<double>(), hcap, &nh, nullptr);
       h->sqrt_test = false;
       h->self_first = HS_NO_SELF;

@@ -92,6 +92,8 @@ struct RankState {
   hipStream_t stream = nullptr;
   DevBuf send, recv, counts, io_centers, io_q, io_id, io_table, io_dist, all_q, all_id, all_table, all_dist;
   std::vector<char> host_send;  // loopback: this rank's record
+  std::vector<uint32_t> h_q, h_id, h_table;  // loopback with devices: this rank's hits on the host
+  std::vector<double> h_dist;
   std::string err;
 };
 
@@ -178,7 +180,8 @@ struct hs_comm {
   std::condition_variable cv;
   uint32_t arrived = 0;
   uint64_t generation = 0;
-  std::vector<uint64_t> counts, offsets, caps;  // published by each rank for the current call
+  bool has_devices = false;  // (always true for RCCL) the ranks have GPUs: hs_comm_query may run
+  std::vector<uint64_t> pub;  // [world][4] words published by each rank for the current exchange
   RankState& rs(uint32_t rank) { return ranks[per_process ? 0 : rank]; }
   void barrier() {
     if (per_process || world == 1) return;
@@ -223,6 +226,12 @@ hs_status rfail(hs_comm* c, uint32_t rank, hs_status st, const std::string& msg)
       return rfail(c, rank, HS_ERR_HIP, std::string(#expr) + ": " + rccl()->GetErrorString(e_)); \
   } while (0)
 
+#define HS_DIST_CHECK(expr)           \
+  do {                                \
+    hs_status st_ = (expr);           \
+    if (st_ != HS_OK) return st_;     \
+  } while (0)
+
 bool rank_ok(const hs_comm* c, uint32_t rank) {
   return c && rank < c->world && (!c->per_process || rank == c->my_rank);
 }
@@ -249,10 +258,8 @@ hs_status hs_comm_create(int kind, const int* devices, uint32_t world, hs_comm**
   c->kind = kind;
   c->world = world;
   c->ranks.resize(world);
-  c->counts.assign(world, 0);
-  c->offsets.assign(world, 0);
-  c->caps.assign(world, 0);
-  if (kind == HS_COMM_LOOPBACK) {
+  c->pub.assign((size_t)world * 4, 0);
+  if (kind == HS_COMM_LOOPBACK && !devices) {
     *out = c;
     return HS_OK;
   }
@@ -261,6 +268,21 @@ hs_status hs_comm_create(int kind, const int* devices, uint32_t world, hs_comm**
     delete c;
     return say(err, err_cap, HS_ERR_NO_DEVICE, "no usable gfx950 device");
   }
+  if (kind == HS_COMM_LOOPBACK) {
+    // host-memory transport between ranks that HAVE devices (several ranks may share one): hs_comm_query
+    // runs each rank's search on its device and exchanges the hits through host memory
+    for (uint32_t r = 0; r < world; ++r) {
+      if (devices[r] < 0 || devices[r] >= n_dev) {
+        delete c;
+        return say(err, err_cap, HS_ERR_NO_DEVICE, "device ordinal out of range");
+      }
+      c->ranks[r].device = devices[r];
+    }
+    c->has_devices = true;
+    *out = c;
+    return HS_OK;
+  }
+  c->has_devices = true;
   std::vector<int> devs(world);
   for (uint32_t r = 0; r < world; ++r) {
     devs[r] = devices ? devices[r] : (int)r;
@@ -326,16 +348,16 @@ hs_status hs_comm_create_rank(const char id[HS_COMM_ID_BYTES], uint32_t rank, ui
   c->world = world;
   c->my_rank = rank;
   c->ranks.resize(1);
-  c->counts.assign(world, 0);
-  c->offsets.assign(world, 0);
-  c->caps.assign(world, 0);
+  c->pub.assign((size_t)world * 4, 0);
+  c->has_devices = true;
   c->ranks[0].device = device;
   ncclUniqueId u;
   memcpy(&u, id, sizeof(u));
   if (hipSetDevice(device) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->ranks[0].stream, hipStreamNonBlocking) != hipSuccess) {
-    delete c;
-    return say(err, err_cap, HS_ERR_HIP, "cannot create a stream on the rank's device");
+      hipStreamCreateWithFlags(&c->ranks[0].stream, hipStreamNonBlocking) != hipSuccess ||
+      c->ranks[0].counts.reserve((size_t)(world + 1) * 32) != hipSuccess) {  // phase 1 of every exchange
+    hs_comm_destroy(c);
+    return say(err, err_cap, HS_ERR_HIP, "cannot create a stream / the counts buffer on the rank's device");
   }
   ncclResult_t e = R->CommInitRank(&c->ranks[0].comm, (int)world, u, (int)rank);
   if (e != ncclSuccess) {
@@ -349,13 +371,13 @@ hs_status hs_comm_create_rank(const char id[HS_COMM_ID_BYTES], uint32_t rank, ui
 void hs_comm_destroy(hs_comm* c) {
   if (!c) return;
   for (RankState& r : c->ranks) {
-    if (c->kind == HS_COMM_RCCL_LOCAL) {
+    if (c->has_devices) {
       (void)hipSetDevice(r.device);
       if (r.stream) (void)hipStreamSynchronize(r.stream);
       DevBuf* bufs[] = {&r.send, &r.recv, &r.counts, &r.io_centers, &r.io_q, &r.io_id, &r.io_table, &r.io_dist,
                         &r.all_q, &r.all_id, &r.all_table, &r.all_dist};
       for (DevBuf* b : bufs) b->release();
-      if (r.comm) (void)rccl()->CommDestroy(r.comm);
+      if (r.comm) (void)rccl()->CommDestroy(r.comm);  // (null for the host-memory transport)
       if (r.stream) (void)hipStreamDestroy(r.stream);
     }
   }
@@ -375,62 +397,94 @@ hs_status hs_comm_barrier(hs_comm* c, uint32_t rank) {
   return HS_OK;
 }
 
-hs_status hs_allgather_hits(hs_comm* c, uint32_t rank, const uint32_t* q, const uint32_t* id,
-                            const uint32_t* table, const double* dist, uint64_t n_local,
-                            uint32_t q_offset, uint32_t* out_q, uint32_t* out_id, uint32_t* out_table,
-                            double* out_dist, uint64_t cap, uint64_t* n_total) {
-  if (!rank_ok(c, rank) || !n_total) return HS_ERR_INVALID;
-  if (n_local && (!q || !id || !dist)) return HS_ERR_INVALID;
-  if (n_local >= (1ull << 31)) return rfail(c, rank, HS_ERR_INVALID, "more than 2^31 - 1 hits on one rank");
+// ---- the exchange -----------------------------------------------------------------------------------
+// Rule of this file: once a rank has entered an exchange, every rendezvous and every collective of that
+// exchange is passed by EVERY rank, whatever happened to it locally.  A rank's local failure (a bad
+// argument, a failed allocation, a failed query) travels as a status word in phase 1 and every rank
+// then takes the same decision from the same words: all of them stop (the failed rank with its own
+// status, the others with HS_ERR_PEER), or all of them report the capacity they need, or all of them
+// move data.
+}  // extern "C"
+
+namespace {
+
+// Phase 1: four words per rank {n, q_offset, cap, status}, read by every rank.  Threads of one process:
+// two rendezvous (all published, all read); one process per rank: one 32-byte all-gather through the
+// buffer hs_comm_create_rank reserved.
+hs_status publish_words(hs_comm* c, uint32_t rank, const uint64_t mine[4], std::vector<uint64_t>* all) {
+  const uint32_t world = c->world;
+  all->assign((size_t)world * 4, 0);
+  if (c->per_process && world > 1) {
+    RankState& me = c->rs(rank);
+    Rccl* R = rccl();
+    HSD_HIP(c, rank, me.counts.reserve((size_t)(world + 1) * 32));  // (reserved at creation: cannot fail here)
+    char* d_mine = static_cast<char*>(me.counts.p) + (size_t)world * 32;
+    HSD_HIP(c, rank, hipMemcpyAsync(d_mine, mine, 32, hipMemcpyHostToDevice, me.stream));
+    HSD_NCCL(c, rank, R->AllGather(d_mine, me.counts.p, 32, ncclChar, me.comm, me.stream));
+    HSD_HIP(c, rank, hipMemcpyAsync(all->data(), me.counts.p, (size_t)world * 32, hipMemcpyDeviceToHost, me.stream));
+    HSD_HIP(c, rank, hipStreamSynchronize(me.stream));
+    return HS_OK;
+  }
+  memcpy(&c->pub[(size_t)rank * 4], mine, 32);
+  c->barrier();  // everyone has published
+  *all = c->pub;
+  c->barrier();  // everyone has read: the next call may publish again
+  return HS_OK;
+}
+
+// The first failed rank of a published status column, or world if none.
+uint32_t first_failed(const std::vector<uint64_t>& all, uint32_t world, int col) {
+  for (uint32_t r = 0; r < world; ++r)
+    if (all[(size_t)r * 4 + col] != (uint64_t)HS_OK) return r;
+  return world;
+}
+
+hs_status peer_failed(hs_comm* c, uint32_t rank, uint32_t r, uint64_t st, hs_status own) {
+  if (own != HS_OK) return own;  // (its message is already in place)
+  return rfail(c, rank, HS_ERR_PEER, "rank " + std::to_string(r) + " failed with status " + std::to_string(st) +
+                                         "; nothing was exchanged");
+}
+
+// in_host: q / id / table / dist are HOST pointers (loopback); otherwise pointers of the rank's GPU.
+// `lst` = what happened to this rank before the exchange (HS_OK, or the failure it carries into it).
+hs_status allgather_impl(hs_comm* c, uint32_t rank, hs_status lst, const uint32_t* q, const uint32_t* id,
+                         const uint32_t* table, const double* dist, uint64_t n_local, uint32_t q_offset,
+                         uint32_t* out_q, uint32_t* out_id, uint32_t* out_table, double* out_dist, uint64_t cap,
+                         uint64_t* n_total) {
   RankState& me = c->rs(rank);
   const uint32_t world = c->world;
   const bool loop = c->kind == HS_COMM_LOOPBACK;
   Rccl* R = loop ? nullptr : rccl();
-  if (!loop) HSD_HIP(c, rank, hipSetDevice(me.device));
-  // ---- phase 1: counts and query offsets of all ranks
-  if (c->per_process && world > 1) {
-    HSD_HIP(c, rank, me.counts.reserve((size_t)(world + 1) * 24));
-    uint64_t mine[3] = {n_local, q_offset, cap};
-    char* d_mine = static_cast<char*>(me.counts.p) + (size_t)world * 24;
-    HSD_HIP(c, rank, hipMemcpyAsync(d_mine, mine, 24, hipMemcpyHostToDevice, me.stream));
-    HSD_NCCL(c, rank, R->AllGather(d_mine, me.counts.p, 24, ncclChar, me.comm, me.stream));
-    std::vector<uint64_t> all((size_t)world * 3);
-    HSD_HIP(c, rank, hipMemcpyAsync(all.data(), me.counts.p, (size_t)world * 24, hipMemcpyDeviceToHost, me.stream));
-    HSD_HIP(c, rank, hipStreamSynchronize(me.stream));
-    for (uint32_t r = 0; r < world; ++r) {
-      c->counts[r] = all[3 * r];
-      c->offsets[r] = all[3 * r + 1];
-      c->caps[r] = all[3 * r + 2];
-    }
-  } else {
-    c->counts[rank] = n_local;
-    c->offsets[rank] = q_offset;
-    c->caps[rank] = cap;
-    c->barrier();  // everyone has published
-  }
-  uint64_t m = 0, total = 0;
+  if (lst == HS_OK && n_local && (!q || !id || !dist)) lst = rfail(c, rank, HS_ERR_INVALID, "null hit arrays");
+  if (lst == HS_OK && n_local >= (1ull << 31)) lst = rfail(c, rank, HS_ERR_INVALID, "more than 2^31 - 1 hits on one rank");
+  if (lst == HS_OK && !loop && hipSetDevice(me.device) != hipSuccess)
+    lst = rfail(c, rank, HS_ERR_HIP, "hipSetDevice failed on the rank's device");
+  // ---- phase 1: counts, query offsets, capacities and states of all ranks
+  // (a rank without output arrays offers no capacity: the decision stays one for all ranks)
+  const bool outs = out_q && out_id && out_dist;
+  const uint64_t mine[4] = {lst == HS_OK ? n_local : 0, q_offset, outs ? cap : 0, (uint64_t)lst};
+  std::vector<uint64_t> all;
+  HS_DIST_CHECK(publish_words(c, rank, mine, &all));
+  uint64_t m = 0, total = 0, cap_min = ~0ull;
+  std::vector<uint64_t> cnt(world);
   for (uint32_t r = 0; r < world; ++r) {
-    m = std::max(m, c->counts[r]);
-    total += c->counts[r];
-    cap = std::min(cap, c->caps[r]);  // one decision for all ranks: the smallest capacity offered
+    cnt[r] = all[(size_t)r * 4];
+    m = std::max(m, cnt[r]);
+    total += cnt[r];
+    cap_min = std::min(cap_min, all[(size_t)r * 4 + 2]);  // one decision for all ranks: the smallest capacity offered
   }
-  std::vector<uint64_t> cnt(c->counts);  // private copy: the shared one is reused by the next call
   m = pad_even(m);
   *n_total = total;
-  if (total > cap) {
-    c->barrier();  // nobody overwrites counts before everyone has read them
-    return rfail(c, rank, HS_ERR_CAPACITY, "hit buffers too small; see *n_total");
-  }
-  if (total && (!out_q || !out_id || !out_dist)) {
-    c->barrier();
-    return HS_ERR_INVALID;
-  }
+  const uint32_t bad = first_failed(all, world, 3);
+  if (bad < world) return peer_failed(c, rank, bad, all[(size_t)bad * 4 + 3], lst);
+  if (total > cap_min) return rfail(c, rank, HS_ERR_CAPACITY, "hit buffers too small; see *n_total");
+  if (!total) return HS_OK;
   const size_t rb = rec_bytes(m);
   if (loop) {
     // ---- phase 2 (host memory): publish the record, rendezvous, copy every rank's
     me.host_send.resize(std::max<size_t>(rb, 8));
     host_pack(q, id, table, dist, n_local, m, q_offset, me.host_send.data());
-    c->barrier();  // all records are in place (and all counts read)
+    c->barrier();  // all records are in place
     uint64_t off = 0;
     for (uint32_t r = 0; r < world; ++r) {
       host_unpack(c->ranks[r].host_send.data(), m, cnt[r], off, out_q, out_id, out_table, out_dist);
@@ -439,16 +493,22 @@ hs_status hs_allgather_hits(hs_comm* c, uint32_t rank, const uint32_t* q, const 
     c->barrier();  // nobody repacks while a neighbour still reads
     return HS_OK;
   }
-  // ---- phase 2 (RCCL): pack, ONE all-gather, unpack
-  if (!c->per_process) c->barrier();  // all counts read before anyone's next call republishes
-  if (!m) return HS_OK;
-  HSD_HIP(c, rank, me.send.reserve(rb));
-  HSD_HIP(c, rank, me.recv.reserve(rb * world));
+  // ---- phase 2 (RCCL): the buffers first -- and a second, one-word round, so that a rank that cannot
+  // get them keeps everybody out of the collective -- then pack, ONE all-gather, unpack
+  hs_status rst = HS_OK;
+  if (me.send.reserve(rb) != hipSuccess || me.recv.reserve(rb * world) != hipSuccess)
+    rst = rfail(c, rank, HS_ERR_NOMEM, "no memory for the exchange buffers");
+  const uint64_t ready[4] = {(uint64_t)rst, 0, 0, 0};
+  HS_DIST_CHECK(publish_words(c, rank, ready, &all));
+  const uint32_t bad2 = first_failed(all, world, 0);
+  if (bad2 < world) return peer_failed(c, rank, bad2, all[(size_t)bad2 * 4], rst);
   const unsigned pb = (unsigned)((m + 255) / 256);
   hs_pack_hits_kernel<<<pb, 256, 0, me.stream>>>(q, id, table, dist, n_local, m, q_offset,
                                                  static_cast<char*>(me.send.p));
-  HSD_HIP(c, rank, hipGetLastError());
+  // (a failed launch leaves the record unwritten; the collective is still entered, then reported)
+  const hipError_t pack_err = hipGetLastError();
   HSD_NCCL(c, rank, R->AllGather(me.send.p, me.recv.p, rb, ncclChar, me.comm, me.stream));
+  HSD_HIP(c, rank, pack_err);
   uint64_t off = 0;
   for (uint32_t r = 0; r < world; ++r) {
     if (cnt[r]) {
@@ -463,62 +523,117 @@ hs_status hs_allgather_hits(hs_comm* c, uint32_t rank, const uint32_t* q, const 
   return HS_OK;
 }
 
-hs_status hs_comm_query(hs_comm* c, uint32_t rank, hs_handle* h, const double* centers, uint64_t nq_local,
-                        uint32_t q_offset, double R, uint32_t* hit_q, uint32_t* hit_id,
-                        uint32_t* hit_table, double* hit_dist, uint64_t cap, uint64_t* n_total) {
-  if (!rank_ok(c, rank) || !h || !n_total || (nq_local && !centers)) return HS_ERR_INVALID;
-  if (c->kind == HS_COMM_LOOPBACK) return rfail(c, rank, HS_ERR_INVALID, "hs_comm_query needs a GPU communicator");
+}  // namespace
+
+extern "C" {
+
+hs_status hs_allgather_hits(hs_comm* c, uint32_t rank, const uint32_t* q, const uint32_t* id,
+                            const uint32_t* table, const double* dist, uint64_t n_local,
+                            uint32_t q_offset, uint32_t* out_q, uint32_t* out_id, uint32_t* out_table,
+                            double* out_dist, uint64_t cap, uint64_t* n_total) {
+  // (a call that cannot even name its rank cannot take part: the one early return)
+  if (!rank_ok(c, rank) || !n_total) return HS_ERR_INVALID;
+  return allgather_impl(c, rank, HS_OK, q, id, table, dist, n_local, q_offset, out_q, out_id, out_table, out_dist,
+                        cap, n_total);
+}
+
+}  // extern "C"
+
+namespace {
+
+// hs_comm_query / hs_comm_query_codes: the block as centres [nq_local][d] or as residue codes [nq_local][k]
+hs_status comm_query_impl(hs_comm* c, uint32_t rank, hs_handle* h, const double* centers, const uint8_t* qcodes,
+                          uint64_t nq_local, uint32_t q_offset, double R, uint32_t* hit_q, uint32_t* hit_id,
+                          uint32_t* hit_table, double* hit_dist, uint64_t cap, uint64_t* n_total) {
+  if (!rank_ok(c, rank) || !n_total) return HS_ERR_INVALID;  // cannot take part at all
   RankState& me = c->rs(rank);
-  HSD_HIP(c, rank, hipSetDevice(me.device));
-  // this rank's block on its GPU, then the search with HBM-resident outputs
+  const bool loop = c->kind == HS_COMM_LOOPBACK;
+  // Everything up to the exchange can fail on this rank alone: the failure is kept in `lst` and carried
+  // INTO the exchange (with no hits), where every rank learns of it -- never an early return that would
+  // leave the other ranks waiting at a rendezvous or inside ncclAllGather.
+  hs_status lst = HS_OK;
+  auto keep = [&](hs_status st, const std::string& msg) {
+    if (lst == HS_OK && st != HS_OK) {
+      lst = st;
+      me.err = msg;
+    }
+  };
+  auto hip = [&](hipError_t e, const char* what) {
+    if (e != hipSuccess)
+      keep(e == hipErrorOutOfMemory ? HS_ERR_NOMEM : HS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    return e == hipSuccess;
+  };
+  if (!h || (nq_local && !centers && !qcodes)) keep(HS_ERR_INVALID, "null handle or centres");
+  if (loop && !c->has_devices) keep(HS_ERR_INVALID, "hs_comm_query needs a communicator whose ranks have devices");
   hs_params prm;
-  if (hs_get_params(h, &prm) != HS_OK) return HS_ERR_INVALID;
-  if (prm.device != me.device) return rfail(c, rank, HS_ERR_INVALID, "the handle is bound to another device than the rank");
+  memset(&prm, 0, sizeof(prm));
+  if (lst == HS_OK && hs_get_params(h, &prm) != HS_OK) keep(HS_ERR_INVALID, "hs_get_params failed");
+  if (lst == HS_OK && prm.device != me.device) keep(HS_ERR_INVALID, "the handle is bound to another device than the rank");
+  if (lst == HS_OK) hip(hipSetDevice(me.device), "hipSetDevice");
+  // this rank's block on its GPU, then the search with HBM-resident outputs
   const uint64_t d = 8ull * prm.k;
-  const size_t cbytes = (size_t)nq_local * d * 8;
-  HSD_HIP(c, rank, me.io_centers.reserve(std::max<size_t>(16, cbytes)));
-  if (cbytes) HSD_HIP(c, rank, hipMemcpy(me.io_centers.p, centers, cbytes, hipMemcpyHostToDevice));
+  const size_t cbytes = qcodes ? (size_t)nq_local * prm.k : (size_t)nq_local * d * 8;
+  const void* const src = qcodes ? (const void*)qcodes : (const void*)centers;
+  if (lst == HS_OK && hip(me.io_centers.reserve(std::max<size_t>(16, cbytes)), "centres: hipMalloc") && cbytes)
+    hip(hipMemcpy(me.io_centers.p, src, cbytes, hipMemcpyHostToDevice), "centres: hipMemcpy");
   uint64_t lcap = std::max<uint64_t>(me.io_q.cap / 4, std::max<uint64_t>(1024, 16 * nq_local)), n_local = 0;
-  hs_status st;
-  for (;;) {
-    HSD_HIP(c, rank, me.io_q.reserve(lcap * 4));
-    HSD_HIP(c, rank, me.io_id.reserve(lcap * 4));
-    HSD_HIP(c, rank, me.io_table.reserve(lcap * 4));
-    HSD_HIP(c, rank, me.io_dist.reserve(lcap * 8));
-    st = hs_query_dev(h, static_cast<const double*>(me.io_centers.p), nq_local, R,
-                      static_cast<uint32_t*>(me.io_q.p), static_cast<uint32_t*>(me.io_id.p),
-                      static_cast<uint32_t*>(me.io_table.p), static_cast<double*>(me.io_dist.p), lcap,
-                      &n_local, nullptr);
+  while (lst == HS_OK) {
+    if (!hip(me.io_q.reserve(lcap * 4), "hits: hipMalloc") || !hip(me.io_id.reserve(lcap * 4), "hits: hipMalloc") ||
+        !hip(me.io_table.reserve(lcap * 4), "hits: hipMalloc") || !hip(me.io_dist.reserve(lcap * 8), "hits: hipMalloc"))
+      break;
+    const hs_status st =
+        qcodes ? hs_query_codes_dev(h, static_cast<const uint8_t*>(me.io_centers.p), nq_local, R,
+                                    static_cast<uint32_t*>(me.io_q.p), static_cast<uint32_t*>(me.io_id.p),
+                                    static_cast<uint32_t*>(me.io_table.p), static_cast<double*>(me.io_dist.p), lcap,
+                                    &n_local, nullptr)
+               : hs_query_dev(h, static_cast<const double*>(me.io_centers.p), nq_local, R,
+                              static_cast<uint32_t*>(me.io_q.p), static_cast<uint32_t*>(me.io_id.p),
+                              static_cast<uint32_t*>(me.io_table.p), static_cast<double*>(me.io_dist.p), lcap,
+                              &n_local, nullptr);
     if (st == HS_ERR_CAPACITY) {
       lcap = n_local + n_local / 8 + 1024;
       continue;
     }
+    if (st != HS_OK) keep(st, std::string("hs_query_dev: ") + hs_last_error(h));
     break;
   }
-  // a failed rank still takes part in the exchange (with no hits), so the others do not hang
-  const hs_status qst = st;
-  if (qst != HS_OK) {
-    me.err = std::string("hs_query_dev: ") + hs_last_error(h);
-    n_local = 0;
+  if (lst != HS_OK) n_local = 0;
+  hs_status st;
+  if (loop) {
+    // ranks with devices over the host-memory transport (two ranks may share a GPU: the protocol of
+    // hs_motif_both_points --gpus n on a box with fewer GPUs): this rank's hits to the host, the
+    // exchange writes straight into the caller's arrays
+    me.h_q.resize(n_local);
+    me.h_id.resize(n_local);
+    me.h_table.resize(n_local);
+    me.h_dist.resize(n_local);
+    if (n_local) {
+      hip(hipMemcpy(me.h_q.data(), me.io_q.p, n_local * 4, hipMemcpyDeviceToHost), "hits: hipMemcpy");
+      hip(hipMemcpy(me.h_id.data(), me.io_id.p, n_local * 4, hipMemcpyDeviceToHost), "hits: hipMemcpy");
+      hip(hipMemcpy(me.h_table.data(), me.io_table.p, n_local * 4, hipMemcpyDeviceToHost), "hits: hipMemcpy");
+      hip(hipMemcpy(me.h_dist.data(), me.io_dist.p, n_local * 8, hipMemcpyDeviceToHost), "hits: hipMemcpy");
+    }
+    return allgather_impl(c, rank, lst, me.h_q.data(), me.h_id.data(), hit_table ? me.h_table.data() : nullptr,
+                          me.h_dist.data(), lst == HS_OK ? n_local : 0, q_offset, hit_q, hit_id, hit_table, hit_dist,
+                          cap, n_total);
   }
   uint64_t acap = std::max<uint64_t>(me.all_q.cap / 4, std::max<uint64_t>(1024, cap));
   for (;;) {
-    HSD_HIP(c, rank, me.all_q.reserve(acap * 4));
-    HSD_HIP(c, rank, me.all_id.reserve(acap * 4));
-    HSD_HIP(c, rank, me.all_table.reserve(acap * 4));
-    HSD_HIP(c, rank, me.all_dist.reserve(acap * 8));
-    st = hs_allgather_hits(c, rank, static_cast<const uint32_t*>(me.io_q.p), static_cast<const uint32_t*>(me.io_id.p),
-                           static_cast<const uint32_t*>(me.io_table.p), static_cast<const double*>(me.io_dist.p),
-                           n_local, q_offset, static_cast<uint32_t*>(me.all_q.p),
-                           static_cast<uint32_t*>(me.all_id.p), static_cast<uint32_t*>(me.all_table.p),
-                           static_cast<double*>(me.all_dist.p), acap, n_total);
+    if (lst == HS_OK)
+      (void)(hip(me.all_q.reserve(acap * 4), "all hits: hipMalloc") && hip(me.all_id.reserve(acap * 4), "all hits: hipMalloc") &&
+             hip(me.all_table.reserve(acap * 4), "all hits: hipMalloc") && hip(me.all_dist.reserve(acap * 8), "all hits: hipMalloc"));
+    if (lst != HS_OK) n_local = 0;
+    st = allgather_impl(c, rank, lst, static_cast<const uint32_t*>(me.io_q.p), static_cast<const uint32_t*>(me.io_id.p),
+                        static_cast<const uint32_t*>(me.io_table.p), static_cast<const double*>(me.io_dist.p),
+                        n_local, q_offset, static_cast<uint32_t*>(me.all_q.p),
+                        static_cast<uint32_t*>(me.all_id.p), static_cast<uint32_t*>(me.all_table.p),
+                        static_cast<double*>(me.all_dist.p), acap, n_total);
     if (st == HS_ERR_CAPACITY) {  // every rank sees the same total and repeats the exchange
       acap = *n_total + 1024;
       continue;
     }
     break;
   }
-  if (qst != HS_OK) return qst;
   if (st != HS_OK) return st;
   const uint64_t nt = *n_total;
   if (nt > cap) return rfail(c, rank, HS_ERR_CAPACITY, "hit buffers too small; see *n_total");
@@ -530,6 +645,27 @@ hs_status hs_comm_query(hs_comm* c, uint32_t rank, hs_handle* h, const double* c
     HSD_HIP(c, rank, hipMemcpy(hit_dist, me.all_dist.p, nt * 8, hipMemcpyDeviceToHost));
   }
   return HS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+hs_status hs_comm_query(hs_comm* c, uint32_t rank, hs_handle* h, const double* centers, uint64_t nq_local,
+                        uint32_t q_offset, double R, uint32_t* hit_q, uint32_t* hit_id,
+                        uint32_t* hit_table, double* hit_dist, uint64_t cap, uint64_t* n_total) {
+  return comm_query_impl(c, rank, h, centers, nullptr, nq_local, q_offset, R, hit_q, hit_id, hit_table, hit_dist,
+                         cap, n_total);
+}
+
+hs_status hs_comm_query_codes(hs_comm* c, uint32_t rank, hs_handle* h, const uint8_t* qcodes, uint64_t nq_local,
+                              uint32_t q_offset, double R, uint32_t* hit_q, uint32_t* hit_id,
+                              uint32_t* hit_table, double* hit_dist, uint64_t cap, uint64_t* n_total) {
+  if (nq_local && !qcodes && rank_ok(c, rank) && n_total)  // (takes part, as a failed rank)
+    return comm_query_impl(c, rank, nullptr, nullptr, nullptr, nq_local, q_offset, R, hit_q, hit_id, hit_table,
+                           hit_dist, cap, n_total);
+  return comm_query_impl(c, rank, h, nullptr, qcodes, nq_local, q_offset, R, hit_q, hit_id, hit_table, hit_dist,
+                         cap, n_total);
 }
 
 }  // extern "C"

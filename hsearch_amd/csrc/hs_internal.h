@@ -110,9 +110,11 @@ __host__ __device__ inline bool hs_key_equal(const int32_t* x, const int32_t* y,
 // The survivor list's counter is 32 bits (the batch's counters block, word 0).  A batch whose filters
 // pass more than ~4e9 pairs (a radius close to the typical distance of bucket mates) would wrap it
 // silently: every reservation that lands in the last 2^28 slots raises HS_CNT_SURVIVOR_OVERFLOW in
-// the same block -- reservations are <= 64 slots, so one does before the counter wraps -- and the
-// host repeats the batch in halves (hs_capi.hip run_query).
+// the same block -- reservations are <= 256 slots (hs_join8.hip JRES), so one does before the counter
+// wraps -- and the host repeats the batch in halves (hs_capi.hip run_query).
 #define HS_CNT_SURVIVOR_OVERFLOW 21
+// hs_query_codes: a query's residue code lay outside the alphabet (hs_check_codes_kernel)
+#define HS_CNT_BAD_QUERY_CODE 22
 #ifdef __HIPCC__
 __device__ __forceinline__ uint32_t hs_reserve_survivors(uint32_t* prov_count, uint32_t n) {
   const uint32_t base = atomicAdd(prov_count, n);
@@ -142,7 +144,9 @@ static inline int hs_packed_words(int k) { return (k + 24) / 25; }
 
 // ---- primitive wrappers (hs_prims.hip, rocPRIM behind them) --------------------------------------
 size_t hs_sort_pairs_u64_u32_temp(size_t n);
-// keys ordered by their bits [0, end_bit) only
+// keys ordered by their bits [begin_bit, end_bit) only; begin_bit > 0 is refused (hipErrorInvalidValue)
+// unless hs_sort_partial_bits_ok(n): only rocPRIM's onesweep path handles such a range (hs_prims.hip)
+bool hs_sort_partial_bits_ok(size_t n);
 hipError_t hs_sort_pairs_u64_u32(void* temp, size_t temp_bytes, const uint64_t* kin, uint64_t* kout,
                                  const uint32_t* vin, uint32_t* vout, size_t n, int begin_bit, int end_bit,
                                  hipStream_t s);
@@ -227,6 +231,9 @@ hipError_t hs_launch_pack(const uint8_t* d_codes, uint64_t n, int k, int alphabe
 hipError_t hs_launch_gather_packed(const uint4* d_packed_all, const uint32_t* d_ids_sorted,
                                    uint64_t n, int PW, uint4* d_out, hipStream_t s);
 hipError_t hs_launch_set_u32(uint32_t* d_p, uint32_t v, hipStream_t s);
+// d_out[i] = d_in[i] if it is a row of the table (< alphabet), else 0 and *d_bad |= 1
+hipError_t hs_launch_check_codes(const uint8_t* d_in, uint64_t n_bytes, int alphabet, uint8_t* d_out,
+                                 uint32_t* d_bad, hipStream_t s);
 // windows of length k of every sequence of a residue buffer -> codes [n_windows][k] (+ the buffer
 // position of every window); d_win_off[s] = number of the first window of sequence s
 hipError_t hs_launch_windows(const uint8_t* d_residues, uint32_t n_residues, const uint32_t* d_seq_start,

@@ -289,6 +289,27 @@ __global__ __launch_bounds__(256) void hs_pack_kernel(const uint8_t* __restrict_
   if (any_bad) atomicOr(bad, 1u);
 }
 
+// hs_query_codes: the caller's query codes into the handle's own buffer, checked on the way -- a byte
+// that is no row of the coordinate table raises the flag (the call then fails) and is stored as 0, so
+// that no kernel of the batch indexes a table with it.  16 bytes per thread.
+__global__ __launch_bounds__(256) void hs_check_codes_kernel(const uint8_t* __restrict__ in, uint64_t n_bytes,
+                                                             uint32_t alphabet, uint8_t* __restrict__ out,
+                                                             uint32_t* __restrict__ bad) {
+  const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+  if (i0 >= n_bytes) return;
+  bool any_bad = false;
+  const uint64_t i1 = i0 + 16 < n_bytes ? i0 + 16 : n_bytes;
+  for (uint64_t i = i0; i < i1; ++i) {
+    uint8_t c = in[i];
+    if (c >= alphabet) {
+      any_bad = true;
+      c = 0;
+    }
+    out[i] = c;
+  }
+  if (any_bad) atomicOr(bad, 1u);
+}
+
 __global__ __launch_bounds__(256) void hs_gather_packed_kernel(const uint4* __restrict__ packed_all,
                                                                const uint32_t* __restrict__ ids,
                                                                uint64_t n, int PW,
@@ -1372,6 +1393,13 @@ hipError_t hs_launch_probe(const hs_tables_dev& tabs, const int32_t* d_qints, ui
   hs_probe_slow_kernel<<<64, 256, 0, s>>>(tabs, d_qints, K, L, seed, d_qstart, d_qcount, d_nslices,
                                           d_cand_out, d_cand_total, d_slow, d_dir_base, nb_total,
                                           d_bucket_count, d_qbucket, d_qrank);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_check_codes(const uint8_t* d_in, uint64_t n_bytes, int alphabet, uint8_t* d_out,
+                                 uint32_t* d_bad, hipStream_t s) {
+  if (!n_bytes) return hipSuccess;
+  hs_check_codes_kernel<<<blocks_for((n_bytes + 15) / 16), 256, 0, s>>>(d_in, n_bytes, (uint32_t)alphabet, d_out, d_bad);
   return hipGetLastError();
 }
 

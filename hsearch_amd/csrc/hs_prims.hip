@@ -16,9 +16,19 @@ size_t hs_sort_pairs_u64_u32_temp(size_t n) {
                                   (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 64, 0);
   return bytes;
 }
+// A bit range that starts above bit 0 and ends at the key's last bit is only safe on rocPRIM's
+// onesweep path.  Up to radix_sort_config<>::merge_sort_limit items (1024 * 1024 here) the library
+// block-sorts on [begin_bit, end_bit) and then MERGES with radix_merge_compare<.., true, T>(begin_bit,
+// end_bit - begin_bit), whose mask is (T(1) << (radix_bits + start_bit)) - 1
+// (rocprim/device/detail/device_radix_sort.hpp:685): with end_bit == 64 that is 1 << 64, undefined;
+// the host evaluates it to a mask of the bits BELOW begin_bit, the merge then runs under an order its
+// sorted blocks do not have, and its merge-path partitions leave their ranges -- the GPU memory fault
+// of this library's first 48-bit sort (round 2).  The limit is taken from the library, not copied.
+bool hs_sort_partial_bits_ok(size_t n) { return n > rocprim::radix_sort_config<>::merge_sort_limit; }
 hipError_t hs_sort_pairs_u64_u32(void* temp, size_t temp_bytes, const uint64_t* kin, uint64_t* kout,
                                  const uint32_t* vin, uint32_t* vout, size_t n, int begin_bit, int end_bit,
                                  hipStream_t s) {
+  if (begin_bit > 0 && !hs_sort_partial_bits_ok(n)) return hipErrorInvalidValue;
   return rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, n, begin_bit, end_bit, s);
 }
 

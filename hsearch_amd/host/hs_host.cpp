@@ -114,15 +114,21 @@ struct HandleCloser {
   ~HandleCloser() { hs_destroy(h); }
 };
 
+// how the rank threads exchange hits (SetShardTransport)
+ShardTransport g_shard_transport = kTransportRccl;
+
+
 // The device part of Search(): index build (through `build`, on a fresh handle) and the query loop,
 // on one GPU (devices.size() == 1 and !sharded: hs_query, no communicator) or query-sharded over
 // several: one host thread and one handle per GPU, the index built on every GPU, rank
 // r searching its contiguous block of centres, hits all-gathered over RCCL (hs_comm_query) so that
 // every rank -- rank 0 writes the file -- holds all hits in the reference's order.
+// qcodes != null: the centres are k-mers of the handle's coordinate table, given as residue codes
+// [nq][k]; they cross PCIe as k bytes each (hs_query_codes) and `flat` is unused.
 int RunSearch(hs_params prm, const Planes& planes, const double* coords,
               const std::function<hs_status(hs_handle*, uint32_t rank)>& build, const double* flat,
-              uint64_t nq, double R, const std::vector<int>& devices, bool sharded, SearchHits* out,
-              std::string* err, std::vector<uint64_t>* table_sizes) {
+              const uint8_t* qcodes, uint64_t nq, double R, const std::vector<int>& devices, bool sharded,
+              SearchHits* out, std::string* err, std::vector<uint64_t>* table_sizes) {
   const uint32_t world = (uint32_t)devices.size();
   if (!world) {
     if (err) *err = "no device given";
@@ -165,8 +171,10 @@ int RunSearch(hs_params prm, const Planes& planes, const double* coords,
       out->id.resize(cap);
       out->table.resize(cap);
       out->dist.resize(cap);
-      st = hs_query(h, flat, nq, R, out->q.data(), out->id.data(), out->table.data(), out->dist.data(),
-                    cap, &out->n, nullptr);
+      st = qcodes ? hs_query_codes(h, qcodes, nq, R, out->q.data(), out->id.data(), out->table.data(),
+                                   out->dist.data(), cap, &out->n, nullptr)
+                  : hs_query(h, flat, nq, R, out->q.data(), out->id.data(), out->table.data(), out->dist.data(),
+                             cap, &out->n, nullptr);
       if (st == HS_ERR_CAPACITY) {
         cap = out->n;
         continue;
@@ -178,7 +186,8 @@ int RunSearch(hs_params prm, const Planes& planes, const double* coords,
   }
   char cerr[256] = "";
   hs_comm* comm = nullptr;
-  hs_status cst = hs_comm_create(HS_COMM_RCCL_LOCAL, devices.data(), world, &comm, cerr, sizeof(cerr));
+  hs_status cst = hs_comm_create(g_shard_transport == kTransportLoopback ? HS_COMM_LOOPBACK : HS_COMM_RCCL_LOCAL,
+                                 devices.data(), world, &comm, cerr, sizeof(cerr));
   if (cst != HS_OK) {
     if (err) *err = std::string("hs_comm_create: ") + cerr;
     return cst;
@@ -212,8 +221,16 @@ int RunSearch(hs_params prm, const Planes& planes, const double* coords,
       dst->id.resize(cap);
       dst->table.resize(cap);
       dst->dist.resize(cap);
-      st = hs_comm_query(comm, r, h, flat + lo * d, hi - lo, (uint32_t)lo, R, dst->q.data(), dst->id.data(),
-                         dst->table.data(), dst->dist.data(), cap, &dst->n);
+      hs_handle* hq = h;
+#ifdef HS_TEST_HOOKS
+      // fault injection (test build of the programs only): this rank enters the exchange having failed
+      if (const char* fr = getenv("HS_TEST_FAIL_RANK"))
+        if ((uint32_t)atoi(fr) == r) hq = nullptr;
+#endif
+      st = qcodes ? hs_comm_query_codes(comm, r, hq, qcodes + lo * prm.k, hi - lo, (uint32_t)lo, R, dst->q.data(),
+                                        dst->id.data(), dst->table.data(), dst->dist.data(), cap, &dst->n)
+                  : hs_comm_query(comm, r, hq, flat + lo * d, hi - lo, (uint32_t)lo, R, dst->q.data(),
+                                  dst->id.data(), dst->table.data(), dst->dist.data(), cap, &dst->n);
       if (st == HS_ERR_CAPACITY) {
         cap = dst->n;
         continue;
@@ -250,6 +267,8 @@ bool FlattenCenters(const std::vector<Point>& centers, uint32_t dim, std::vector
 
 }  // namespace
 
+void SetShardTransport(ShardTransport t) { g_shard_transport = t; }
+
 int Search(const std::vector<Point>& kmers, const std::vector<Point>& centers,
            const std::vector<std::string>& kmer_names, const std::vector<std::string>& center_names,
            const uint32_t& hash_K, const uint32_t& hash_L, const double& hash_W,
@@ -285,8 +304,8 @@ int SearchSharded(const std::vector<Point>& kmers, const std::vector<Point>& cen
   SearchHits hits;
   const int st = RunSearch(prm, planes, table.data(),
                            [&](hs_handle* h, uint32_t) { return hs_index_build(h, codes.data(), kmers.size()); },
-                           flat.data(), centers.size(), hash_R, devices, use_comm || devices.size() > 1, &hits,
-                           err, table_sizes);
+                           flat.data(), nullptr, centers.size(), hash_R, devices, use_comm || devices.size() > 1,
+                           &hits, err, table_sizes);
   if (st != HS_OK) return st;
   std::ofstream fout(output_file.c_str());
   for (uint64_t i = 0; i < hits.n; ++i)  // :240-241
@@ -339,8 +358,13 @@ int SearchProteinsSharded(const ProteinDB& db, uint32_t kmer_length, const std::
                           const uint32_t& hash_L, const double& hash_W, const double& hash_R,
                           const std::string& output_file, const Planes& planes,
                           const std::vector<int>& devices, bool use_comm, std::string* err,
-                          std::vector<uint64_t>* table_sizes, uint64_t* n_windows, bool best_per_position) {
+                          std::vector<uint64_t>* table_sizes, uint64_t* n_windows, bool best_per_position,
+                          const std::vector<uint8_t>* center_codes) {
   const uint32_t dim = 8 * kmer_length;
+  if (center_codes && center_codes->size() != centers.size() * (size_t)kmer_length) {
+    if (err) *err = "centre codes do not match the centres";
+    return HS_ERR_INVALID;
+  }
   if (kmer_length == 0 || planes.dim != dim || planes.K != hash_K || planes.L != hash_L ||
       planes.W != hash_W) {
     if (err) *err = "planes do not match (dim, K, L, W)";
@@ -385,7 +409,8 @@ int SearchProteinsSharded(const ProteinDB& db, uint32_t kmer_length, const std::
         if (rank == 0) n_win = nw;
         return bst;
       },
-      flat.data(), centers.size(), hash_R, devices, use_comm || devices.size() > 1, &hits, err, table_sizes);
+      flat.data(), center_codes ? center_codes->data() : nullptr, centers.size(), hash_R, devices,
+      use_comm || devices.size() > 1, &hits, err, table_sizes);
   if (rst != HS_OK) return rst;
   if (n_windows) *n_windows = n_win;
   const uint64_t n_hits = hits.n;
@@ -586,7 +611,7 @@ bool ReadPlanesFile(const std::string& path, uint32_t dim, uint32_t K, uint32_t 
 }
 
 bool CentersFromKmers(const std::vector<Kmer>& kmers, uint32_t kmer_length, std::vector<std::string>* names,
-                      std::vector<Point>* centers, std::string* err) {
+                      std::vector<Point>* centers, std::string* err, std::vector<uint8_t>* codes) {
   for (const Kmer& km : kmers) {
     if (km.seq.size() != kmer_length) {
       if (err) *err = "centre " + km.name + " does not have " + std::to_string(kmer_length) + " residues";
@@ -602,6 +627,7 @@ bool CentersFromKmers(const std::vector<Kmer>& kmers, uint32_t kmer_length, std:
         return false;
       }
       for (int j = 0; j < 8; ++j) pt.data[8 * p + j] = HS_AA_COORDS[row][j];  // hclust2.cpp:57-59
+      if (codes) codes->push_back((uint8_t)row);
     }
     names->push_back(km.name);
     centers->push_back(pt);

@@ -60,6 +60,13 @@ int Search(const std::vector<Point>& kmers, const std::vector<Point>& centers,
            const double& hash_R, const std::string& output_file, const Planes& planes, int device,
            std::string* err, std::vector<uint64_t>* table_sizes = nullptr);
 
+// How the rank threads of the *Sharded() functions exchange their hits: RCCL over xGMI (one rank per
+// GPU; the default), or host memory between rank threads whose `devices` may repeat -- the whole rank
+// protocol (barrier, capacity decision, failed-rank handling) on a box with fewer GPUs than ranks,
+// which RCCL refuses (`hs_motif_both_points --transport loopback`).  Process-wide; set before the call.
+enum ShardTransport { kTransportRccl = 0, kTransportLoopback = 1 };
+void SetShardTransport(ShardTransport t);
+
 // Search() spread over the GPUs `devices` of this node: one host thread and one handle
 // per GPU, the index replicated (built on every GPU), centre i searched by the rank owning its
 // contiguous block (hs_shard_bounds), the hits all-gathered over RCCL (include/hsearch_dist.h) and
@@ -78,8 +85,9 @@ bool ReadPlanesFile(const std::string& path, uint32_t dim, uint32_t K, uint32_t 
 // Centres given as k-mers (">name" line, then the k letters -- the k-mer FASTA hclust2.cpp:231-241
 // reads) instead of a points file: embedded exactly from the table (KmerToCoordinates,
 // hclust2.cpp:49-62).  A letter outside the 20-letter alphabet or another length is an error.
+// codes (optional) receives the same centres as rows of the coordinate table, [n][k].
 bool CentersFromKmers(const std::vector<Kmer>& kmers, uint32_t kmer_length, std::vector<std::string>* names,
-                      std::vector<Point>* centers, std::string* err);
+                      std::vector<Point>* centers, std::string* err, std::vector<uint8_t>* codes = nullptr);
 
 // ---- FASTA database: k-mers enumerated on the device ------------------------
 // ProteinDB of protein.hpp:41-71: lines starting with '>' are names, every other non-empty line is
@@ -116,7 +124,10 @@ int SearchProteinsSharded(const ProteinDB& db, uint32_t kmer_length, const std::
                           const std::string& output_file, const Planes& planes,
                           const std::vector<int>& devices, bool use_comm, std::string* err,
                           std::vector<uint64_t>* table_sizes = nullptr, uint64_t* n_windows = nullptr,
-                          bool best_per_position = false);
+                          bool best_per_position = false, const std::vector<uint8_t>* center_codes = nullptr);
+// center_codes (CentersFromKmers): the centres are k-mers of the exact table -- the one a FASTA
+// database is embedded from -- and travel to the GPU as residue codes (hs_query_codes: k bytes per
+// centre instead of 64 k); the hits are those of the embedded centres, bit for bit.
 // best_per_position: what kmer_search.cpp's Search() accumulates in `matches` (:90,113-121) and
 // never writes -- for every database window with a hit, its nearest centre: tables ascending,
 // centres ascending within a table, replaced only by a strictly smaller distance.  Written as

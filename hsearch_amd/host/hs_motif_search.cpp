@@ -11,7 +11,8 @@
 // --planes-out writes), --device, --gpus n (the centres are sharded over GPUs
 // device .. device+n-1 of this node, one host thread and one replicated index per GPU, hits
 // all-gathered over RCCL and written in the same order -- the output file is the same for every
-// n), and -g becomes optional (without it the evaluation step is skipped).  -c may also name a
+// n; --transport loopback runs the same rank threads with all ranks on --device and the exchange
+// through host memory), and -g becomes optional (without it the evaluation step is skipped).  -c may also name a
 // k-mer FASTA file (">name" + k letters, the format hclust2.cpp:231-241 reads): the centres are
 // then embedded exactly from the table.  -d may also name a protein FASTA file (the
 // database kmer_search.cpp:180-181 takes): every length-k window of every sequence is then a DB
@@ -53,6 +54,8 @@ const Opt kOpts[] = {
     {"seed", 's', "seed of the LSH planes [random_device]", false},
     {"device", 'G', "GPU ordinal (the first one with --gpus) [0]", false},
     {"gpus", 'N', "shard the centres over this many GPUs, hits all-gathered over RCCL [off: one GPU, no communicator]", false},
+    {"transport", 'X', "with --gpus: rccl (one rank per GPU, the default) or loopback (host memory between the rank threads, all ranks on --device: the rank protocol on a box with fewer GPUs)", false},
+    {"centers-as-points", 'E', "k-mer centres over a FASTA database: send them embedded (8k doubles each) instead of as residue codes [0]", false},
     {"planes", 'p', "read the planes from this file (as written by --planes-out) instead of drawing them", false},
     {"planes-out", 'P', "write the planes (binary doubles a[L][K][d] then b[L][K])", false},
     {"ref-compat-eq-swap", 'Q', "FASTA database: exchange E and Q like the reference's ProteinDB [0]", false},
@@ -138,6 +141,7 @@ int main(int argc, const char* argv[]) {
   try {
     std::vector<std::string> kmer_names, center_names;
     std::vector<hsearch::Point> kmers, centers;
+    std::vector<uint8_t> center_codes;  // -c <k-mers.fa>: the centres as rows of the coordinate table
     const bool fasta_db = LooksLikeFasta(val["db"]);
     hsearch::ProteinDB prodb;
     if (fasta_db) {
@@ -164,7 +168,7 @@ int main(int argc, const char* argv[]) {
         fprintf(stderr, "cannot open %s\n", val["center"].c_str());
         return EXIT_FAILURE;
       }
-      if (!hsearch::CentersFromKmers(ckmers, kmer_length, &center_names, &centers, &cerr)) {
+      if (!hsearch::CentersFromKmers(ckmers, kmer_length, &center_names, &centers, &cerr, &center_codes)) {
         fprintf(stderr, "ERROR: %s\n", cerr.c_str());
         return EXIT_FAILURE;
       }
@@ -190,8 +194,14 @@ int main(int argc, const char* argv[]) {
       fprintf(stderr, "ERROR: --gpus must be 1..64\n");
       return EXIT_FAILURE;
     }
+    const bool loopback = val.count("transport") && val["transport"] == "loopback";
+    if (val.count("transport") && !loopback && val["transport"] != "rccl") {
+      fprintf(stderr, "ERROR: --transport must be rccl or loopback\n");
+      return EXIT_FAILURE;
+    }
+    if (loopback) hsearch::SetShardTransport(hsearch::kTransportLoopback);
     std::vector<int> devices;
-    for (int g = 0; g < n_gpus; ++g) devices.push_back(device + g);
+    for (int g = 0; g < n_gpus; ++g) devices.push_back(loopback ? device : device + g);
     if (val.count("planes-out")) {
       std::ofstream pf(val["planes-out"].c_str(), std::ios::binary);
       pf.write(reinterpret_cast<const char*>(planes.a.data()), planes.a.size() * sizeof(double));
@@ -201,7 +211,10 @@ int main(int argc, const char* argv[]) {
       printf("hash_K = %u hash_L = %u planes = %s\n", hash_K, hash_L, val["planes"].c_str());
     else
       printf("hash_K = %u hash_L = %u seed = %u\n", hash_K, hash_L, seed);
-    if (use_comm) printf("gpus = %d (devices %d..%d, RCCL all-gather of hits)\n", n_gpus, device, device + n_gpus - 1);
+    if (use_comm && loopback)
+      printf("gpus = %d (%d ranks on device %d, hits exchanged through host memory)\n", n_gpus, n_gpus, device);
+    else if (use_comm)
+      printf("gpus = %d (devices %d..%d, RCCL all-gather of hits)\n", n_gpus, device, device + n_gpus - 1);
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     std::string err;
@@ -212,7 +225,11 @@ int main(int argc, const char* argv[]) {
                                                   hash_W, hash_R, val["output"], planes, devices, use_comm,
                                                   &err, &table_sizes, &n_windows,
                                                   val.count("best-per-position") &&
-                                                      atoi(val["best-per-position"].c_str()) != 0)
+                                                      atoi(val["best-per-position"].c_str()) != 0,
+                                                  // k-mer centres over a FASTA database share its exact
+                                                  // table: they go to the GPU as codes (hs_query_codes)
+                                                  center_codes.empty() || val.count("centers-as-points")
+                                                      ? nullptr : &center_codes)
                  : hsearch::SearchSharded(kmers, centers, kmer_names, center_names, hash_K, hash_L, hash_W,
                                           hash_R, val["output"], planes, devices, use_comm, &err,
                                           &table_sizes);

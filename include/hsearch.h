@@ -43,7 +43,9 @@ typedef enum hs_status {
   HS_ERR_STATE = 5,         /* e.g. query before hs_index_build */
   HS_ERR_KEY_COLLISION = 6, /* 64-bit key fingerprints collided for every retry seed */
   HS_ERR_NOMEM = 7,
-  HS_ERR_IO = 8             /* index file missing, truncated, or written for other parameters */
+  HS_ERR_IO = 8,            /* index file missing, truncated, or written for other parameters */
+  HS_ERR_PEER = 9           /* hsearch_dist.h: ANOTHER rank of the communicator failed before the exchange;
+                               nothing was exchanged (the failed rank returns its own status) */
 } hs_status;
 
 /* Replaces the (dimension, hash_K, hash_W) arguments of LSH::LSH (lsh.hpp:10-17) and the
@@ -86,6 +88,8 @@ typedef struct hs_profile {
                                  it did not run) ... */
   uint32_t join_wide;         /* ... and 1 if the rows carried all 8 coordinate columns (short k-mers, large
                                  radii), 0 for the 4 filter columns */
+  uint64_t join_async_retries; /* batches whose join was launched on a capacity hint that turned out too small
+                                  (or illegal) and ran a second time: exclude such a call from kernel timings */
 } hs_profile;
 
 typedef struct hs_index_info {
@@ -232,6 +236,21 @@ HS_API hs_status hs_query_dev(hs_handle* h, const double* d_centers, uint64_t nq
                               uint32_t* d_hit_q, uint32_t* d_hit_id, uint32_t* d_hit_table,
                               double* d_hit_dist, uint64_t cap, uint64_t* n_hits,
                               uint64_t* d_cand);
+
+/* The same search for queries that ARE k-mers -- the usual centres of the reference's own pipeline:
+ * hclust2 embeds k-mer strings (KmerToCoordinates, hclust2.cpp:49-62) and `motif_both_points -c`
+ * is fed k-mers embedded exactly from the table -- given as residue codes qcodes[nq][k] (rows of the
+ * coordinate table, like the DB's): k bytes per query across PCIe instead of 8d = 64 k.  Results are
+ * those of hs_query on the embedded codes, bit for bit (hash, filter rows and the exact fp64 distance
+ * all read the table rows an embedded centre would hold).  A code outside the alphabet is
+ * HS_ERR_INVALID.  hs_query_codes_dev: every pointer except n_hits in device memory. */
+HS_API hs_status hs_query_codes(hs_handle* h, const uint8_t* qcodes, uint64_t nq, double R,
+                                uint32_t* hit_q, uint32_t* hit_id, uint32_t* hit_table, double* hit_dist,
+                                uint64_t cap, uint64_t* n_hits, uint64_t* cand);
+HS_API hs_status hs_query_codes_dev(hs_handle* h, const uint8_t* d_qcodes, uint64_t nq, double R,
+                                    uint32_t* d_hit_q, uint32_t* d_hit_id, uint32_t* d_hit_table,
+                                    double* d_hit_dist, uint64_t cap, uint64_t* n_hits,
+                                    uint64_t* d_cand);
 
 /* ---- brute force (row a11) ---------------------------------------------------------------------- */
 

@@ -12,6 +12,11 @@
  * own host thread (single process, HS_COMM_RCCL_LOCAL / HS_COMM_LOOPBACK) or its own process
  * (hs_comm_create_rank).  A rank's device pointers live on that rank's GPU.  Status codes and the
  * two-call capacity protocol are those of hsearch.h.
+ *
+ * Failures: a rank whose own part fails (bad argument, allocation, hs_query_dev) still takes part in
+ * the exchange -- its status travels with the counts -- and then EVERY rank returns without exchanging
+ * data: the failed rank with its own status, the others with HS_ERR_PEER.  No rank is left waiting at a
+ * rendezvous or inside a collective because a neighbour returned early.
  */
 #ifndef HSEARCH_DIST_H
 #define HSEARCH_DIST_H
@@ -26,12 +31,17 @@ typedef struct hs_comm hs_comm;
 
 enum {
   HS_COMM_RCCL_LOCAL = 0, /* `world` GPUs of THIS process (ncclCommInitAll), one host thread per rank */
-  HS_COMM_LOOPBACK = 1    /* no GPU: every pointer is a HOST pointer, the exchange goes through host
-                             memory.  Test transport for the layout / merge logic; the programs
-                             under hsearch_amd/host never use it. */
+  HS_COMM_LOOPBACK = 1    /* the exchange goes through HOST memory between the rank threads; the pointers of
+                             hs_allgather_hits are HOST pointers.  Created without devices it needs no
+                             GPU (the CPU tests of the layout / merge logic); created WITH devices --
+                             several ranks may name the same one -- hs_comm_query runs every rank's search
+                             on its device and exchanges the hits through host memory: the whole rank
+                             protocol on a box with fewer GPUs than ranks (hs_motif_both_points
+                             --transport loopback; RCCL refuses two ranks on one device). */
 };
 
-/* devices[world]: HIP ordinals of the ranks (ignored for HS_COMM_LOOPBACK; NULL = 0..world-1). */
+/* devices[world]: HIP ordinals of the ranks.  HS_COMM_RCCL_LOCAL: distinct, NULL = 0..world-1.
+ * HS_COMM_LOOPBACK: NULL = no devices (hs_comm_query is refused), else any valid ordinals. */
 HS_API hs_status hs_comm_create(int kind, const int* devices, uint32_t world, hs_comm** out, char* err,
                                 uint32_t err_cap);
 /* One process per GPU: rank 0 obtains an id (hs_comm_unique_id), the launcher hands it to the
@@ -74,6 +84,13 @@ HS_API hs_status hs_comm_query(hs_comm* c, uint32_t rank, hs_handle* h, const do
                                uint64_t nq_local, uint32_t q_offset, double R, uint32_t* hit_q,
                                uint32_t* hit_id, uint32_t* hit_table, double* hit_dist, uint64_t cap,
                                uint64_t* n_total);
+
+/* The same for a block of queries given as residue codes [nq_local][k] (hs_query_codes_dev: k bytes
+ * per query to the GPU instead of 8d). */
+HS_API hs_status hs_comm_query_codes(hs_comm* c, uint32_t rank, hs_handle* h, const uint8_t* qcodes,
+                                     uint64_t nq_local, uint32_t q_offset, double R, uint32_t* hit_q,
+                                     uint32_t* hit_id, uint32_t* hit_table, double* hit_dist, uint64_t cap,
+                                     uint64_t* n_total);
 
 #ifdef __cplusplus
 }

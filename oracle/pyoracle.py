@@ -41,7 +41,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(_HERE, "libhs_oracle.so")
+        # HS_ORACLE_LIB: another build of the restatement (the sanitizer build, tests/test_sanitizers_cpu.py)
+        path = os.environ.get("HS_ORACLE_LIB") or os.path.join(_HERE, "libhs_oracle.so")
         if not os.path.exists(path):
             build()
         _lib = C.CDLL(path)

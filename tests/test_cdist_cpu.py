@@ -116,3 +116,39 @@ def test_python_and_cxx_gathers_agree_over_two_real_processes():
            for k in ("q", "id", "table", "dist")}
     for k in cat:
         assert np.array_equal(got[0][k], cat[k]) and np.array_equal(got[1][k], cat[k])
+
+
+@pytest.mark.parametrize("world,bad", [(2, 1), (3, 0), (4, 2)])
+def test_a_failed_rank_stops_every_rank_and_nobody_waits(world, bad):
+    """a rank that fails before the exchange must still take part in it.  Rank `bad` offers
+    hits without arrays (HS_ERR_INVALID on that rank): it returns its own status, every other rank
+    HS_ERR_PEER, nothing is written, no thread is left at a rendezvous -- and the communicator keeps
+    working for the next (healthy) call."""
+    rng = np.random.default_rng(50 + world)
+    local = [_fake_hits(rng, 5 + r, 10) for r in range(world)]
+    comm = cdist.Comm(cdist.LOOPBACK, world)
+
+    def broken(r):
+        out = dict(q=np.full(64, 77, np.uint32), id=np.empty(64, np.uint32), table=np.empty(64, np.uint32),
+                   dist=np.empty(64, np.float64))
+        h = local[r]
+        args = (None, None, None, None) if r == bad else (h["q"], h["id"], h["table"], h["dist"])
+        st, tot = comm.allgather_hits(r, *args, len(h["q"]), 0, out["q"], out["id"], out["table"], out["dist"], 64)
+        return st, out["q"]
+    for r, (st, q) in enumerate(_run_ranks(world, broken)):
+        assert st == (capi.HS_ERR_INVALID if r == bad else capi.HS_ERR_PEER), (r, st)
+        assert np.all(q == 77)
+    assert "failed" in comm.last_error((bad + 1) % world)
+    got = _run_ranks(world, lambda r: comm.gather_host(r, local[r], 0))
+    assert np.array_equal(got[0]["id"], np.concatenate([l["id"] for l in local]))
+    comm.close()
+
+
+def test_comm_query_is_refused_without_devices_on_every_rank():
+    """hs_comm_query over a loopback communicator created WITHOUT devices: every rank gets
+    HS_ERR_INVALID through the exchange (no early return: both threads come back)."""
+    world = 2
+    comm = cdist.Comm(cdist.LOOPBACK, world)
+    sts = _run_ranks(world, lambda r: comm.query_status(r, None, np.zeros((1, 200)), 0, 40.0))
+    assert sts == [capi.HS_ERR_INVALID] * world
+    comm.close()

@@ -75,3 +75,65 @@ def test_comm_query_equals_plain_query(oracle):
     c2.close()
     eng.close()
     _ = oracle
+
+
+def test_rank_threads_with_two_live_handles_over_the_loopback(oracle):
+    """Two (and three) rank threads, each with its OWN handle and index on GPU 0, through hs_comm_query
+    over the host-memory transport created with devices: every rank gets every rank's hits in the
+    reference's order = the one-handle query; blocks given as residue codes give the same
+    (hs_comm_query_codes); the capacity retry is one decision; and a rank whose search fails (its
+    handle has no index: HS_ERR_STATE) takes part in the exchange -- it returns its own status, the
+    others HS_ERR_PEER, no thread hangs, and the communicator serves the next call."""
+    import threading
+    k, K, L, W, R, n, nq = 25, 8, 6, 150.0, 40.0, 30000, 901
+    a, b = synth.make_planes(k, K, L, W, seed=61)
+    codes = synth.make_db(n, k, seed=62)
+    qcodes, _ = synth.make_query_codes(codes, nq, seed=64)
+    centers = synth.embed(qcodes)
+    one = Engine(k, K, L, W, a, b, device=0)
+    one.index_build(codes)
+    want = one.query(centers, R)
+    one.close()
+    assert len(want["q"]) > 100
+    _ = oracle
+
+    def run(world, fn):
+        out, err = [None] * world, []
+
+        def body(r):
+            try:
+                out[r] = fn(r)
+            except BaseException as e:   # noqa
+                err.append((r, repr(e)))
+        ts = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=120)
+        assert not any(t.is_alive() for t in ts), "ranks hung"
+        assert not err, err
+        return out
+    for world in (2, 3):
+        comm = cdist.Comm(cdist.LOOPBACK, world, devices=[0] * world)
+        engs = [Engine(k, K, L, W, a, b, device=0) for _ in range(world)]
+        for e in engs:
+            e.index_build(codes)
+        blocks = [cdist.shard_bounds(nq, world, r) for r in range(world)]
+        for as_codes in (False, True):
+            got = run(world, lambda r: comm.query(r, engs[r], (qcodes if as_codes else centers)[blocks[r][0]:blocks[r][1]],
+                                                  blocks[r][0], R, cap=8, codes=as_codes))   # cap=8: the retry
+            for r in range(world):
+                for f in ("q", "id", "table", "dist"):
+                    assert np.array_equal(got[r][f], want[f]), (world, r, f, as_codes)
+        # rank 1's handle loses its index (a new plane family drops it): its query fails
+        engs[1].set_planes(a, b)
+        sts = run(world, lambda r: comm.query_status(r, engs[r], centers[blocks[r][0]:blocks[r][1]], blocks[r][0], R,
+                                                     cap=1 << 16))
+        assert sts[1] == capi.HS_ERR_STATE and all(s == capi.HS_ERR_PEER for i, s in enumerate(sts) if i != 1), sts
+        assert "rank 1 failed" in comm.last_error(0)
+        engs[1].index_build(codes)
+        got = run(world, lambda r: comm.query(r, engs[r], centers[blocks[r][0]:blocks[r][1]], blocks[r][0], R))
+        assert np.array_equal(got[0]["id"], want["id"])
+        for e in engs:
+            e.close()
+        comm.close()

@@ -26,10 +26,13 @@ def _exact_d2(codes_rows, centers_rows):
 
 
 def test_config2_search_properties():
-    k, K, L, W, R, n, nq = 25, 16, 8, 200.0, 40.0, 10_000_000, 100_000
+    # W = 212: the bench default (bench.py; the smallest W of the committed sweep with radius recall
+    # >= 0.9), i.e. exactly the workload the headline number is quoted on
+    k, K, L, W, R, n, nq = 25, 16, 8, 212.0, 40.0, 10_000_000, 100_000
     a, b = synth.make_planes(k, K, L, W)
     codes = synth.make_db(n, k)
-    centers, src = synth.make_queries(codes, nq)
+    qcodes, src = synth.make_query_codes(codes, nq)
+    centers = synth.embed(qcodes)                       # = synth.make_queries(codes, nq): bench.py's queries
     eng = Engine(k, K, L, W, a, b)
     info = eng.index_build(codes)
     assert info["n"] == n and sum(info["n_buckets"]) > 0
@@ -38,6 +41,12 @@ def test_config2_search_properties():
         eng.set_verify_mode(mode)
         res[mode] = eng.query(centers, R)
         assert (eng.profile()["join_i8_batches"] > 0) == (mode == "join")
+    # the same queries as residue codes (hs_query_codes: no centre is ever embedded with the int8 join)
+    eng.set_verify_mode("auto")
+    as_codes = eng.query_codes(qcodes, R)
+    assert eng.profile()["join_i8_batches"] > 0
+    for f in ("q", "id", "table", "dist", "cand"):
+        assert np.array_equal(as_codes[f], res["join"][f]), f
     j, s = res["join"], res["stream"]
     for f in ("q", "id", "table", "dist"):
         assert np.array_equal(res["join16"][f], s[f]), f

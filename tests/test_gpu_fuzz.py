@@ -72,7 +72,9 @@ def test_random_configuration_matches_oracle(oracle, seed):
     thin = {"HS_JOIN_MIN_Q": "3", "HS_JOIN_MIN_M": "16"} if seed % 3 == 0 else {}
     os.environ.update(thin)
     try:
-        eng = Engine(c["k"], c["K"], c["L"], c["W"], c["a"], c["b"], coords=c["table"])
+        # (HS_TEST_SPLIT_ABOVE in the environment: the library's test build, which has that hook)
+        eng = Engine(c["k"], c["K"], c["L"], c["W"], c["a"], c["b"], coords=c["table"],
+                     hooks=bool(os.environ.get("HS_TEST_SPLIT_ABOVE")))
     finally:
         for key in thin:
             del os.environ[key]

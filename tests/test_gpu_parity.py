@@ -218,8 +218,10 @@ def test_wide_rows_by_radius(oracle, monkeypatch, tmp_path, k, R):
 
 def test_batches_split_when_the_survivor_counter_would_overflow(oracle, monkeypatch):
     """A batch whose filters pass more pairs than the 32-bit survivor counter holds is repeated in
-    halves (hs_capi.hip run_query).  HS_TEST_SPLIT_ABOVE makes every batch above 150 queries report
-    that overflow: hits, order, candidates and the self-join's edges are those of the unsplit run."""
+    halves (hs_capi.hip run_query).  HS_TEST_SPLIT_ABOVE -- a hook of the library's TEST build only
+    (libhsearch_amd_hooks.so: the same kernel objects, C-ABI layer compiled with -DHS_TEST_HOOKS) --
+    makes every batch above 150 queries report that overflow: hits, order, candidates and the
+    self-join's edges are those of the unsplit run of the product library."""
     k, K, L, W, R, n, nq = 25, 4, 5, 150.0, 45.0, 20011, 1203
     a, b = synth.make_planes(k, K, L, W, seed=35)
     codes = synth.make_db(n, k, seed=36)
@@ -230,7 +232,7 @@ def test_batches_split_when_the_survivor_counter_would_overflow(oracle, monkeypa
     plain = eng.self_join(R, sqrt_test=True)
     eng.close()
     monkeypatch.setenv("HS_TEST_SPLIT_ABOVE", "150")
-    eng = Engine(k, K, L, W, a, b)
+    eng = Engine(k, K, L, W, a, b, hooks=True)
     eng.index_build(codes)
     for mode in ("auto", "stream"):
         eng.set_verify_mode(mode)
@@ -644,6 +646,39 @@ def test_build_sorts_again_when_partial_fingerprints_interleave(monkeypatch):
             assert np.array_equal(res[other][2][key], res["0"][2][key])
 
 
+@pytest.mark.parametrize("n", [(1 << 20) - 1, 1 << 20, (1 << 20) + 1])
+def test_build_at_the_sort_path_boundary(monkeypatch, n):
+    """rocPRIM sorts up to merge_sort_limit = 2^20 items with a merge sort whose comparator for a bit
+    range ending at bit 64 is built from 1 << 64 (hs_prims.hip): the build may hand it a range only
+    above that size.  Round 2's cut was n >= 2^20, one too early.  Builds at the boundary and either
+    side of it -- hs_index_build and hs_index_build_subset -- equal the all-bits build, and the
+    exact-copy queries find their k-mers."""
+    k, K, L, W, R, nq = 25, 8, 2, 150.0, 30.0, 1500
+    a, b = synth.make_planes(k, K, L, W, seed=75)
+    codes = synth.make_db(n, k, seed=76)
+    src = np.random.default_rng(77).integers(0, n, size=nq)
+    centers = synth.embed(codes[src])
+    res = {}
+    for mode in ("0", None, "subset"):
+        monkeypatch.delenv("HS_SORT_FROM_BIT", raising=False)
+        if mode == "0":
+            monkeypatch.setenv("HS_SORT_FROM_BIT", "0")
+        eng = Engine(k, K, L, W, a, b)
+        info = eng.index_build_subset(codes, None) if mode == "subset" else eng.index_build(codes)
+        res[mode] = (info["n_buckets"], info["max_bucket"], eng.query(centers, R))
+        eng.close()
+    got = res["0"][2]
+    first = {}
+    for q, i, t in zip(got["q"].tolist(), got["id"].tolist(), got["table"].tolist()):
+        if i == src[q]:
+            first[q] = t
+    assert all(first.get(q) == 0 for q in range(nq))      # an exact copy shares its k-mer's bucket in table 0
+    for other in (None, "subset"):
+        assert res[other][0] == res["0"][0] and res[other][1] == res["0"][1]
+        for key in ("q", "id", "table", "dist", "cand"):
+            assert np.array_equal(res[other][2][key], got[key])
+
+
 @pytest.mark.parametrize("k,K,L,W,R", [(25, 6, 5, 120.0, 45.0), (25, 2, 3, 400.0, 42.0), (15, 5, 4, 90.0, 32.0),
                                       (39, 6, 3, 260.0, 50.0)])
 def test_probe_grouping_by_counting_sort_and_by_probe_sort(oracle, monkeypatch, k, K, L, W, R):
@@ -707,17 +742,86 @@ def test_hit_ordering_paths_with_many_hits_per_query(oracle, monkeypatch):
     want = oracle.search(a, b, W, R, oracle.embed_codes(codes), centers)
     per_q = np.bincount(want["q"], minlength=nq)
     assert per_q.max() > 500 and np.median(per_q) < 20
-    eng = Engine(k, K, L, W, a, b)
-    eng.index_build(codes)
+    want_few = oracle.search(a, b, W, R, oracle.embed_codes(codes), centers[40:])
     for sort_all in (False, True):
         monkeypatch.delenv("HS_SORT_HITS", raising=False)
         if sort_all:
             monkeypatch.setenv("HS_SORT_HITS", "1")
+        eng = Engine(k, K, L, W, a, b)      # (a handle reads its environment switches when it is created)
+        eng.index_build(codes)
         for mode in ("auto", "stream"):
             eng.set_verify_mode(mode)
             _assert_hits_equal(eng.query(centers, R), want)
         # without the family queries every query stays under 128 hits: the in-kernel ordering
         few = eng.query(centers[40:], R)
-        want_few = oracle.search(a, b, W, R, oracle.embed_codes(codes), centers[40:])
         _assert_hits_equal(few, want_few)
+        eng.close()
+
+
+@pytest.mark.parametrize("k,K,L,W,R", [(25, 6, 5, 140.0, 42.0), (15, 5, 4, 90.0, 32.0), (39, 6, 3, 260.0, 50.0),
+                                      (60, 4, 3, 400.0, 70.0), (25, 20, 32, 320.0, 45.0)])
+def test_queries_given_as_residue_codes(oracle, k, K, L, W, R):
+    """hs_query_codes -- the queries are k-mers (the reference's usual centres:
+    KmerToCoordinates, hclust2.cpp:49-62) given as k residue codes instead of 8k doubles.  Hits, order,
+    candidates and fp64 distances equal hs_query's on the embedded codes and the oracle's, in every
+    verify mode: with the int8 join the whole batch runs from the codes (no centre is ever embedded),
+    otherwise (streaming filter, fp16 join, k > 50) they are embedded on the device.  Several batches; a
+    code outside the alphabet is HS_ERR_INVALID; custom coordinate tables."""
+    from hsearch_amd import capi
+    n, nq = 20011, 1203
+    a, b = synth.make_planes(k, K, L, W, seed=85)
+    codes = synth.make_db(n, k, seed=86)
+    qcodes, _ = synth.make_query_codes(codes, nq, seed=87)
+    centers = synth.embed(qcodes)
+    want = oracle.search(a, b, W, R, oracle.embed_codes(codes), centers)
+    assert len(want["q"]) > 100
+    eng = Engine(k, K, L, W, a, b)
+    eng.index_build(codes)
+    for mode in ("auto", "join", "stream", "join16"):
+        eng.set_verify_mode(mode)
+        got = eng.query_codes(qcodes, R)
+        assert np.array_equal(got["cand"], want["cand"]), mode
+        _assert_hits_equal(got, want)
+        prof = eng.profile()
+        if mode in ("auto", "join") and k <= 50:
+            assert prof["join_i8_batches"] > 0
+        ref = eng.query(centers, R)
+        for key in ("q", "id", "table", "dist", "cand"):
+            assert np.array_equal(got[key], ref[key]), (mode, key)
+    eng.set_verify_mode("auto")
+    bad = qcodes.copy()
+    bad[nq // 2, k // 2] = 20
+    with pytest.raises(capi.HsError) as e:
+        eng.query_codes(bad, R)
+    assert e.value.status == capi.HS_ERR_INVALID
+    _assert_hits_equal(eng.query_codes(qcodes, R), want)          # the handle is fine afterwards
+    assert len(eng.query_codes(qcodes[:0], R)["q"]) == 0
+    eng.close()
+
+
+def test_queries_as_codes_in_batches_and_custom_table(oracle, monkeypatch):
+    k, K, L, W, R, n, nq = 25, 5, 4, 120.0, 44.0, 9001, 777
+    rng = np.random.default_rng(90)
+    table = rng.normal(0.0, 6.0, size=(11, 8))                     # an 11-letter alphabet of its own
+    a, b = synth.make_planes(k, K, L, W, seed=91)
+    codes = rng.integers(0, 11, size=(n, k), dtype=np.uint8)
+    qcodes = codes[rng.integers(0, n, size=nq)].copy()
+    qcodes[np.arange(nq), rng.integers(0, k, size=nq)] = rng.integers(0, 11, size=nq, dtype=np.uint8)
+    pts = table[codes].reshape(n, -1)
+    centers = table[qcodes].reshape(nq, -1)
+    want = oracle.search(a, b, W, R, pts, centers)
+    assert len(want["q"]) > 100
+    monkeypatch.setenv("HS_QUERY_BATCH", "100")
+    eng = Engine(k, K, L, W, a, b, coords=table)
+    eng.index_build(codes)
+    for mode in ("auto", "stream"):
+        eng.set_verify_mode(mode)
+        got = eng.query_codes(qcodes, R)
+        assert np.array_equal(got["cand"], want["cand"])
+        _assert_hits_equal(got, want)
+    bad = qcodes.copy()
+    bad[5, 3] = 11                                                  # a row the table does not have
+    from hsearch_amd import capi
+    with pytest.raises(capi.HsError):
+        eng.query_codes(bad, R)
     eng.close()

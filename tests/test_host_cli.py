@@ -9,7 +9,9 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BIN = os.path.join(ROOT, "hsearch_amd", "bin", "hs_motif_both_points")
+# HS_HOST_BIN_DIR: another build of the programs (the sanitizer build, tests/test_sanitizers_cpu.py)
+BIN_DIR = os.environ.get("HS_HOST_BIN_DIR") or os.path.join(ROOT, "hsearch_amd", "bin")
+BIN = os.path.join(BIN_DIR, "hs_motif_both_points")
 
 
 def _bin():
@@ -125,7 +127,7 @@ def test_cli_lossy_points_file_and_evaluate(tmp_path, oracle):
 def test_hclust2_cli_matches_reference_golden(tmp_path, golden_dir):
     """hs_hclust2 -k kmers.fa -l k -K -L -W -T -o out --seed s  ==  the compiled reference's hclust2
     Clustering() with its LSH objects seeded s, s+1, ... (byte-identical clusters file)."""
-    binary = os.path.join(ROOT, "hsearch_amd", "bin", "hs_hclust2")
+    binary = os.path.join(BIN_DIR, "hs_hclust2")
     if not os.path.exists(binary):
         subprocess.run(["make", "-C", os.path.join(ROOT, "hsearch_amd", "host")], check=True,
                        stdout=subprocess.DEVNULL)
@@ -240,6 +242,9 @@ def test_cli_gpus_planes_file_and_kmer_centres(tmp_path, oracle):
     r = subprocess.run([_bin(), "-o", str(tmp_path / "x"), "-d", db, "-c", cen, "--planes", planes, "-l", str(k),
                         "-K", str(K + 1), "-L", str(L), "-W", repr(W), "-T", repr(R)], capture_output=True, text=True)
     assert r.returncode == 1 and "does not hold" in r.stderr
+    cfa_ok = str(tmp_path / "cen_ok.fa")
+    with open(cfa_ok, "w") as g:
+        g.write(open(cfa).read())
     with open(cfa, "a") as g:
         g.write(">short\nARND\n")
     r = subprocess.run([_bin(), "-o", str(tmp_path / "x"), "-d", db, "-c", cfa, "--planes", planes] + common,
@@ -257,6 +262,68 @@ def test_cli_gpus_planes_file_and_kmer_centres(tmp_path, oracle):
     p1, _ = run("fa_plain", "-d", fa, "-c", cen, "--planes", planes)
     p2, _ = run("fa_gpus1", "-d", fa, "-c", cen, "--planes", planes, "--gpus", "1")
     assert p1 == p2
+    # k-mer centres over a FASTA database travel as residue codes (hs_query_codes, 25 bytes each): the
+    # same file as the embedded centres give (points file; --centers-as-points), plain and sharded
+    p3, _ = run("fa_codes", "-d", fa, "-c", cfa_ok, "--planes", planes)
+    p4, _ = run("fa_codes_emb", "-d", fa, "-c", cfa_ok, "--planes", planes, "--centers-as-points", "1")
+    p5, _ = run("fa_codes_g1", "-d", fa, "-c", cfa_ok, "--planes", planes, "--gpus", "1")
+    assert p3 == p1 and p4 == p1 and p5 == p1 and len(p1.splitlines()) > 0
+
+
+@pytest.mark.gpu
+def test_cli_two_rank_threads_with_live_handles_over_loopback(tmp_path, oracle):
+    """VERDICT r02 item 5: hsearch::SearchSharded's rank threads with TWO live handles.  RCCL refuses
+    two ranks on one device, so --transport loopback puts both ranks on --device and exchanges the hits
+    through host memory: the barrier / capacity / failed-rank protocol with real hs_query_dev calls.
+    --gpus 2 and 3 write byte for byte what --gpus 1 and the plain path write (points and FASTA
+    database, centres as points and as codes); a rank made to fail (test build of the program:
+    HS_TEST_FAIL_RANK) ends the run with an error on every rank instead of hanging rank 0."""
+    k, K, L, W, R, seed = 25, 6, 5, 140.0, 40.0, 78
+    rng = np.random.default_rng(12)
+    letters = "ARNDCQEGHILKMFPSTWYV"
+    codes = rng.integers(0, 20, size=(3000, k), dtype=np.uint8)
+    pts = oracle.embed_codes(codes)
+    qcodes = codes[rng.choice(len(codes), 121, replace=False)].copy()   # 121: uneven blocks
+    for row in qcodes:
+        for _ in range(int(rng.integers(0, 4))):
+            row[rng.integers(0, k)] = rng.integers(0, 20)
+    db, cen, cfa, fa = [str(tmp_path / n) for n in ("db.points", "cen.points", "cen.fa", "db.fa")]
+    _write_points(db, pts)
+    with open(cen, "w") as f, open(cfa, "w") as g:
+        for i, row in enumerate(qcodes):
+            f.write("c%d\n" % i + " ".join("%.17g" % v for v in oracle.embed_codes(row[None])[0]) + "\n")
+            g.write(">c%d\n%s\n" % (i, "".join(letters[c] for c in row)))
+    with open(fa, "w") as f:
+        for i in range(6):
+            f.write(">prot%d x\n%s\n" % (i, "".join(letters[c] for c in rng.integers(0, 20, size=200))))
+    common = ["-l", str(k), "-K", str(K), "-L", str(L), "-W", repr(W), "-T", repr(R), "--seed", str(seed)]
+
+    def run(out, *extra, binary=None, env=None, ok=True):
+        r = subprocess.run([binary or _bin(), "-o", str(tmp_path / out)] + common + list(extra),
+                           capture_output=True, text=True, timeout=300, env=env)
+        if ok:
+            assert r.returncode == 0, r.stderr
+            return open(tmp_path / out).read(), r.stdout
+        return r
+    plain, _ = run("plain", "-d", db, "-c", cen)
+    assert len(plain.splitlines()) >= 80
+    for n in (1, 2, 3):
+        got, so = run("lb%d" % n, "-d", db, "-c", cen, "--gpus", str(n), "--transport", "loopback")
+        assert "%d ranks on device 0" % n in so and got == plain
+    fa_plain, _ = run("fa_plain", "-d", fa, "-c", cfa, "--centers-as-points", "1")
+    assert len(fa_plain.splitlines()) > 0
+    for extra in ((), ("--centers-as-points", "1")):
+        got, _ = run("fa_lb2", "-d", fa, "-c", cfa, "--gpus", "2", "--transport", "loopback", *extra)
+        assert got == fa_plain
+    # a failed rank: everybody stops, nobody hangs (timeout above), the message names the rank
+    hooks = _bin() + "_hooks"
+    env = dict(os.environ, HS_TEST_FAIL_RANK="1")
+    r = run("fail", "-d", db, "-c", cen, "--gpus", "2", "--transport", "loopback", binary=hooks, env=env, ok=False)
+    assert r.returncode == 1 and "hs_comm_query" in r.stderr
+    got, _ = run("nofail", "-d", db, "-c", cen, "--gpus", "2", "--transport", "loopback", binary=hooks)
+    assert got == plain
+    r = run("bad", "-d", db, "-c", cen, "--gpus", "2", "--transport", "smoke", ok=False)
+    assert r.returncode == 1 and "--transport" in r.stderr
 
 
 @pytest.mark.gpu
@@ -313,7 +380,7 @@ def test_cli_best_centre_per_position(tmp_path, oracle):
 def test_pcluster_pregroup_cli_matches_oracle(tmp_path, oracle):
     """hs_pcluster_pregroup (pcluster.cpp:11-81 on the GPU) groups proteins
     exactly as the oracle's KLSH restatement (itself pinned to the reference's KLSH object)."""
-    exe = os.path.join(ROOT, "hsearch_amd", "bin", "hs_pcluster_pregroup")
+    exe = os.path.join(BIN_DIR, "hs_pcluster_pregroup")
     _bin()
     rng = np.random.default_rng(12)
     letters = "ARNDCQEGHILKMFPSTWYV"
@@ -346,7 +413,7 @@ def test_pcluster_pregroup_cli_matches_oracle(tmp_path, oracle):
 # ---- row a11 as a program, SURVEY 8(f) row 4: noLSH search, evaluate2, centroid builder ----------
 def _tool(name):
     _bin()
-    return os.path.join(ROOT, "hsearch_amd", "bin", name)
+    return os.path.join(BIN_DIR, name)
 
 
 def _points_text(names, pts):
