@@ -90,6 +90,7 @@ struct Knobs {
   bool no_thin8 = false;           // HS_NO_THIN8: thin segments through the streaming filter
   bool sort_hits = false;          // HS_SORT_HITS: order hits by the radix sort, not per query
   bool sync_items = false;         // HS_SYNC_ITEMS: read the join's item count back before launching it
+  bool no_join_r = false;          // HS_NO_JOIN_R: every segment through the query-streaming join kernel
   int seg_mode = 0;                // HS_SEG_MODE=sparse|dense: 1 / 2; 0 = by the bucket : probe ratio
   int sort_from_bit = 16;          // HS_SORT_FROM_BIT: lowest fingerprint bit the build's sort looks at
   uint32_t query_batch = 0;        // HS_QUERY_BATCH: queries per batch (0: by L)
@@ -146,6 +147,8 @@ struct hs_handle {
   uint64_t all_codes_n = 0;
   DevBuf bs_ints2[2], bs_keys2[2], bs_iota2[2], bs_keys_sorted, bs_rle_unique, bs_rle_counts, bs_small,
       bs_sort_temp, bs_slow_q;  // index-build scratch (build_tables)
+  DevBuf seg_res;   // cut_items: flags + scan of the segments that go to the query-resident join kernel
+  DevBuf jconst;    // 128 copies of the gamma slots' constant factors (hs_join8r_kernel's fourth lane quarter)
   DevBuf c16s, item_desc, probe_slow, jtab8, slice_ql, qhits;  // qhits: per-query hit counts, offsets, fill
   DevBuf c8b, prov2;  // survivor refinement: second int8 row per query, the refined survivor list
   bool join8_tables_ok = false;  // int8 can carry the coordinate table
@@ -395,6 +398,7 @@ void read_knobs(hs_handle* h) {
   kn.no_thin8 = on("HS_NO_THIN8");
   kn.sort_hits = on("HS_SORT_HITS");
   kn.sync_items = on("HS_SYNC_ITEMS");
+  kn.no_join_r = on("HS_NO_JOIN_R");
   if (const char* m = getenv("HS_SEG_MODE")) kn.seg_mode = !strcmp(m, "sparse") ? 1 : !strcmp(m, "dense") ? 2 : 0;
   if (const char* m = getenv("HS_SORT_FROM_BIT")) kn.sort_from_bit = std::max(0, std::min(60, atoi(m)));
   if (const char* m = getenv("HS_QUERY_BATCH")) kn.query_batch = (uint32_t)std::max(1, atoi(m));
@@ -544,6 +548,18 @@ hs_status hs_create(const hs_params* params, const double* a, const double* b, c
   HS_HIP(h, hs_launch_jtables8(h->coords.as<double>(), h->alphabet, h->jtab8.p, h->jtab8.as<float>() + 128,
                                reinterpret_cast<uint32_t*>(h->jtab8.as<char>() + 640),
                                h->jtab8.as<char>() + 1024, h->jtab8.as<char>() + 1536, h->stream));
+  {
+    HS_HIP(h, h->jconst.reserve(2048));
+    uint32_t rep_[128][4];
+    for (int i = 0; i < 128; ++i) {
+      rep_[i][0] = 0x7f7f0000u;  // = tab8[HS_J8_CONST_AT] (hs_jtables8_kernel): bytes ROW-16.. of a member row
+      rep_[i][1] = 0x7f7f7f7fu;
+      rep_[i][2] = 0x7f7f7f7fu;
+      rep_[i][3] = 0x017f7f7fu;
+    }
+    HS_HIP(h, hipMemcpyAsync(h->jconst.p, rep_, 2048, hipMemcpyHostToDevice, h->stream));
+    HS_HIP(h, hipStreamSynchronize(h->stream));  // rep_ goes out of scope
+  }
   uint32_t unsafe8 = 1;
   float scale8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   HS_HIP(h, hipMemcpyAsync(&unsafe8, h->jtab8.as<char>() + 640, 4, hipMemcpyDeviceToHost, h->stream));
@@ -630,7 +646,7 @@ void hs_destroy(hs_handle* h) {
                     &h->proj_xmeta, &h->slice_ql, &h->qhits, &h->bs_ints2[0], &h->bs_ints2[1], &h->bs_keys2[0],
                     &h->bs_keys2[1], &h->bs_iota2[0], &h->bs_iota2[1], &h->bs_keys_sorted, &h->bs_rle_unique,
                     &h->bs_rle_counts, &h->bs_small, &h->bs_sort_temp, &h->bs_slow_q, &h->all_codes,
-                    &h->subset_ids, &h->qcodes_buf, &h->qembed};
+                    &h->subset_ids, &h->qcodes_buf, &h->qembed, &h->seg_res, &h->jconst};
   for (DevBuf* bf : bufs) bf->release();
   h->sj_host.release();
   for (int l = 0; l < HS_MAX_L; ++l) {
@@ -727,27 +743,39 @@ static inline int seg_shift_of(const hs_handle* h) {
 // Segments -> work items of jm members x <= 2048 queries: routing (join or streaming), the item
 // numbering order (many-query segments first), item offsets.  Workspace reuse: seg_keys = flags and
 // their scan, seg_vals = order, seg_keys_sorted = item counts in that order (all free by now).
-static hs_status cut_items(hs_handle* h, uint32_t nql, uint32_t jm, unsigned long long* d_jstats) {
+// max_q_res > 0: segments with at most that many probing queries form the item list's tail, whose bounds
+// go to seg_n[2..3] (hs_join8r_kernel's share).
+static hs_status cut_items(hs_handle* h, uint32_t nql, uint32_t jm, unsigned long long* d_jstats,
+                           uint32_t max_q_res) {
   const size_t n1 = (size_t)nql + 1;
   uint32_t* big = h->seg_keys.as<uint32_t>();
   uint32_t* big_pos = big + n1;
   uint32_t* order = h->seg_vals.as<uint32_t>();
   uint32_t* items_ord = h->seg_keys_sorted.as<uint32_t>();
+  uint32_t *res = nullptr, *res_pos = nullptr;
+  if (max_q_res) {
+    HS_HIP(h, h->seg_res.reserve(2 * n1 * 4));
+    res = h->seg_res.as<uint32_t>();
+    res_pos = res + n1;
+  }
   HS_HIP(h, hs_launch_seg_route(h->seg_key.as<uint64_t>(), h->seg_cnt.as<uint32_t>(),
                                 h->seg_qoff.as<uint32_t>(), h->seg_n.as<uint32_t>(),
                                 h->sorted_ql.as<uint32_t>(), h->qcount.as<uint32_t>(), nql,
-                                h->join_min_q, h->join_min_m, jm, (int)h->p.L, seg_shift_of(h),
+                                h->join_min_q, h->join_min_m, jm, (int)h->p.L, seg_shift_of(h), max_q_res,
                                 h->seg_items.as<uint32_t>(), d_jstats, h->nslices.as<uint32_t>(),
                                 h->stream));
   HS_HIP(h, hipMemsetAsync(big + nql, 0, 4, h->stream));
+  if (res) HS_HIP(h, hipMemsetAsync(res + nql, 0, 4, h->stream));
   HS_HIP(h, hipMemsetAsync(items_ord + nql, 0, 4, h->stream));
-  HS_HIP(h, hs_launch_seg_big(h->seg_cnt.as<uint32_t>(), h->seg_items.as<uint32_t>(), nql, 512u, big,
-                              h->stream));
+  HS_HIP(h, hs_launch_seg_big(h->seg_cnt.as<uint32_t>(), h->seg_items.as<uint32_t>(), nql, 512u, max_q_res, big,
+                              res, h->stream));
   HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, big, big_pos, n1, h->stream));
-  HS_HIP(h, hs_launch_seg_order(big_pos, h->seg_items.as<uint32_t>(), nql, order, items_ord,
+  if (res) HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, res, res_pos, n1, h->stream));
+  HS_HIP(h, hs_launch_seg_order(big_pos, res_pos, h->seg_items.as<uint32_t>(), nql, order, items_ord,
                                 h->stream));
   HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, items_ord, h->item_off.as<uint32_t>(), n1,
                                   h->stream));
+  HS_HIP(h, hs_launch_item_split(h->item_off.as<uint32_t>(), res_pos, nql, h->seg_n.as<uint32_t>() + 2, h->stream));
   return HS_OK;
 }
 
@@ -815,8 +843,9 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
   uint32_t* d_small = small.as<uint32_t>();
   double ms_hash = 0, ms_sort = 0, ms_gather = 0;
   const bool with_rec8 = h->join8_tables_ok && k <= 50;
-  HS_HIP(h, h->t_packed.reserve(std::max<size_t>(16, (size_t)L * n * PW * 16)));
-  if (with_rec8) HS_HIP(h, h->t_rec8.reserve(std::max<size_t>(16, (size_t)L * n * 16)));
+  // (+ 128 entries: hs_join8r_kernel reads a bucket's ragged last member tile without clamping)
+  HS_HIP(h, h->t_packed.reserve(((size_t)L * n + HS_JM_WAVE) * PW * 16));
+  if (with_rec8) HS_HIP(h, h->t_rec8.reserve(((size_t)L * n + HS_JM_WAVE) * 16));
   HS_HIP(h, h->t_pos.reserve(std::max<size_t>(16, (size_t)L * n * 4)));
   // hash + fingerprints of table t into buffer t & 1, on the side stream
   auto hash_table = [&](int t) -> hs_status {
@@ -1379,8 +1408,8 @@ hs_status hs_index_load(hs_handle* h, const char* path) {
     if (bad) return fail(h, HS_ERR_IO, "index file holds a residue code outside the alphabet");
   }
   const bool with_rec8 = h->join8_tables_ok && k <= 50;
-  HS_HIP(h, h->t_packed.reserve(std::max<size_t>(16, (size_t)L * n * PW * 16)));
-  if (with_rec8) HS_HIP(h, h->t_rec8.reserve(std::max<size_t>(16, (size_t)L * n * 16)));
+  HS_HIP(h, h->t_packed.reserve(((size_t)L * n + HS_JM_WAVE) * PW * 16));
+  if (with_rec8) HS_HIP(h, h->t_rec8.reserve(((size_t)L * n + HS_JM_WAVE) * 16));
   HS_HIP(h, h->t_pos.reserve(std::max<size_t>(16, (size_t)L * n * 4)));
   uint32_t* d_flag = h->counters.as<uint32_t>() + 16;  // [16] failure bits, [17 + l] largest bucket
   HS_HIP(h, hipMemsetAsync(d_flag, 0, (1 + HS_MAX_L) * 4, h->stream));
@@ -1557,7 +1586,7 @@ static hs_status ensure_rec8w(hs_handle* h) {
   if (h->wide8 || h->rec8w_ready) return HS_OK;
   const size_t n = h->n;
   const int L = (int)h->p.L;
-  HS_HIP(h, h->t_rec8w.reserve(std::max<size_t>(16, (size_t)L * n * 16)));
+  HS_HIP(h, h->t_rec8w.reserve(((size_t)L * n + HS_JM_WAVE) * 16));
   for (int l = 0; l < L; ++l)
     HS_HIP(h, hs_launch_gather_rec8(h->packed_all.as<uint4>(), h->tabs.t[l].ids, (uint32_t)n, (int)h->p.k, 1,
                                     h->jtab8.p, h->jtab8.as<char>() + 1536, h->jtab8.as<float>() + 128,
@@ -1710,7 +1739,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
   }
   unsigned long long* d_jstats = reinterpret_cast<unsigned long long*>(d_cnt + 10);
   uint32_t n_items = 0, n_slices = 1, jm = HS_JM_BLOCK;
-  bool async_items = false;
+  bool async_items = false, use_r = false;
   const int seg_shift = seg_shift_of(h);
   if (use_join) {
     const size_t n1 = (size_t)nql + 1;
@@ -1749,7 +1778,10 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
                                     h->seg_qoff.as<uint32_t>(), n1, h->stream));
     // work items: one wave's 128 members for the wave-independent int8 join, 512 otherwise
     jm = use_i8 ? hs_join8_members_per_item(k, wide) : HS_JM_BLOCK;
-    HS_CHECK(cut_items(h, nql, jm, d_jstats));
+    // k <= 25 with 4-column rows: segments probed by at most HS_JR_MAXQ queries of the batch go to the
+    // query-resident kernel (hs_join8r_kernel), as the tail of the item list
+    use_r = use_i8 && !wide && k <= 25 && !h->knobs.no_join_r;
+    HS_CHECK(cut_items(h, nql, jm, d_jstats, use_r ? HS_JR_MAXQ : 0u));
     if (use_i8)
       HS_HIP(h, hs_launch_gather_c8t(h->c16.p, h->sorted_ql.as<uint32_t>(), h->seg_qoff.as<uint32_t>(),
                                      nql, L, k, wide, h->c16s.p, h->stream));
@@ -1792,8 +1824,9 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
       HS_HIP(h, hipMemcpyAsync(&unsafe, d_unsafe, 4, hipMemcpyDeviceToHost, h->stream));
       if (jm != HS_JM_BLOCK) {  // the fp16 kernel works on 512-member items: cut the segments again
         jm = HS_JM_BLOCK;
+        use_r = false;
         HS_HIP(h, hipMemsetAsync(d_jstats, 0, 16, h->stream));
-        HS_CHECK(cut_items(h, nql, jm, d_jstats));
+        HS_CHECK(cut_items(h, nql, jm, d_jstats, 0u));
         HS_HIP(h, hipMemcpyAsync(&n_items, h->item_off.as<uint32_t>() + nql, 4, hipMemcpyDeviceToHost,
                                  h->stream));
       }
@@ -1882,7 +1915,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
       HS_HIP(h, h->temp.reserve(hs_scan_u32_temp(n1q) + 256));
     }
     HS_HIP(h, hipEventRecord(h->ev[3], h->stream));
-    if (launches) HS_HIP(h, hipMemsetAsync(d_cnt + 32, 0, 4, h->stream));  // retry: the item counter again
+    if (launches) HS_HIP(h, hipMemsetAsync(d_cnt + 32, 0, 8, h->stream));  // retry: the item counters again
     if (thin8)
       HS_HIP(h, hs_launch_thin8(h->tabs, rec8, h->n, h->c16.p, jtab_rows,
                                 h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
@@ -1906,12 +1939,20 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
                                      nullptr, n_blocks, h->stream));
     } else {
       HS_HIP(h, hipEventRecord(h->ev[11], h->stream));  // the join kernel alone: ev[11] .. ev[10]
-      if (n_items && use_i8)
+      if (n_items && use_i8) {
+        // the head [0, split) of the item list through the query-streaming kernel, the tail through the
+        // query-resident one (split == the item count when no segment qualifies or use_r is off)
+        const uint32_t* const d_split = h->seg_n.as<uint32_t>() + 2;
         HS_HIP(h, hs_launch_join8w(h->item_desc.as<uint4>(), n_items, h->tabs.t[0].packed,
                                    rec8, h->c16s.p, jtab_rows, k, wide, d_cnt, prov_cap,
                                    h->prov.as<uint2>(), d_cnt + 32, h->n_cu * h->join_blocks_per_cu,
-                                   async_items ? h->item_off.as<uint32_t>() + nql : nullptr,
+                                   use_r ? d_split : (async_items ? h->item_off.as<uint32_t>() + nql : nullptr),
                                    h->pairs_per_item, h->stream));
+        if (use_r)
+          HS_HIP(h, hs_launch_join8r(h->item_desc.as<uint4>(), n_items, d_split, h->tabs.t[0].packed, rec8,
+                                     h->c16s.p, jtab_rows, h->jconst.p, d_cnt, prov_cap, h->prov.as<uint2>(),
+                                     d_cnt + 33, h->n_cu * h->join_blocks_per_cu, h->pairs_per_item, h->stream));
+      }
       else if (n_items)
         HS_HIP(h, hs_launch_join(h->item_desc.as<uint4>(), n_items, h->tabs.t[0].packed,
                                  h->sorted_ql.as<uint32_t>(),

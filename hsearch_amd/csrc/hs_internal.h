@@ -338,6 +338,8 @@ hipError_t hs_launch_seg_route(const uint64_t* d_seg_key, const uint32_t* d_seg_
                                const uint32_t* d_seg_qoff, const uint32_t* d_n_seg,
                                const uint32_t* d_sorted_ql, const uint32_t* d_qcount, uint32_t n_max,
                                uint32_t min_q, uint32_t min_m, uint32_t jm, int L, int shift,
+                               uint32_t max_q_resident /* segments up to this many queries are issued in
+                               16-query column tiles (hs_join8r_kernel); 0: none */,
                                uint32_t* d_items, unsigned long long* d_stats, uint32_t* d_nslices,
                                hipStream_t s);
 hipError_t hs_launch_item_desc(const hs_tables_dev& tabs, const uint64_t* d_seg_key,
@@ -349,10 +351,19 @@ hipError_t hs_launch_item_desc(const hs_tables_dev& tabs, const uint64_t* d_seg_
                                then the capacity */, uint4* d_desc, hipStream_t s);
 // item numbering order of the segments: many-query segments first (stable two-class partition):
 // d_big[n + 1] flags (last = 0) -> exclusive scan -> d_order[n], d_items_ordered[n]
+// ... and LAST the segments with at most max_q_resident probing queries (d_res flags, null / 0: no such
+// class): their items are the tail [split[0], split[1]) of the item list, taken by the query-resident
+// join kernel (hs_join8r_kernel)
 hipError_t hs_launch_seg_big(const uint32_t* d_seg_cnt, const uint32_t* d_items, uint32_t n,
-                             uint32_t min_q, uint32_t* d_big, hipStream_t s);
-hipError_t hs_launch_seg_order(const uint32_t* d_big_pos, const uint32_t* d_items, uint32_t n,
-                               uint32_t* d_order, uint32_t* d_items_ordered, hipStream_t s);
+                             uint32_t min_q, uint32_t max_q_resident, uint32_t* d_big, uint32_t* d_res,
+                             hipStream_t s);
+hipError_t hs_launch_seg_order(const uint32_t* d_big_pos, const uint32_t* d_res_pos, const uint32_t* d_items,
+                               uint32_t n, uint32_t* d_order, uint32_t* d_items_ordered, hipStream_t s);
+hipError_t hs_launch_item_split(const uint32_t* d_item_off, const uint32_t* d_res_pos, uint32_t n,
+                                uint32_t* d_split, hipStream_t s);
+// queries of a segment the query-resident join keeps in registers (two 32-query tiles: with three the
+// kernel spills at two waves per SIMD)
+#define HS_JR_MAXQ 64u
 // members per work item: 512 (one workgroup tile) for the staged kernels, 128 (one wave) for the
 // wave-independent int8 join
 #define HS_JM_BLOCK 512u
@@ -409,6 +420,14 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
                             uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov,
                             uint32_t* d_item_counter, int n_blocks, const uint32_t* d_n_items,
                             double pairs_per_item, hipStream_t s);
+// the item list's tail [d_split[0], d_split[1]) (segments with <= HS_JR_MAXQ probing queries; k <= 25,
+// 4-column rows) through the query-resident form; d_cn_rep = 128 copies of the gamma slots' constant
+// factors (HS_J8_CONST bytes); the packed / record arrays must be readable 128 entries past their end
+hipError_t hs_launch_join8r(const uint4* d_desc, uint32_t desc_cap, const uint32_t* d_split,
+                            const uint4* d_packed_base, const uint4* d_rec_base, const void* d_c8t,
+                            const void* d_tab8, const void* d_cn_rep, uint32_t* d_prov_count, uint32_t prov_cap,
+                            uint2* d_prov, uint32_t* d_item_counter, int n_blocks, double pairs_per_item,
+                            hipStream_t s);
 // bucket-ordered packed copy of one table (k <= 25) + the per-entry 16-byte A-row tails of the
 // int8 join (d_out_rec[i] belongs to d_out_packed[i])
 hipError_t hs_launch_gather_rec8(const uint4* d_packed_all, const uint32_t* d_ids_sorted, uint32_t n,

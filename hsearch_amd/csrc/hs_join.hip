@@ -208,6 +208,7 @@ __global__ __launch_bounds__(256) void hs_seg_route_kernel(const uint64_t* __res
                                                            const uint32_t* __restrict__ qcount,
                                                            uint32_t n_max, uint32_t min_q,
                                                            uint32_t min_m, uint32_t jm, int L, int shift,
+                                                           uint32_t max_q_resident,
                                                            uint32_t* __restrict__ items,
                                                            unsigned long long* __restrict__ stats) {
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
@@ -224,7 +225,9 @@ __global__ __launch_bounds__(256) void hs_seg_route_kernel(const uint64_t* __res
       it = ((m + jm - 1) / jm) * ((nq + jqg - 1) / jqg);
       // MFMA pairs actually issued (128-row waves x 32-column chunks) vs real pairs
       const uint32_t rm = jm < HS_JM_BLOCK ? jm : 32u * JT;  // rows of one wave's member tile
-      issued = (unsigned long long)((m + rm - 1) / rm * rm) * ((nq + JQ - 1) / JQ * JQ);
+      // (the query-resident kernel issues 16-query column tiles, the others 32-query tiles)
+      const uint32_t cq = nq <= max_q_resident ? 16u : (uint32_t)JQ;
+      issued = (unsigned long long)((m + rm - 1) / rm * rm) * ((nq + cq - 1) / cq * cq);
       real = (unsigned long long)m * nq;
     }
   }
@@ -268,24 +271,48 @@ __global__ __launch_bounds__(256) void hs_seg_unslice_kernel(const uint32_t* __r
 // Item numbering order of the segments: those with many probing queries first (a stable
 // two-class partition).  The join hands items out from a counter, so the last ones handed out
 // should be small.  big[j] -> exclusive scan -> order[] and the item counts in that order.
+// Item numbering order of the segments, three classes, stable inside each: many-query segments first
+// (>= min_q probing queries: the long items that should start early), then the rest, and LAST the
+// segments with at most max_q_resident probing queries (0: no such class) -- their items form the tail
+// [split, total) of the item list, which the query-resident join kernel (hs_join8r_kernel) takes while
+// the head goes to the query-streaming one.
 __global__ __launch_bounds__(256) void hs_seg_big_kernel(const uint32_t* __restrict__ seg_cnt,
                                                          const uint32_t* __restrict__ items,
-                                                         uint32_t n, uint32_t min_q,
-                                                         uint32_t* __restrict__ big) {
+                                                         uint32_t n, uint32_t min_q, uint32_t max_q_resident,
+                                                         uint32_t* __restrict__ big,
+                                                         uint32_t* __restrict__ res) {
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-  if (j < n) big[j] = (items[j] && seg_cnt[j] >= min_q) ? 1u : 0u;
+  if (j >= n) return;
+  const uint32_t c = seg_cnt[j];
+  const bool has = items[j] != 0u;
+  big[j] = (has && c >= min_q) ? 1u : 0u;
+  if (res) res[j] = (has && c <= max_q_resident && c < min_q) ? 1u : 0u;
 }
+// big_pos / res_pos have n + 1 entries: [n] = number of segments of the class (res_pos may be null)
 __global__ __launch_bounds__(256) void hs_seg_order_kernel(const uint32_t* __restrict__ big_pos,
+                                                           const uint32_t* __restrict__ res_pos,
                                                            const uint32_t* __restrict__ items,
                                                            uint32_t n, uint32_t* __restrict__ order,
                                                            uint32_t* __restrict__ items_ordered) {
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
-  // big_pos has n + 1 entries: [n] = number of big segments
   const bool big = big_pos[j + 1] != big_pos[j];
-  const uint32_t pos = big ? big_pos[j] : big_pos[n] + (j - big_pos[j]);
+  const bool res = res_pos && res_pos[j + 1] != res_pos[j];
+  const uint32_t n_big = big_pos[n], n_res = res_pos ? res_pos[n] : 0u;
+  const uint32_t before_res = res_pos ? res_pos[j] : 0u;
+  const uint32_t pos = big ? big_pos[j]
+                       : res ? (n - n_res) + before_res
+                             : n_big + (j - big_pos[j] - before_res);
   order[pos] = j;
   items_ordered[pos] = items[j];
+}
+// split[0] = first item of the query-resident class, split[1] = number of items
+__global__ void hs_item_split_kernel(const uint32_t* __restrict__ item_off, const uint32_t* __restrict__ res_pos,
+                                     uint32_t n, uint32_t* __restrict__ split) {
+  if (threadIdx.x || blockIdx.x) return;
+  const uint32_t n_res = res_pos ? res_pos[n] : 0u;
+  split[0] = item_off[n - n_res];
+  split[1] = item_off[n];
 }
 
 // One descriptor (2 x uint4) per work item:
@@ -644,24 +671,30 @@ hipError_t hs_launch_seg_route(const uint64_t* d_seg_key, const uint32_t* d_seg_
                                const uint32_t* d_seg_qoff, const uint32_t* d_n_seg,
                                const uint32_t* d_sorted_ql, const uint32_t* d_qcount, uint32_t n_max,
                                uint32_t min_q, uint32_t min_m, uint32_t jm, int L, int shift,
-                               uint32_t* d_items, unsigned long long* d_stats, uint32_t* d_nslices,
-                               hipStream_t s) {
+                               uint32_t max_q_resident, uint32_t* d_items, unsigned long long* d_stats,
+                               uint32_t* d_nslices, hipStream_t s) {
   hs_seg_route_kernel<<<blocks_for((uint64_t)n_max + 1), 256, 0, s>>>(
       d_seg_key, d_seg_cnt, d_seg_qoff, d_n_seg, d_sorted_ql, d_qcount, n_max, min_q, min_m, jm, L,
-      shift, d_items, d_stats);
+      shift, max_q_resident, d_items, d_stats);
   hs_seg_unslice_kernel<<<blocks_for(n_max), 256, 0, s>>>(d_seg_qoff, d_n_seg, d_items, d_sorted_ql,
                                                          n_max, d_nslices);
   return hipGetLastError();
 }
 
 hipError_t hs_launch_seg_big(const uint32_t* d_seg_cnt, const uint32_t* d_items, uint32_t n,
-                             uint32_t min_q, uint32_t* d_big, hipStream_t s) {
-  hs_seg_big_kernel<<<blocks_for(n), 256, 0, s>>>(d_seg_cnt, d_items, n, min_q, d_big);
+                             uint32_t min_q, uint32_t max_q_resident, uint32_t* d_big, uint32_t* d_res,
+                             hipStream_t s) {
+  hs_seg_big_kernel<<<blocks_for(n), 256, 0, s>>>(d_seg_cnt, d_items, n, min_q, max_q_resident, d_big, d_res);
   return hipGetLastError();
 }
-hipError_t hs_launch_seg_order(const uint32_t* d_big_pos, const uint32_t* d_items, uint32_t n,
-                               uint32_t* d_order, uint32_t* d_items_ordered, hipStream_t s) {
-  hs_seg_order_kernel<<<blocks_for(n), 256, 0, s>>>(d_big_pos, d_items, n, d_order, d_items_ordered);
+hipError_t hs_launch_seg_order(const uint32_t* d_big_pos, const uint32_t* d_res_pos, const uint32_t* d_items,
+                               uint32_t n, uint32_t* d_order, uint32_t* d_items_ordered, hipStream_t s) {
+  hs_seg_order_kernel<<<blocks_for(n), 256, 0, s>>>(d_big_pos, d_res_pos, d_items, n, d_order, d_items_ordered);
+  return hipGetLastError();
+}
+hipError_t hs_launch_item_split(const uint32_t* d_item_off, const uint32_t* d_res_pos, uint32_t n,
+                                uint32_t* d_split, hipStream_t s) {
+  hs_item_split_kernel<<<1, 64, 0, s>>>(d_item_off, d_res_pos, n, d_split);
   return hipGetLastError();
 }
 

@@ -961,18 +961,20 @@ __device__ __forceinline__ void load_btile_x(intx4 (&B)[2][2], const uint4* __re
   B[1][1] = intx4{(int)v11.x, (int)v11.y, (int)v11.z, (int)v11.w};
 }
 
-// sign bit of the result = AND of the sign bits of a group's 4 x 2 accumulator tiles
+// sign bit of the result = AND of the sign bits of a group's 4 x NCOL accumulator tiles
+template <int NCOL = 2>
 __device__ __forceinline__ uint32_t and_tree_x(const intx4 (&acc)[4][2]) {
   uint32_t a = 0xffffffffu;
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < NCOL; ++c)
       a = a & (uint32_t)acc[t][c][0] & (uint32_t)acc[t][c][1] & (uint32_t)acc[t][c][2] & (uint32_t)acc[t][c][3];
   return a;
 }
 
-// Survivors of one group (row tiles T0 .. T0 + 3) against the 32 queries at segment-relative offset qc
+// Survivors of one group (row tiles T0 .. T0 + 3) against the 16 NCOL queries at segment-relative offset qc
+template <int NCOL = 2>
 __device__ __forceinline__ void emit_survivors_x(const intx4 (&acc)[4][2], int T0, uint32_t qc, uint32_t qoff,
                                                  uint32_t q_end, uint32_t wbase, uint32_t M, uint32_t mstart,
                                                  int lane, uint32_t& res_base, uint32_t& res_used,
@@ -982,7 +984,7 @@ __device__ __forceinline__ void emit_survivors_x(const intx4 (&acc)[4][2], int T
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < NCOL; ++c) {
       const uint32_t any = (uint32_t)acc[t][c][0] & (uint32_t)acc[t][c][1] & (uint32_t)acc[t][c][2] &
                            (uint32_t)acc[t][c][3];
       if (!__ballot((int)any >= 0)) continue;  // no survivor in this 16 x 16 tile
@@ -1238,6 +1240,201 @@ __global__ __launch_bounds__(256, 2) void hs_join8x_kernel(
     atomicMax(&g_join8_timing[7], (unsigned long long)(tlast - tstart));
   }
 #endif
+}
+
+
+// ------------------------------------------------------------------ join, query-resident form
+// Segments probed by FEW queries of the batch (<= HS_JR_MAXQ = 64: configs[2]'s shape at its swept W
+// has ~ 28 per work item, 1.7e7 work items per step).  hs_join8x_kernel treats every work item alike:
+// descriptor, member operands, then the item's query tiles streamed from L2 -- three tiles fetched per
+// item whether they exist or not, with their address arithmetic; at one or two query tiles per item
+// that fixed cost is the kernel (measured: 449 vector instructions and 51 MFMAs per item, the vector
+// pipe busier than the matrix pipe).  Here the QUERIES are the stationary operand: a segment's <= 64
+// query rows are loaded into registers once, when the wave enters the segment, and the wave then only
+// streams member tiles through them -- consecutive work items of the item list are consecutive
+// 128-member tiles of the same bucket.  Per item what remains is the member operand build, the MFMAs of
+// the 16-query column tiles that EXIST (1..4: no padding to 32 columns, no tile of a neighbour), the sign
+// test, and eight loads for the item two ahead (two register sets, so that a member tile has two item
+// times to arrive from HBM).  Same work items, descriptors, operands, filter value and survivor list as
+// hs_join8x_kernel; the item list's tail [range[0], range[1]) is this kernel's share.
+//
+// Loads and waits.  The matrix loop waits on vector-memory loads by count, in issue order.  The query
+// tiles are (re)loaded inside a branch -- segment changed -- and the compiler would charge the code
+// after the branch with a full drain; so the branch itself consumes the tiles it loaded (an empty asm
+// that reads the registers): the drain sits inside the branch, once per segment, and the common path
+// only ever waits for the member tile it is about to use.
+// One work item of hs_join8r_kernel: 128 members (MK: the lanes' eight 16-byte loads) against the NCT
+// 16-query column tiles of the resident query rows.  The members' operands are built and used in two
+// halves of four row tiles (the whole item's would not fit beside two member sets in flight): build,
+// then per 32-query tile the half's MFMAs and their sign test.  When both halves are built MK is free
+// and takes the members of the item after next (`next_members`).
+template <int NCT>
+__device__ __forceinline__ void join8r_item(uint4 (&MK)[8], const uint4* __restrict__ next_members,
+                                            const intx4 (&Bq)[2][2][2], const uint2* sPair, int q, int up,
+                                            uint32_t low_half, uint32_t qoff, uint32_t nQ, uint32_t wbase,
+                                            uint32_t M, uint32_t mstart, int lane, uint32_t& res_base,
+                                            uint32_t& res_used, uint32_t* __restrict__ prov_count,
+                                            uint32_t prov_cap, uint2* __restrict__ prov) {
+  constexpr int NT = (NCT + 1) / 2;  // 32-query tiles, the last one with one or two 16-query column tiles
+  constexpr bool ODD = (NCT & 1) != 0;
+  intx4 acc[4][2];
+  intx4 A[4][2];
+  const uint32_t bs = (20u * (uint32_t)q) & 31u;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const uint4 mk = MK[4 * half + t];
+      const uint32_t x0 = __builtin_amdgcn_permlane32_swap(mk.x, mk.y, false, false)[0];
+      const uint32_t y0 = __builtin_amdgcn_permlane32_swap(mk.y, mk.z, false, false)[0];
+      const uint32_t z0 = __builtin_amdgcn_permlane32_swap(mk.z, mk.w, false, false)[0];
+      const uint32_t w0 = mk.w & low_half;
+      const uint32_t x = __funnelshift_r(x0, y0, bs), z = __funnelshift_r(z0, w0, bs), w = w0 >> bs;
+      const uint2 p0 = sPair[x & 1023u], p1 = sPair[(x >> 10) & 1023u];
+      const uint2 p2 = sPair[(z >> 16) & 1023u], p3 = sPair[__funnelshift_r(z, w, 26) & 1023u];
+      A[t][0] = intx4{(int)p0.x, (int)p0.y, (int)p1.x, (int)p1.y};
+      const intx4 lk = intx4{(int)p2.x, (int)p2.y, (int)p3.x, (int)p3.y};
+      const intx4 own = intx4{(int)mk.x, (int)mk.y, (int)mk.z, (int)mk.w};
+      A[t][1] = up ? own : lk;  // q = 2: the member's record, q = 3: the constants it loaded
+    }
+    if (half == 1) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) MK[t] = next_members[16 * t];
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const bool one = ODD && u == NT - 1;  // this tile has a single column tile
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+            if (c == 0 || !one)
+              acc[t][c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t][s2], Bq[u][s2][c],
+                                                                s2 ? acc[t][c] : intx4{0, 0, 0, 0}, 0, 0, 0);
+      // (one accumulator set: the sign test follows its MFMAs -- the SIMD's other wave fills the matrix
+      // pipe meanwhile; a second set, to test one group beside the next one's MFMAs, does not fit beside
+      // two member sets in flight)
+      const uint32_t sG = one ? and_tree_x<1>(acc) : and_tree_x<2>(acc);
+      if (__ballot((int)sG >= 0)) {
+        if (one)
+          emit_survivors_x<1>(acc, 4 * half, 32u * (uint32_t)u, qoff, nQ, wbase, M, mstart, lane, res_base, res_used,
+                              prov_count, prov_cap, prov);
+        else
+          emit_survivors_x<2>(acc, 4 * half, 32u * (uint32_t)u, qoff, nQ, wbase, M, mstart, lane, res_base, res_used,
+                              prov_count, prov_cap, prov);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void hs_join8r_kernel(
+    const uint4* __restrict__ desc, const uint32_t* __restrict__ range, uint32_t desc_cap,
+    const uint4* __restrict__ packed_base, const uint4* __restrict__ rec_base, const uint4* __restrict__ c8t,
+    const uint4* __restrict__ tab8, const uint4* __restrict__ cn_rep, uint32_t* __restrict__ prov_count,
+    uint32_t prov_cap, uint2* __restrict__ prov, uint32_t* __restrict__ item_counter, uint32_t G) {
+  const uint32_t first = __builtin_amdgcn_readfirstlane(range[0]);
+  const uint32_t n_items = min(__builtin_amdgcn_readfirstlane(range[1]), desc_cap);  // (absolute) end of the list
+  __shared__ uint2 sPair[1024];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, q = lane >> 4, up = lane >> 5;
+  for (int e = tid; e < 1024; e += 256) sPair[e] = make_uint2(tab8[e & 31].x, tab8[e >> 5].x);
+  __syncthreads();  // the only one: the table is read-only from here on
+  const uint32_t first_dynamic = first + gridDim.x * 4u * G;
+  uint32_t item = first + (blockIdx.x * 4u + (uint32_t)wave) * G;
+  if (item >= n_items) return;
+  uint32_t res_base = 0, res_used = JRES;
+  uint32_t next_chunk_v = 0;
+  if (lane == 0) next_chunk_v = atomicAdd(item_counter, G);
+  uint32_t pf_item = item, pf_chunk_end = item + G;
+#define HS_ADVANCE_PF()                                                                  \
+  {                                                                                      \
+    ++pf_item;                                                                           \
+    if (pf_item == pf_chunk_end) {                                                       \
+      pf_item = first_dynamic + __builtin_amdgcn_readfirstlane(next_chunk_v);            \
+      pf_chunk_end = pf_item + G;                                                        \
+      if (lane == 0 && pf_item < n_items) next_chunk_v = atomicAdd(item_counter, G);     \
+    }                                                                                    \
+  }
+  // descriptors of the current item, the next one and the one after (whose members are fetched now)
+  uint4 d0 = uniform4(desc[2 * (uint64_t)item]), d1 = uniform4(desc[2 * (uint64_t)item + 1]);
+  HS_ADVANCE_PF()
+  uint32_t next_item = pf_item;
+  uint4 nd0 = d0, nd1 = d1;
+  if (next_item < n_items) {
+    nd0 = uniform4(desc[2 * (uint64_t)next_item]);
+    nd1 = uniform4(desc[2 * (uint64_t)next_item + 1]);
+  }
+  // Member loads: lane (n, q) of row tile t takes entry e0 + 16 t + n of the packed array (q = 0, 1: the
+  // two quarters need the same 16 bytes), of the record array (q = 2), or -- q = 3 -- the constant factors
+  // of the gamma slots, from a block that repeats them 128 times so that the same offsets apply.  One
+  // 64-bit base per lane and item, eight loads at immediate offsets.  No clamping at a bucket's ragged
+  // end: the rows past it read the next bucket's entries (the arrays are padded by 128 entries) and
+  // are masked when survivors are emitted.
+  const uint4* const lane_base = (q == 3 ? cn_rep : (up ? rec_base : packed_base)) + n;
+  const int64_t lane_mask = q == 3 ? 0 : -1;
+#define HS_LOAD_MEMBERS_R(MK, D0)                                                                   \
+  {                                                                                                 \
+    const int64_t e0_ = (int64_t)(((uint64_t)(D0).y << 32) | (uint64_t)(D0).x) + (int64_t)(D0).w * 128; \
+    const uint4* p_ = lane_base + (e0_ & lane_mask);                                                \
+    _Pragma("unroll") for (int t = 0; t < 8; ++t) MK[t] = p_[16 * t];                                \
+  }
+  uint4 mkA[8], mkB[8];
+  intx4 Bq[2][2][2];
+  HS_LOAD_MEMBERS_R(mkA, d0)
+  HS_LOAD_MEMBERS_R(mkB, nd0)
+  uint32_t cur_qoff = 0xffffffffu;
+  const uint32_t low_half = up ? 0u : 0xffffffffu;
+  bool has_next;
+#define HS_ITEM_STEP(MK)                                                                                       \
+  {                                                                                                            \
+    const uint32_t M = d0.z, mt = d0.w;                                                                        \
+    const uint32_t qoff = d1.x, nQ = d1.z, mstart = d1.w;                                                      \
+    const uint32_t wbase = mt * 128u;                                                                          \
+    has_next = next_item < n_items;                                                                            \
+    HS_ADVANCE_PF() /* pf_item = the item after next */                                                        \
+    uint4 nnd0 = d0, nnd1 = d1;                                                                                \
+    if (pf_item < n_items) {                                                                                   \
+      nnd0 = uniform4(desc[2 * (uint64_t)pf_item]);                                                            \
+      nnd1 = uniform4(desc[2 * (uint64_t)pf_item + 1]);                                                        \
+    }                                                                                                          \
+    if (qoff != cur_qoff) { /* a new segment: its query rows into registers, and wait for them HERE */         \
+      cur_qoff = qoff;                                                                                         \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                          \
+        const uint32_t qu_ = 32u * u < nQ ? 32u * u : 0u;                                                      \
+        load_btile_x(Bq[u], c8t, qoff + qu_, min(32u, nQ - qu_), lane);                                        \
+      }                                                                                                        \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                            \
+        asm volatile("" ::"v"(Bq[u][0][0]), "v"(Bq[u][0][1]), "v"(Bq[u][1][0]), "v"(Bq[u][1][1]));             \
+    }                                                                                                          \
+    /* members of the item after next: their address now, the loads when MK has been consumed */             \
+    const int64_t e2_ = (int64_t)(((uint64_t)nnd0.y << 32) | (uint64_t)nnd0.x) + (int64_t)nnd0.w * 128;         \
+    const uint4* nm_ = lane_base + (e2_ & lane_mask);                                                          \
+    switch ((nQ + 15u) >> 4) {                                                                                 \
+      case 1: join8r_item<1>(MK, nm_, Bq, sPair, q, up, low_half, qoff, nQ, wbase, M, mstart, lane, res_base, res_used, prov_count, prov_cap, prov); break; \
+      case 2: join8r_item<2>(MK, nm_, Bq, sPair, q, up, low_half, qoff, nQ, wbase, M, mstart, lane, res_base, res_used, prov_count, prov_cap, prov); break; \
+      case 3: join8r_item<3>(MK, nm_, Bq, sPair, q, up, low_half, qoff, nQ, wbase, M, mstart, lane, res_base, res_used, prov_count, prov_cap, prov); break; \
+      default: join8r_item<4>(MK, nm_, Bq, sPair, q, up, low_half, qoff, nQ, wbase, M, mstart, lane, res_base, res_used, prov_count, prov_cap, prov); break; \
+    }                                                                                                          \
+    item = next_item;                                                                                          \
+    next_item = pf_item;                                                                                       \
+    d0 = nd0;                                                                                                  \
+    d1 = nd1;                                                                                                  \
+    nd0 = nnd0;                                                                                                \
+    nd1 = nnd1;                                                                                                \
+  }
+  for (;;) {
+    HS_ITEM_STEP(mkA)
+    if (!has_next) break;
+    HS_ITEM_STEP(mkB)
+    if (!has_next) break;
+  }
+#undef HS_ITEM_STEP
+#undef HS_LOAD_MEMBERS_R
+#undef HS_ADVANCE_PF
+  close_reservation(prov, res_base, res_used, prov_cap, lane);
 }
 
 // Thin segments (too few probing queries or members for MFMA tiles) with the int8 join on: the SAME
@@ -1584,6 +1781,29 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_join8_timing), t, sizeof(t));
   }
 #endif
+  return hipGetLastError();
+}
+
+// The tail [d_split[0], d_split[1]) of the item list -- the segments with at most HS_JR_MAXQ probing
+// queries, k <= 25, 4-column rows -- through the query-resident kernel.  d_cn_rep: the constant factors
+// of the gamma slots, 128 times over (2 KB).  *d_item_counter zeroed by the caller.
+hipError_t hs_launch_join8r(const uint4* d_desc, uint32_t desc_cap, const uint32_t* d_split,
+                            const uint4* d_packed_base, const uint4* d_rec_base, const void* d_c8t,
+                            const void* d_tab8, const void* d_cn_rep, uint32_t* d_prov_count, uint32_t prov_cap,
+                            uint2* d_prov, uint32_t* d_item_counter, int n_blocks, double pairs_per_item,
+                            hipStream_t s) {
+  if (!desc_cap) return hipSuccess;
+  // chunks of consecutive items = consecutive member tiles of one bucket (the query rows stay); sized like
+  // hs_launch_join8w's, from the previous batch's pairs per item
+  static const uint32_t g_env = getenv("HS_JOIN_CHUNK_R") ? (uint32_t)atoi(getenv("HS_JOIN_CHUNK_R")) : 0u;
+  uint32_t G = 16u;
+  if (pairs_per_item > 0.0) G = (uint32_t)std::max(8.0, std::min(64.0, 1.4e5 / pairs_per_item * 8.0));
+  const uint32_t n_waves = (uint32_t)n_blocks * 4u;
+  G = std::max(2u, std::min(G, std::max(2u, desc_cap / (n_waves * 32u))));
+  if (g_env) G = g_env;
+  hs_join8r_kernel<<<n_blocks, 256, 0, s>>>(d_desc, d_split, desc_cap, d_packed_base, d_rec_base, (const uint4*)d_c8t,
+                                            (const uint4*)d_tab8, (const uint4*)d_cn_rep, d_prov_count, prov_cap,
+                                            d_prov, d_item_counter, G);
   return hipGetLastError();
 }
 

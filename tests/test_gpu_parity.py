@@ -825,3 +825,41 @@ def test_queries_as_codes_in_batches_and_custom_table(oracle, monkeypatch):
     with pytest.raises(capi.HsError):
         eng.query_codes(bad, R)
     eng.close()
+
+
+@pytest.mark.parametrize("K,W,nq", [(2, 400.0, 3000), (3, 300.0, 1203), (5, 160.0, 6000), (8, 150.0, 900)])
+def test_query_resident_and_query_streaming_join_kernels(oracle, monkeypatch, K, W, nq):
+    """k <= 25 with 4-column rows: segments (bucket x the batch's queries probing it) with at most 64
+    probing queries go through hs_join8r_kernel (query rows resident in registers, member tiles
+    streamed, 16-query column tiles), the others through hs_join8x_kernel (member operands resident,
+    query tiles streamed).  Coarse to fine keys give segments of every class -- 1..16, 17..32, 33..48,
+    49..64 and more queries; buckets of one member up to thousands, ragged last tiles -- and both
+    routings (default; HS_NO_JOIN_R: everything through the streaming kernel) must give the oracle's
+    candidates, hits, order and distances, also with several query batches per call."""
+    k, L, R, n = 25, 4, 44.0, 30011
+    a, b = synth.make_planes(k, K, L, W, seed=95)
+    codes = synth.make_db(n, k, seed=96)
+    centers, _ = synth.make_queries(codes, nq, seed=97, jitter=0.2)
+    want = oracle.search(a, b, W, R, oracle.embed_codes(codes), centers)
+    assert len(want["q"]) > 300
+    seen = {}
+    for routing in ("default", "no_r", "batches"):
+        monkeypatch.delenv("HS_NO_JOIN_R", raising=False)
+        monkeypatch.delenv("HS_QUERY_BATCH", raising=False)
+        if routing == "no_r":
+            monkeypatch.setenv("HS_NO_JOIN_R", "1")
+        if routing == "batches":
+            monkeypatch.setenv("HS_QUERY_BATCH", "257")
+        eng = Engine(k, K, L, W, a, b)
+        eng.index_build(codes)
+        eng.set_verify_mode("join")
+        for rep in range(2):          # the second call runs on the first one's capacity hint (no host round trip)
+            got = eng.query(centers, R)
+            assert np.array_equal(got["cand"], want["cand"]), (routing, rep)
+            _assert_hits_equal(got, want)
+        p = eng.profile()
+        assert p["join_i8_batches"] > 0 and p["join_pairs"] > 0
+        seen[routing] = (p["join_pairs"], p["join_pairs_issued"])
+        eng.close()
+    # the same pairs either way; the resident kernel issues 16-query column tiles: no more padding, mostly less
+    assert seen["default"][0] == seen["no_r"][0] and seen["default"][1] <= seen["no_r"][1]

@@ -256,9 +256,10 @@ def test_cli_gpus_planes_file_and_kmer_centres(tmp_path, oracle):
     assert r.returncode == 1 and "GPU" in r.stderr
     # FASTA database through the sharded path
     fa = str(tmp_path / "db.fa")
-    with open(fa, "w") as f:
+    with open(fa, "w") as f:   # proteins made of the centres' own k-mers (+ other DB k-mers): every centre has hits
         for i in range(6):
-            f.write(">prot%d x\n%s\n" % (i, "".join(letters[c] for c in rng.integers(0, 20, size=200))))
+            rows = np.concatenate([qcodes[20 * i:20 * i + 20], codes[40 * i:40 * i + 8]])
+            f.write(">prot%d x\n%s\n" % (i, "".join(letters[c] for c in rows.ravel())))
     p1, _ = run("fa_plain", "-d", fa, "-c", cen, "--planes", planes)
     p2, _ = run("fa_gpus1", "-d", fa, "-c", cen, "--planes", planes, "--gpus", "1")
     assert p1 == p2
@@ -293,9 +294,10 @@ def test_cli_two_rank_threads_with_live_handles_over_loopback(tmp_path, oracle):
         for i, row in enumerate(qcodes):
             f.write("c%d\n" % i + " ".join("%.17g" % v for v in oracle.embed_codes(row[None])[0]) + "\n")
             g.write(">c%d\n%s\n" % (i, "".join(letters[c] for c in row)))
-    with open(fa, "w") as f:
-        for i in range(6):
-            f.write(">prot%d x\n%s\n" % (i, "".join(letters[c] for c in rng.integers(0, 20, size=200))))
+    with open(fa, "w") as f:   # proteins made of the centres' own k-mers (+ other DB k-mers): every centre has hits
+        for i in range(11):
+            rows = np.concatenate([qcodes[11 * i:11 * i + 11], codes[50 * i:50 * i + 8]])
+            f.write(">prot%d x\n%s\n" % (i, "".join(letters[c] for c in rows.ravel())))
     common = ["-l", str(k), "-K", str(K), "-L", str(L), "-W", repr(W), "-T", repr(R), "--seed", str(seed)]
 
     def run(out, *extra, binary=None, env=None, ok=True):

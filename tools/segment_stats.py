@@ -1,10 +1,13 @@
-"""Distribution of the C2 join work over segments (bucket x probing queries): where do pairs and
-A-operand builds go?  Host-side analysis on top of the C ABI (hash_points + cand)."""
+"""Distribution of the join work over segments (bucket x the queries of the batch that probe it): where
+do pairs, work items (128 members) and issued MFMA columns go?  Host-side analysis on top of the C ABI
+(hash_points + cand).  argv: n L K W nq  (default: configs[2]'s per-GPU shape at W = 160)."""
 import sys
 import numpy as np
 sys.path.insert(0, '.')
 from hsearch_amd import Engine, synth
-k, K, L, W, R, n, nq = 25, 16, 8, 200.0, 40.0, 10_000_000, 100_000
+a_ = sys.argv[1:]
+n, L, K, W, nq = (int(a_[0]), int(a_[1]), int(a_[2]), float(a_[3]), int(a_[4])) if len(a_) >= 5 else (100_000_000, 32, 20, 160.0, 125_000)
+k, R = 25, 40.0
 a, b = synth.make_planes(k, K, L, W); codes = synth.make_db(n, k); centers, _ = synth.make_queries(codes, nq)
 eng = Engine(k, K, L, W, a, b); eng.index_build(codes)
 ints = eng.hash_points(centers)                  # [nq][L][K]
@@ -19,16 +22,20 @@ for l in range(L):
 segs = np.concatenate(segs); segs = segs[segs[:, 0] > 0]
 M, Q = segs[:, 0], segs[:, 1]
 pairs = M * Q
-builds = np.ceil(M / 128) * np.ceil(Q / 2048)     # wave-level A builds (128 members each)
-print("segments", len(segs), "pairs %.3e" % pairs.sum(), "wave A-builds %.3e" % builds.sum())
-for lo, hi in [(1, 2), (3, 7), (8, 31), (32, 127), (128, 511), (512, 2047), (2048, 10**9)]:
+items = np.ceil(M / 128) * np.ceil(Q / 8192)
+tiles32 = np.ceil(M / 128) * np.ceil(Q / 32)      # 32-column query tiles issued today
+tiles16 = np.ceil(M / 128) * np.ceil(Q / 16)      # 16-column granularity
+print("segments %d  probes %d  pairs %.3e  items(128) %.3e  issued/useful: 32-col %.2f, 16-col %.2f" % (
+    len(segs), Q.sum(), pairs.sum(), items.sum(), tiles32.sum() * 128 * 32 / pairs.sum(), tiles16.sum() * 128 * 16 / pairs.sum()))
+print("by queries per segment:")
+for lo, hi in [(1, 1), (2, 4), (5, 8), (9, 16), (17, 32), (33, 48), (49, 64), (65, 96), (97, 256), (257, 10**9)]:
     m = (Q >= lo) & (Q <= hi)
-    print("nQ %5d..%-9d segs %7d  pairs %5.1f%%  builds %5.1f%%  mean M %8.0f" % (lo, hi, m.sum(), 100 * pairs[m].sum() / pairs.sum(), 100 * builds[m].sum() / builds.sum(), M[m].mean() if m.any() else 0))
-# wave-item view (128 members x <= 2048 queries per item): items and 32-query tiles per class
-j = (Q >= 3) & (M >= 16)
-items = np.ceil(M / 128) * np.ceil(Q / 2048)
-tiles = np.ceil(M / 128) * np.ceil(Q / 32)
-print("joined: items %.3e tiles %.3e" % (items[j].sum(), tiles[j].sum()))
-for lo, hi in [(3, 32), (33, 96), (97, 256), (257, 512), (513, 2048), (2049, 10**9)]:
-    m = j & (Q >= lo) & (Q <= hi)
-    print("nQ %5d..%-9d items %5.1f%%  tiles %5.1f%%  tiles/item %6.1f" % (lo, hi, 100 * items[m].sum() / items[j].sum(), 100 * tiles[m].sum() / tiles[j].sum(), tiles[m].sum() / max(1, items[m].sum())))
+    print("  nQ %4d..%-10d segs %8d  pairs %5.1f%%  items %5.1f%%  tiles32 %5.1f%%  mean M %9.0f" % (
+        lo, hi, m.sum(), 100 * pairs[m].sum() / pairs.sum(), 100 * items[m].sum() / items.sum(),
+        100 * tiles32[m].sum() / tiles32.sum(), M[m].mean() if m.any() else 0))
+print("by members per segment:")
+for lo, hi in [(1, 16), (17, 128), (129, 512), (513, 2048), (2049, 8192), (8193, 32768), (32769, 10**9)]:
+    m = (M >= lo) & (M <= hi)
+    print("  M %6d..%-10d segs %8d  pairs %5.1f%%  items %5.1f%%  mean nQ %7.1f  row fill %4.2f" % (
+        lo, hi, m.sum(), 100 * pairs[m].sum() / pairs.sum(), 100 * items[m].sum() / items.sum(), Q[m].mean() if m.any() else 0,
+        M[m].sum() / (np.ceil(M[m] / 128) * 128).sum() if m.any() else 0))
