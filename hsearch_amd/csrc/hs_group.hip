@@ -1,0 +1,412 @@
+// hs_group.hip -- index build, SURVEY 8(a) a7: grouping one table's n k-mers by their HashKey.
+//
+// The reference inserts every k-mer into an unordered_map keyed by the HashKey string
+// (motif_both_points.cpp:212-218, hclust2.cpp:74-84).  The index wants, per table, the ids grouped by
+// key -- ascending inside a bucket -- and the distinct keys' fingerprints in ascending order (the
+// directory a probe searches).  Round 1 / 2 radix-sorted all n (64-bit fingerprint, id) pairs with
+// rocPRIM: 6 - 8 passes of 24 bytes per pair at ~ 0.8 TB/s on this part (ROCm 7.2 ships no gfx950
+// tuning for it), two thirds of the build's device time.
+//
+// Buckets are FEW (10^5 of 10^7 k-mers at configs[1], 4 10^6 of 10^8 at configs[2]'s shape) and very
+// skewed (the largest holds 6.5 % of the database), so here the fingerprints are never sorted as such:
+//   1. every k-mer's fingerprint goes into an open-addressing table (one 8-byte slot read per k-mer in
+//      the common case -- the hot buckets' slots stay in L2 -- and one CAS per DISTINCT key); the k-mer
+//      keeps its slot number;
+//   2. the distinct fingerprints are compacted out of the table and sorted -- nb of them, a small sort
+//      (rocPRIM, on all 64 bits) -- which gives every slot the RANK of its key in the directory;
+//   3. the k-mers carry 32-bit ranks now: a stable LSD radix sort of (rank, id) over ceil(log2 nb) bits,
+//      8 bits per pass, written here (histogram per 4096-element tile, one scan over digits x tiles,
+//      stable scatter through an LDS-staged tile): 2 - 3 passes of 20 bytes per pair;
+//   4. bucket boundaries fall out of the sorted ranks; every k-mer's bucket ints are then compared with
+//      its bucket's tuple (identical in the common case, by HashKey string otherwise: aliased strings
+//      share a fingerprint by construction, a fingerprint collision is reported and the build repeated
+//      with the next seed) -- the exact-string-equality proof of hs_check_runs_kernel, without the
+//      dependence on sorted neighbours.
+// Skew does not matter to any step: the hot key's k-mers read one cached slot, and the LSD passes count
+// digits of ranks.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "hs_internal.h"
+
+namespace {
+
+constexpr uint64_t FP_EMPTY = ~0ull;
+constexpr int RS_BITS = 8, RS_BINS = 1 << RS_BITS;
+constexpr uint32_t RS_TILE = 4096;  // elements per block of the radix passes: 256 threads x 16
+
+inline unsigned blocks_for(uint64_t n, unsigned per = 256) { return (unsigned)((n + per - 1) / per); }
+
+// ---- 1. fingerprints -> slots of an open-addressing table ------------------------------------------
+// T[C] (C a power of two >= n / 2, zero ... all FP_EMPTY at entry), slot = top bits of the fingerprint,
+// linear probing.  slot_of[i] = the slot that holds keys[i].  The slot is read with an L2-coherent load
+// first: the hot bucket's thousands of k-mers per wave would otherwise all CAS the same address.
+__global__ __launch_bounds__(256) void hs_fp_insert_kernel(const uint64_t* __restrict__ keys, uint64_t n,
+                                                           uint64_t* __restrict__ T, uint32_t cmask, int shift,
+                                                           uint32_t* __restrict__ slot_of,
+                                                           uint32_t* __restrict__ flag) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k = keys[i];
+  if (k == FP_EMPTY) {  // the one value the table cannot hold (2^-64 per key): the caller falls back
+    atomicOr(flag, 8u);
+    slot_of[i] = 0;
+    return;
+  }
+  uint32_t s = (uint32_t)(k >> shift) & cmask;
+  // (bounded: with the table at most ~ half full a chain of thousands does not occur; a build whose keys
+  // are nearly all distinct -- a tiny W -- ends here and takes the sorting path)
+  const uint32_t max_probe = cmask < 4095u ? cmask : 4095u;
+  for (uint32_t probe = 0; probe <= max_probe; ++probe) {
+    uint64_t v = __hip_atomic_load(&T[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v == FP_EMPTY) {
+      v = atomicCAS(reinterpret_cast<unsigned long long*>(&T[s]), (unsigned long long)FP_EMPTY, (unsigned long long)k);
+      if (v == FP_EMPTY) v = k;
+    }
+    if (v == k) {
+      slot_of[i] = s;
+      return;
+    }
+    s = (s + 1) & cmask;
+  }
+  atomicOr(flag, 16u);  // table (nearly) full: the caller falls back
+  slot_of[i] = 0;
+}
+
+// ---- 2. distinct keys out of the table ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void hs_fp_count_kernel(const uint64_t* __restrict__ T, uint32_t C,
+                                                          uint32_t* __restrict__ blk_cnt) {
+  // one block per 1024 slots
+  const uint32_t base = blockIdx.x * 1024u;
+  uint32_t c = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t s = base + threadIdx.x + 256u * j;
+    c += (s < C && T[s] != FP_EMPTY) ? 1u : 0u;
+  }
+  for (int off = 32; off; off >>= 1) c += __shfl_xor(c, off);
+  __shared__ uint32_t sw[4];
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = sw[0] + sw[1] + sw[2] + sw[3];
+}
+
+__global__ __launch_bounds__(256) void hs_fp_compact_kernel(const uint64_t* __restrict__ T, uint32_t C,
+                                                            const uint32_t* __restrict__ blk_off,
+                                                            uint64_t* __restrict__ dk, uint32_t* __restrict__ ds) {
+  const uint32_t base = blockIdx.x * 1024u;
+  __shared__ uint32_t s_run;
+  if (threadIdx.x == 0) s_run = blk_off[blockIdx.x];
+  __syncthreads();
+  __shared__ uint32_t sw[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {  // 256 consecutive slots per round, in slot order
+    const uint32_t s = base + 256u * j + threadIdx.x;
+    const uint64_t v = s < C ? T[s] : FP_EMPTY;
+    const bool live = v != FP_EMPTY;
+    const unsigned long long m = __ballot(live);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sw[w] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t before = 0;
+    for (int x = 0; x < w; ++x) before += sw[x];
+    const uint32_t total = sw[0] + sw[1] + sw[2] + sw[3];
+    if (live) {
+      const uint32_t o = s_run + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      dk[o] = v;
+      ds[o] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_run += total;
+    __syncthreads();
+  }
+}
+
+// rank_of_slot[ds_sorted[r]] = r
+__global__ __launch_bounds__(256) void hs_rank_slots_kernel(const uint32_t* __restrict__ ds_sorted, uint32_t nb,
+                                                            uint32_t* __restrict__ rank_of_slot) {
+  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+  if (r < nb) rank_of_slot[ds_sorted[r]] = r;
+}
+
+// slot_of[i] <- rank of k-mer i's key (in place)
+__global__ __launch_bounds__(256) void hs_rank_kmers_kernel(uint32_t* __restrict__ slot_of, uint64_t n,
+                                                            const uint32_t* __restrict__ rank_of_slot) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) slot_of[i] = rank_of_slot[slot_of[i]];
+}
+
+// ---- 3. stable LSD radix pass over (rank, id): 8 bits ------------------------------------------------
+// hist[d * n_tiles + tile] = elements of the tile with digit d
+__global__ __launch_bounds__(256) void hs_rs_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift,
+                                                         uint32_t n_tiles, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[RS_BINS];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * RS_TILE;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const uint32_t e = base + 256u * j + threadIdx.x;
+    if (e < n) atomicAdd(&h[(keys[e] >> shift) & (RS_BINS - 1)], 1u);
+  }
+  __syncthreads();
+  hist[(uint64_t)threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// Element order inside a tile (= the order the sort must keep): wave w holds elements w * 1024 ..
+// w * 1024 + 1023 in 16 chunks of 64 consecutive elements.  Rank of an element among the tile's
+// elements with its digit = (elements of earlier waves) + (of earlier chunks of its wave) + (of
+// lower lanes of its chunk: a ballot per digit bit).
+__global__ __launch_bounds__(256) void hs_rs_scatter_kernel(const uint32_t* __restrict__ keys_in,
+                                                            const uint32_t* __restrict__ ids_in /* null: iota */,
+                                                            uint32_t n, int shift, uint32_t n_tiles,
+                                                            const uint32_t* __restrict__ hist_scanned,
+                                                            uint32_t* __restrict__ keys_out,
+                                                            uint32_t* __restrict__ ids_out) {
+  __shared__ uint32_t wh[4][RS_BINS];   // per wave: running count per digit, then the wave's exclusive prefix
+  __shared__ uint32_t tstart[RS_BINS];  // tile-local start of every digit's run
+  __shared__ uint32_t gbase[RS_BINS];   // global start of the tile's run of every digit
+  __shared__ uint2 stage[RS_TILE];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int d = tid; d < 4 * RS_BINS; d += 256) (&wh[0][0])[d] = 0;
+  gbase[tid] = hist_scanned[(uint64_t)tid * n_tiles + blockIdx.x];
+  __syncthreads();
+  const uint32_t base = blockIdx.x * RS_TILE + (uint32_t)w * 1024u;
+  uint32_t key[16], id[16], loc[16];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const uint32_t e = base + 64u * c + (uint32_t)lane;
+    const bool live = e < n;
+    key[c] = live ? keys_in[e] : 0xffffffffu;
+    id[c] = live ? (ids_in ? ids_in[e] : e) : 0xffffffffu;
+  }
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    // (elements past the end count as digit 255: they sit at the very end of the last tile, so every
+    // live element of that digit ranks before them, and they are not written)
+    const uint32_t e = base + 64u * c + (uint32_t)lane;
+    const uint32_t d = e < n ? (key[c] >> shift) & (RS_BINS - 1) : (uint32_t)(RS_BINS - 1);
+    unsigned long long m = ~0ull;
+#pragma unroll
+    for (int b = 0; b < RS_BITS; ++b) {
+      const unsigned long long bal = __ballot((d >> b) & 1u);
+      m &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    const uint32_t before = wh[w][d];  // (every lane of the digit reads it before its leader adds)
+    const uint32_t rank = (uint32_t)__popcll(m & lt);
+    __builtin_amdgcn_wave_barrier();
+    if (rank == 0) wh[w][d] = before + (uint32_t)__popcll(m);
+    __builtin_amdgcn_wave_barrier();
+    loc[c] = before + rank;
+  }
+  __syncthreads();
+  {  // per digit: the waves' counts -> exclusive prefix over the waves; tile total
+    const uint32_t c0 = wh[0][tid], c1 = wh[1][tid], c2 = wh[2][tid], c3 = wh[3][tid];
+    wh[0][tid] = 0;
+    wh[1][tid] = c0;
+    wh[2][tid] = c0 + c1;
+    wh[3][tid] = c0 + c1 + c2;
+    tstart[tid] = c0 + c1 + c2 + c3;
+  }
+  __syncthreads();
+  if (w == 0) {  // exclusive scan of the 256 tile totals by one wave: 4 digits per lane
+    uint32_t v[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] = tstart[4 * lane + j];
+      sum += v[j];
+    }
+    uint32_t inc = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = __shfl_up(inc, off);
+      if (lane >= off) inc += o;
+    }
+    uint32_t run = inc - sum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      tstart[4 * lane + j] = run;
+      run += v[j];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const uint32_t e = base + 64u * c + (uint32_t)lane;
+    if (e < n) {
+      const uint32_t d = (key[c] >> shift) & (RS_BINS - 1);
+      stage[tstart[d] + wh[w][d] + loc[c]] = make_uint2(key[c], id[c]);
+    }
+  }
+  __syncthreads();
+  const uint32_t live_in_tile = min(RS_TILE, n - blockIdx.x * RS_TILE);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const uint32_t p = 256u * j + (uint32_t)tid;
+    if (p < live_in_tile) {
+      const uint2 v = stage[p];
+      const uint32_t d = (v.x >> shift) & (RS_BINS - 1);
+      const uint32_t o = gbase[d] + (p - tstart[d]);
+      keys_out[o] = v.x;
+      ids_out[o] = v.y;
+    }
+  }
+}
+
+// ---- 4. boundaries, bucket sizes, the string-equality proof ------------------------------------------
+__global__ __launch_bounds__(256) void hs_dir_start_kernel(const uint32_t* __restrict__ ranks_sorted, uint32_t n,
+                                                           uint32_t nb, uint32_t* __restrict__ dir_start) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) dir_start[nb] = n;
+  if (i >= n) return;
+  const uint32_t r = ranks_sorted[i];
+  if (i == 0 || ranks_sorted[i - 1] != r) dir_start[r] = i;
+}
+
+__global__ __launch_bounds__(256) void hs_dir_max_kernel(const uint32_t* __restrict__ dir_start, uint32_t nb,
+                                                         uint32_t* __restrict__ out_max) {
+  uint32_t m = 0;
+  for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < nb; r += gridDim.x * 256) m = max(m, dir_start[r + 1] - dir_start[r]);
+  for (int off = 32; off; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out_max, m);
+}
+
+// Every k-mer against its bucket's tuple (the tuple of the bucket's first member, dir_tuple[rank]): the
+// identical case is settled here; a k-mer whose ints differ from the tuple's -- aliased strings, or a
+// fingerprint collision -- is queued (slow[0] = count, slow[1..] = k-mer numbers) for the string compare.
+__global__ __launch_bounds__(256) void hs_check_members_kernel(const uint32_t* __restrict__ rank, uint64_t n,
+                                                               const int32_t* __restrict__ ints, int K,
+                                                               const int32_t* __restrict__ dir_tuple,
+                                                               uint32_t* __restrict__ slow, uint32_t slow_cap) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int32_t* px = ints + i * (uint64_t)K;
+  const int32_t* py = dir_tuple + (uint64_t)rank[i] * K;
+  bool same = true;
+  if ((K & 3) == 0) {
+    int4 vx[HS_MAX_K / 4], vy[HS_MAX_K / 4];
+#pragma unroll
+    for (int j4 = 0; j4 < HS_MAX_K / 4; ++j4)
+      if (4 * j4 < K) {
+        vx[j4] = reinterpret_cast<const int4*>(px)[j4];
+        vy[j4] = reinterpret_cast<const int4*>(py)[j4];
+      }
+#pragma unroll
+    for (int j4 = 0; j4 < HS_MAX_K / 4; ++j4)
+      if (4 * j4 < K)
+        same = same && vx[j4].x == vy[j4].x && vx[j4].y == vy[j4].y && vx[j4].z == vy[j4].z && vx[j4].w == vy[j4].w;
+  } else {
+    for (int j = 0; j < K; ++j) same = same && (px[j] == py[j]);
+  }
+  if (same) return;
+  const uint32_t at = atomicAdd(slow, 1u);
+  if (at < slow_cap) slow[1 + at] = (uint32_t)i;
+}
+
+// flag |= 1: equal fingerprints, different key strings (a collision); flag |= 2: the queue overflowed
+// (the caller repeats with exhaustive = true: every k-mer compared as strings)
+__global__ __launch_bounds__(256) void hs_check_members_slow_kernel(const uint32_t* __restrict__ rank, uint64_t n_all,
+                                                                    const int32_t* __restrict__ ints, int K,
+                                                                    const int32_t* __restrict__ dir_tuple,
+                                                                    const uint32_t* __restrict__ slow,
+                                                                    uint32_t slow_cap, uint32_t* __restrict__ flag) {
+  const uint64_t total = n_all ? n_all : min(slow[0], slow_cap);
+  if (!n_all && slow[0] > slow_cap) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(flag, 2u);
+    return;
+  }
+  for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (uint64_t)gridDim.x * 256) {
+    const uint64_t i = n_all ? t : slow[1 + t];
+    int32_t x[HS_MAX_K], y[HS_MAX_K];
+    const int32_t* px = ints + i * (uint64_t)K;
+    const int32_t* py = dir_tuple + (uint64_t)rank[i] * K;
+    for (int j = 0; j < K; ++j) {
+      x[j] = px[j];
+      y[j] = py[j];
+    }
+    if (!hs_key_equal(x, y, K)) atomicOr(flag, 1u);
+  }
+}
+
+}  // namespace
+
+// slots of the fingerprint table for n k-mers: a power of two >= n (load factor = distinct keys / slots
+// <= 1 always, a few per cent on the benchmark shapes)
+uint32_t hs_group_table_slots(uint64_t n) {
+  uint32_t c = 1024;
+  while ((uint64_t)c < n && c < (1u << 31)) c <<= 1;
+  return c;
+}
+
+hipError_t hs_launch_fp_insert(const uint64_t* d_keys, uint64_t n, uint64_t* d_table, uint32_t C,
+                               uint32_t* d_slot_of, uint32_t* d_flag, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(d_table, 0xff, (size_t)C * 8, s);
+  if (e != hipSuccess || !n) return e;
+  int log2c = 0;
+  while ((1u << log2c) < C) ++log2c;
+  hs_fp_insert_kernel<<<blocks_for(n), 256, 0, s>>>(d_keys, n, d_table, C - 1, 64 - log2c, d_slot_of, d_flag);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_fp_count(const uint64_t* d_table, uint32_t C, uint32_t* d_blk_cnt, hipStream_t s) {
+  hs_fp_count_kernel<<<(C + 1023) / 1024, 256, 0, s>>>(d_table, C, d_blk_cnt);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_fp_compact(const uint64_t* d_table, uint32_t C, const uint32_t* d_blk_off, uint64_t* d_dk,
+                                uint32_t* d_ds, hipStream_t s) {
+  hs_fp_compact_kernel<<<(C + 1023) / 1024, 256, 0, s>>>(d_table, C, d_blk_off, d_dk, d_ds);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_rank_slots(const uint32_t* d_ds_sorted, uint32_t nb, uint32_t* d_rank_of_slot, hipStream_t s) {
+  if (!nb) return hipSuccess;
+  hs_rank_slots_kernel<<<blocks_for(nb), 256, 0, s>>>(d_ds_sorted, nb, d_rank_of_slot);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_rank_kmers(uint32_t* d_slot_of, uint64_t n, const uint32_t* d_rank_of_slot, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hs_rank_kmers_kernel<<<blocks_for(n), 256, 0, s>>>(d_slot_of, n, d_rank_of_slot);
+  return hipGetLastError();
+}
+
+uint32_t hs_rs_tiles(uint64_t n) { return (uint32_t)((n + RS_TILE - 1) / RS_TILE); }
+
+hipError_t hs_launch_rs_hist(const uint32_t* d_keys, uint32_t n, int shift, uint32_t* d_hist, hipStream_t s) {
+  const uint32_t nt = hs_rs_tiles(n);
+  hs_rs_hist_kernel<<<nt, 256, 0, s>>>(d_keys, n, shift, nt, d_hist);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_rs_scatter(const uint32_t* d_keys_in, const uint32_t* d_ids_in, uint32_t n, int shift,
+                                const uint32_t* d_hist_scanned, uint32_t* d_keys_out, uint32_t* d_ids_out,
+                                hipStream_t s) {
+  const uint32_t nt = hs_rs_tiles(n);
+  hs_rs_scatter_kernel<<<nt, 256, 0, s>>>(d_keys_in, d_ids_in, n, shift, nt, d_hist_scanned, d_keys_out, d_ids_out);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_dir_start(const uint32_t* d_ranks_sorted, uint32_t n, uint32_t nb, uint32_t* d_dir_start,
+                               uint32_t* d_max, hipStream_t s) {
+  hs_dir_start_kernel<<<blocks_for(n), 256, 0, s>>>(d_ranks_sorted, n, nb, d_dir_start);
+  hs_dir_max_kernel<<<std::min(1024u, blocks_for(nb)), 256, 0, s>>>(d_dir_start, nb, d_max);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_check_members(const uint32_t* d_rank, uint64_t n, const int32_t* d_ints, int K,
+                                   const int32_t* d_dir_tuple, uint32_t* d_flag, uint32_t* d_slow, uint32_t slow_cap,
+                                   bool exhaustive, hipStream_t s) {
+  if (!n) return hipSuccess;
+  if (exhaustive) {
+    hs_check_members_slow_kernel<<<1024, 256, 0, s>>>(d_rank, n, d_ints, K, d_dir_tuple, d_slow, slow_cap, d_flag);
+    return hipGetLastError();
+  }
+  hipError_t e = hipMemsetAsync(d_slow, 0, 4, s);
+  if (e != hipSuccess) return e;
+  hs_check_members_kernel<<<blocks_for(n), 256, 0, s>>>(d_rank, n, d_ints, K, d_dir_tuple, d_slow, slow_cap);
+  hs_check_members_slow_kernel<<<64, 256, 0, s>>>(d_rank, 0, d_ints, K, d_dir_tuple, d_slow, slow_cap, d_flag);
+  return hipGetLastError();
+}

@@ -1263,67 +1263,144 @@ __global__ __launch_bounds__(256, 2) void hs_join8x_kernel(
 // after the branch with a full drain; so the branch itself consumes the tiles it loaded (an empty asm
 // that reads the registers): the drain sits inside the branch, once per segment, and the common path
 // only ever waits for the member tile it is about to use.
-// One work item of hs_join8r_kernel: 128 members (MK: the lanes' eight 16-byte loads) against the NCT
-// 16-query column tiles of the resident query rows.  The members' operands are built and used in two
-// halves of four row tiles (the whole item's would not fit beside two member sets in flight): build,
-// then per 32-query tile the half's MFMAs and their sign test.  When both halves are built MK is free
-// and takes the members of the item after next (`next_members`).
-template <int NCT>
-__device__ __forceinline__ void join8r_item(uint4 (&MK)[8], const uint4* __restrict__ next_members,
-                                            const intx4 (&Bq)[2][2][2], const uint2* sPair, int q, int up,
-                                            uint32_t low_half, uint32_t qoff, uint32_t nQ, uint32_t wbase,
-                                            uint32_t M, uint32_t mstart, int lane, uint32_t& res_base,
-                                            uint32_t& res_used, uint32_t* __restrict__ prov_count,
-                                            uint32_t prov_cap, uint2* __restrict__ prov) {
+// Query tile of hs_join8r_kernel: the rows are the same (hs_gather_c8t_kernel), the K layout is the
+// member side's -- lane row 0, 1, 3 carries positions 8 j .. 8 j + 3 in k-step 0 and 8 j + 4 .. 8 j + 7 in
+// k-step 1 (j = 0, 1, 2), row 2 the record, then the constants -- so lane (n, row) takes the 16-byte
+// pieces {0, 2, 6, 4}[row] and {1, 3, 7, 5}[row] of query row 16 c + n (piece g of row j of a tile with
+// nr rows sits at g nr + j).
+__device__ __forceinline__ void load_btile_r(intx4 (&B)[2][2], const uint4* __restrict__ c8t, uint32_t row0,
+                                             uint32_t nr, int lane) {
+  const char* t0 = reinterpret_cast<const char*>(c8t + (uint64_t)row0 * 8);
+  const uint32_t n = (uint32_t)lane & 15u, row = (uint32_t)lane >> 4;
+  const uint32_t g0 = row == 0 ? 0u : row == 1 ? 2u : row == 2 ? 6u : 4u;
+  const uint32_t r0 = min(n, nr - 1u), r1 = min(16u + n, nr - 1u);
+  const uint32_t o00 = (g0 * nr + r0) * 16u, o01 = (g0 * nr + r1) * 16u;
+  const uint32_t o10 = ((g0 + 1u) * nr + r0) * 16u, o11 = ((g0 + 1u) * nr + r1) * 16u;
+  const uint4 v00 = *reinterpret_cast<const uint4*>(t0 + o00), v01 = *reinterpret_cast<const uint4*>(t0 + o01);
+  const uint4 v10 = *reinterpret_cast<const uint4*>(t0 + o10), v11 = *reinterpret_cast<const uint4*>(t0 + o11);
+  B[0][0] = intx4{(int)v00.x, (int)v00.y, (int)v00.z, (int)v00.w};
+  B[0][1] = intx4{(int)v01.x, (int)v01.y, (int)v01.z, (int)v01.w};
+  B[1][0] = intx4{(int)v10.x, (int)v10.y, (int)v10.z, (int)v10.w};
+  B[1][1] = intx4{(int)v11.x, (int)v11.y, (int)v11.z, (int)v11.w};
+}
+
+// hs_join8r_kernel works on HALF items: four row tiles (64 members) at a time -- the whole item's
+// operands would not fit beside two member sets in flight -- in two steps that the kernel software-
+// pipelines across halves and items:
+//   join8r_lookup   the half's table lookups are ISSUED (addresses from the lanes' loaded member words) ...
+//   join8r_half     ... and one half-step later, when they have long arrived, the operand is completed
+//                   (row 2 takes its record) and meets the NCT 16-query column tiles of the resident query
+//                   rows: per 32-query tile the MFMAs, then their sign test.
+// Lanes of rows 0, 1, 3 hold 16 bytes of the member's packed word from the dword their eight positions
+// start in (bit sh of it): four ten-bit fields = four pair lookups, two per k-step.  Row 2 holds the
+// member's record (k-step 0 as loaded) and looks its k-step 1 up at the two table entries that carry the
+// constant factors (m2 = 0 cancels its field bits, rc2 / rc3 address them).  No lane needs another lane's
+// load: the query rows are permuted to this layout instead (load_btile_r).
+// A group (half x tile) with a survivor -- a few per cent of them -- leaves its 32 sign bits per lane
+// (bit 8 t + 4 c + i = accumulator i of row tile t, column tile c) in the wave's LDS slot of that group
+// and its number in the returned mask; the item's survivors are written out ONCE, after the item, by the
+// caller (the survivor code inlined at every group made the kernel 140 KB of instructions: 2.2 x the
+// instruction cache).
+__device__ __forceinline__ void join8r_lookup(intx4 (&A)[4][2], const uint4 (&MK)[8], int half, const char* sPairR,
+                                              uint32_t sh, uint32_t rc, uint32_t m2, uint32_t rc2, uint32_t rc3) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const uint4 mk = MK[4 * half + t];
+    const uint32_t x0 = __builtin_amdgcn_alignbit(mk.y, mk.x, sh), x1 = __builtin_amdgcn_alignbit(mk.z, mk.y, sh);
+    const uint32_t a0 = ((x0 << 5) & 0x7fe0u) | rc, a1 = ((x0 >> 5) & 0x7fe0u) | rc;
+    const uint32_t a2 = ((x0 >> 15) & m2) | rc2, a3 = (__builtin_amdgcn_alignbit(x1, x0, 25) & m2) | rc3;
+    const uint2 p0 = *reinterpret_cast<const uint2*>(sPairR + a0), p1 = *reinterpret_cast<const uint2*>(sPairR + a1);
+    const uint2 p2 = *reinterpret_cast<const uint2*>(sPairR + a2), p3 = *reinterpret_cast<const uint2*>(sPairR + a3);
+    A[t][0] = intx4{(int)p0.x, (int)p0.y, (int)p1.x, (int)p1.y};
+    A[t][1] = intx4{(int)p2.x, (int)p2.y, (int)p3.x, (int)p3.y};
+  }
+}
+
+// the lookups have arrived (this is where the wave waits for them): row 2 takes its record
+__device__ __forceinline__ void join8r_finish(intx4 (&A)[4][2], const uint4 (&MK)[8], int half, bool row2) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const uint4 mk = MK[4 * half + t];
+    A[t][0] = row2 ? intx4{(int)mk.x, (int)mk.y, (int)mk.z, (int)mk.w} : A[t][0];
+  }
+}
+
+template <int NCT, int HALF>
+__device__ __forceinline__ uint32_t join8r_half(const intx4 (&A)[4][2], const intx4 (&Bq)[2][2][2],
+                                                uint32_t* __restrict__ smask /* [8][64] + lane */) {
   constexpr int NT = (NCT + 1) / 2;  // 32-query tiles, the last one with one or two 16-query column tiles
   constexpr bool ODD = (NCT & 1) != 0;
   intx4 acc[4][2];
-  intx4 A[4][2];
-  const uint32_t bs = (20u * (uint32_t)q) & 31u;
+  uint32_t gmask = 0;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int u = 0; u < NT; ++u) {
+    const bool one = ODD && u == NT - 1;  // this tile has a single column tile
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const uint4 mk = MK[4 * half + t];
-      const uint32_t x0 = __builtin_amdgcn_permlane32_swap(mk.x, mk.y, false, false)[0];
-      const uint32_t y0 = __builtin_amdgcn_permlane32_swap(mk.y, mk.z, false, false)[0];
-      const uint32_t z0 = __builtin_amdgcn_permlane32_swap(mk.z, mk.w, false, false)[0];
-      const uint32_t w0 = mk.w & low_half;
-      const uint32_t x = __funnelshift_r(x0, y0, bs), z = __funnelshift_r(z0, w0, bs), w = w0 >> bs;
-      const uint2 p0 = sPair[x & 1023u], p1 = sPair[(x >> 10) & 1023u];
-      const uint2 p2 = sPair[(z >> 16) & 1023u], p3 = sPair[__funnelshift_r(z, w, 26) & 1023u];
-      A[t][0] = intx4{(int)p0.x, (int)p0.y, (int)p1.x, (int)p1.y};
-      const intx4 lk = intx4{(int)p2.x, (int)p2.y, (int)p3.x, (int)p3.y};
-      const intx4 own = intx4{(int)mk.x, (int)mk.y, (int)mk.z, (int)mk.w};
-      A[t][1] = up ? own : lk;  // q = 2: the member's record, q = 3: the constants it loaded
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+          if (c == 0 || !one)
+            acc[t][c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t][s2], Bq[u][s2][c],
+                                                              s2 ? acc[t][c] : intx4{0, 0, 0, 0}, 0, 0, 0);
+    const uint32_t sG = one ? and_tree_x<1>(acc) : and_tree_x<2>(acc);
+    if (__ballot((int)sG >= 0)) {
+      uint32_t neg = 0;  // bit 8 t + 4 c + i = sign of acc[t][c][i]: shift the sign bits in, last one first
+#pragma unroll
+      for (int t = 3; t >= 0; --t)
+#pragma unroll
+        for (int c = 1; c >= 0; --c)
+#pragma unroll
+          for (int i = 3; i >= 0; --i)
+            neg = __builtin_amdgcn_alignbit(neg, (c == 1 && one) ? 0xffffffffu : (uint32_t)acc[t][c][i], 31);
+      smask[(HALF * NT + u) * 64] = ~neg;
+      gmask |= 1u << (HALF * NT + u);
     }
-    if (half == 1) {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) MK[t] = next_members[16 * t];
-    }
-#pragma unroll
-    for (int u = 0; u < NT; ++u) {
-      const bool one = ODD && u == NT - 1;  // this tile has a single column tile
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int c = 0; c < 2; ++c)
-            if (c == 0 || !one)
-              acc[t][c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t][s2], Bq[u][s2][c],
-                                                                s2 ? acc[t][c] : intx4{0, 0, 0, 0}, 0, 0, 0);
-      // (one accumulator set: the sign test follows its MFMAs -- the SIMD's other wave fills the matrix
-      // pipe meanwhile; a second set, to test one group beside the next one's MFMAs, does not fit beside
-      // two member sets in flight)
-      const uint32_t sG = one ? and_tree_x<1>(acc) : and_tree_x<2>(acc);
-      if (__ballot((int)sG >= 0)) {
-        if (one)
-          emit_survivors_x<1>(acc, 4 * half, 32u * (uint32_t)u, qoff, nQ, wbase, M, mstart, lane, res_base, res_used,
-                              prov_count, prov_cap, prov);
-        else
-          emit_survivors_x<2>(acc, 4 * half, 32u * (uint32_t)u, qoff, nQ, wbase, M, mstart, lane, res_base, res_used,
-                              prov_count, prov_cap, prov);
+  }
+  return gmask;
+}
+
+// The survivors of one item of hs_join8r_kernel from the sign masks its groups left in LDS (see
+// join8r_item): group g = half * NT + u covers members wbase + 64 half .. + 63 (row tile t: 16 t + 4 q + i)
+// and the queries 32 u + 16 c + n.
+__device__ __forceinline__ void join8r_emit(uint32_t gmask, int NT, const uint32_t* __restrict__ smask,
+                                            uint32_t qoff, uint32_t nQ, uint32_t wbase, uint32_t M, uint32_t mstart,
+                                            int lane, uint32_t& res_base, uint32_t& res_used,
+                                            uint32_t* __restrict__ prov_count, uint32_t prov_cap,
+                                            uint2* __restrict__ prov) {
+  const uint32_t n = (uint32_t)lane & 15u, q = (uint32_t)lane >> 4;
+  while (gmask) {
+    const int g = __ffs((int)gmask) - 1;
+    gmask &= gmask - 1;
+    const int half = g / NT, u = g - half * NT;
+    uint32_t mask = smask[g * 64];
+    while (__ballot(mask != 0)) {
+      uint32_t idx = 0, ql = 0;
+      bool pass = false;
+      if (mask) {
+        const int b = __ffs((int)mask) - 1;
+        mask &= mask - 1;
+        const uint32_t col = 32u * (uint32_t)u + 16u * (uint32_t)((b >> 2) & 1) + n;
+        idx = wbase + 64u * (uint32_t)half + 16u * (uint32_t)(b >> 3) + 4u * q + (uint32_t)(b & 3);
+        ql = HS_PROV_INDIRECT | (qoff + col);
+        pass = idx < M && col < nQ;
+      }
+      const unsigned long long m = __ballot(pass);
+      if (m) {
+        const uint32_t cnt = (uint32_t)__popcll(m);
+        if (res_used + cnt > JRES) {
+          close_reservation(prov, res_base, res_used, prov_cap, lane);
+          uint32_t base = 0;
+          if (lane == 0) base = hs_reserve_survivors(prov_count, (uint32_t)JRES);
+          res_base = __builtin_amdgcn_readfirstlane(base);
+          res_used = 0;
+        }
+        if (pass) {
+          const uint32_t o = res_base + res_used + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          if (o < prov_cap) prov[o] = make_uint2(ql, mstart + idx);
+        }
+        res_used += cnt;
       }
     }
   }
@@ -1336,12 +1413,24 @@ __global__ __launch_bounds__(256, 2) void hs_join8r_kernel(
     uint32_t prov_cap, uint2* __restrict__ prov, uint32_t* __restrict__ item_counter, uint32_t G) {
   const uint32_t first = __builtin_amdgcn_readfirstlane(range[0]);
   const uint32_t n_items = min(__builtin_amdgcn_readfirstlane(range[1]), desc_cap);  // (absolute) end of the list
-  __shared__ uint2 sPair[1024];
+  // x^ of TWO consecutive residues per lookup (entry r1 << 5 | r0 = {x^(r0), x^(r1)}), four copies side by
+  // side -- lane l reads copy l & 3 -- so that the 32 lanes of an LDS access group spread their random
+  // entries over four times as many banks (the single copy spent 72 % of the LDS cycles on conflicts); then
+  // the two entries that hold the constant factors of the gamma slots
+  constexpr uint32_t CONST_AT = 1024u * 32u;  // byte address of the constants' first entry
+  __shared__ uint2 sPairR[1024 * 4 + 2];
+  __shared__ uint32_t sMask[4][8][64];  // per wave: the sign masks of an item's groups that had a survivor
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = lane & 15, q = lane >> 4, up = lane >> 5;
-  for (int e = tid; e < 1024; e += 256) sPair[e] = make_uint2(tab8[e & 31].x, tab8[e >> 5].x);
-  __syncthreads();  // the only one: the table is read-only from here on
+  const int n = lane & 15, row = lane >> 4;
+  for (int e = tid; e < 4096; e += 256) sPairR[e] = make_uint2(tab8[(e >> 2) & 31].x, tab8[e >> 7].x);
+  if (tid == 0) {
+    const uint4 cn = tab8[HS_J8_CONST_AT];
+    sPairR[4096] = make_uint2(cn.x, cn.y);
+    sPairR[4097] = make_uint2(cn.z, cn.w);
+  }
+  __syncthreads();  // the only one: the tables are read-only from here on
+  uint32_t* const smask = &sMask[wave][0][lane];
   const uint32_t first_dynamic = first + gridDim.x * 4u * G;
   uint32_t item = first + (blockIdx.x * 4u + (uint32_t)wave) * G;
   if (item >= n_items) return;
@@ -1358,7 +1447,16 @@ __global__ __launch_bounds__(256, 2) void hs_join8r_kernel(
       if (lane == 0 && pf_item < n_items) next_chunk_v = atomicAdd(item_counter, G);     \
     }                                                                                    \
   }
-  // descriptors of the current item, the next one and the one after (whose members are fetched now)
+  // Descriptors of the current item, the next one and the one after (whose members are fetched now) in
+  // scalar registers.  They arrive through VECTOR loads (every lane the same address), issued one item
+  // before they are read: scalar loads share their counter with the LDS lookups of the operand build, and
+  // the two complete out of order, so every wait for a lookup would also wait for a descriptor still on its
+  // way from memory (the descriptor array is streamed once: it never hits the scalar cache); vector loads
+  // count in issue order with the member loads, and a descriptor requested a whole item ago has arrived
+  // when the members of the item before it have.
+  uint32_t vzero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));  // a zero the compiler cannot see through: keeps the loads vector loads
+  const uint4* const desc_v = desc + vzero;
   uint4 d0 = uniform4(desc[2 * (uint64_t)item]), d1 = uniform4(desc[2 * (uint64_t)item + 1]);
   HS_ADVANCE_PF()
   uint32_t next_item = pf_item;
@@ -1367,68 +1465,111 @@ __global__ __launch_bounds__(256, 2) void hs_join8r_kernel(
     nd0 = uniform4(desc[2 * (uint64_t)next_item]);
     nd1 = uniform4(desc[2 * (uint64_t)next_item + 1]);
   }
+  HS_ADVANCE_PF()
+  uint32_t nn_item = pf_item;  // the item after next: its descriptor is on its way in dv0 / dv1
+  uint4 dv0, dv1;
+  {
+    const uint64_t ix_ = nn_item < n_items ? nn_item : item;
+    dv0 = desc_v[2 * ix_];
+    dv1 = desc_v[2 * ix_ + 1];
+  }
   // Member loads: lane (n, q) of row tile t takes entry e0 + 16 t + n of the packed array (q = 0, 1: the
   // two quarters need the same 16 bytes), of the record array (q = 2), or -- q = 3 -- the constant factors
   // of the gamma slots, from a block that repeats them 128 times so that the same offsets apply.  One
   // 64-bit base per lane and item, eight loads at immediate offsets.  No clamping at a bucket's ragged
   // end: the rows past it read the next bucket's entries (the arrays are padded by 128 entries) and
   // are masked when survivors are emitted.
-  const uint4* const lane_base = (q == 3 ? cn_rep : (up ? rec_base : packed_base)) + n;
-  const int64_t lane_mask = q == 3 ? 0 : -1;
+  // row 0, 1, 3: j = 0, 1, 2 -- positions 8 j .. 8 j + 7 start at bit 40 j of the packed word: dword j, bit 8 j
+  const bool row2 = row == 2;
+  const uint32_t jj = row == 3 ? 2u : (uint32_t)row;
+  const char* const lane_base = (row2 ? reinterpret_cast<const char*>(rec_base)
+                                      : reinterpret_cast<const char*>(packed_base) + 4u * jj) + 16 * n;
+  const uint32_t sh = row2 ? 0u : 8u * jj;
+  const uint32_t rc = 8u * ((uint32_t)lane & 3u);
+  const uint32_t m2 = row2 ? 0u : 0x7fe0u, rc2 = row2 ? CONST_AT : rc, rc3 = row2 ? CONST_AT + 8u : rc;
+  const char* const sPairB = reinterpret_cast<const char*>(sPairR);
 #define HS_LOAD_MEMBERS_R(MK, D0)                                                                   \
   {                                                                                                 \
     const int64_t e0_ = (int64_t)(((uint64_t)(D0).y << 32) | (uint64_t)(D0).x) + (int64_t)(D0).w * 128; \
-    const uint4* p_ = lane_base + (e0_ & lane_mask);                                                \
-    _Pragma("unroll") for (int t = 0; t < 8; ++t) MK[t] = p_[16 * t];                                \
+    const char* p_ = lane_base + e0_ * 16;                                                          \
+    _Pragma("unroll") for (int t = 0; t < 8; ++t) MK[t] = *reinterpret_cast<const uint4*>(p_ + 256 * t); \
   }
   uint4 mkA[8], mkB[8];
   intx4 Bq[2][2][2];
   HS_LOAD_MEMBERS_R(mkA, d0)
   HS_LOAD_MEMBERS_R(mkB, nd0)
   uint32_t cur_qoff = 0xffffffffu;
-  const uint32_t low_half = up ? 0u : 0xffffffffu;
   bool has_next;
-#define HS_ITEM_STEP(MK)                                                                                       \
+#define HS_ITEM_STEP(MK, MKN)                                                                                  \
   {                                                                                                            \
     const uint32_t M = d0.z, mt = d0.w;                                                                        \
     const uint32_t qoff = d1.x, nQ = d1.z, mstart = d1.w;                                                      \
     const uint32_t wbase = mt * 128u;                                                                          \
     has_next = next_item < n_items;                                                                            \
-    HS_ADVANCE_PF() /* pf_item = the item after next */                                                        \
-    uint4 nnd0 = d0, nnd1 = d1;                                                                                \
-    if (pf_item < n_items) {                                                                                   \
-      nnd0 = uniform4(desc[2 * (uint64_t)pf_item]);                                                            \
-      nnd1 = uniform4(desc[2 * (uint64_t)pf_item + 1]);                                                        \
+    /* the descriptor requested one item ago (= this item's once more when there is no item after next) */    \
+    const uint4 nnd0 = uniform4(dv0), nnd1 = uniform4(dv1);                                                    \
+    HS_ADVANCE_PF() /* pf_item = three items on: its descriptor is requested now */                            \
+    {                                                                                                          \
+      const uint64_t ix_ = pf_item < n_items ? pf_item : (next_item < n_items ? next_item : item);             \
+      dv0 = desc_v[2 * ix_];                                                                                   \
+      dv1 = desc_v[2 * ix_ + 1];                                                                               \
     }                                                                                                          \
     if (qoff != cur_qoff) { /* a new segment: its query rows into registers, and wait for them HERE */         \
       cur_qoff = qoff;                                                                                         \
       _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                          \
         const uint32_t qu_ = 32u * u < nQ ? 32u * u : 0u;                                                      \
-        load_btile_x(Bq[u], c8t, qoff + qu_, min(32u, nQ - qu_), lane);                                        \
+        load_btile_r(Bq[u], c8t, qoff + qu_, min(32u, nQ - qu_), lane);                                        \
       }                                                                                                        \
       _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                            \
         asm volatile("" ::"v"(Bq[u][0][0]), "v"(Bq[u][0][1]), "v"(Bq[u][1][0]), "v"(Bq[u][1][1]));             \
     }                                                                                                          \
     /* members of the item after next: their address now, the loads when MK has been consumed */             \
     const int64_t e2_ = (int64_t)(((uint64_t)nnd0.y << 32) | (uint64_t)nnd0.x) + (int64_t)nnd0.w * 128;         \
-    const uint4* nm_ = lane_base + (e2_ & lane_mask);                                                          \
-    switch ((nQ + 15u) >> 4) {                                                                                 \
-      case 1: join8r_item<1>(MK, nm_, Bq, sPair, q, up, low_half, qoff, nQ, wbase, M, mstart, lane, res_base, res_used, prov_count, prov_cap, prov); break; \
-      case 2: join8r_item<2>(MK, nm_, Bq, sPair, q, up, low_half, qoff, nQ, wbase, M, mstart, lane, res_base, res_used, prov_count, prov_cap, prov); break; \
-      case 3: join8r_item<3>(MK, nm_, Bq, sPair, q, up, low_half, qoff, nQ, wbase, M, mstart, lane, res_base, res_used, prov_count, prov_cap, prov); break; \
-      default: join8r_item<4>(MK, nm_, Bq, sPair, q, up, low_half, qoff, nQ, wbase, M, mstart, lane, res_base, res_used, prov_count, prov_cap, prov); break; \
+    const char* nm_ = lane_base + e2_ * 16;                                                                    \
+    const uint32_t nct_ = (nQ + 15u) >> 4;                                                                     \
+    uint32_t gm_;                                                                                              \
+    /* AP holds the lookups of this item's first half, issued one half-step ago: complete it (the wait for     \
+       them sits here, with nothing younger in flight: the LDS counter has four bits, sixteen younger lookups  \
+       could not be told apart from them), send the second half's lookups out, compute the first half */       \
+    join8r_finish(AP, MK, 0, row2);                                                                            \
+    join8r_lookup(AQ, MK, 1, sPairB, sh, rc, m2, rc2, rc3);                                                    \
+    switch (nct_) {                                                                                            \
+      case 1: gm_ = join8r_half<1, 0>(AP, Bq, smask); break;                                                   \
+      case 2: gm_ = join8r_half<2, 0>(AP, Bq, smask); break;                                                   \
+      case 3: gm_ = join8r_half<3, 0>(AP, Bq, smask); break;                                                   \
+      default: gm_ = join8r_half<4, 0>(AP, Bq, smask); break;                                                  \
     }                                                                                                          \
+    /* MK's first half is consumed: the first half of the members of the item after next */                    \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) MK[t] = *reinterpret_cast<const uint4*>(nm_ + 256 * t);      \
+    /* second half: complete, send out the NEXT item's first half (its members were requested one item ago;    \
+       the same item's when there is none), compute */                                                         \
+    join8r_finish(AQ, MK, 1, row2);                                                                            \
+    join8r_lookup(AP, MKN, 0, sPairB, sh, rc, m2, rc2, rc3);                                                   \
+    switch (nct_) {                                                                                            \
+      case 1: gm_ |= join8r_half<1, 1>(AQ, Bq, smask); break;                                                  \
+      case 2: gm_ |= join8r_half<2, 1>(AQ, Bq, smask); break;                                                  \
+      case 3: gm_ |= join8r_half<3, 1>(AQ, Bq, smask); break;                                                  \
+      default: gm_ |= join8r_half<4, 1>(AQ, Bq, smask); break;                                                 \
+    }                                                                                                          \
+    /* ... and the second half */                                                                              \
+    _Pragma("unroll") for (int t = 4; t < 8; ++t) MK[t] = *reinterpret_cast<const uint4*>(nm_ + 256 * t);      \
+    if (gm_)                                                                                                   \
+      join8r_emit(gm_, (int)((nct_ + 1u) >> 1), smask, qoff, nQ, wbase, M, mstart, lane, res_base, res_used,   \
+                  prov_count, prov_cap, prov);                                                                 \
     item = next_item;                                                                                          \
-    next_item = pf_item;                                                                                       \
+    next_item = nn_item;                                                                                       \
+    nn_item = pf_item;                                                                                         \
     d0 = nd0;                                                                                                  \
     d1 = nd1;                                                                                                  \
     nd0 = nnd0;                                                                                                \
     nd1 = nnd1;                                                                                                \
   }
+  intx4 AP[4][2], AQ[4][2];
+  join8r_lookup(AP, mkA, 0, sPairB, sh, rc, m2, rc2, rc3);  // the first item's first half
   for (;;) {
-    HS_ITEM_STEP(mkA)
+    HS_ITEM_STEP(mkA, mkB)
     if (!has_next) break;
-    HS_ITEM_STEP(mkB)
+    HS_ITEM_STEP(mkB, mkA)
     if (!has_next) break;
   }
 #undef HS_ITEM_STEP
