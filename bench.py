@@ -293,7 +293,7 @@ class Workload:
             self.step(hdist, HsError, use_dist)
         acc = dict(verify_ms=0.0, hash_ms=0.0, probe_ms=0.0, fin_ms=0.0, join_ms=0.0, launches=0, join_batches=0,
                    join_i8=0, retries=0)
-        jstat, qproj, join_rows, cand, hits_local = (0, 0, 0), (0, 0), (128, 0), 0, 0
+        jstat, qproj, join_rows, cand, hits_local = (0, 0, 0, 0), (0, 0), (128, 0), 0, 0
         gathered = None
         fence()
         t0 = time.perf_counter()
@@ -309,7 +309,7 @@ class Workload:
             acc["join_ms"] += p["ms_join"]
             acc["join_i8"] += p["join_i8_batches"]
             acc["retries"] += p["join_async_retries"]
-            jstat = (p["join_items"], p["join_pairs"], p["join_pairs_issued"])
+            jstat = (p["join_items"], p["join_pairs"], p["join_pairs_issued"], p["join_items_resident"])
             if p["join_i8_batches"]:
                 join_rows = (int(p["join_row_bytes"]), int(p["join_wide"]))
             qproj = (p["hash_values"], p["hash_flagged"])
@@ -355,6 +355,9 @@ class Workload:
                     "frac": tf / peak, "traffic": traffic, "traffic_source": traffic_src,
                     "flop_per_step": flop, "pairs_per_step": jstat[1],
                     "pairs_issued_per_step": jstat[2], "work_items_per_step": jstat[0],
+                    # ... of which in segments with few probing queries, run by hs_join8r_kernel (query rows
+                    # resident, member tiles streamed); the rest by the kernel named above
+                    "work_items_query_resident": jstat[3],
                     "issued_over_useful": (jstat[2] / jstat[1]) if jstat[1] else None,
                     "issued_tops": (jstat[2] * 2.0 * jk / (j_ms * 1e-3) / 1e12) if j_ms > 0 else 0.0,
                     "kernel_ms_per_step": j_ms, "streaming_kernel_ms_per_step": v_ms - j_ms,

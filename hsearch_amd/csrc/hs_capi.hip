@@ -91,11 +91,15 @@ struct Knobs {
   bool sort_hits = false;          // HS_SORT_HITS: order hits by the radix sort, not per query
   bool sync_items = false;         // HS_SYNC_ITEMS: read the join's item count back before launching it
   bool no_join_r = false;          // HS_NO_JOIN_R: every segment through the query-streaming join kernel
+  bool force_join_r = false;       // HS_FORCE_JOIN_R: the query-resident kernel for its class whatever its share
+  bool build_sort = false;         // HS_BUILD_SORT: group a table's k-mers by sorting (fingerprint, id) pairs
+                                   // (rocPRIM; rounds 1-2) instead of hs_group.hip's table + rank sort
   int seg_mode = 0;                // HS_SEG_MODE=sparse|dense: 1 / 2; 0 = by the bucket : probe ratio
   int sort_from_bit = 16;          // HS_SORT_FROM_BIT: lowest fingerprint bit the build's sort looks at
   uint32_t query_batch = 0;        // HS_QUERY_BATCH: queries per batch (0: by L)
 #ifdef HS_TEST_HOOKS
   uint32_t test_split_above = 0;   // HS_TEST_SPLIT_ABOVE: batches above this size report a survivor overflow
+  bool test_group_fallback = false;  // HS_TEST_GROUP_FALLBACK: the build's fingerprint table reports itself full
 #endif
 };
 
@@ -147,6 +151,7 @@ struct hs_handle {
   uint64_t all_codes_n = 0;
   DevBuf bs_ints2[2], bs_keys2[2], bs_iota2[2], bs_keys_sorted, bs_rle_unique, bs_rle_counts, bs_small,
       bs_sort_temp, bs_slow_q;  // index-build scratch (build_tables)
+  DevBuf bs_fptab, bs_blk, bs_dk, bs_hist, bs_rank;  // ... of the table + rank-sort grouping (hs_group.hip)
   DevBuf seg_res;   // cut_items: flags + scan of the segments that go to the query-resident join kernel
   DevBuf jconst;    // 128 copies of the gamma slots' constant factors (hs_join8r_kernel's fourth lane quarter)
   DevBuf c16s, item_desc, probe_slow, jtab8, slice_ql, qhits;  // qhits: per-query hit counts, offsets, fill
@@ -169,6 +174,12 @@ struct hs_handle {
   // work items of the last joined batch x 1.25: with it the next batch sizes its descriptor array
   // without asking the device (the kernels clamp to the real count; an overflow repeats the batch)
   uint32_t item_cap_hint = 0;
+  // share of the last joined batch's work items that lay in segments with few probing queries (the
+  // query-resident kernel's class); < 0: unknown.  That kernel pays when the class is the bulk of the items
+  // (configs[2]'s shape: 90 %); where it is a minority (configs[1]: the extra launch costs more than the
+  // class's items cost in the streaming kernel) the next batch runs everything through the streaming kernel
+  double resident_share = -1.0;
+  uint32_t resident_age = 0;     // joined batches since it was measured (measured again every 64)
   int join_blocks_per_cu = 2;                // resident workgroups of hs_join_kernel per CU
   DevBuf jtab, c16, seg_keys, seg_keys_sorted, seg_vals, sorted_ql, seg_key, seg_cnt, seg_qoff,
       seg_items, item_off, seg_n;
@@ -234,6 +245,8 @@ void drop_index(hs_handle* h) {
   h->order_failed_R = 0.0;
   h->item_cap_hint = 0;
   h->pairs_per_item = 0.0;
+  h->resident_share = -1.0;
+  h->resident_age = 0;
 }
 
 hs_status ensure_device(hs_handle* h) {
@@ -399,11 +412,14 @@ void read_knobs(hs_handle* h) {
   kn.sort_hits = on("HS_SORT_HITS");
   kn.sync_items = on("HS_SYNC_ITEMS");
   kn.no_join_r = on("HS_NO_JOIN_R");
+  kn.force_join_r = on("HS_FORCE_JOIN_R");
+  kn.build_sort = on("HS_BUILD_SORT");
   if (const char* m = getenv("HS_SEG_MODE")) kn.seg_mode = !strcmp(m, "sparse") ? 1 : !strcmp(m, "dense") ? 2 : 0;
   if (const char* m = getenv("HS_SORT_FROM_BIT")) kn.sort_from_bit = std::max(0, std::min(60, atoi(m)));
   if (const char* m = getenv("HS_QUERY_BATCH")) kn.query_batch = (uint32_t)std::max(1, atoi(m));
 #ifdef HS_TEST_HOOKS
   if (const char* m = getenv("HS_TEST_SPLIT_ABOVE")) kn.test_split_above = (uint32_t)std::max(0, atoi(m));
+  kn.test_group_fallback = on("HS_TEST_GROUP_FALLBACK");
 #endif
   if (const char* m = getenv("HS_HASH_MODE")) {
     if (!strcmp(m, "exact")) h->hash_mode = 1;
@@ -646,7 +662,8 @@ void hs_destroy(hs_handle* h) {
                     &h->proj_xmeta, &h->slice_ql, &h->qhits, &h->bs_ints2[0], &h->bs_ints2[1], &h->bs_keys2[0],
                     &h->bs_keys2[1], &h->bs_iota2[0], &h->bs_iota2[1], &h->bs_keys_sorted, &h->bs_rle_unique,
                     &h->bs_rle_counts, &h->bs_small, &h->bs_sort_temp, &h->bs_slow_q, &h->all_codes,
-                    &h->subset_ids, &h->qcodes_buf, &h->qembed, &h->seg_res, &h->jconst};
+                    &h->subset_ids, &h->qcodes_buf, &h->qembed, &h->seg_res, &h->jconst, &h->bs_fptab, &h->bs_blk,
+                    &h->bs_dk, &h->bs_hist, &h->bs_rank};
   for (DevBuf* bf : bufs) bf->release();
   h->sj_host.release();
   for (int l = 0; l < HS_MAX_L; ++l) {
@@ -802,13 +819,17 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
   hipStream_t hash_stream = h->stream2;
   const bool own_hash_stream = false;
   const bool serial = h->knobs.build_serial;  // measurement: no overlap
+  // grouping by key: hs_group.hip (table of distinct fingerprints + a radix sort on 32-bit ranks) unless
+  // HS_BUILD_SORT asks for the full-width sort of rounds 1-2 (which also remains the fallback of a table
+  // the other path cannot take: a fingerprint equal to its empty marker, or nearly all keys distinct)
+  const bool group_by_rank = !h->knobs.build_sort && n < (1ull << 31);
   struct Guard {
     hs_handle* h;
     hipStream_t* hs;
     bool own;
     hipEvent_t* e[3];
     int ne[3];
-    DevBuf* b[12];
+    DevBuf* b[17];
     ~Guard() {
       // nothing may still be running on either stream when the scratch goes away
       if (*hs) (void)hipStreamSynchronize(*hs);
@@ -824,7 +845,7 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
     }
   } guard = {h, &hash_stream, own_hash_stream, {ev_hashed, ev_free, ev_t}, {2, 2, 4},
              {&ints2[0], &ints2[1], &keys2[0], &keys2[1], &iota2[0], &iota2[1], &keys_sorted, &rle_unique,
-              &rle_counts, &small, &sort_temp, &slow_q}};
+              &rle_counts, &small, &sort_temp, &slow_q, &h->bs_fptab, &h->bs_blk, &h->bs_dk, &h->bs_hist, &h->bs_rank}};
   for (int i = 0; i < 2; ++i) {
     HS_HIP(h, hipEventCreateWithFlags(&ev_hashed[i], hipEventDisableTiming));
     HS_HIP(h, hipEventCreateWithFlags(&ev_free[i], hipEventDisableTiming));
@@ -853,8 +874,9 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
     if (t >= 2) HS_HIP(h, hipStreamWaitEvent(hash_stream, ev_free[u], 0));  // table t - 2 is done with it
     HS_HIP(h, hipEventRecord(ev_t[2 * u], hash_stream));
     HS_CHECK(hash_dispatch(h, h->codes.as<uint8_t>(), nullptr, n, t, ints2[u].as<int32_t>(), K, u, hash_stream));
-    HS_HIP(h, hs_launch_keys(ints2[u].as<int32_t>(), n, K, K, seed, keys2[u].as<uint64_t>(),
-                             iota2[u].as<uint32_t>(), hash_stream));
+    if (!group_by_rank)  // (hs_group.hip fingerprints the bucket ints itself, in its one pass over them)
+      HS_HIP(h, hs_launch_keys(ints2[u].as<int32_t>(), n, K, K, seed, keys2[u].as<uint64_t>(),
+                               iota2[u].as<uint32_t>(), hash_stream));
     HS_HIP(h, hipEventRecord(ev_t[2 * u + 1], hash_stream));
     HS_HIP(h, hipEventRecord(ev_hashed[u], hash_stream));
     return HS_OK;
@@ -884,7 +906,81 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
     // the memory fault of this sort's first draft.  (HS_SORT_FROM_BIT: 0 = every bit at once; the tests
     // pass 56 to see the second sort happen.)
     const int from_bit0 = hs_sort_partial_bits_ok((size_t)n) ? h->knobs.sort_from_bit : 0;
-    for (int from_bit = from_bit0; n; from_bit = 0) {
+    bool grouped = false;   // the table + rank-sort path produced this table's ids and directory
+    const uint32_t slow_cap_g = 1u << 16;
+    if (group_by_rank && n) {
+      const uint32_t C = hs_group_table_slots(n), n_blk = (C + 1023) / 1024, n_tiles = hs_rs_blocks(n);
+      HS_HIP(h, h->bs_fptab.reserve((size_t)C * 16));   // slots + the slots' full fingerprints
+      HS_HIP(h, h->bs_blk.reserve(2 * ((size_t)n_blk + 2) * 4));
+      HS_HIP(h, h->bs_rank.reserve((size_t)n * 4));
+      HS_HIP(h, h->bs_hist.reserve(2 * (size_t)((size_t)256 * n_tiles + 64) * 4));
+      HS_HIP(h, slow_q.reserve(((size_t)slow_cap_g + 1) * 4));
+      uint32_t* blk_cnt = h->bs_blk.as<uint32_t>();
+      uint32_t* blk_off = blk_cnt + n_blk + 2;
+      uint32_t* rank = h->bs_rank.as<uint32_t>();
+      HS_HIP(h, hs_launch_group_insert(ints.as<int32_t>(), n, K, seed, h->bs_fptab.as<uint64_t>(), C, rank,
+                                       slow_q.as<uint32_t>(), slow_cap_g, d_small + 1, h->stream));
+      HS_HIP(h, hs_launch_fp_count(h->bs_fptab.as<uint64_t>(), C, blk_cnt, h->stream));
+      HS_HIP(h, hipMemsetAsync(blk_cnt + n_blk, 0, 4, h->stream));
+      HS_HIP(h, hs_exclusive_scan_u32(sort_temp.p, sort_temp.cap, blk_cnt, blk_off, (size_t)n_blk + 1, h->stream));
+      uint32_t host2[2] = {0, 0};
+      HS_HIP(h, hipMemcpyAsync(&host2[0], blk_off + n_blk, 4, hipMemcpyDeviceToHost, h->stream));
+      HS_HIP(h, hipMemcpyAsync(&host2[1], d_small + 1, 4, hipMemcpyDeviceToHost, h->stream));
+      HS_HIP(h, hipStreamSynchronize(h->stream));   // the table's one round trip: its number of buckets
+#ifdef HS_TEST_HOOKS
+      if (h->knobs.test_group_fallback && (l & 1)) host2[1] |= 16u;  // (every other table, so that both forms mix)
+#endif
+      if (h->knobs.build_debug && (host2[1] & 48u))
+        fprintf(stderr, "table %d: grouping by rank not possible (flag 0x%x), sorting\n", l, host2[1]);
+      if (host2[1] & 1u) {  // one fingerprint, two HashKey strings: the caller tries the next seed
+        *collided = true;
+        return HS_OK;
+      }
+      if (!(host2[1] & 48u)) {
+        nb = host2[0];
+        grouped = true;
+        HS_HIP(h, h->t_dirkey[l].reserve(std::max<size_t>(16, (size_t)nb * 8)));
+        HS_HIP(h, h->t_dirstart[l].reserve(((size_t)nb + 1) * 4));
+        HS_HIP(h, h->t_dirtuple[l].reserve(std::max<size_t>(16, (size_t)nb * K * 4)));
+        HS_HIP(h, h->bs_dk.reserve((size_t)nb * 16 + 64));   // distinct keys (8) + their slots (4) + slots sorted (4)
+        uint64_t* dk = h->bs_dk.as<uint64_t>();
+        uint32_t* ds = reinterpret_cast<uint32_t*>(dk + nb);
+        uint32_t* ds_sorted = ds + nb;
+        HS_HIP(h, hs_launch_fp_compact(h->bs_fptab.as<uint64_t>(), C, blk_off, dk, ds, h->stream));
+        HS_HIP(h, hs_sort_pairs_u64_u32(sort_temp.p, sort_temp.cap, dk, h->t_dirkey[l].as<uint64_t>(), ds, ds_sorted,
+                                        nb, 0, 64, h->stream));
+        // (the table's slots are free now: they take the rank of every slot's key)
+        uint32_t* rank_of_slot = h->bs_fptab.as<uint32_t>();
+        HS_HIP(h, hs_launch_rank_slots(ds_sorted, nb, rank_of_slot, h->stream));
+        HS_HIP(h, hs_launch_rank_kmers(rank, n, rank_of_slot, h->stream));
+        // stable LSD radix sort of (rank, id) on the bits the ranks have; the last pass writes the table's ids
+        const int bits = std::max(1, bit_width_u32(nb ? nb - 1 : 0));
+        const int n_pass = (bits + 7) / 8;
+        uint32_t* kbuf[2] = {keys_sorted.as<uint32_t>(), keys_sorted.as<uint32_t>() + n};
+        uint32_t* ibuf[2] = {h->t_ids[l].as<uint32_t>(), rle_counts.as<uint32_t>()};   // pass p writes ibuf[(n_pass - 1 - p) & 1]
+        uint32_t* hist = h->bs_hist.as<uint32_t>();
+        uint32_t* hist_scanned = hist + ((size_t)256 * n_tiles + 64);
+        const uint32_t* kin = rank;
+        const uint32_t* iin = nullptr;
+        for (int p = 0; p < n_pass; ++p) {
+          uint32_t* kout = kbuf[p & 1];
+          uint32_t* iout = ibuf[(n_pass - 1 - p) & 1];
+          HS_HIP(h, hs_launch_rs_hist(kin, (uint32_t)n, 8 * p, hist, h->stream));
+          HS_HIP(h, hs_exclusive_scan_u32(sort_temp.p, sort_temp.cap, hist, hist_scanned, (size_t)256 * n_tiles, h->stream));
+          HS_HIP(h, hs_launch_rs_scatter(kin, iin, (uint32_t)n, 8 * p, hist_scanned, kout, iout, h->stream));
+          kin = kout;
+          iin = iout;
+        }
+        HS_HIP(h, hs_launch_dir_start(kin, (uint32_t)n, nb, h->t_dirstart[l].as<uint32_t>(), d_small + 2, h->stream));
+        HS_HIP(h, hs_launch_dir_tuples(h->t_dirstart[l].as<uint32_t>(), h->t_ids[l].as<uint32_t>(), ints.as<int32_t>(),
+                                       nb, K, h->t_dirtuple[l].as<int32_t>(), h->stream));
+      } else {
+        HS_HIP(h, hipMemsetAsync(d_small, 0, 64, h->stream));
+        // the sorting path needs the fingerprints and the ids 0 .. n - 1 as its values
+        HS_HIP(h, hs_launch_keys(ints.as<int32_t>(), n, K, K, seed, keys.as<uint64_t>(), iota.as<uint32_t>(), h->stream));
+      }
+    }
+    for (int from_bit = from_bit0; n && !grouped; from_bit = 0) {
       HS_HIP(h, hs_sort_pairs_u64_u32(sort_temp.p, sort_temp.cap, keys.as<uint64_t>(),
                                       keys_sorted.as<uint64_t>(), iota.as<uint32_t>(),
                                       h->t_ids[l].as<uint32_t>(), n, from_bit, 64, h->stream));
@@ -920,6 +1016,7 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
       *collided = true;
       return HS_OK;
     }
+    if (!grouped) {
     HS_HIP(h, h->t_dirkey[l].reserve(std::max<size_t>(16, (size_t)nb * 8)));
     HS_HIP(h, h->t_dirstart[l].reserve(((size_t)nb + 1) * 4));
     HS_HIP(h, h->t_dirtuple[l].reserve(std::max<size_t>(16, (size_t)nb * K * 4)));
@@ -934,6 +1031,7 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
     HS_HIP(h, hs_launch_dir_tuples(h->t_dirstart[l].as<uint32_t>(), h->t_ids[l].as<uint32_t>(),
                                    ints.as<int32_t>(), nb, K, h->t_dirtuple[l].as<int32_t>(),
                                    h->stream));
+    }
     HS_HIP(h, hipEventRecord(ev_free[l & 1], h->stream));  // ints / keys / iota of this table are free
     HS_HIP(h, hipEventRecord(h->ev[2], h->stream));
     if (with_rec8)
@@ -1780,7 +1878,8 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
     jm = use_i8 ? hs_join8_members_per_item(k, wide) : HS_JM_BLOCK;
     // k <= 25 with 4-column rows: segments probed by at most HS_JR_MAXQ queries of the batch go to the
     // query-resident kernel (hs_join8r_kernel), as the tail of the item list
-    use_r = use_i8 && !wide && k <= 25 && !h->knobs.no_join_r;
+    use_r = use_i8 && !wide && k <= 25 && !h->knobs.no_join_r &&
+            (h->knobs.force_join_r || h->resident_share < 0.0 || h->resident_share >= 0.5 || h->resident_age >= 64);
     HS_CHECK(cut_items(h, nql, jm, d_jstats, use_r ? HS_JR_MAXQ : 0u));
     if (use_i8)
       HS_HIP(h, hs_launch_gather_c8t(h->c16.p, h->sorted_ql.as<uint32_t>(), h->seg_qoff.as<uint32_t>(),
@@ -2009,6 +2108,8 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
     if (async_items)
       HS_HIP(h, hipMemcpyAsync(&n_items_real, h->item_off.as<uint32_t>() + nql, 4, hipMemcpyDeviceToHost,
                                h->stream));
+    if (use_join && use_i8 && n_items)  // [41] first item of the few-query class, [42] items (cut_items)
+      HS_HIP(h, hipMemcpyAsync(h->pin_cnt + 41, h->seg_n.as<uint32_t>() + 2, 8, hipMemcpyDeviceToHost, h->stream));
     HS_HIP(h, hipStreamSynchronize(h->stream));
     // > ~4e9 survivors: run_query halves the batch (HS_TEST_SPLIT_ABOVE=n: as if every batch of more
     // than n queries had overflowed -- the tests' handle on the splitting logic)
@@ -2079,6 +2180,12 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
   if (async_items) n_items = n_items_real;
   h->prof.join_items += n_items;
   if (use_i8 && n_items) h->item_cap_hint = n_items + n_items / 4 + 4096;
+  if (use_i8 && n_items) ++h->resident_age;
+  if (use_i8 && n_items && use_r && h->pin_cnt[42]) {
+    h->resident_age = 0;
+    h->resident_share = (double)(h->pin_cnt[42] - h->pin_cnt[41]) / (double)h->pin_cnt[42];
+    h->prof.join_items_resident += h->pin_cnt[42] - h->pin_cnt[41];
+  }
   if (use_i8 && n_items) {  // sizes the next batch's counter chunks (hs_launch_join8w)
     unsigned long long issued = 0;
     memcpy(&issued, host_cnt + 10, 8);

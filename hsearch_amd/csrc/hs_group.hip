@@ -9,19 +9,19 @@
 //
 // Buckets are FEW (10^5 of 10^7 k-mers at configs[1], 4 10^6 of 10^8 at configs[2]'s shape) and very
 // skewed (the largest holds 6.5 % of the database), so here the fingerprints are never sorted as such:
-//   1. every k-mer's fingerprint goes into an open-addressing table (one 8-byte slot read per k-mer in
-//      the common case -- the hot buckets' slots stay in L2 -- and one CAS per DISTINCT key); the k-mer
-//      keeps its slot number;
-//   2. the distinct fingerprints are compacted out of the table and sorted -- nb of them, a small sort
-//      (rocPRIM, on all 64 bits) -- which gives every slot the RANK of its key in the directory;
+//   1. every k-mer's key goes into an open-addressing table, found there by its fingerprint and PROVED
+//      there by its bucket ints against the slot's representative (one 8-byte slot read and one cached
+//      tuple per k-mer in the common case, one CAS per DISTINCT key); the k-mer keeps its slot number;
+//   2. the distinct keys' fingerprints are compacted out of the table and sorted -- nb of them, a small
+//      sort (rocPRIM, on all 64 bits) -- which gives every slot the RANK of its key in the directory;
 //   3. the k-mers carry 32-bit ranks now: a stable LSD radix sort of (rank, id) over ceil(log2 nb) bits,
 //      8 bits per pass, written here (histogram per 4096-element tile, one scan over digits x tiles,
 //      stable scatter through an LDS-staged tile): 2 - 3 passes of 20 bytes per pair;
-//   4. bucket boundaries fall out of the sorted ranks; every k-mer's bucket ints are then compared with
-//      its bucket's tuple (identical in the common case, by HashKey string otherwise: aliased strings
-//      share a fingerprint by construction, a fingerprint collision is reported and the build repeated
-//      with the next seed) -- the exact-string-equality proof of hs_check_runs_kernel, without the
-//      dependence on sorted neighbours.
+//   4. bucket boundaries fall out of the sorted ranks.
+// Bucket membership is exactly the reference's string equality: step 1 lets a k-mer into a slot only
+// when its ints equal the representative's or -- hs_group_insert_slow_kernel -- when the HashKey strings
+// do (aliased tuples share a fingerprint by construction); two strings under one fingerprint are
+// reported and the build repeats with the next seed, as with the sorting form.
 // Skew does not matter to any step: the hot key's k-mers read one cached slot, and the LSD passes count
 // digits of ranks.
 #include <hip/hip_runtime.h>
@@ -39,40 +39,147 @@ constexpr uint32_t RS_TILE = 4096;  // elements per block of the radix passes: 2
 
 inline unsigned blocks_for(uint64_t n, unsigned per = 256) { return (unsigned)((n + per - 1) / per); }
 
-// ---- 1. fingerprints -> slots of an open-addressing table ------------------------------------------
-// T[C] (C a power of two >= n / 2, zero ... all FP_EMPTY at entry), slot = top bits of the fingerprint,
-// linear probing.  slot_of[i] = the slot that holds keys[i].  The slot is read with an L2-coherent load
-// first: the hot bucket's thousands of k-mers per wave would otherwise all CAS the same address.
-__global__ __launch_bounds__(256) void hs_fp_insert_kernel(const uint64_t* __restrict__ keys, uint64_t n,
-                                                           uint64_t* __restrict__ T, uint32_t cmask, int shift,
-                                                           uint32_t* __restrict__ slot_of,
-                                                           uint32_t* __restrict__ flag) {
+// ---- 1. bucket ints -> fingerprint -> slot of an open-addressing table, membership proved on the way ----
+// T[C] (C a power of two >= n, all FP_EMPTY at entry), slot from the fingerprint's top bits, linear
+// probing.  A slot holds (top 32 bits of the fingerprint) << 32 | id of the k-mer that claimed it (its
+// representative).  A k-mer that meets its 32 bits compares its K bucket ints with the representative's:
+// identical (the common case; the hot buckets' representatives stay in cache) = same HashKey string = this
+// is its slot.  Ints that differ -- aliased strings ((1,23) and (12,3) have one string and, by
+// construction, one fingerprint), a fingerprint collision, or just equal top halves -- send the k-mer to
+// the queue of hs_group_insert_slow_kernel, which settles it by the strings themselves.  One pass over
+// the bucket ints does what the fingerprint kernel, the table insert and the membership proof of the
+// first draft did in three (the proof alone moved 160 bytes per k-mer).
+// slot_of[i] = the slot of k-mer i's key (0xffffffff: queued).  slow[0] = queued count, slow[1..] = ids.
+__global__ __launch_bounds__(256) void hs_group_insert_kernel(const int32_t* __restrict__ ints, uint64_t n, int K,
+                                                              uint32_t seed, uint64_t* __restrict__ T,
+                                                              uint64_t* __restrict__ Tfp, uint32_t cmask, int shift,
+                                                              uint32_t* __restrict__ slot_of,
+                                                              uint32_t* __restrict__ slow, uint32_t slow_cap,
+                                                              uint32_t* __restrict__ flag) {
+  __shared__ int32_t s_t[HS_MAX_K * 256];  // the thread's K ints, [j][thread]
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const uint64_t k = keys[i];
-  if (k == FP_EMPTY) {  // the one value the table cannot hold (2^-64 per key): the caller falls back
-    atomicOr(flag, 8u);
-    slot_of[i] = 0;
-    return;
+  const int32_t* tg = ints + i * (uint64_t)K;
+  int32_t* t = s_t + threadIdx.x;
+  if ((K & 3) == 0) {
+    int4 v[HS_MAX_K / 4];
+#pragma unroll
+    for (int j4 = 0; j4 < HS_MAX_K / 4; ++j4)
+      if (4 * j4 < K) v[j4] = reinterpret_cast<const int4*>(tg)[j4];
+#pragma unroll
+    for (int j4 = 0; j4 < HS_MAX_K / 4; ++j4)
+      if (4 * j4 < K) {
+        t[256 * (4 * j4)] = v[j4].x;
+        t[256 * (4 * j4 + 1)] = v[j4].y;
+        t[256 * (4 * j4 + 2)] = v[j4].z;
+        t[256 * (4 * j4 + 3)] = v[j4].w;
+      }
+  } else {
+    for (int j = 0; j < K; ++j) t[256 * j] = tg[j];
   }
-  uint32_t s = (uint32_t)(k >> shift) & cmask;
-  // (bounded: with the table at most ~ half full a chain of thousands does not occur; a build whose keys
-  // are nearly all distinct -- a tiny W -- ends here and takes the sorting path)
+  uint64_t hk = hs_key_init(seed);
+  for (int j = 0; j < K; ++j) hk = hs_key_put_int(hk, t[256 * j]);
+  const uint64_t fp = hs_key_fin(hk);
+  const uint64_t hi = fp >> 32;
+  const uint64_t mine = (hi << 32) | (uint64_t)i;
+  uint32_t s = (uint32_t)(fp >> shift) & cmask;
+  // (bounded: the table is at most as full as distinct keys / k-mers; a chain of thousands means nearly
+  // every key is distinct -- a tiny W -- and the build takes the sorting path)
   const uint32_t max_probe = cmask < 4095u ? cmask : 4095u;
   for (uint32_t probe = 0; probe <= max_probe; ++probe) {
-    uint64_t v = __hip_atomic_load(&T[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (v == FP_EMPTY) {
-      v = atomicCAS(reinterpret_cast<unsigned long long*>(&T[s]), (unsigned long long)FP_EMPTY, (unsigned long long)k);
-      if (v == FP_EMPTY) v = k;
+    uint64_t w = __hip_atomic_load(&T[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (w == FP_EMPTY) {
+      w = atomicCAS(reinterpret_cast<unsigned long long*>(&T[s]), (unsigned long long)FP_EMPTY, (unsigned long long)mine);
+      if (w == FP_EMPTY) {  // claimed: this k-mer represents the key (its full fingerprint for the directory)
+        Tfp[s] = fp;
+        slot_of[i] = s;
+        return;
+      }
     }
-    if (v == k) {
-      slot_of[i] = s;
+    if ((w >> 32) == hi) {
+      const int32_t* pr = ints + (uint64_t)(uint32_t)w * K;
+      bool same = true;
+      if ((K & 3) == 0) {
+        for (int j4 = 0; 4 * j4 < K; ++j4) {
+          const int4 r = reinterpret_cast<const int4*>(pr)[j4];
+          same = same && r.x == t[256 * (4 * j4)] && r.y == t[256 * (4 * j4 + 1)] && r.z == t[256 * (4 * j4 + 2)] &&
+                 r.w == t[256 * (4 * j4 + 3)];
+        }
+      } else {
+        for (int j = 0; j < K; ++j) same = same && pr[j] == t[256 * j];
+      }
+      if (same) {
+        slot_of[i] = s;
+        return;
+      }
+      // equal top halves, different ints: by the strings, in the slow kernel (which probes again from the start)
+      const uint32_t at = atomicAdd(slow, 1u);
+      if (at < slow_cap) slow[1 + at] = (uint32_t)i;
+      slot_of[i] = 0xffffffffu;
       return;
     }
     s = (s + 1) & cmask;
   }
   atomicOr(flag, 16u);  // table (nearly) full: the caller falls back
   slot_of[i] = 0;
+}
+
+// The queued k-mers, one thread each, with the whole rule: a slot whose 32 bits match belongs to the
+// k-mer if the HashKey STRINGS are equal; if they differ and the full fingerprints are equal it is a
+// fingerprint collision (flag 1: the caller rebuilds with the next seed); otherwise the probe goes on.
+__global__ __launch_bounds__(256) void hs_group_insert_slow_kernel(const int32_t* __restrict__ ints, int K,
+                                                                   uint32_t seed, uint64_t* __restrict__ T,
+                                                                   uint64_t* __restrict__ Tfp, uint32_t cmask, int shift,
+                                                                   uint32_t* __restrict__ slot_of,
+                                                                   const uint32_t* __restrict__ slow,
+                                                                   uint32_t slow_cap, uint32_t* __restrict__ flag) {
+  const uint32_t total = slow[0];
+  if (total > slow_cap) {  // more than the queue holds (massively aliased keys): the caller falls back
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(flag, 32u);
+    return;
+  }
+  for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < total; q += gridDim.x * 256) {
+    const uint32_t i = slow[1 + q];
+    int32_t x[HS_MAX_K], y[HS_MAX_K];
+    for (int j = 0; j < K; ++j) x[j] = ints[(uint64_t)i * K + j];
+    const uint64_t fp = hs_key_of(x, K, seed);
+    const uint64_t hi = fp >> 32;
+    const uint64_t mine = (hi << 32) | (uint64_t)i;
+    uint32_t s = (uint32_t)(fp >> shift) & cmask;
+    const uint32_t max_probe = cmask < 4095u ? cmask : 4095u;
+    bool done = false;
+    for (uint32_t probe = 0; probe <= max_probe && !done; ++probe) {
+      uint64_t w = __hip_atomic_load(&T[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (w == FP_EMPTY) {
+        w = atomicCAS(reinterpret_cast<unsigned long long*>(&T[s]), (unsigned long long)FP_EMPTY, (unsigned long long)mine);
+        if (w == FP_EMPTY) {
+          Tfp[s] = fp;
+          slot_of[i] = s;
+          done = true;
+          break;
+        }
+      }
+      if ((w >> 32) == hi) {
+        for (int j = 0; j < K; ++j) y[j] = ints[(uint64_t)(uint32_t)w * K + j];
+        if (hs_key_equal(x, y, K)) {
+          slot_of[i] = s;
+          done = true;
+          break;
+        }
+        if (hs_key_of(y, K, seed) == fp) {  // one fingerprint, two strings
+          atomicOr(flag, 1u);
+          slot_of[i] = s;
+          done = true;
+          break;
+        }
+      }
+      s = (s + 1) & cmask;
+    }
+    if (!done) {
+      atomicOr(flag, 16u);
+      slot_of[i] = 0;
+    }
+  }
 }
 
 // ---- 2. distinct keys out of the table ----------------------------------------------------------------
@@ -93,8 +200,10 @@ __global__ __launch_bounds__(256) void hs_fp_count_kernel(const uint64_t* __rest
   if (threadIdx.x == 0) blk_cnt[blockIdx.x] = sw[0] + sw[1] + sw[2] + sw[3];
 }
 
+// dk = the full fingerprint of the slot's key (Tfp, written by the k-mer that claimed the slot), ds = the slot
 __global__ __launch_bounds__(256) void hs_fp_compact_kernel(const uint64_t* __restrict__ T, uint32_t C,
                                                             const uint32_t* __restrict__ blk_off,
+                                                            const uint64_t* __restrict__ Tfp,
                                                             uint64_t* __restrict__ dk, uint32_t* __restrict__ ds) {
   const uint32_t base = blockIdx.x * 1024u;
   __shared__ uint32_t s_run;
@@ -115,7 +224,7 @@ __global__ __launch_bounds__(256) void hs_fp_compact_kernel(const uint64_t* __re
     const uint32_t total = sw[0] + sw[1] + sw[2] + sw[3];
     if (live) {
       const uint32_t o = s_run + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      dk[o] = v;
+      dk[o] = Tfp[s];
       ds[o] = s;
     }
     __syncthreads();
@@ -139,20 +248,27 @@ __global__ __launch_bounds__(256) void hs_rank_kmers_kernel(uint32_t* __restrict
 }
 
 // ---- 3. stable LSD radix pass over (rank, id): 8 bits ------------------------------------------------
-// hist[d * n_tiles + tile] = elements of the tile with digit d
+// A block owns a CONTIGUOUS range of tiles (tiles_per_block of them), so the digit x block histogram that
+// has to be scanned is 256 x RS_BLOCKS words whatever n is (one scan over digits x tiles -- 6 10^6 words at
+// n = 10^8 -- took rocPRIM's look-back scan longer than the scatter itself), and the scatter walks its tiles
+// in order with the running start of every digit in LDS.
+// hist[d * n_blocks + b] = elements of block b's tiles with digit d
 __global__ __launch_bounds__(256) void hs_rs_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift,
-                                                         uint32_t n_tiles, uint32_t* __restrict__ hist) {
+                                                         uint32_t tiles_per_block, uint32_t* __restrict__ hist) {
   __shared__ uint32_t h[RS_BINS];
   h[threadIdx.x] = 0;
   __syncthreads();
-  const uint32_t base = blockIdx.x * RS_TILE;
+  for (uint32_t tl = 0; tl < tiles_per_block; ++tl) {
+    const uint64_t base = ((uint64_t)blockIdx.x * tiles_per_block + tl) * RS_TILE;
+    if (base >= n) break;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const uint32_t e = base + 256u * j + threadIdx.x;
-    if (e < n) atomicAdd(&h[(keys[e] >> shift) & (RS_BINS - 1)], 1u);
+    for (int j = 0; j < 16; ++j) {
+      const uint64_t e = base + 256u * j + threadIdx.x;
+      if (e < n) atomicAdd(&h[(keys[e] >> shift) & (RS_BINS - 1)], 1u);
+    }
   }
   __syncthreads();
-  hist[(uint64_t)threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];
+  hist[(uint64_t)threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
 }
 
 // Element order inside a tile (= the order the sort must keep): wave w holds elements w * 1024 ..
@@ -161,7 +277,7 @@ __global__ __launch_bounds__(256) void hs_rs_hist_kernel(const uint32_t* __restr
 // lower lanes of its chunk: a ballot per digit bit).
 __global__ __launch_bounds__(256) void hs_rs_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                             const uint32_t* __restrict__ ids_in /* null: iota */,
-                                                            uint32_t n, int shift, uint32_t n_tiles,
+                                                            uint32_t n, int shift, uint32_t tiles_per_block,
                                                             const uint32_t* __restrict__ hist_scanned,
                                                             uint32_t* __restrict__ keys_out,
                                                             uint32_t* __restrict__ ids_out) {
@@ -170,88 +286,97 @@ __global__ __launch_bounds__(256) void hs_rs_scatter_kernel(const uint32_t* __re
   __shared__ uint32_t gbase[RS_BINS];   // global start of the tile's run of every digit
   __shared__ uint2 stage[RS_TILE];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  for (int d = tid; d < 4 * RS_BINS; d += 256) (&wh[0][0])[d] = 0;
-  gbase[tid] = hist_scanned[(uint64_t)tid * n_tiles + blockIdx.x];
-  __syncthreads();
-  const uint32_t base = blockIdx.x * RS_TILE + (uint32_t)w * 1024u;
-  uint32_t key[16], id[16], loc[16];
+  gbase[tid] = hist_scanned[(uint64_t)tid * gridDim.x + blockIdx.x];
   const unsigned long long lt = (1ull << lane) - 1ull;
+  for (uint32_t tl = 0; tl < tiles_per_block; ++tl) {
+    const uint64_t tile_base = ((uint64_t)blockIdx.x * tiles_per_block + tl) * RS_TILE;
+    if (tile_base >= n) break;  // (block-uniform)
+    for (int d = tid; d < 4 * RS_BINS; d += 256) (&wh[0][0])[d] = 0;
+    __syncthreads();
+    const uint32_t base = (uint32_t)tile_base + (uint32_t)w * 1024u;
+    uint32_t key[16], id[16], loc[16];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) {
-    const uint32_t e = base + 64u * c + (uint32_t)lane;
-    const bool live = e < n;
-    key[c] = live ? keys_in[e] : 0xffffffffu;
-    id[c] = live ? (ids_in ? ids_in[e] : e) : 0xffffffffu;
-  }
-#pragma unroll
-  for (int c = 0; c < 16; ++c) {
-    // (elements past the end count as digit 255: they sit at the very end of the last tile, so every
-    // live element of that digit ranks before them, and they are not written)
-    const uint32_t e = base + 64u * c + (uint32_t)lane;
-    const uint32_t d = e < n ? (key[c] >> shift) & (RS_BINS - 1) : (uint32_t)(RS_BINS - 1);
-    unsigned long long m = ~0ull;
-#pragma unroll
-    for (int b = 0; b < RS_BITS; ++b) {
-      const unsigned long long bal = __ballot((d >> b) & 1u);
-      m &= ((d >> b) & 1u) ? bal : ~bal;
+    for (int c = 0; c < 16; ++c) {
+      const uint32_t e = base + 64u * c + (uint32_t)lane;
+      const bool live = e < n;
+      key[c] = live ? keys_in[e] : 0xffffffffu;
+      id[c] = live ? (ids_in ? ids_in[e] : e) : 0xffffffffu;
     }
-    const uint32_t before = wh[w][d];  // (every lane of the digit reads it before its leader adds)
-    const uint32_t rank = (uint32_t)__popcll(m & lt);
-    __builtin_amdgcn_wave_barrier();
-    if (rank == 0) wh[w][d] = before + (uint32_t)__popcll(m);
-    __builtin_amdgcn_wave_barrier();
-    loc[c] = before + rank;
-  }
-  __syncthreads();
-  {  // per digit: the waves' counts -> exclusive prefix over the waves; tile total
-    const uint32_t c0 = wh[0][tid], c1 = wh[1][tid], c2 = wh[2][tid], c3 = wh[3][tid];
-    wh[0][tid] = 0;
-    wh[1][tid] = c0;
-    wh[2][tid] = c0 + c1;
-    wh[3][tid] = c0 + c1 + c2;
-    tstart[tid] = c0 + c1 + c2 + c3;
-  }
-  __syncthreads();
-  if (w == 0) {  // exclusive scan of the 256 tile totals by one wave: 4 digits per lane
-    uint32_t v[4], sum = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      v[j] = tstart[4 * lane + j];
-      sum += v[j];
-    }
-    uint32_t inc = sum;
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t o = __shfl_up(inc, off);
-      if (lane >= off) inc += o;
-    }
-    uint32_t run = inc - sum;
+    for (int c = 0; c < 16; ++c) {
+      // (elements past the end count as digit 255: they sit at the very end of the last tile, so every
+      // live element of that digit ranks before them, and they are not written)
+      const uint32_t e = base + 64u * c + (uint32_t)lane;
+      const uint32_t d = e < n ? (key[c] >> shift) & (RS_BINS - 1) : (uint32_t)(RS_BINS - 1);
+      unsigned long long m = ~0ull;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      tstart[4 * lane + j] = run;
-      run += v[j];
+      for (int b = 0; b < RS_BITS; ++b) {
+        const unsigned long long bal = __ballot((d >> b) & 1u);
+        m &= ((d >> b) & 1u) ? bal : ~bal;
+      }
+      const uint32_t before = wh[w][d];  // (every lane of the digit reads it before its leader adds)
+      const uint32_t rank = (uint32_t)__popcll(m & lt);
+      __builtin_amdgcn_wave_barrier();
+      if (rank == 0) wh[w][d] = before + (uint32_t)__popcll(m);
+      __builtin_amdgcn_wave_barrier();
+      loc[c] = before + rank;
     }
-  }
-  __syncthreads();
+    __syncthreads();
+    uint32_t tile_cnt;
+    {  // per digit: the waves' counts -> exclusive prefix over the waves; tile total
+      const uint32_t c0 = wh[0][tid], c1 = wh[1][tid], c2 = wh[2][tid], c3 = wh[3][tid];
+      wh[0][tid] = 0;
+      wh[1][tid] = c0;
+      wh[2][tid] = c0 + c1;
+      wh[3][tid] = c0 + c1 + c2;
+      tile_cnt = c0 + c1 + c2 + c3;
+      tstart[tid] = tile_cnt;
+    }
+    __syncthreads();
+    if (w == 0) {  // exclusive scan of the 256 tile totals by one wave: 4 digits per lane
+      uint32_t v[4], sum = 0;
 #pragma unroll
-  for (int c = 0; c < 16; ++c) {
-    const uint32_t e = base + 64u * c + (uint32_t)lane;
-    if (e < n) {
-      const uint32_t d = (key[c] >> shift) & (RS_BINS - 1);
-      stage[tstart[d] + wh[w][d] + loc[c]] = make_uint2(key[c], id[c]);
-    }
-  }
-  __syncthreads();
-  const uint32_t live_in_tile = min(RS_TILE, n - blockIdx.x * RS_TILE);
+      for (int j = 0; j < 4; ++j) {
+        v[j] = tstart[4 * lane + j];
+        sum += v[j];
+      }
+      uint32_t inc = sum;
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+      }
+      uint32_t run = inc - sum;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const uint32_t p = 256u * j + (uint32_t)tid;
-    if (p < live_in_tile) {
-      const uint2 v = stage[p];
-      const uint32_t d = (v.x >> shift) & (RS_BINS - 1);
-      const uint32_t o = gbase[d] + (p - tstart[d]);
-      keys_out[o] = v.x;
-      ids_out[o] = v.y;
+      for (int j = 0; j < 4; ++j) {
+        tstart[4 * lane + j] = run;
+        run += v[j];
+      }
     }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const uint32_t e = base + 64u * c + (uint32_t)lane;
+      if (e < n) {
+        const uint32_t d = (key[c] >> shift) & (RS_BINS - 1);
+        stage[tstart[d] + wh[w][d] + loc[c]] = make_uint2(key[c], id[c]);
+      }
+    }
+    __syncthreads();
+    const uint32_t live_in_tile = (uint32_t)min((uint64_t)RS_TILE, (uint64_t)n - tile_base);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint32_t p = 256u * j + (uint32_t)tid;
+      if (p < live_in_tile) {
+        const uint2 v = stage[p];
+        const uint32_t d = (v.x >> shift) & (RS_BINS - 1);
+        const uint32_t o = gbase[d] + (p - tstart[d]);
+        keys_out[o] = v.x;
+        ids_out[o] = v.y;
+      }
+    }
+    __syncthreads();
+    // (the dead elements of the last tile were counted as digit 255: nothing follows them)
+    gbase[tid] += tile_cnt;
   }
 }
 
@@ -273,64 +398,18 @@ __global__ __launch_bounds__(256) void hs_dir_max_kernel(const uint32_t* __restr
   if ((threadIdx.x & 63) == 0 && m) atomicMax(out_max, m);
 }
 
-// Every k-mer against its bucket's tuple (the tuple of the bucket's first member, dir_tuple[rank]): the
-// identical case is settled here; a k-mer whose ints differ from the tuple's -- aliased strings, or a
-// fingerprint collision -- is queued (slow[0] = count, slow[1..] = k-mer numbers) for the string compare.
-__global__ __launch_bounds__(256) void hs_check_members_kernel(const uint32_t* __restrict__ rank, uint64_t n,
-                                                               const int32_t* __restrict__ ints, int K,
-                                                               const int32_t* __restrict__ dir_tuple,
-                                                               uint32_t* __restrict__ slow, uint32_t slow_cap) {
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int32_t* px = ints + i * (uint64_t)K;
-  const int32_t* py = dir_tuple + (uint64_t)rank[i] * K;
-  bool same = true;
-  if ((K & 3) == 0) {
-    int4 vx[HS_MAX_K / 4], vy[HS_MAX_K / 4];
-#pragma unroll
-    for (int j4 = 0; j4 < HS_MAX_K / 4; ++j4)
-      if (4 * j4 < K) {
-        vx[j4] = reinterpret_cast<const int4*>(px)[j4];
-        vy[j4] = reinterpret_cast<const int4*>(py)[j4];
-      }
-#pragma unroll
-    for (int j4 = 0; j4 < HS_MAX_K / 4; ++j4)
-      if (4 * j4 < K)
-        same = same && vx[j4].x == vy[j4].x && vx[j4].y == vy[j4].y && vx[j4].z == vy[j4].z && vx[j4].w == vy[j4].w;
-  } else {
-    for (int j = 0; j < K; ++j) same = same && (px[j] == py[j]);
-  }
-  if (same) return;
-  const uint32_t at = atomicAdd(slow, 1u);
-  if (at < slow_cap) slow[1 + at] = (uint32_t)i;
-}
-
-// flag |= 1: equal fingerprints, different key strings (a collision); flag |= 2: the queue overflowed
-// (the caller repeats with exhaustive = true: every k-mer compared as strings)
-__global__ __launch_bounds__(256) void hs_check_members_slow_kernel(const uint32_t* __restrict__ rank, uint64_t n_all,
-                                                                    const int32_t* __restrict__ ints, int K,
-                                                                    const int32_t* __restrict__ dir_tuple,
-                                                                    const uint32_t* __restrict__ slow,
-                                                                    uint32_t slow_cap, uint32_t* __restrict__ flag) {
-  const uint64_t total = n_all ? n_all : min(slow[0], slow_cap);
-  if (!n_all && slow[0] > slow_cap) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(flag, 2u);
-    return;
-  }
-  for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (uint64_t)gridDim.x * 256) {
-    const uint64_t i = n_all ? t : slow[1 + t];
-    int32_t x[HS_MAX_K], y[HS_MAX_K];
-    const int32_t* px = ints + i * (uint64_t)K;
-    const int32_t* py = dir_tuple + (uint64_t)rank[i] * K;
-    for (int j = 0; j < K; ++j) {
-      x[j] = px[j];
-      y[j] = py[j];
-    }
-    if (!hs_key_equal(x, y, K)) atomicOr(flag, 1u);
-  }
+__global__ __launch_bounds__(256) void hs_iota_u32_kernel(uint32_t* __restrict__ out, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = i;
 }
 
 }  // namespace
+
+hipError_t hs_launch_iota_u32(uint32_t* d_out, uint32_t n, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hs_iota_u32_kernel<<<blocks_for(n), 256, 0, s>>>(d_out, n);
+  return hipGetLastError();
+}
 
 // slots of the fingerprint table for n k-mers: a power of two >= n (load factor = distinct keys / slots
 // <= 1 always, a few per cent on the benchmark shapes)
@@ -340,13 +419,32 @@ uint32_t hs_group_table_slots(uint64_t n) {
   return c;
 }
 
-hipError_t hs_launch_fp_insert(const uint64_t* d_keys, uint64_t n, uint64_t* d_table, uint32_t C,
-                               uint32_t* d_slot_of, uint32_t* d_flag, hipStream_t s) {
+// blocks of the radix passes: each owns ceil(tiles / blocks) consecutive tiles
+constexpr uint32_t RS_BLOCKS = 2048;
+uint32_t hs_rs_blocks(uint64_t n) {
+  const uint64_t tiles = (n + RS_TILE - 1) / RS_TILE;
+  return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(tiles, RS_BLOCKS));
+}
+static uint32_t rs_tiles_per_block(uint64_t n) {
+  const uint64_t tiles = (n + RS_TILE - 1) / RS_TILE;
+  const uint32_t nb = hs_rs_blocks(n);
+  return (uint32_t)((tiles + nb - 1) / nb);
+}
+
+// d_table: 2 C words -- the slots, then the full fingerprints of the slots' keys
+hipError_t hs_launch_group_insert(const int32_t* d_ints, uint64_t n, int K, uint32_t seed, uint64_t* d_table,
+                                  uint32_t C, uint32_t* d_slot_of, uint32_t* d_slow, uint32_t slow_cap,
+                                  uint32_t* d_flag, hipStream_t s) {
   hipError_t e = hipMemsetAsync(d_table, 0xff, (size_t)C * 8, s);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(d_slow, 0, 4, s);
   if (e != hipSuccess || !n) return e;
   int log2c = 0;
   while ((1u << log2c) < C) ++log2c;
-  hs_fp_insert_kernel<<<blocks_for(n), 256, 0, s>>>(d_keys, n, d_table, C - 1, 64 - log2c, d_slot_of, d_flag);
+  hs_group_insert_kernel<<<blocks_for(n), 256, 0, s>>>(d_ints, n, K, seed, d_table, d_table + C, C - 1, 64 - log2c,
+                                                       d_slot_of, d_slow, slow_cap, d_flag);
+  hs_group_insert_slow_kernel<<<64, 256, 0, s>>>(d_ints, K, seed, d_table, d_table + C, C - 1, 64 - log2c, d_slot_of,
+                                                 d_slow, slow_cap, d_flag);
   return hipGetLastError();
 }
 
@@ -357,7 +455,7 @@ hipError_t hs_launch_fp_count(const uint64_t* d_table, uint32_t C, uint32_t* d_b
 
 hipError_t hs_launch_fp_compact(const uint64_t* d_table, uint32_t C, const uint32_t* d_blk_off, uint64_t* d_dk,
                                 uint32_t* d_ds, hipStream_t s) {
-  hs_fp_compact_kernel<<<(C + 1023) / 1024, 256, 0, s>>>(d_table, C, d_blk_off, d_dk, d_ds);
+  hs_fp_compact_kernel<<<(C + 1023) / 1024, 256, 0, s>>>(d_table, C, d_blk_off, d_table + C, d_dk, d_ds);
   return hipGetLastError();
 }
 
@@ -373,19 +471,16 @@ hipError_t hs_launch_rank_kmers(uint32_t* d_slot_of, uint64_t n, const uint32_t*
   return hipGetLastError();
 }
 
-uint32_t hs_rs_tiles(uint64_t n) { return (uint32_t)((n + RS_TILE - 1) / RS_TILE); }
-
 hipError_t hs_launch_rs_hist(const uint32_t* d_keys, uint32_t n, int shift, uint32_t* d_hist, hipStream_t s) {
-  const uint32_t nt = hs_rs_tiles(n);
-  hs_rs_hist_kernel<<<nt, 256, 0, s>>>(d_keys, n, shift, nt, d_hist);
+  hs_rs_hist_kernel<<<hs_rs_blocks(n), 256, 0, s>>>(d_keys, n, shift, rs_tiles_per_block(n), d_hist);
   return hipGetLastError();
 }
 
 hipError_t hs_launch_rs_scatter(const uint32_t* d_keys_in, const uint32_t* d_ids_in, uint32_t n, int shift,
                                 const uint32_t* d_hist_scanned, uint32_t* d_keys_out, uint32_t* d_ids_out,
                                 hipStream_t s) {
-  const uint32_t nt = hs_rs_tiles(n);
-  hs_rs_scatter_kernel<<<nt, 256, 0, s>>>(d_keys_in, d_ids_in, n, shift, nt, d_hist_scanned, d_keys_out, d_ids_out);
+  hs_rs_scatter_kernel<<<hs_rs_blocks(n), 256, 0, s>>>(d_keys_in, d_ids_in, n, shift, rs_tiles_per_block(n),
+                                                       d_hist_scanned, d_keys_out, d_ids_out);
   return hipGetLastError();
 }
 
@@ -393,20 +488,5 @@ hipError_t hs_launch_dir_start(const uint32_t* d_ranks_sorted, uint32_t n, uint3
                                uint32_t* d_max, hipStream_t s) {
   hs_dir_start_kernel<<<blocks_for(n), 256, 0, s>>>(d_ranks_sorted, n, nb, d_dir_start);
   hs_dir_max_kernel<<<std::min(1024u, blocks_for(nb)), 256, 0, s>>>(d_dir_start, nb, d_max);
-  return hipGetLastError();
-}
-
-hipError_t hs_launch_check_members(const uint32_t* d_rank, uint64_t n, const int32_t* d_ints, int K,
-                                   const int32_t* d_dir_tuple, uint32_t* d_flag, uint32_t* d_slow, uint32_t slow_cap,
-                                   bool exhaustive, hipStream_t s) {
-  if (!n) return hipSuccess;
-  if (exhaustive) {
-    hs_check_members_slow_kernel<<<1024, 256, 0, s>>>(d_rank, n, d_ints, K, d_dir_tuple, d_slow, slow_cap, d_flag);
-    return hipGetLastError();
-  }
-  hipError_t e = hipMemsetAsync(d_slow, 0, 4, s);
-  if (e != hipSuccess) return e;
-  hs_check_members_kernel<<<blocks_for(n), 256, 0, s>>>(d_rank, n, d_ints, K, d_dir_tuple, d_slow, slow_cap);
-  hs_check_members_slow_kernel<<<64, 256, 0, s>>>(d_rank, 0, d_ints, K, d_dir_tuple, d_slow, slow_cap, d_flag);
   return hipGetLastError();
 }

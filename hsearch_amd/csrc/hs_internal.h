@@ -166,23 +166,28 @@ hipError_t hs_rle_u64(void* temp, size_t temp_bytes, const uint64_t* in, uint64_
                       uint32_t* counts_out, uint32_t* runs_out, size_t n, hipStream_t s);
 
 // ---- grouping a table's k-mers by key without sorting fingerprints (hs_group.hip) -----------------
-// fingerprints -> slots of an open-addressing table d_table[C] (C = hs_group_table_slots(n)): d_slot_of[i]
-// = slot of d_keys[i]; *d_flag |= 8 if a fingerprint equals the table's empty marker, 16 if the table
-// filled up (either way the caller takes the sorting path)
+// bucket ints -> slots of an open-addressing table d_table[2 C] (C = hs_group_table_slots(n) slots, then the
+// slots' full fingerprints), membership
+// proved against the slot's representative: d_slot_of[i] = slot of k-mer i's key.  *d_flag |= 1: a
+// fingerprint collision (one fingerprint, two HashKey strings: rebuild with another seed); 16: the table
+// filled up; 32: more k-mers with aliased keys than the queue d_slow (count + slow_cap ids) holds -- with
+// 16 or 32 the caller takes the sorting path for this table.
 uint32_t hs_group_table_slots(uint64_t n);
-hipError_t hs_launch_fp_insert(const uint64_t* d_keys, uint64_t n, uint64_t* d_table, uint32_t C,
-                               uint32_t* d_slot_of, uint32_t* d_flag, hipStream_t s);
+hipError_t hs_launch_iota_u32(uint32_t* d_out, uint32_t n, hipStream_t s);
+hipError_t hs_launch_group_insert(const int32_t* d_ints, uint64_t n, int K, uint32_t seed, uint64_t* d_table,
+                                  uint32_t C, uint32_t* d_slot_of, uint32_t* d_slow, uint32_t slow_cap,
+                                  uint32_t* d_flag, hipStream_t s);
 // distinct keys per block of 1024 slots; after an exclusive scan of those counts (d_blk_off, with the
-// total at [n_blocks]): the distinct keys d_dk and their slots d_ds in slot order
+// total at [n_blocks]): the distinct keys' fingerprints d_dk and their slots d_ds in slot order
 hipError_t hs_launch_fp_count(const uint64_t* d_table, uint32_t C, uint32_t* d_blk_cnt, hipStream_t s);
 hipError_t hs_launch_fp_compact(const uint64_t* d_table, uint32_t C, const uint32_t* d_blk_off, uint64_t* d_dk,
                                 uint32_t* d_ds, hipStream_t s);
 // d_rank_of_slot[d_ds_sorted[r]] = r; then d_slot_of[i] <- rank of k-mer i's key, in place
 hipError_t hs_launch_rank_slots(const uint32_t* d_ds_sorted, uint32_t nb, uint32_t* d_rank_of_slot, hipStream_t s);
 hipError_t hs_launch_rank_kmers(uint32_t* d_slot_of, uint64_t n, const uint32_t* d_rank_of_slot, hipStream_t s);
-// one stable LSD radix pass (8 bits from `shift`) over (key, id): histogram [256][hs_rs_tiles(n)], the
+// one stable LSD radix pass (8 bits from `shift`) over (key, id): histogram [256][hs_rs_blocks(n)], the
 // caller's exclusive scan over it, scatter (d_ids_in null: ids 0 .. n - 1)
-uint32_t hs_rs_tiles(uint64_t n);
+uint32_t hs_rs_blocks(uint64_t n);
 hipError_t hs_launch_rs_hist(const uint32_t* d_keys, uint32_t n, int shift, uint32_t* d_hist, hipStream_t s);
 hipError_t hs_launch_rs_scatter(const uint32_t* d_keys_in, const uint32_t* d_ids_in, uint32_t n, int shift,
                                 const uint32_t* d_hist_scanned, uint32_t* d_keys_out, uint32_t* d_ids_out,
@@ -190,12 +195,6 @@ hipError_t hs_launch_rs_scatter(const uint32_t* d_keys_in, const uint32_t* d_ids
 // bucket boundaries from the sorted ranks (d_dir_start[nb + 1]) and the largest bucket (atomicMax into *d_max)
 hipError_t hs_launch_dir_start(const uint32_t* d_ranks_sorted, uint32_t n, uint32_t nb, uint32_t* d_dir_start,
                                uint32_t* d_max, hipStream_t s);
-// every k-mer's bucket ints against its bucket's tuple d_dir_tuple[rank]: *d_flag |= 1 on a fingerprint
-// collision (equal fingerprints, different HashKey strings), |= 2 if the queue of non-identical tuples
-// (d_slow: count + slow_cap entries) overflowed -- the caller then repeats with exhaustive = true
-hipError_t hs_launch_check_members(const uint32_t* d_rank, uint64_t n, const int32_t* d_ints, int K,
-                                   const int32_t* d_dir_tuple, uint32_t* d_flag, uint32_t* d_slow, uint32_t slow_cap,
-                                   bool exhaustive, hipStream_t s);
 
 // ---- projection on the matrix cores (hs_proj.hip) ------------------------------------------------
 // The coordinate table in 16-bit fixed point for the codes path: per residue the high and low digit

@@ -88,6 +88,8 @@ typedef struct hs_profile {
                                  it did not run) ... */
   uint32_t join_wide;         /* ... and 1 if the rows carried all 8 coordinate columns (short k-mers, large
                                  radii), 0 for the 4 filter columns */
+  uint64_t join_items_resident; /* of join_items: those of segments with few probing queries, run by the
+                                   query-resident kernel (hs_join8r_kernel) */
   uint64_t join_async_retries; /* batches whose join was launched on a capacity hint that turned out too small
                                   (or illegal) and ran a second time: exclude such a call from kernel timings */
 } hs_profile;

@@ -630,6 +630,7 @@ def test_build_sorts_again_when_partial_fingerprints_interleave(monkeypatch):
     codes = synth.make_db(n, k, seed=56)
     centers, _ = synth.make_queries(codes, nq, seed=57, jitter=0.2)
     res = {}
+    monkeypatch.setenv("HS_BUILD_SORT", "1")     # the sorting form of the grouping (default: hs_group.hip)
     for from_bit in ("0", "56", None):
         monkeypatch.delenv("HS_SORT_FROM_BIT", raising=False)
         if from_bit is not None:
@@ -659,8 +660,11 @@ def test_build_at_the_sort_path_boundary(monkeypatch, n):
     src = np.random.default_rng(77).integers(0, n, size=nq)
     centers = synth.embed(codes[src])
     res = {}
-    for mode in ("0", None, "subset"):
+    for mode in ("0", None, "subset", "group"):
         monkeypatch.delenv("HS_SORT_FROM_BIT", raising=False)
+        monkeypatch.setenv("HS_BUILD_SORT", "1")     # the sorting form of the grouping, whose boundary this is ...
+        if mode == "group":
+            monkeypatch.delenv("HS_BUILD_SORT")      # ... and the default form (hs_group.hip) beside it
         if mode == "0":
             monkeypatch.setenv("HS_SORT_FROM_BIT", "0")
         eng = Engine(k, K, L, W, a, b)
@@ -673,7 +677,7 @@ def test_build_at_the_sort_path_boundary(monkeypatch, n):
         if i == src[q]:
             first[q] = t
     assert all(first.get(q) == 0 for q in range(nq))      # an exact copy shares its k-mer's bucket in table 0
-    for other in (None, "subset"):
+    for other in (None, "subset", "group"):
         assert res[other][0] == res["0"][0] and res[other][1] == res["0"][1]
         for key in ("q", "id", "table", "dist", "cand"):
             assert np.array_equal(res[other][2][key], got[key])
@@ -863,3 +867,60 @@ def test_query_resident_and_query_streaming_join_kernels(oracle, monkeypatch, K,
         eng.close()
     # the same pairs either way; the resident kernel issues 16-query column tiles: no more padding, mostly less
     assert seen["default"][0] == seen["no_r"][0] and seen["default"][1] <= seen["no_r"][1]
+
+
+@pytest.mark.parametrize("k,K,L,W,n", [(25, 16, 4, 200.0, 300007), (25, 4, 3, 0.5, 50021), (15, 3, 5, 60.0, 4099),
+                                       (25, 20, 3, 160.0, 1), (39, 6, 2, 260.0, 70001), (25, 1, 2, 1.0e6, 9001)])
+def test_grouping_by_rank_equals_grouping_by_sort(oracle, monkeypatch, tmp_path, k, K, L, W, n):
+    """Index build, SURVEY 8(a) a7: the default grouping (hs_group.hip: table of distinct fingerprints,
+    ranks, a radix sort of (rank, id) of its own) against the full-width sort of (fingerprint, id) pairs
+    (HS_BUILD_SORT=1, rounds 1-2): the same index FILE byte for byte -- ids per bucket, directory keys,
+    boundaries, tuples -- the same bucket statistics, the oracle's table sizes, and the oracle's hits.
+    Shapes: many k-mers per bucket, nearly every k-mer its own bucket (W = 0.5: the table fills up and the
+    build falls back to sorting), one k-mer, one bucket per table (W = 10^6), two packed words."""
+    a, b = synth.make_planes(k, K, L, W, seed=105)
+    codes = synth.make_db(n, k, seed=106)
+    centers, _ = synth.make_queries(codes, min(500, 5 * n), seed=107, jitter=0.2)
+    R = 30.0 + k
+    ix = oracle.Index(a, b, W, oracle.embed_codes(codes))
+    want = ix.query(centers, R)
+    files = {}
+    for form in ("rank", "sort"):
+        monkeypatch.delenv("HS_BUILD_SORT", raising=False)
+        if form == "sort":
+            monkeypatch.setenv("HS_BUILD_SORT", "1")
+        eng = Engine(k, K, L, W, a, b)
+        info = eng.index_build(codes)
+        assert info["n_buckets"] == ix.table_sizes(), form
+        got = eng.query(centers, R)
+        assert np.array_equal(got["cand"], want["cand"]), form
+        _assert_hits_equal(got, want)
+        path = str(tmp_path / (form + ".idx"))
+        eng.index_save(path)
+        files[form] = (open(path, "rb").read(), info["max_bucket"])
+        eng.index_build(codes[: max(1, n // 2)])          # a rebuild on the warm handle (scratch reused)
+        assert eng.index_info()["n"] == max(1, n // 2)
+        eng.close()
+    assert files["rank"][1] == files["sort"][1]
+    assert files["rank"][0] == files["sort"][0]
+
+
+def test_grouping_falls_back_to_the_sort_per_table(oracle, monkeypatch):
+    """A table whose fingerprint table fills up (nearly every key distinct) or meets the one fingerprint it
+    cannot hold is grouped by the full-width sort instead, table by table.  The library's TEST build
+    (HS_TEST_GROUP_FALLBACK) reports that condition for every other table: same index, same hits."""
+    k, K, L, W, R, n, nq = 25, 6, 5, 140.0, 45.0, 40009, 800
+    a, b = synth.make_planes(k, K, L, W, seed=115)
+    codes = synth.make_db(n, k, seed=116)
+    centers, _ = synth.make_queries(codes, nq, seed=117, jitter=0.2)
+    ix = oracle.Index(a, b, W, oracle.embed_codes(codes))
+    want = ix.query(centers, R)
+    monkeypatch.setenv("HS_TEST_GROUP_FALLBACK", "1")
+    eng = Engine(k, K, L, W, a, b, hooks=True)
+    for _ in range(2):
+        info = eng.index_build(codes)
+        assert info["n_buckets"] == ix.table_sizes()
+        got = eng.query(centers, R)
+        assert np.array_equal(got["cand"], want["cand"])
+        _assert_hits_equal(got, want)
+    eng.close()
