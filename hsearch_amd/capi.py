@@ -19,7 +19,8 @@ EXPORTS = ["hs_create", "hs_destroy", "hs_last_error", "hs_get_profile", "hs_get
            "hs_clustering_begin", "hs_clustering_table_edges", "hs_clustering_table_apply",
            "hs_clustering_end",
            "hs_embed_codes", "hs_hash_codes", "hs_hash_points", "hs_key_string", "hs_key_fingerprint",
-           "hs_key_strings_equal", "hs_index_build", "hs_index_build_subset", "hs_index_build_windows", "hs_index_save", "hs_index_load", "hs_index_file_check", "hs_klsh_draw_planes", "hs_klsh_codes",
+           "hs_key_strings_equal", "hs_index_build", "hs_index_build_subset", "hs_index_build_windows", "hs_index_shard_begin", "hs_index_shard_hash_dev", "hs_index_shard_group_dev",
+           "hs_index_shard_tuples_dev", "hs_index_shard_finish_dev", "hs_index_shard_end", "hs_index_save", "hs_index_load", "hs_index_file_check", "hs_klsh_draw_planes", "hs_klsh_codes",
            "hs_index_info_get", "hs_query", "hs_query_dev", "hs_query_codes", "hs_query_codes_dev", "hs_bruteforce",
            "hs_bruteforce_topk"]
 
@@ -297,6 +298,35 @@ class Engine:
         self._check(self._lib.hs_index_build_subset(self._h, _vp(codes_all), C.c_uint64(n_all),
                                                     _vp(sub) if sub is not None else C.c_void_p(0),
                                                     C.c_uint64(n_sub)))
+        return self.index_info()
+
+    # -- a7 with the hashing spread over ranks (hs_index_shard_*: pointers are device pointers, ints)
+    def shard_begin(self, codes, rank, world):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        assert codes.ndim == 2 and codes.shape[1] == self.k
+        lo, cnt = C.c_uint64(0), C.c_uint64(0)
+        self._check(self._lib.hs_index_shard_begin(self._h, _vp(codes), C.c_uint64(codes.shape[0]), C.c_uint32(rank),
+                                                   C.c_uint32(world), C.byref(lo), C.byref(cnt)))
+        return lo.value, cnt.value
+
+    def shard_hash(self, l, seed, d_fp_block):
+        self._check(self._lib.hs_index_shard_hash_dev(self._h, C.c_uint32(l), C.c_uint32(seed), C.c_void_p(d_fp_block)))
+
+    def shard_group(self, l, d_fp_all):
+        nb = C.c_uint32(0)
+        self._check(self._lib.hs_index_shard_group_dev(self._h, C.c_uint32(l), C.c_void_p(d_fp_all), C.byref(nb)))
+        return nb.value
+
+    def shard_tuples(self, l, d_tuples):
+        self._check(self._lib.hs_index_shard_tuples_dev(self._h, C.c_uint32(l), C.c_void_p(d_tuples)))
+
+    def shard_finish(self, l, d_tuples_all):
+        col = C.c_uint32(0)
+        self._check(self._lib.hs_index_shard_finish_dev(self._h, C.c_uint32(l), C.c_void_p(d_tuples_all), C.byref(col)))
+        return col.value
+
+    def shard_end(self, seed):
+        self._check(self._lib.hs_index_shard_end(self._h, C.c_uint32(seed)))
         return self.index_info()
 
     def index_build_windows(self, residues, seq_start):

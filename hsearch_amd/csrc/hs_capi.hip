@@ -152,6 +152,10 @@ struct hs_handle {
   DevBuf bs_ints2[2], bs_keys2[2], bs_iota2[2], bs_keys_sorted, bs_rle_unique, bs_rle_counts, bs_small,
       bs_sort_temp, bs_slow_q;  // index-build scratch (build_tables)
   DevBuf bs_fptab, bs_blk, bs_dk, bs_hist, bs_rank;  // ... of the table + rank-sort grouping (hs_group.hip)
+  // hs_index_shard_*: the build with the hashing spread over ranks (this rank's block of the k-mers)
+  bool shard_open = false;
+  uint32_t shard_lo = 0, shard_cnt = 0, shard_seed = 0, shard_nb = 0;
+  int shard_table = -1;
   DevBuf seg_res;   // cut_items: flags + scan of the segments that go to the query-resident join kernel
   DevBuf jconst;    // 128 copies of the gamma slots' constant factors (hs_join8r_kernel's fourth lane quarter)
   DevBuf c16s, item_desc, probe_slow, jtab8, slice_ql, qhits;  // qhits: per-query hit counts, offsets, fill
@@ -1155,6 +1159,198 @@ hs_status hs_index_build(hs_handle* h, const uint8_t* codes, uint64_t n) {
   HS_HIP(h, hipEventRecord(h->ev[8], h->stream));
   if (n) HS_HIP(h, hipMemcpyAsync(h->codes.p, codes, (size_t)n * k, hipMemcpyHostToDevice, h->stream));
   return index_build_resident(h, n);
+}
+
+// ---- index build with the hashing spread over ranks ("Index build" row) --------------
+// The index is replicated, so every rank holds all n k-mers; what is spread is the evaluation of the
+// L x K hash functions (the matrix-core part of the build): rank r does it for its contiguous block of
+// the k-mers (hs_shard_bounds' rule) and the ranks exchange 8-byte fingerprints instead.  Per table:
+//   hs_index_shard_hash_dev    bucket ints + fingerprints of the rank's block
+//   <all-gather of the fingerprints, blocks in rank order = id order>
+//   hs_index_shard_group_dev   every rank groups all n fingerprints (sort, directory)
+//   hs_index_shard_tuples_dev  the bucket ints of the buckets whose FIRST member the rank hashed
+//   <sum over ranks: every bucket's tuple>
+//   hs_index_shard_finish_dev  exact-membership proof of the rank's own k-mers against the tuples, the
+//                              bucket-ordered copies; *collided = one fingerprint, two HashKey strings
+//   <max over ranks of collided: if set, every rank starts over with seed + 1>
+// then hs_index_shard_end.  The index is the one hs_index_build builds, bit for bit.
+hs_status hs_index_shard_begin(hs_handle* h, const uint8_t* codes, uint64_t n, uint32_t rank, uint32_t world,
+                               uint64_t* block_lo, uint64_t* block_count) {
+  if (!h || (n && !codes) || !world || rank >= world) return HS_ERR_INVALID;
+  if (n >= (1ull << 31)) return fail(h, HS_ERR_INVALID, "n must be < 2^31 (ids are 32-bit, as in the reference)");
+  hs_status st = ensure_device(h);
+  if (st) return st;
+  drop_index(h);
+  h->n = n;
+  memset(&h->prof, 0, sizeof(h->prof));
+  memset(&h->info, 0, sizeof(h->info));
+  const int k = (int)h->p.k, K = (int)h->p.K, L = (int)h->p.L, PW = h->PW;
+  HS_HIP(h, h->codes.reserve(std::max<size_t>(16, (size_t)n * k)));
+  HS_HIP(h, h->counters.reserve(256));
+  HS_HIP(h, hipEventRecord(h->ev[8], h->stream));
+  if (n) HS_HIP(h, hipMemcpyAsync(h->codes.p, codes, (size_t)n * k, hipMemcpyHostToDevice, h->stream));
+  HS_HIP(h, h->packed_all.reserve(std::max<size_t>(16, (size_t)n * PW * 16)));
+  if (n) {
+    HS_HIP(h, hipMemsetAsync(h->counters.p, 0, 256, h->stream));
+    HS_HIP(h, hs_launch_pack(h->codes.as<uint8_t>(), n, k, h->alphabet, h->packed_all.as<uint4>(),
+                             h->counters.as<uint32_t>(), h->stream));
+    uint32_t bad = 0;
+    HS_HIP(h, hipMemcpyAsync(&bad, h->counters.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    if (bad) return fail(h, HS_ERR_INVALID, "residue code outside the alphabet in the DB");
+  }
+  const uint64_t base = n / world, rem = n % world;   // = hs_shard_bounds (hsearch_dist.h)
+  const uint64_t lo = (uint64_t)rank * base + std::min<uint64_t>(rank, rem), cnt = base + (rank < rem ? 1 : 0);
+  h->shard_lo = (uint32_t)lo;
+  h->shard_cnt = (uint32_t)cnt;
+  h->shard_open = true;
+  h->shard_table = -1;
+  if (block_lo) *block_lo = lo;
+  if (block_count) *block_count = cnt;
+  const bool with_rec8 = h->join8_tables_ok && k <= 50;
+  HS_HIP(h, h->t_packed.reserve(((size_t)L * n + HS_JM_WAVE) * PW * 16));
+  if (with_rec8) HS_HIP(h, h->t_rec8.reserve(((size_t)L * n + HS_JM_WAVE) * 16));
+  HS_HIP(h, h->t_pos.reserve(std::max<size_t>(16, (size_t)L * n * 4)));
+  HS_HIP(h, h->bs_ints2[0].reserve(std::max<size_t>(16, (size_t)cnt * K * 4)));
+  HS_HIP(h, h->bs_iota2[0].reserve(std::max<size_t>(16, (size_t)n * 4)));
+  HS_HIP(h, h->bs_keys_sorted.reserve(std::max<size_t>(16, (size_t)n * 8)));
+  HS_HIP(h, h->bs_rle_unique.reserve(std::max<size_t>(16, (size_t)n * 8)));
+  HS_HIP(h, h->bs_rle_counts.reserve(std::max<size_t>(16, (size_t)n * 4)));
+  HS_HIP(h, h->bs_small.reserve(64));
+  HS_HIP(h, h->bs_sort_temp.reserve(std::max(std::max(hs_sort_pairs_u64_u32_temp(n), hs_rle_u64_temp(n)),
+                                             hs_scan_u32_temp(n + 1)) + 256));
+  return HS_OK;
+}
+
+hs_status hs_index_shard_hash_dev(hs_handle* h, uint32_t l, uint32_t seed, uint64_t* d_fp_block) {
+  if (!h || !h->shard_open || l >= h->p.L || (h->shard_cnt && !d_fp_block)) return HS_ERR_INVALID;
+  hs_status st = ensure_device(h);
+  if (st) return st;
+  const int K = (int)h->p.K;
+  h->shard_table = (int)l;
+  h->shard_seed = seed;
+  if (!h->shard_cnt) return HS_OK;
+  HS_HIP(h, hipEventRecord(h->ev[0], h->stream));
+  HS_CHECK(hash_dispatch(h, h->codes.as<uint8_t>() + (uint64_t)h->shard_lo * h->p.k, nullptr, h->shard_cnt, (int)l,
+                         h->bs_ints2[0].as<int32_t>(), K, 0, h->stream));
+  HS_HIP(h, hs_launch_keys(h->bs_ints2[0].as<int32_t>(), h->shard_cnt, K, K, seed, d_fp_block, nullptr, h->stream));
+  HS_HIP(h, hipEventRecord(h->ev[1], h->stream));
+  HS_HIP(h, hipStreamSynchronize(h->stream));
+  h->prof.ms_hash += ev_ms(h, 0, 1);
+  return hash_account(h, h->shard_cnt, K, 0);
+}
+
+hs_status hs_index_shard_group_dev(hs_handle* h, uint32_t l, const uint64_t* d_fp_all, uint32_t* n_buckets) {
+  if (!h || !h->shard_open || (int)l != h->shard_table || !n_buckets || (h->n && !d_fp_all)) return HS_ERR_INVALID;
+  hs_status st = ensure_device(h);
+  if (st) return st;
+  const uint64_t n = h->n;
+  const int K = (int)h->p.K;
+  *n_buckets = 0;
+  uint32_t* d_small = h->bs_small.as<uint32_t>();
+  HS_HIP(h, h->t_ids[l].reserve(std::max<size_t>(16, (size_t)n * 4)));
+  HS_HIP(h, hipMemsetAsync(d_small, 0, 64, h->stream));
+  uint32_t nb = 0;
+  if (n) {
+    HS_HIP(h, hipEventRecord(h->ev[1], h->stream));
+    HS_HIP(h, hs_launch_iota_u32(h->bs_iota2[0].as<uint32_t>(), (uint32_t)n, h->stream));
+    HS_HIP(h, hs_sort_pairs_u64_u32(h->bs_sort_temp.p, h->bs_sort_temp.cap, d_fp_all, h->bs_keys_sorted.as<uint64_t>(),
+                                    h->bs_iota2[0].as<uint32_t>(), h->t_ids[l].as<uint32_t>(), n, 0, 64, h->stream));
+    HS_HIP(h, hs_rle_u64(h->bs_sort_temp.p, h->bs_sort_temp.cap, h->bs_keys_sorted.as<uint64_t>(),
+                         h->bs_rle_unique.as<uint64_t>(), h->bs_rle_counts.as<uint32_t>(), d_small, n, h->stream));
+    HS_HIP(h, hipMemcpyAsync(&nb, d_small, 4, hipMemcpyDeviceToHost, h->stream));
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+  }
+  HS_HIP(h, h->t_dirkey[l].reserve(std::max<size_t>(16, (size_t)nb * 8)));
+  HS_HIP(h, h->t_dirstart[l].reserve(((size_t)nb + 1) * 4));
+  HS_HIP(h, h->t_dirtuple[l].reserve(std::max<size_t>(16, (size_t)nb * K * 4)));
+  if (nb) {
+    HS_HIP(h, hipMemcpyAsync(h->t_dirkey[l].p, h->bs_rle_unique.p, (size_t)nb * 8, hipMemcpyDeviceToDevice, h->stream));
+    HS_HIP(h, hs_exclusive_scan_u32(h->bs_sort_temp.p, h->bs_sort_temp.cap, h->bs_rle_counts.as<uint32_t>(),
+                                    h->t_dirstart[l].as<uint32_t>(), nb, h->stream));
+    HS_HIP(h, hs_launch_max_u32(h->bs_rle_counts.as<uint32_t>(), nb, d_small + 2, h->stream));
+  }
+  HS_HIP(h, hs_launch_set_u32(h->t_dirstart[l].as<uint32_t>() + nb, (uint32_t)n, h->stream));
+  HS_HIP(h, hipEventRecord(h->ev[2], h->stream));
+  uint32_t max_count = 0;
+  HS_HIP(h, hipMemcpyAsync(&max_count, d_small + 2, 4, hipMemcpyDeviceToHost, h->stream));
+  HS_HIP(h, hipStreamSynchronize(h->stream));
+  if (n) h->prof.ms_sort += ev_ms(h, 1, 2);
+  h->shard_nb = nb;
+  h->info.n_buckets[l] = nb;
+  h->info.max_bucket[l] = max_count;
+  *n_buckets = nb;
+  return HS_OK;
+}
+
+hs_status hs_index_shard_tuples_dev(hs_handle* h, uint32_t l, int32_t* d_tuples) {
+  if (!h || !h->shard_open || (int)l != h->shard_table || (h->shard_nb && !d_tuples)) return HS_ERR_INVALID;
+  hs_status st = ensure_device(h);
+  if (st) return st;
+  HS_HIP(h, hs_launch_shard_first_tuples(h->t_dirstart[l].as<uint32_t>(), h->t_ids[l].as<uint32_t>(),
+                                         h->bs_ints2[0].as<int32_t>(), h->shard_lo, h->shard_cnt, h->shard_nb,
+                                         (int)h->p.K, d_tuples, h->stream));
+  HS_HIP(h, hipStreamSynchronize(h->stream));
+  return HS_OK;
+}
+
+hs_status hs_index_shard_finish_dev(hs_handle* h, uint32_t l, const int32_t* d_tuples_all, uint32_t* collided) {
+  if (!h || !h->shard_open || (int)l != h->shard_table || !collided || (h->shard_nb && !d_tuples_all))
+    return HS_ERR_INVALID;
+  hs_status st = ensure_device(h);
+  if (st) return st;
+  const uint64_t n = h->n;
+  const int K = (int)h->p.K, k = (int)h->p.k, PW = h->PW;
+  const uint32_t nb = h->shard_nb;
+  uint32_t* d_small = h->bs_small.as<uint32_t>();
+  uint4* const tab_packed = h->t_packed.as<uint4>() + (size_t)l * n * PW;
+  const bool with_rec8 = h->join8_tables_ok && k <= 50;
+  *collided = 0;
+  if (nb) HS_HIP(h, hipMemcpyAsync(h->t_dirtuple[l].p, d_tuples_all, (size_t)nb * K * 4, hipMemcpyDeviceToDevice, h->stream));
+  HS_HIP(h, hipEventRecord(h->ev[2], h->stream));
+  if (n) {
+    HS_HIP(h, hs_launch_invert_perm(h->t_ids[l].as<uint32_t>(), (uint32_t)n, h->t_pos.as<uint32_t>() + (size_t)l * n,
+                                    h->stream));
+    HS_HIP(h, hipMemsetAsync(d_small + 1, 0, 4, h->stream));
+    HS_HIP(h, hs_launch_shard_check(h->bs_ints2[0].as<int32_t>(), h->shard_lo, h->shard_cnt, K,
+                                    h->t_pos.as<uint32_t>() + (size_t)l * n, h->t_dirstart[l].as<uint32_t>(), nb,
+                                    h->t_dirtuple[l].as<int32_t>(), d_small + 1, h->stream));
+    if (with_rec8)
+      HS_HIP(h, hs_launch_gather_rec8(h->packed_all.as<uint4>(), h->t_ids[l].as<uint32_t>(), (uint32_t)n, k, h->wide8,
+                                      h->jtab8.p, h->jtab8.as<char>() + 1536, h->jtab8.as<float>() + 128, tab_packed,
+                                      h->t_rec8.as<uint4>() + (size_t)l * n, h->stream));
+    else
+      HS_HIP(h, hs_launch_gather_packed(h->packed_all.as<uint4>(), h->t_ids[l].as<uint32_t>(), n, PW, tab_packed,
+                                        h->stream));
+  }
+  HS_HIP(h, hipEventRecord(h->ev[3], h->stream));
+  uint32_t flag = 0;
+  HS_HIP(h, hipMemcpyAsync(&flag, d_small + 1, 4, hipMemcpyDeviceToHost, h->stream));
+  HS_HIP(h, hipStreamSynchronize(h->stream));
+  h->prof.ms_gather += ev_ms(h, 2, 3);
+  *collided = flag & 1u;
+  hs_table_dev& tb = h->tabs.t[l];
+  tb.dir_key = h->t_dirkey[l].as<uint64_t>();
+  tb.dir_start = h->t_dirstart[l].as<uint32_t>();
+  tb.dir_tuple = h->t_dirtuple[l].as<int32_t>();
+  tb.packed = tab_packed;
+  tb.ids = h->t_ids[l].as<uint32_t>();
+  tb.pos_of = h->t_pos.as<uint32_t>() + (size_t)l * n;
+  tb.nb = nb;
+  h->shard_table = -1;
+  return HS_OK;
+}
+
+hs_status hs_index_shard_end(hs_handle* h, uint32_t key_seed) {
+  if (!h || !h->shard_open) return HS_ERR_INVALID;
+  hs_status st = ensure_device(h);
+  if (st) return st;
+  h->shard_open = false;
+  h->key_seed = key_seed;
+  HS_HIP(h, hipEventRecord(h->ev[9], h->stream));
+  HS_HIP(h, hipStreamSynchronize(h->stream));
+  h->prof.ms_total = ev_ms(h, 8, 9);
+  return finish_index(h);
 }
 
 hs_status hs_index_build_subset(hs_handle* h, const uint8_t* codes_all, uint64_t n_all,

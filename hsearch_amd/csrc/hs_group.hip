@@ -490,3 +490,72 @@ hipError_t hs_launch_dir_start(const uint32_t* d_ranks_sorted, uint32_t n, uint3
   hs_dir_max_kernel<<<std::min(1024u, blocks_for(nb)), 256, 0, s>>>(d_dir_start, nb, d_max);
   return hipGetLastError();
 }
+
+// ---- index build with the hashing spread over ranks ("Index build") ---------------------
+// A rank evaluates the hash functions for its block [lo, lo + cnt) of the k-mers only; the fingerprints
+// are all-gathered, every rank groups all of them, and the exact-membership proof is done by the rank that
+// HAS a k-mer's bucket ints, against the bucket's tuple -- the tuple of the bucket's first member, which
+// the rank owning that k-mer contributes (hs_shard_first_tuples_kernel: zeros elsewhere, the ranks' arrays
+// are summed).
+namespace {
+
+__global__ __launch_bounds__(256) void hs_shard_first_tuples_kernel(const uint32_t* __restrict__ dir_start,
+                                                                    const uint32_t* __restrict__ ids,
+                                                                    const int32_t* __restrict__ ints_block,
+                                                                    uint32_t lo, uint32_t cnt, uint32_t nb, int K,
+                                                                    int32_t* __restrict__ tuples) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (uint64_t)nb * K) return;
+  const uint32_t bkt = (uint32_t)(t / K);
+  const int j = (int)(t % K);
+  const uint32_t first = ids[dir_start[bkt]];
+  tuples[t] = (first >= lo && first - lo < cnt) ? ints_block[(uint64_t)(first - lo) * K + j] : 0;
+}
+
+// own k-mer i (id lo + i): its bucket = the one whose range holds its sorted position; its ints against
+// the bucket's tuple.  flag |= 1: equal fingerprints, different HashKey strings.
+__global__ __launch_bounds__(256) void hs_shard_check_kernel(const int32_t* __restrict__ ints_block, uint32_t lo,
+                                                             uint32_t cnt, int K, const uint32_t* __restrict__ pos_of,
+                                                             const uint32_t* __restrict__ dir_start, uint32_t nb,
+                                                             const int32_t* __restrict__ dir_tuple,
+                                                             uint32_t* __restrict__ flag) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= cnt) return;
+  const uint32_t p = pos_of[lo + i];
+  uint32_t a = 0, b = nb;  // largest r with dir_start[r] <= p
+  while (b - a > 1) {
+    const uint32_t mid = (a + b) >> 1;
+    if (dir_start[mid] <= p) a = mid; else b = mid;
+  }
+  const int32_t* px = ints_block + (uint64_t)i * K;
+  const int32_t* py = dir_tuple + (uint64_t)a * K;
+  bool same = true;
+  for (int j = 0; j < K; ++j) same = same && px[j] == py[j];
+  if (same) return;
+  int32_t x[HS_MAX_K], y[HS_MAX_K];
+  for (int j = 0; j < K; ++j) {
+    x[j] = px[j];
+    y[j] = py[j];
+  }
+  if (!hs_key_equal(x, y, K)) atomicOr(flag, 1u);
+}
+
+}  // namespace
+
+hipError_t hs_launch_shard_first_tuples(const uint32_t* d_dir_start, const uint32_t* d_ids, const int32_t* d_ints_block,
+                                        uint32_t lo, uint32_t cnt, uint32_t nb, int K, int32_t* d_tuples,
+                                        hipStream_t s) {
+  if (!nb) return hipSuccess;
+  hs_shard_first_tuples_kernel<<<blocks_for((uint64_t)nb * K), 256, 0, s>>>(d_dir_start, d_ids, d_ints_block, lo, cnt,
+                                                                            nb, K, d_tuples);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_shard_check(const int32_t* d_ints_block, uint32_t lo, uint32_t cnt, int K,
+                                 const uint32_t* d_pos_of, const uint32_t* d_dir_start, uint32_t nb,
+                                 const int32_t* d_dir_tuple, uint32_t* d_flag, hipStream_t s) {
+  if (!cnt) return hipSuccess;
+  hs_shard_check_kernel<<<blocks_for(cnt), 256, 0, s>>>(d_ints_block, lo, cnt, K, d_pos_of, d_dir_start, nb,
+                                                        d_dir_tuple, d_flag);
+  return hipGetLastError();
+}

@@ -196,6 +196,16 @@ hipError_t hs_launch_rs_scatter(const uint32_t* d_keys_in, const uint32_t* d_ids
 hipError_t hs_launch_dir_start(const uint32_t* d_ranks_sorted, uint32_t n, uint32_t nb, uint32_t* d_dir_start,
                                uint32_t* d_max, hipStream_t s);
 
+// index build with the hashing spread over ranks: d_tuples[nb][K] = the bucket ints of every bucket whose
+// first member lies in this rank's block [lo, lo + cnt) (zeros elsewhere); the exact-membership proof of
+// the block's k-mers against the buckets' tuples (*d_flag |= 1: one fingerprint, two HashKey strings)
+hipError_t hs_launch_shard_first_tuples(const uint32_t* d_dir_start, const uint32_t* d_ids, const int32_t* d_ints_block,
+                                        uint32_t lo, uint32_t cnt, uint32_t nb, int K, int32_t* d_tuples,
+                                        hipStream_t s);
+hipError_t hs_launch_shard_check(const int32_t* d_ints_block, uint32_t lo, uint32_t cnt, int K,
+                                 const uint32_t* d_pos_of, const uint32_t* d_dir_start, uint32_t nb,
+                                 const int32_t* d_dir_tuple, uint32_t* d_flag, hipStream_t s);
+
 // ---- projection on the matrix cores (hs_proj.hip) ------------------------------------------------
 // The coordinate table in 16-bit fixed point for the codes path: per residue the high and low digit
 // bytes of its 8 coordinates, an upper bound of its 1-norm, the scale 2^-ex and dx = 2^-(ex+1).

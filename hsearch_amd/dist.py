@@ -145,3 +145,66 @@ def clustering_sharded(k, K, L, W, a, b, codes, R, device=0, coords=None, group=
         ai, aj = gather(ei, ej)
         st.table_apply(l, ai, aj)
     return st.end()
+
+
+class TorchShardOps:
+    """The collectives of index_build_sharded over torch.distributed (RCCL = backend "nccl": tensors stay on
+    the rank's GPU; gloo: they pass through host memory).  Tensors in, tensors out, on `dev`."""
+
+    def __init__(self, group=None, device=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.dev = torch.device(device) if device is not None else torch.device("cpu")
+        self.host = dist.get_backend(group) != "nccl"
+
+    def allgather_blocks(self, block, counts):
+        """block: int64 tensor [counts[rank]] -> int64 [sum(counts)], blocks in rank order (padded to the
+        largest block for the collective: blocks differ by at most one element)."""
+        m = max(counts)
+        pad = torch.zeros(m, dtype=block.dtype, device="cpu" if self.host else block.device)
+        pad[:block.numel()] = block.cpu() if self.host else block
+        out = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(out, pad, group=self.group)
+        return torch.cat([o[:c] for o, c in zip(out, counts)]).to(self.dev)
+
+    def allreduce_sum(self, t):
+        x = t.cpu() if self.host else t
+        dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
+        return x.to(self.dev)
+
+    def allreduce_max_int(self, v):
+        x = torch.tensor([int(v)], dtype=torch.int64, device="cpu" if self.host else self.dev)
+        dist.all_reduce(x, op=dist.ReduceOp.MAX, group=self.group)
+        return int(x.item())
+
+
+def index_build_sharded(eng, codes, ops, max_seeds=4):
+    """SURVEY 8(e), "Index build": hs_index_build with the evaluation of the hash functions spread over the
+    ranks of `ops` (include/hsearch.h, hs_index_shard_*): per table every rank hashes its block of the
+    k-mers, the 8-byte fingerprints are all-gathered, every rank groups all of them, the buckets' tuples
+    are summed from the ranks that hashed each bucket's first member, and every rank proves the exact
+    HashKey-string membership of its own k-mers.  A fingerprint collision anywhere restarts every rank
+    with the next seed, as hs_index_build does locally.  `eng`: an Engine (or anything with its shard_*
+    methods); `ops`: TorchShardOps or an object with the same three methods.  Returns the index info."""
+    n = len(codes)
+    lo, cnt = eng.shard_begin(codes, ops.rank, ops.world)
+    counts = []
+    for r in range(ops.world):
+        l0, h0 = shard_bounds(n, r, ops.world)
+        counts.append(h0 - l0)
+    assert (lo, cnt) == (shard_bounds(n, ops.rank, ops.world)[0], counts[ops.rank])
+    for seed in range(max_seeds):
+        collided = 0
+        for l in range(eng.L):
+            fp_block = torch.empty(max(cnt, 1), dtype=torch.int64, device=ops.dev)
+            eng.shard_hash(l, seed, fp_block.data_ptr())
+            fp_all = ops.allgather_blocks(fp_block[:cnt], counts).contiguous()
+            nb = eng.shard_group(l, fp_all.data_ptr())
+            tup = torch.zeros(max(nb, 1) * eng.K, dtype=torch.int32, device=ops.dev)
+            eng.shard_tuples(l, tup.data_ptr())
+            tup_all = ops.allreduce_sum(tup).contiguous()
+            collided |= eng.shard_finish(l, tup_all.data_ptr())
+        if not ops.allreduce_max_int(collided):
+            return eng.shard_end(seed)
+    raise RuntimeError("key fingerprints collided for %d seeds" % max_seeds)

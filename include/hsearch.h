@@ -184,6 +184,34 @@ HS_API hs_status hs_index_build_subset(hs_handle* h, const uint8_t* codes_all, u
 HS_API hs_status hs_index_build_windows(hs_handle* h, const uint8_t* residues, uint64_t n_residues,
                                         const uint64_t* seq_start, uint64_t n_seq,
                                         uint64_t* n_windows, uint32_t* window_pos);
+/* SURVEY 8(e), "Index build" row -- the build loop of Search() (motif_both_points.cpp:212-218) with the
+ * evaluation of the hash functions SPREAD OVER RANKS (one handle per rank = GPU).  The index is replicated,
+ * so every rank is given all n k-mers; rank r evaluates the L x K functions for its contiguous block of
+ * them only (hs_shard_bounds' rule: *block_lo, *block_count), the ranks all-gather 8-byte fingerprints,
+ * every rank groups all of them, and the exact HashKey-string membership proof of a k-mer is made by the
+ * rank that hashed it, against the bucket's tuple -- the bucket ints of the bucket's first member,
+ * contributed by the rank that hashed THAT k-mer.  The caller does the collectives (RCCL, or anything
+ * else); every pointer with a d_ prefix is device memory of the handle's GPU.  Per table l = 0 .. L-1:
+ *   hs_index_shard_hash_dev(h, l, seed, d_fp_block[block_count])     fingerprints of the rank's block
+ *   <all-gather: d_fp_all[n], blocks in rank order>
+ *   hs_index_shard_group_dev(h, l, d_fp_all, &nb)                    the table's buckets: nb of them
+ *   hs_index_shard_tuples_dev(h, l, d_tuples[nb][K])                 zeros but for the buckets whose first
+ *                                                                    member lies in the rank's block
+ *   <sum over ranks (all-reduce): d_tuples_all[nb][K]>
+ *   hs_index_shard_finish_dev(h, l, d_tuples_all, &collided)         proof of the own block, bucket-ordered copies
+ * and after the last table <max over ranks of collided over all tables>: if set (two HashKey strings
+ * under one fingerprint), start over from table 0 with seed + 1 (hs_index_build tries seeds 0..3); else
+ * hs_index_shard_end(h, seed).  The index equals hs_index_build's bit for bit (same file from
+ * hs_index_save). */
+HS_API hs_status hs_index_shard_begin(hs_handle* h, const uint8_t* codes, uint64_t n, uint32_t rank,
+                                      uint32_t world, uint64_t* block_lo, uint64_t* block_count);
+HS_API hs_status hs_index_shard_hash_dev(hs_handle* h, uint32_t l, uint32_t seed, uint64_t* d_fp_block);
+HS_API hs_status hs_index_shard_group_dev(hs_handle* h, uint32_t l, const uint64_t* d_fp_all, uint32_t* n_buckets);
+HS_API hs_status hs_index_shard_tuples_dev(hs_handle* h, uint32_t l, int32_t* d_tuples);
+HS_API hs_status hs_index_shard_finish_dev(hs_handle* h, uint32_t l, const int32_t* d_tuples_all,
+                                           uint32_t* collided);
+HS_API hs_status hs_index_shard_end(hs_handle* h, uint32_t key_seed);
+
 /* SURVEY 8(f) row 2 -- persistent index (no reference analogue: the reference rebuilds its tables
  * on every run, motif_both_points.cpp:206-218).  hs_index_save writes parameters, planes,
  * coordinate table, residue codes and the L tables (ids + bucket directory) of a built handle;

@@ -157,3 +157,111 @@ def test_sharded_clustering_host_path_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok
+
+
+class _FakeShardEngine:
+    """The per-rank steps of hs_index_shard_* restated in numpy on the oracle's bucket ints (this is a test
+    of hsearch_amd.dist.index_build_sharded's plumbing over a real process group, not of the kernels;
+    tests/test_gpu_parity.py::test_index_build_with_the_hashing_spread_over_ranks runs the real steps)."""
+
+    def __init__(self, O, k, K, L, W, a, b):
+        self.O, self.k, self.K, self.L, self.W, self.a, self.b = O, k, K, L, W, a, b
+        self.tables = []
+
+    @staticmethod
+    def _view(ptr, count, ctype, dtype):
+        import ctypes
+        return np.frombuffer((ctype * count).from_address(ptr), dtype=dtype)
+
+    def shard_begin(self, codes, rank, world):
+        self.codes, self.n = codes, len(codes)
+        self.lo, hi = hdist.shard_bounds(self.n, rank, world)
+        self.cnt = hi - self.lo
+        return self.lo, self.cnt
+
+    def shard_hash(self, l, seed, ptr):
+        from hsearch_amd import capi
+        import ctypes
+        pts = self.O.embed_codes(self.codes[self.lo:self.lo + self.cnt])
+        self.ints = self.O.hash_all(self.a[l:l + 1], self.b[l:l + 1], self.W, pts)[:, 0, :]
+        fp = np.array([capi.key_fingerprint(t, seed) for t in self.ints], dtype=np.uint64)
+        self._view(ptr, max(self.cnt, 1), ctypes.c_uint64, np.uint64)[:self.cnt] = fp
+
+    def shard_group(self, l, ptr):
+        import ctypes
+        fp = self._view(ptr, self.n, ctypes.c_uint64, np.uint64).copy()
+        self.ids = np.argsort(fp, kind="stable").astype(np.uint32)
+        self.dir_key, self.dir_start = np.unique(fp[self.ids], return_index=True)
+        return len(self.dir_key)
+
+    def shard_tuples(self, l, ptr):
+        import ctypes
+        nb = len(self.dir_key)
+        out = self._view(ptr, max(nb, 1) * self.K, ctypes.c_int32, np.int32)
+        first = self.ids[self.dir_start].astype(np.int64)
+        mine = (first >= self.lo) & (first < self.lo + self.cnt)
+        tup = np.zeros((nb, self.K), dtype=np.int32)
+        tup[mine] = self.ints[first[mine] - self.lo]
+        out[:nb * self.K] = tup.ravel()
+
+    def shard_finish(self, l, ptr):
+        from hsearch_amd import capi
+        import ctypes
+        nb = len(self.dir_key)
+        tup = self._view(ptr, max(nb, 1) * self.K, ctypes.c_int32, np.int32)[:nb * self.K].reshape(nb, self.K).copy()
+        pos_of = np.empty(self.n, dtype=np.int64)
+        pos_of[self.ids] = np.arange(self.n)
+        collided = 0
+        for i in range(self.cnt):
+            r = np.searchsorted(self.dir_start, pos_of[self.lo + i], side="right") - 1
+            if not capi.key_strings_equal(self.ints[i], tup[r]):
+                collided = 1
+        self.tables.append((self.ids.copy(), self.dir_key.copy(), self.dir_start.copy(), tup))
+        return collided
+
+    def shard_end(self, seed):
+        return dict(n=self.n, n_buckets=[len(t[1]) for t in self.tables], key_seed=seed)
+
+
+def _shard_build_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle as O
+    k, K, L, W, n = 25, 4, 3, 100.0, 1501          # 1501: uneven blocks
+    a, b = synth.make_planes(k, K, L, W, seed=51)
+    codes = synth.make_db(n, k, seed=52)
+    eng = _FakeShardEngine(O, k, K, L, W, a, b)
+    info = hdist.index_build_sharded(eng, codes, hdist.TorchShardOps())
+    # the unsharded result of the same restatement
+    one = _FakeShardEngine(O, k, K, L, W, a, b)
+
+    class Solo:
+        rank, world, dev = 0, 1, torch.device("cpu")
+        def allgather_blocks(self, block, counts): return block
+        def allreduce_sum(self, t): return t
+        def allreduce_max_int(self, v): return int(v)
+    info1 = hdist.index_build_sharded(one, codes, Solo())
+    ok = info["n_buckets"] == info1["n_buckets"] == O.Index(a, b, W, O.embed_codes(codes)).table_sizes()
+    for t, t1 in zip(eng.tables, one.tables):
+        ok = ok and all(np.array_equal(x, y) for x, y in zip(t, t1))
+    ret.put((rank, bool(ok), info["n_buckets"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_index_build_world2():
+    """SURVEY 8(e), "Index build": the exchange steps of the sharded build (all-gather of uneven fingerprint
+    blocks, sum of the buckets' tuples, max of the collision flags) over a real gloo process group of two:
+    both ranks end with the tables of the unsharded build."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_build_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [ret.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in got) and got[0][2] == got[1][2]

@@ -850,7 +850,10 @@ def test_query_resident_and_query_streaming_join_kernels(oracle, monkeypatch, K,
     for routing in ("default", "no_r", "batches"):
         monkeypatch.delenv("HS_NO_JOIN_R", raising=False)
         monkeypatch.delenv("HS_QUERY_BATCH", raising=False)
+        # (by default the resident kernel runs only while its class is the bulk of a batch's items)
+        monkeypatch.setenv("HS_FORCE_JOIN_R", "1")
         if routing == "no_r":
+            monkeypatch.delenv("HS_FORCE_JOIN_R")
             monkeypatch.setenv("HS_NO_JOIN_R", "1")
         if routing == "batches":
             monkeypatch.setenv("HS_QUERY_BATCH", "257")
@@ -924,3 +927,56 @@ def test_grouping_falls_back_to_the_sort_per_table(oracle, monkeypatch):
         assert np.array_equal(got["cand"], want["cand"])
         _assert_hits_equal(got, want)
     eng.close()
+
+
+@pytest.mark.parametrize("world,n,k,K,L,W", [(4, 40009, 25, 6, 5, 140.0), (3, 1001, 15, 3, 4, 60.0), (2, 5, 25, 4, 2, 100.0),
+                                             (4, 30011, 25, 2, 3, 3.0)])
+def test_index_build_with_the_hashing_spread_over_ranks(oracle, tmp_path, world, n, k, K, L, W):
+    """SURVEY 8(e) "Index build" row: every rank hashes only its block of the k-mers,
+    the ranks exchange fingerprints and the buckets' tuples, every rank proves the membership of its own
+    k-mers (hs_index_shard_*).  Emulated on one GPU: `world` handles, the collectives done here on torch
+    tensors.  Every rank's index FILE equals hs_index_build's byte for byte, and its hits the oracle's."""
+    import torch
+    from hsearch_amd import dist as hdist
+    a, b = synth.make_planes(k, K, L, W, seed=125)
+    codes = synth.make_db(n, k, seed=126)
+    centers, _ = synth.make_queries(codes, min(300, 20 * n), seed=127, jitter=0.2)
+    R = 30.0 + k
+    plain = Engine(k, K, L, W, a, b)
+    plain.index_build(codes)
+    ref = str(tmp_path / "plain.idx")
+    plain.index_save(ref)
+    want = oracle.search(a, b, W, R, oracle.embed_codes(codes), centers)
+    _assert_hits_equal(plain.query(centers, R), want)
+    plain.close()
+    dev = torch.device("cuda", 0)
+    engs = [Engine(k, K, L, W, a, b) for _ in range(world)]
+    blocks = [e.shard_begin(codes, r, world) for r, e in enumerate(engs)]
+    assert [b0 for b0, _ in blocks] == [hdist.shard_bounds(n, r, world)[0] for r in range(world)]
+    assert sum(c for _, c in blocks) == n
+    for l in range(L):
+        fps = []
+        for r, e in enumerate(engs):
+            t = torch.empty(max(blocks[r][1], 1), dtype=torch.int64, device=dev)
+            e.shard_hash(l, 0, t.data_ptr())
+            fps.append(t[:blocks[r][1]])
+        fp_all = torch.cat(fps).contiguous()                      # the all-gather
+        nbs = [e.shard_group(l, fp_all.data_ptr()) for e in engs]
+        assert len(set(nbs)) == 1
+        tups = []
+        for e in engs:
+            t = torch.zeros(max(nbs[0], 1) * K, dtype=torch.int32, device=dev)
+            e.shard_tuples(l, t.data_ptr())
+            tups.append(t)
+        tup_all = torch.stack(tups).sum(0).to(torch.int32).contiguous()   # the all-reduce
+        assert all(e.shard_finish(l, tup_all.data_ptr()) == 0 for e in engs)
+    for r, e in enumerate(engs):
+        info = e.shard_end(0)
+        assert info["n"] == n
+        path = str(tmp_path / ("rank%d.idx" % r))
+        e.index_save(path)
+        assert open(path, "rb").read() == open(ref, "rb").read(), r
+        got = e.query(centers, R)
+        assert np.array_equal(got["cand"], want["cand"])
+        _assert_hits_equal(got, want)
+        e.close()
