@@ -128,6 +128,9 @@ struct hs_handle {
   // bucket-ordered packed copies of all tables in ONE allocation ([L][n][PW]), and the int8 join's
   // per-entry records ([L][n], k <= 50 only) at the same entry numbers
   DevBuf t_packed, t_rec8;
+  // the records once more in four bytes per entry ([L][n]; k <= 25 with 4-column rows: what the
+  // query-resident join kernel reads instead of t_rec8 -- it is bound by the bytes it moves per member)
+  DevBuf t_rho;
   // member records of the wide rows for k = 21..25 (built when a call's radius first asks for them)
   DevBuf t_rec8w;
   bool rec8w_ready = false;
@@ -666,7 +669,7 @@ void hs_destroy(hs_handle* h) {
                     &h->proj_xmeta, &h->slice_ql, &h->qhits, &h->bs_ints2[0], &h->bs_ints2[1], &h->bs_keys2[0],
                     &h->bs_keys2[1], &h->bs_iota2[0], &h->bs_iota2[1], &h->bs_keys_sorted, &h->bs_rle_unique,
                     &h->bs_rle_counts, &h->bs_small, &h->bs_sort_temp, &h->bs_slow_q, &h->all_codes,
-                    &h->subset_ids, &h->qcodes_buf, &h->qembed, &h->seg_res, &h->jconst, &h->bs_fptab, &h->bs_blk,
+                    &h->subset_ids, &h->qcodes_buf, &h->qembed, &h->seg_res, &h->jconst, &h->t_rho, &h->bs_fptab, &h->bs_blk,
                     &h->bs_dk, &h->bs_hist, &h->bs_rank};
   for (DevBuf* bf : bufs) bf->release();
   h->sj_host.release();
@@ -871,6 +874,8 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
   // (+ 128 entries: hs_join8r_kernel reads a bucket's ragged last member tile without clamping)
   HS_HIP(h, h->t_packed.reserve(((size_t)L * n + HS_JM_WAVE) * PW * 16));
   if (with_rec8) HS_HIP(h, h->t_rec8.reserve(((size_t)L * n + HS_JM_WAVE) * 16));
+  const bool with_rho = with_rec8 && k <= 25 && !h->wide8;
+  if (with_rho) HS_HIP(h, h->t_rho.reserve(((size_t)L * n + HS_JM_WAVE + 4) * 4));
   HS_HIP(h, h->t_pos.reserve(std::max<size_t>(16, (size_t)L * n * 4)));
   // hash + fingerprints of table t into buffer t & 1, on the side stream
   auto hash_table = [&](int t) -> hs_status {
@@ -1042,7 +1047,8 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
       HS_HIP(h, hs_launch_gather_rec8(h->packed_all.as<uint4>(), h->t_ids[l].as<uint32_t>(), (uint32_t)n,
                                       k, h->wide8, h->jtab8.p, h->jtab8.as<char>() + 1536,
                                       h->jtab8.as<float>() + 128, tab_packed,
-                                      h->t_rec8.as<uint4>() + (size_t)l * n, h->stream));
+                                      h->t_rec8.as<uint4>() + (size_t)l * n,
+                                      with_rho ? h->t_rho.as<uint32_t>() + (size_t)l * n : nullptr, h->stream));
     else
       HS_HIP(h, hs_launch_gather_packed(h->packed_all.as<uint4>(), h->t_ids[l].as<uint32_t>(), n, PW,
                                         tab_packed, h->stream));
@@ -1105,7 +1111,8 @@ static hs_status finish_index(hs_handle* h) {
     h->tabs.t[l].jump_shift = 64 - J;
   }
   HS_HIP(h, hipStreamSynchronize(h->stream));
-  uint64_t bytes = h->codes.cap + h->packed_all.cap + h->t_packed.cap + h->t_rec8.cap + h->t_rec8w.cap + h->t_pos.cap;
+  uint64_t bytes = h->codes.cap + h->packed_all.cap + h->t_packed.cap + h->t_rec8.cap + h->t_rec8w.cap + h->t_rho.cap +
+                   h->t_pos.cap;
   for (uint32_t l = 0; l < h->p.L; ++l)
     bytes += h->t_dirkey[l].cap + h->t_dirstart[l].cap + h->t_dirtuple[l].cap + h->t_ids[l].cap +
              h->t_dirjump[l].cap;
@@ -1210,6 +1217,7 @@ hs_status hs_index_shard_begin(hs_handle* h, const uint8_t* codes, uint64_t n, u
   const bool with_rec8 = h->join8_tables_ok && k <= 50;
   HS_HIP(h, h->t_packed.reserve(((size_t)L * n + HS_JM_WAVE) * PW * 16));
   if (with_rec8) HS_HIP(h, h->t_rec8.reserve(((size_t)L * n + HS_JM_WAVE) * 16));
+  if (with_rec8 && k <= 25 && !h->wide8) HS_HIP(h, h->t_rho.reserve(((size_t)L * n + HS_JM_WAVE + 4) * 4));
   HS_HIP(h, h->t_pos.reserve(std::max<size_t>(16, (size_t)L * n * 4)));
   HS_HIP(h, h->bs_ints2[0].reserve(std::max<size_t>(16, (size_t)cnt * K * 4)));
   HS_HIP(h, h->bs_iota2[0].reserve(std::max<size_t>(16, (size_t)n * 4)));
@@ -1318,7 +1326,8 @@ hs_status hs_index_shard_finish_dev(hs_handle* h, uint32_t l, const int32_t* d_t
     if (with_rec8)
       HS_HIP(h, hs_launch_gather_rec8(h->packed_all.as<uint4>(), h->t_ids[l].as<uint32_t>(), (uint32_t)n, k, h->wide8,
                                       h->jtab8.p, h->jtab8.as<char>() + 1536, h->jtab8.as<float>() + 128, tab_packed,
-                                      h->t_rec8.as<uint4>() + (size_t)l * n, h->stream));
+                                      h->t_rec8.as<uint4>() + (size_t)l * n,
+                                      (k <= 25 && !h->wide8) ? h->t_rho.as<uint32_t>() + (size_t)l * n : nullptr, h->stream));
     else
       HS_HIP(h, hs_launch_gather_packed(h->packed_all.as<uint4>(), h->t_ids[l].as<uint32_t>(), n, PW, tab_packed,
                                         h->stream));
@@ -1704,6 +1713,8 @@ hs_status hs_index_load(hs_handle* h, const char* path) {
   const bool with_rec8 = h->join8_tables_ok && k <= 50;
   HS_HIP(h, h->t_packed.reserve(((size_t)L * n + HS_JM_WAVE) * PW * 16));
   if (with_rec8) HS_HIP(h, h->t_rec8.reserve(((size_t)L * n + HS_JM_WAVE) * 16));
+  const bool with_rho = with_rec8 && k <= 25 && !h->wide8;
+  if (with_rho) HS_HIP(h, h->t_rho.reserve(((size_t)L * n + HS_JM_WAVE + 4) * 4));
   HS_HIP(h, h->t_pos.reserve(std::max<size_t>(16, (size_t)L * n * 4)));
   uint32_t* d_flag = h->counters.as<uint32_t>() + 16;  // [16] failure bits, [17 + l] largest bucket
   HS_HIP(h, hipMemsetAsync(d_flag, 0, (1 + HS_MAX_L) * 4, h->stream));
@@ -1737,7 +1748,8 @@ hs_status hs_index_load(hs_handle* h, const char* path) {
       HS_HIP(h, hs_launch_gather_rec8(h->packed_all.as<uint4>(), h->t_ids[l].as<uint32_t>(), (uint32_t)n,
                                       k, h->wide8, h->jtab8.p, h->jtab8.as<char>() + 1536,
                                       h->jtab8.as<float>() + 128, tab_packed,
-                                      h->t_rec8.as<uint4>() + (size_t)l * n, h->stream));
+                                      h->t_rec8.as<uint4>() + (size_t)l * n,
+                                      with_rho ? h->t_rho.as<uint32_t>() + (size_t)l * n : nullptr, h->stream));
     else
       HS_HIP(h, hs_launch_gather_packed(h->packed_all.as<uint4>(), h->t_ids[l].as<uint32_t>(), n, PW,
                                         tab_packed, h->stream));
@@ -1884,7 +1896,7 @@ static hs_status ensure_rec8w(hs_handle* h) {
   for (int l = 0; l < L; ++l)
     HS_HIP(h, hs_launch_gather_rec8(h->packed_all.as<uint4>(), h->tabs.t[l].ids, (uint32_t)n, (int)h->p.k, 1,
                                     h->jtab8.p, h->jtab8.as<char>() + 1536, h->jtab8.as<float>() + 128,
-                                    nullptr, h->t_rec8w.as<uint4>() + (size_t)l * n, h->stream));
+                                    nullptr, h->t_rec8w.as<uint4>() + (size_t)l * n, nullptr, h->stream));
   h->rec8w_ready = true;
   return HS_OK;
 }
@@ -2199,11 +2211,11 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
     uint32_t *qcnt = nullptr, *qoff = nullptr, *qfill = nullptr;
     if (order_here) {
       const size_t n1q = (size_t)nq + 1;
-      HS_HIP(h, h->qhits.reserve(3 * n1q * 4));
+      HS_HIP(h, h->qhits.reserve((5 * n1q + 4) * 4));
       qcnt = h->qhits.as<uint32_t>();
       qoff = qcnt + n1q;
-      qfill = qoff + n1q;
-      HS_HIP(h, hipMemsetAsync(qcnt, 0, 3 * n1q * 4, h->stream));
+      qfill = qoff + n1q;  // (and behind it the lists of the queries a block orders: 4 + 2 nq words)
+      HS_HIP(h, hipMemsetAsync(qcnt, 0, (3 * n1q + 4) * 4, h->stream));
       if (launches) HS_HIP(h, hipMemsetAsync(d_cnt + 20, 0, 4, h->stream));  // retry: the "too many hits" flag
       HS_HIP(h, h->hit_key2.reserve((size_t)hit_cap * 8));
       HS_HIP(h, h->hit_val2.reserve((size_t)hit_cap * 8));
@@ -2244,7 +2256,8 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
                                    use_r ? d_split : (async_items ? h->item_off.as<uint32_t>() + nql : nullptr),
                                    h->pairs_per_item, h->stream));
         if (use_r)
-          HS_HIP(h, hs_launch_join8r(h->item_desc.as<uint4>(), n_items, d_split, h->tabs.t[0].packed, rec8,
+          HS_HIP(h, hs_launch_join8r(h->item_desc.as<uint4>(), n_items, d_split, h->tabs.t[0].packed,
+                                     h->t_rho.as<uint32_t>(),
                                      h->c16s.p, jtab_rows, h->jconst.p, d_cnt, prov_cap, h->prov.as<uint2>(),
                                      d_cnt + 33, h->n_cu * h->join_blocks_per_cu, h->pairs_per_item, h->stream));
       }
@@ -2290,11 +2303,12 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
                                    hit_cap, h->hit_key.as<uint64_t>(), h->hit_val.as<uint64_t>(), qcnt,
                                    h->stream));
       if (order_here) {
+        const size_t n1q_ = (size_t)nq + 1;
         HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, qcnt, qoff, (size_t)nq + 1, h->stream));
         HS_HIP(h, hs_launch_hit_order(h->hit_key.as<uint64_t>(), h->hit_val.as<uint64_t>(), d_cnt + 1, hit_cap,
                                       q_base, nq, qoff, qfill, h->hit_key2.as<uint64_t>(),
-                                      h->hit_val2.as<uint64_t>(), d_cnt + 20, bout->q, bout->id, bout->table,
-                                      bout->dist, bout->room, h->stream));
+                                      h->hit_val2.as<uint64_t>(), d_cnt + 20, qfill + n1q_, bout->q, bout->id,
+                                      bout->table, bout->dist, bout->room, h->n_cu, h->stream));
       }
     }
     HS_HIP(h, hipEventRecord(h->ev[5], h->stream));

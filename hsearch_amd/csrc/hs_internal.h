@@ -355,8 +355,9 @@ hipError_t hs_launch_finalize(const hs_tables_dev& tabs, const uint8_t* d_codes,
 hipError_t hs_launch_hit_order(const uint64_t* d_key, const uint64_t* d_val, const uint32_t* d_hit_count,
                                uint32_t hit_cap, uint32_t q_base, uint32_t nq, const uint32_t* d_qoff,
                                uint32_t* d_qfill, uint64_t* d_key2, uint64_t* d_val2, uint32_t* d_big,
+                               uint32_t* d_qlist /* 4 + 2 nq words, the first four zero */,
                                uint32_t* d_q, uint32_t* d_id, uint32_t* d_table, double* d_dist,
-                               uint64_t out_room, hipStream_t s);
+                               uint64_t out_room, int n_cu, hipStream_t s);
 // self_first: the queries are the indexed k-mers self_first, self_first + 1, ... themselves (the
 // self-join): the pair of a k-mer with itself is not a hit; HS_NO_SELF otherwise
 #define HS_NO_SELF 0xffffffffu
@@ -465,7 +466,8 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
 // 4-column rows) through the query-resident form; d_cn_rep = 128 copies of the gamma slots' constant
 // factors (HS_J8_CONST bytes); the packed / record arrays must be readable 128 entries past their end
 hipError_t hs_launch_join8r(const uint4* d_desc, uint32_t desc_cap, const uint32_t* d_split,
-                            const uint4* d_packed_base, const uint4* d_rec_base, const void* d_c8t,
+                            const uint4* d_packed_base, const uint32_t* d_rho_base /* the records in four bytes */,
+                            const void* d_c8t,
                             const void* d_tab8, const void* d_cn_rep, uint32_t* d_prov_count, uint32_t prov_cap,
                             uint2* d_prov, uint32_t* d_item_counter, int n_blocks, double pairs_per_item,
                             hipStream_t s);
@@ -473,7 +475,9 @@ hipError_t hs_launch_join8r(const uint4* d_desc, uint32_t desc_cap, const uint32
 // int8 join (d_out_rec[i] belongs to d_out_packed[i])
 hipError_t hs_launch_gather_rec8(const uint4* d_packed_all, const uint32_t* d_ids_sorted, uint32_t n,
                                  int k, int wide, const void* d_tab8, const void* d_tabW, const float* d_scale,
-                                 uint4* d_out_packed, uint4* d_out_rec, hipStream_t s);
+                                 uint4* d_out_packed, uint4* d_out_rec,
+                                 uint32_t* d_out_rho /* null, or the record in four bytes (hs_join8r_kernel) */,
+                                 hipStream_t s);
 hipError_t hs_launch_kth_min(const float* d_slice_min, uint32_t nq, uint32_t per_q, uint32_t topk,
                              float* d_thr, hipStream_t s);
 hipError_t hs_launch_topk_exact(const uint8_t* d_codes, const double* d_centers,

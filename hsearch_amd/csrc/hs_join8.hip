@@ -508,7 +508,8 @@ __global__ __launch_bounds__(256) void hs_gather_rec8_kernel(const uint4* __rest
                                                              const uint4* __restrict__ tabW,
                                                              const float* __restrict__ scale,
                                                              uint4* __restrict__ out_packed,
-                                                             uint4* __restrict__ out_rec) {
+                                                             uint4* __restrict__ out_rec,
+                                                             uint32_t* __restrict__ out_rho) {
   // rows {x^, |x|^2 (float bits), L1(x^)}: of the 4 filter columns, or (wide) of all 8
   __shared__ uint4 sTab[32];
   if (threadIdx.x < 32)
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(256) void hs_gather_rec8_kernel(const uint4* __rest
   const int plast = wide ? 1 << 20 : 8 * ks_of(k) - 8;
   double nx = 0.0;
   int l1 = 0;
-  uint32_t xlast = 0;
+  uint32_t xlast = 0, rlast = 32u;  // (32: the k-mer has no residue at that position)
   for (int wd = 0; wd < PW; ++wd) {
     const uint4 pk = packed_all[(uint64_t)ids[t] * PW + wd];
     if (out_packed) out_packed[(uint64_t)t * PW + wd] = pk;  // (null: records only)
@@ -535,7 +536,10 @@ __global__ __launch_bounds__(256) void hs_gather_rec8_kernel(const uint4* __rest
       if (p < k) {
         nx += (double)__uint_as_float(row.y);
         l1 += (int)row.z;
-        if (p == plast) xlast = row.x;
+        if (p == plast) {
+          xlast = row.x;
+          rlast = c & 31u;
+        }
       }
     }
   }
@@ -547,6 +551,26 @@ __global__ __launch_bounds__(256) void hs_gather_rec8_kernel(const uint4* __rest
   digits127<RDIG>((int)rho, d, nullptr);  // too large -> clamped down: more permissive, never less
   out_rec[t] = make_uint4(xlast, pack4(d[0], d[1], d[2], d[3]), pack4(d[4], d[5], d[6], d[7]),
                           pack4(d[8], d[9], d[10], d[11]));
+  // The same record in FOUR bytes, for hs_join8r_kernel (which is bound by the bytes it reads per member):
+  // the digits are a function of q = rho div 127 alone -- digit j = clamp(|q| - 127 j, 0, 127), negated for
+  // q < 0 -- and come from a table there; x^ of the record's position from the residue.  Bits 0..14: 16 |q|
+  // (the byte offset of the digits' table entry), 15: q < 0, 16..22: rho mod 127, 23..30: 4 x that residue.
+  if (out_rho) {
+    int q = (int)rho / 127, rem = (int)rho - q * 127;  // as digits127
+    if (rem < 0) {
+      rem += 127;
+      q -= 1;
+    }
+    if (q > 127 * RDIG) {
+      q = 127 * RDIG;
+      rem = 126;
+    }
+    if (q < -127 * RDIG) {
+      q = -127 * RDIG;
+      rem = 0;
+    }
+    out_rho[t] = ((uint32_t)abs(q) << 4) | (q < 0 ? 0x8000u : 0u) | ((uint32_t)rem << 16) | (rlast << 25);
+  }
 }
 
 #ifdef HS_JOIN_TIMING
@@ -1293,35 +1317,77 @@ __device__ __forceinline__ void load_btile_r(intx4 (&B)[2][2], const uint4* __re
 //                   rows: per 32-query tile the MFMAs, then their sign test.
 // Lanes of rows 0, 1, 3 hold 16 bytes of the member's packed word from the dword their eight positions
 // start in (bit sh of it): four ten-bit fields = four pair lookups, two per k-step.  Row 2 holds the
-// member's record (k-step 0 as loaded) and looks its k-step 1 up at the two table entries that carry the
-// constant factors (m2 = 0 cancels its field bits, rc2 / rc3 address them).  No lane needs another lane's
-// load: the query rows are permuted to this layout instead (load_btile_r).
+// member's record in FOUR bytes (hs_gather_rec8_kernel's out_rho: the kernel is bound by the bytes it reads
+// per member, 16 + 4 instead of 16 + 16): the word carries the byte offset of the table entry that holds
+// the record's twelve digit bytes, looked up in the two slots the other rows use for their first two pairs;
+// its k-step 1 are the two table entries with the constant factors (m2 = 0 cancels its field bits, rc2 / rc3
+// address them).  No lane needs another lane's load: the query rows are permuted to this layout instead
+// (load_btile_r).
 // A group (half x tile) with a survivor -- a few per cent of them -- leaves its 32 sign bits per lane
 // (bit 8 t + 4 c + i = accumulator i of row tile t, column tile c) in the wave's LDS slot of that group
 // and its number in the returned mask; the item's survivors are written out ONCE, after the item, by the
 // caller (the survivor code inlined at every group made the kernel 140 KB of instructions: 2.2 x the
 // instruction cache).
-__device__ __forceinline__ void join8r_lookup(intx4 (&A)[4][2], const uint4 (&MK)[8], int half, const char* sPairR,
-                                              uint32_t sh, uint32_t rc, uint32_t m2, uint32_t rc2, uint32_t rc3) {
+// per-lane constants of the operand build (rows 0, 1, 3 | row 2)
+struct J8rLane {
+  uint32_t sh;    // bit of the loaded word the lane's fields start at: 8 j | 0
+  uint32_t s5;    // field -> byte offset of a pair-table entry: shift 5 | the record word carries its offset: 0
+  uint32_t mA;    // 0x7fe0 | 0x7ff0
+  uint32_t rA, rB;  // copy of the pair table (8 (lane & 3)) | the digit table: 0x8000, 0x8008
+  uint32_t m2, rc2, rc3;  // k-step 1: field mask and copy | 0 and the two entries of the constant factors
+  uint32_t mrem;  // 0 | 0x7f
+  bool row2;
+};
+constexpr uint32_t J8R_DIG_AT = 32768u;                  // digit table: 1398 entries of 16 bytes
+// x^ of one residue: 64 dwords (33 used); on a multiple of 256 bytes (addresses are formed with OR)
+constexpr uint32_t J8R_TAB1_AT = (J8R_DIG_AT + 1398u * 16u + 255u) & ~255u;
+constexpr uint32_t J8R_CONST_AT = J8R_TAB1_AT + 256u;    // the constant factors of the gamma slots: 16 bytes
+constexpr uint32_t J8R_LDS_BYTES = J8R_CONST_AT + 16u;
+static_assert((J8R_DIG_AT & 0x7fffu) == 0 && (J8R_TAB1_AT & 0xffu) == 0 && (J8R_CONST_AT & 0xfu) == 0, "OR-formed addresses");
+
+__device__ __forceinline__ void join8r_lookup(intx4 (&A)[4][2], uint32_t (&XL)[4], const uint4 (&MK)[8], int half,
+                                              const char* sL, const J8rLane& c) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const uint4 mk = MK[4 * half + t];
-    const uint32_t x0 = __builtin_amdgcn_alignbit(mk.y, mk.x, sh), x1 = __builtin_amdgcn_alignbit(mk.z, mk.y, sh);
-    const uint32_t a0 = ((x0 << 5) & 0x7fe0u) | rc, a1 = ((x0 >> 5) & 0x7fe0u) | rc;
-    const uint32_t a2 = ((x0 >> 15) & m2) | rc2, a3 = (__builtin_amdgcn_alignbit(x1, x0, 25) & m2) | rc3;
-    const uint2 p0 = *reinterpret_cast<const uint2*>(sPairR + a0), p1 = *reinterpret_cast<const uint2*>(sPairR + a1);
-    const uint2 p2 = *reinterpret_cast<const uint2*>(sPairR + a2), p3 = *reinterpret_cast<const uint2*>(sPairR + a3);
+    const uint32_t x0 = __builtin_amdgcn_alignbit(mk.y, mk.x, c.sh), x1 = __builtin_amdgcn_alignbit(mk.z, mk.y, c.sh);
+    const uint32_t a0 = ((x0 << c.s5) & c.mA) | c.rA, a1 = ((x0 >> c.s5) & c.mA) | c.rB;
+    const uint32_t a2 = ((x0 >> 15) & c.m2) | c.rc2, a3 = (__builtin_amdgcn_alignbit(x1, x0, 25) & c.m2) | c.rc3;
+    const uint32_t ax = J8R_TAB1_AT | ((x0 >> 23) & 0xfcu);  // (rows 0, 1, 3: some entry of that table, unused)
+    const uint2 p0 = *reinterpret_cast<const uint2*>(sL + a0), p1 = *reinterpret_cast<const uint2*>(sL + a1);
+    const uint2 p2 = *reinterpret_cast<const uint2*>(sL + a2), p3 = *reinterpret_cast<const uint2*>(sL + a3);
+    XL[t] = *reinterpret_cast<const uint32_t*>(sL + ax);
     A[t][0] = intx4{(int)p0.x, (int)p0.y, (int)p1.x, (int)p1.y};
     A[t][1] = intx4{(int)p2.x, (int)p2.y, (int)p3.x, (int)p3.y};
   }
 }
 
-// the lookups have arrived (this is where the wave waits for them): row 2 takes its record
-__device__ __forceinline__ void join8r_finish(intx4 (&A)[4][2], const uint4 (&MK)[8], int half, bool row2) {
+// the lookups have arrived (this is where the wave waits for them): row 2's k-step 0 is the digit
+// pattern of |q| it looked up; it becomes the member's record with x^ of the record's position in its
+// first dword, rho mod 127 in its last byte, and the digits negated should q be negative
+__device__ __forceinline__ void join8r_finish(intx4 (&A)[4][2], const uint32_t (&XL)[4], const uint4 (&MK)[8], int half,
+                                              const J8rLane& c) {
+  uint32_t any_neg = 0;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const uint4 mk = MK[4 * half + t];
-    A[t][0] = row2 ? intx4{(int)mk.x, (int)mk.y, (int)mk.z, (int)mk.w} : A[t][0];
+    const uint32_t w = MK[4 * half + t].x;
+    A[t][0][0] = c.row2 ? (int)XL[t] : A[t][0][0];
+    A[t][0][3] = (int)((((w >> 16) & c.mrem) << 24) | (uint32_t)A[t][0][3]);
+    any_neg |= w;
+  }
+  if (__ballot(c.row2 && (any_neg & 0x8000u))) {  // a negative rho: a k-mer of very small norm (rare)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const uint32_t w = MK[4 * half + t].x;
+      if (c.row2 && (w & 0x8000u)) {
+        // -b per byte for digits b in 0..127: ((~v & 0x7f7f7f7f) + 0x01010101) ^ 0x80808080
+        const uint32_t y = (uint32_t)A[t][0][1], z = (uint32_t)A[t][0][2], u = (uint32_t)A[t][0][3];
+        A[t][0][1] = (int)((((~y) & 0x7f7f7f7fu) + 0x01010101u) ^ 0x80808080u);
+        A[t][0][2] = (int)((((~z) & 0x7f7f7f7fu) + 0x01010101u) ^ 0x80808080u);
+        const uint32_t un = ((((~u) & 0x007f7f7fu) + 0x00010101u) ^ 0x00808080u) & 0x00ffffffu;
+        A[t][0][3] = (int)(un | (u & 0xff000000u));
+      }
+    }
   }
 }
 
@@ -1408,26 +1474,37 @@ __device__ __forceinline__ void join8r_emit(uint32_t gmask, int NT, const uint32
 
 __global__ __launch_bounds__(256, 2) void hs_join8r_kernel(
     const uint4* __restrict__ desc, const uint32_t* __restrict__ range, uint32_t desc_cap,
-    const uint4* __restrict__ packed_base, const uint4* __restrict__ rec_base, const uint4* __restrict__ c8t,
+    const uint4* __restrict__ packed_base, const uint32_t* __restrict__ rho_base, const uint4* __restrict__ c8t,
     const uint4* __restrict__ tab8, const uint4* __restrict__ cn_rep, uint32_t* __restrict__ prov_count,
     uint32_t prov_cap, uint2* __restrict__ prov, uint32_t* __restrict__ item_counter, uint32_t G) {
   const uint32_t first = __builtin_amdgcn_readfirstlane(range[0]);
   const uint32_t n_items = min(__builtin_amdgcn_readfirstlane(range[1]), desc_cap);  // (absolute) end of the list
-  // x^ of TWO consecutive residues per lookup (entry r1 << 5 | r0 = {x^(r0), x^(r1)}), four copies side by
-  // side -- lane l reads copy l & 3 -- so that the 32 lanes of an LDS access group spread their random
-  // entries over four times as many banks (the single copy spent 72 % of the LDS cycles on conflicts); then
-  // the two entries that hold the constant factors of the gamma slots
-  constexpr uint32_t CONST_AT = 1024u * 32u;  // byte address of the constants' first entry
-  __shared__ uint2 sPairR[1024 * 4 + 2];
+  // LDS tables (byte offsets J8R_*): x^ of TWO consecutive residues per lookup (entry r1 << 5 | r0 =
+  // {x^(r0), x^(r1)}), four copies side by side -- lane l reads copy l & 3 -- so that the 32 lanes of an LDS
+  // access group spread their random entries over four times as many banks (the single copy spent 72 % of
+  // the LDS cycles on conflicts); the record digits of every |q| (digit j = clamp(|q| - 127 j, 0, 127) at
+  // byte 4 + j of the entry); x^ of one residue (entry 32 = 0: no residue); the constant factors.
+  __shared__ __attribute__((aligned(16))) unsigned char sLds[J8R_LDS_BYTES];
   __shared__ uint32_t sMask[4][8][64];  // per wave: the sign masks of an item's groups that had a survivor
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, row = lane >> 4;
-  for (int e = tid; e < 4096; e += 256) sPairR[e] = make_uint2(tab8[(e >> 2) & 31].x, tab8[e >> 7].x);
-  if (tid == 0) {
-    const uint4 cn = tab8[HS_J8_CONST_AT];
-    sPairR[4096] = make_uint2(cn.x, cn.y);
-    sPairR[4097] = make_uint2(cn.z, cn.w);
+  {
+    uint2* sp = reinterpret_cast<uint2*>(sLds);
+    for (int e = tid; e < 4096; e += 256) sp[e] = make_uint2(tab8[(e >> 2) & 31].x, tab8[e >> 7].x);
+    uint4* sd = reinterpret_cast<uint4*>(sLds + J8R_DIG_AT);
+    for (int e = tid; e < 1398; e += 256) {
+      uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int j = 0; j < 11; ++j) {
+        const int d = min(127, max(0, e - 127 * j));
+        w[(4 + j) >> 2] |= (uint32_t)d << (8 * ((4 + j) & 3));
+      }
+      sd[e] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    uint32_t* s1 = reinterpret_cast<uint32_t*>(sLds + J8R_TAB1_AT);
+    if (tid < 64) s1[tid] = tid < 32 ? tab8[tid].x : 0u;
+    if (tid == 0) *reinterpret_cast<uint4*>(sLds + J8R_CONST_AT) = tab8[HS_J8_CONST_AT];
   }
   __syncthreads();  // the only one: the tables are read-only from here on
   uint32_t* const smask = &sMask[wave][0][lane];
@@ -1479,20 +1556,32 @@ __global__ __launch_bounds__(256, 2) void hs_join8r_kernel(
   // 64-bit base per lane and item, eight loads at immediate offsets.  No clamping at a bucket's ragged
   // end: the rows past it read the next bucket's entries (the arrays are padded by 128 entries) and
   // are masked when survivors are emitted.
-  // row 0, 1, 3: j = 0, 1, 2 -- positions 8 j .. 8 j + 7 start at bit 40 j of the packed word: dword j, bit 8 j
+  // row 0, 1, 3: j = 0, 1, 2 -- positions 8 j .. 8 j + 7 start at bit 40 j of the packed word: dword j, bit 8 j;
+  // row 2: the member's four-byte record (16 bytes are loaded from it onward: the next members' words, unused)
   const bool row2 = row == 2;
   const uint32_t jj = row == 3 ? 2u : (uint32_t)row;
-  const char* const lane_base = (row2 ? reinterpret_cast<const char*>(rec_base)
-                                      : reinterpret_cast<const char*>(packed_base) + 4u * jj) + 16 * n;
-  const uint32_t sh = row2 ? 0u : 8u * jj;
+  const char* const lane_base = row2 ? reinterpret_cast<const char*>(rho_base) + 4 * n
+                                     : reinterpret_cast<const char*>(packed_base) + 4u * jj + 16 * n;
+  const uint32_t lane_shift = row2 ? 2u : 4u;     // bytes per entry of the lane's array: 4 | 16
+  const uint32_t lane_step = row2 ? 64u : 256u;   // ... per row tile of 16 members
+  J8rLane lc;
+  lc.row2 = row2;
+  lc.sh = row2 ? 0u : 8u * jj;
+  lc.s5 = row2 ? 0u : 5u;
+  lc.mA = row2 ? 0x7ff0u : 0x7fe0u;
   const uint32_t rc = 8u * ((uint32_t)lane & 3u);
-  const uint32_t m2 = row2 ? 0u : 0x7fe0u, rc2 = row2 ? CONST_AT : rc, rc3 = row2 ? CONST_AT + 8u : rc;
-  const char* const sPairB = reinterpret_cast<const char*>(sPairR);
+  lc.rA = row2 ? J8R_DIG_AT : rc;
+  lc.rB = row2 ? J8R_DIG_AT + 8u : rc;
+  lc.m2 = row2 ? 0u : 0x7fe0u;
+  lc.rc2 = row2 ? J8R_CONST_AT : rc;
+  lc.rc3 = row2 ? J8R_CONST_AT + 8u : rc;
+  lc.mrem = row2 ? 0x7fu : 0u;
+  const char* const sPairB = reinterpret_cast<const char*>(sLds);
 #define HS_LOAD_MEMBERS_R(MK, D0)                                                                   \
   {                                                                                                 \
     const int64_t e0_ = (int64_t)(((uint64_t)(D0).y << 32) | (uint64_t)(D0).x) + (int64_t)(D0).w * 128; \
-    const char* p_ = lane_base + e0_ * 16;                                                          \
-    _Pragma("unroll") for (int t = 0; t < 8; ++t) MK[t] = *reinterpret_cast<const uint4*>(p_ + 256 * t); \
+    const char* p_ = lane_base + (e0_ << lane_shift);                                               \
+    _Pragma("unroll") for (int t = 0; t < 8; ++t) MK[t] = *reinterpret_cast<const uint4*>(p_ + lane_step * t); \
   }
   uint4 mkA[8], mkB[8];
   intx4 Bq[2][2][2];
@@ -1525,14 +1614,14 @@ __global__ __launch_bounds__(256, 2) void hs_join8r_kernel(
     }                                                                                                          \
     /* members of the item after next: their address now, the loads when MK has been consumed */             \
     const int64_t e2_ = (int64_t)(((uint64_t)nnd0.y << 32) | (uint64_t)nnd0.x) + (int64_t)nnd0.w * 128;         \
-    const char* nm_ = lane_base + e2_ * 16;                                                                    \
+    const char* nm_ = lane_base + (e2_ << lane_shift);                                                         \
     const uint32_t nct_ = (nQ + 15u) >> 4;                                                                     \
     uint32_t gm_;                                                                                              \
     /* AP holds the lookups of this item's first half, issued one half-step ago: complete it (the wait for     \
        them sits here, with nothing younger in flight: the LDS counter has four bits, sixteen younger lookups  \
        could not be told apart from them), send the second half's lookups out, compute the first half */       \
-    join8r_finish(AP, MK, 0, row2);                                                                            \
-    join8r_lookup(AQ, MK, 1, sPairB, sh, rc, m2, rc2, rc3);                                                    \
+    join8r_finish(AP, XP, MK, 0, lc);                                                                          \
+    join8r_lookup(AQ, XQ, MK, 1, sPairB, lc);                                                                  \
     switch (nct_) {                                                                                            \
       case 1: gm_ = join8r_half<1, 0>(AP, Bq, smask); break;                                                   \
       case 2: gm_ = join8r_half<2, 0>(AP, Bq, smask); break;                                                   \
@@ -1540,11 +1629,11 @@ __global__ __launch_bounds__(256, 2) void hs_join8r_kernel(
       default: gm_ = join8r_half<4, 0>(AP, Bq, smask); break;                                                  \
     }                                                                                                          \
     /* MK's first half is consumed: the first half of the members of the item after next */                    \
-    _Pragma("unroll") for (int t = 0; t < 4; ++t) MK[t] = *reinterpret_cast<const uint4*>(nm_ + 256 * t);      \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) MK[t] = *reinterpret_cast<const uint4*>(nm_ + lane_step * t); \
     /* second half: complete, send out the NEXT item's first half (its members were requested one item ago;    \
        the same item's when there is none), compute */                                                         \
-    join8r_finish(AQ, MK, 1, row2);                                                                            \
-    join8r_lookup(AP, MKN, 0, sPairB, sh, rc, m2, rc2, rc3);                                                   \
+    join8r_finish(AQ, XQ, MK, 1, lc);                                                                          \
+    join8r_lookup(AP, XP, MKN, 0, sPairB, lc);                                                                 \
     switch (nct_) {                                                                                            \
       case 1: gm_ |= join8r_half<1, 1>(AQ, Bq, smask); break;                                                  \
       case 2: gm_ |= join8r_half<2, 1>(AQ, Bq, smask); break;                                                  \
@@ -1552,7 +1641,7 @@ __global__ __launch_bounds__(256, 2) void hs_join8r_kernel(
       default: gm_ |= join8r_half<4, 1>(AQ, Bq, smask); break;                                                 \
     }                                                                                                          \
     /* ... and the second half */                                                                              \
-    _Pragma("unroll") for (int t = 4; t < 8; ++t) MK[t] = *reinterpret_cast<const uint4*>(nm_ + 256 * t);      \
+    _Pragma("unroll") for (int t = 4; t < 8; ++t) MK[t] = *reinterpret_cast<const uint4*>(nm_ + lane_step * t); \
     if (gm_)                                                                                                   \
       join8r_emit(gm_, (int)((nct_ + 1u) >> 1), smask, qoff, nQ, wbase, M, mstart, lane, res_base, res_used,   \
                   prov_count, prov_cap, prov);                                                                 \
@@ -1565,7 +1654,8 @@ __global__ __launch_bounds__(256, 2) void hs_join8r_kernel(
     nd1 = nnd1;                                                                                                \
   }
   intx4 AP[4][2], AQ[4][2];
-  join8r_lookup(AP, mkA, 0, sPairB, sh, rc, m2, rc2, rc3);  // the first item's first half
+  uint32_t XP[4], XQ[4];
+  join8r_lookup(AP, XP, mkA, 0, sPairB, lc);  // the first item's first half
   for (;;) {
     HS_ITEM_STEP(mkA, mkB)
     if (!has_next) break;
@@ -1929,7 +2019,7 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
 // queries, k <= 25, 4-column rows -- through the query-resident kernel.  d_cn_rep: the constant factors
 // of the gamma slots, 128 times over (2 KB).  *d_item_counter zeroed by the caller.
 hipError_t hs_launch_join8r(const uint4* d_desc, uint32_t desc_cap, const uint32_t* d_split,
-                            const uint4* d_packed_base, const uint4* d_rec_base, const void* d_c8t,
+                            const uint4* d_packed_base, const uint32_t* d_rho_base, const void* d_c8t,
                             const void* d_tab8, const void* d_cn_rep, uint32_t* d_prov_count, uint32_t prov_cap,
                             uint2* d_prov, uint32_t* d_item_counter, int n_blocks, double pairs_per_item,
                             hipStream_t s) {
@@ -1942,7 +2032,7 @@ hipError_t hs_launch_join8r(const uint4* d_desc, uint32_t desc_cap, const uint32
   const uint32_t n_waves = (uint32_t)n_blocks * 4u;
   G = std::max(2u, std::min(G, std::max(2u, desc_cap / (n_waves * 32u))));
   if (g_env) G = g_env;
-  hs_join8r_kernel<<<n_blocks, 256, 0, s>>>(d_desc, d_split, desc_cap, d_packed_base, d_rec_base, (const uint4*)d_c8t,
+  hs_join8r_kernel<<<n_blocks, 256, 0, s>>>(d_desc, d_split, desc_cap, d_packed_base, d_rho_base, (const uint4*)d_c8t,
                                             (const uint4*)d_tab8, (const uint4*)d_cn_rep, d_prov_count, prov_cap,
                                             d_prov, d_item_counter, G);
   return hipGetLastError();
@@ -1950,11 +2040,11 @@ hipError_t hs_launch_join8r(const uint4* d_desc, uint32_t desc_cap, const uint32
 
 hipError_t hs_launch_gather_rec8(const uint4* d_packed_all, const uint32_t* d_ids_sorted, uint32_t n,
                                  int k, int wide, const void* d_tab8, const void* d_tabW, const float* d_scale,
-                                 uint4* d_out_packed, uint4* d_out_rec, hipStream_t s) {
+                                 uint4* d_out_packed, uint4* d_out_rec, uint32_t* d_out_rho, hipStream_t s) {
   if (!n) return hipSuccess;
   hs_gather_rec8_kernel<<<blocks_for(n), 256, 0, s>>>(d_packed_all, d_ids_sorted, n, k, hs_packed_words(k), wide,
                                                       (const uint4*)d_tab8, (const uint4*)d_tabW, d_scale,
-                                                      d_out_packed, d_out_rec);
+                                                      d_out_packed, d_out_rec, d_out_rho);
   return hipGetLastError();
 }
 

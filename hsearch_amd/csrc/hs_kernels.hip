@@ -1166,12 +1166,18 @@ __global__ __launch_bounds__(256) void hs_bf_finalize_kernel(const uint8_t* __re
   }
 }
 
-// Ordering of a batch's hits without a sort and without the host knowing their number: hits are
-// bucketed by query (qoff = exclusive scan of the per-query counts hs_finalize_kernel kept), then
-// every query orders its own few hits by (table of first sight, id) and writes them out -- the
-// reference's file order (motif_both_points.cpp:224-245).  A query with more than HS_ORDER_MAX hits
-// raises *big instead (the caller then falls back to the radix sort over the whole list).
-#define HS_ORDER_MAX 128u
+// Ordering of a batch's hits without a sort over the whole list and without the host knowing their
+// number: hits are bucketed by query (qoff = exclusive scan of the per-query counts hs_finalize_kernel
+// kept), then every query orders its own hits by (table of first sight, id) and writes them out -- the
+// reference's file order (motif_both_points.cpp:224-245).  A query with up to HS_ORDER_MAX hits is
+// ordered by one thread (insertion sort); one with more goes on one of two lists (up to 1024 / up to
+// HS_ORDER_BLOCK_MAX hits) whose queries are ordered by a block each, with a bitonic sort in LDS
+// (hs_hit_order_block_kernel): short k-mers at a loose radius have hundreds of hits per query (k = 15 at
+// the C2 sizes: 545 on average), and the radix sort over the whole list those batches fell back to cost
+// as much as their join.  A query with more than HS_ORDER_BLOCK_MAX hits still raises *big (the caller
+// then falls back to that sort).
+#define HS_ORDER_MAX 48u
+#define HS_ORDER_BLOCK_MAX 8192u
 __global__ __launch_bounds__(256) void hs_hit_place_kernel(const uint64_t* __restrict__ key,
                                                            const uint64_t* __restrict__ val,
                                                            const uint32_t* __restrict__ hit_count,
@@ -1192,11 +1198,14 @@ __global__ __launch_bounds__(256) void hs_hit_place_kernel(const uint64_t* __res
   }
 }
 
+// qlist: [0] queries on the list of the 1024-hit blocks, [1] on the list of the larger blocks, [2], [3]
+// the two lists' work counters, then the lists themselves (nq entries each)
 __global__ __launch_bounds__(256) void hs_hit_order_kernel(const uint32_t* __restrict__ qoff, uint32_t nq,
                                                            const uint32_t* __restrict__ hit_count,
                                                            uint32_t hit_cap, uint64_t* __restrict__ key2,
                                                            uint64_t* __restrict__ val2,
                                                            uint32_t* __restrict__ big,
+                                                           uint32_t* __restrict__ qlist,
                                                            uint32_t* __restrict__ out_q,
                                                            uint32_t* __restrict__ out_id,
                                                            uint32_t* __restrict__ out_table,
@@ -1206,8 +1215,13 @@ __global__ __launch_bounds__(256) void hs_hit_order_kernel(const uint32_t* __res
   if (*hit_count > hit_cap) return;  // the batch is repeated with larger buffers anyway
   const uint32_t lo = qoff[q], m = qoff[q + 1] - lo;
   if (!m) return;
-  if (m > HS_ORDER_MAX) {
+  if (m > HS_ORDER_BLOCK_MAX) {
     atomicOr(big, 1u);
+    return;
+  }
+  if (m > HS_ORDER_MAX) {
+    const uint32_t which = m > 1024u ? 1u : 0u;
+    qlist[4 + (size_t)which * nq + atomicAdd(&qlist[which], 1u)] = q;
     return;
   }
   // insertion sort of the query's hits by key (distinct: (table, id) is unique per query)
@@ -1230,6 +1244,68 @@ __global__ __launch_bounds__(256) void hs_hit_order_kernel(const uint32_t* __res
     if (out_table) out_table[o] = (uint32_t)((kk >> 32) & 31u);
     out_id[o] = (uint32_t)kk;
     out_dist[o] = __longlong_as_double((long long)val2[lo + i]);
+  }
+}
+
+// One block per listed query: its hits' (table, id) -- 37 bits -- with the hit's place in the query's
+// range below them -- 27 bits -- sorted as one 64-bit word in LDS, padded with all-ones words to a
+// power of two; the distance follows through the place.  CAP = 1024 or HS_ORDER_BLOCK_MAX words of LDS.
+template <uint32_t CAP>
+__global__ __launch_bounds__(256) void hs_hit_order_block_kernel(const uint32_t* __restrict__ qoff, uint32_t nq,
+                                                                 const uint32_t* __restrict__ hit_count,
+                                                                 uint32_t hit_cap, uint32_t which,
+                                                                 const uint64_t* __restrict__ key2,
+                                                                 const uint64_t* __restrict__ val2,
+                                                                 uint32_t* __restrict__ qlist,
+                                                                 uint32_t* __restrict__ out_q,
+                                                                 uint32_t* __restrict__ out_id,
+                                                                 uint32_t* __restrict__ out_table,
+                                                                 double* __restrict__ out_dist, uint64_t out_room) {
+  __shared__ uint64_t sk[CAP];
+  if (*hit_count > hit_cap) return;
+  const uint32_t n_list = qlist[which];
+  const uint32_t* const list = qlist + 4 + (size_t)which * nq;
+  const uint32_t tid = threadIdx.x;
+  for (;;) {
+    __syncthreads();  // (the previous query's words have been written out)
+    if (tid == 0) sk[0] = atomicAdd(&qlist[2 + which], 1u);  // the block's next query, by way of word 0
+    __syncthreads();
+    const uint32_t at = (uint32_t)sk[0];
+    __syncthreads();
+    if (at >= n_list) return;
+    const uint32_t q = list[at];
+    const uint32_t lo = qoff[q], m = qoff[q + 1] - lo;
+    uint32_t P = 512u;  // (256 threads: every thread has a pair in every step)
+    while (P < m) P <<= 1;
+    for (uint32_t i = tid; i < P; i += 256u)
+      sk[i] = i < m ? ((key2[lo + i] & ((1ull << 37) - 1ull)) << 27) | (uint64_t)i : ~0ull;
+    __syncthreads();
+    for (uint32_t size = 2u; size <= P; size <<= 1) {
+      for (uint32_t stride = size >> 1; stride > 0u; stride >>= 1) {
+        for (uint32_t t = tid; t < (P >> 1); t += 256u) {
+          const uint32_t i = 2u * t - (t & (stride - 1u));  // the pair's lower index
+          const uint32_t j = i + stride;
+          const bool up = (i & size) == 0u;
+          const uint64_t a = sk[i], b = sk[j];
+          if ((a > b) == up) {
+            sk[i] = b;
+            sk[j] = a;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    const uint32_t q_abs = (uint32_t)(key2[lo] >> 37);
+    for (uint32_t i = tid; i < m; i += 256u) {
+      const uint64_t o = (uint64_t)lo + i;
+      if (o >= out_room) break;
+      const uint64_t e = sk[i];
+      const uint64_t ti = e >> 27;
+      out_q[o] = q_abs;
+      if (out_table) out_table[o] = (uint32_t)(ti >> 32) & 31u;
+      out_id[o] = (uint32_t)ti;
+      out_dist[o] = __longlong_as_double((long long)val2[lo + (uint32_t)(e & ((1u << 27) - 1u))]);
+    }
   }
 }
 
@@ -1488,13 +1564,21 @@ hipError_t hs_launch_finalize(const hs_tables_dev& tabs, const uint8_t* d_codes,
 hipError_t hs_launch_hit_order(const uint64_t* d_key, const uint64_t* d_val, const uint32_t* d_hit_count,
                                uint32_t hit_cap, uint32_t q_base, uint32_t nq, const uint32_t* d_qoff,
                                uint32_t* d_qfill, uint64_t* d_key2, uint64_t* d_val2, uint32_t* d_big,
+                               uint32_t* d_qlist /* 4 + 2 nq words, the first four zero */,
                                uint32_t* d_q, uint32_t* d_id, uint32_t* d_table, double* d_dist,
-                               uint64_t out_room, hipStream_t s) {
+                               uint64_t out_room, int n_cu, hipStream_t s) {
   if (!nq) return hipSuccess;
   hs_hit_place_kernel<<<256, 256, 0, s>>>(d_key, d_val, d_hit_count, hit_cap, q_base, d_qoff, d_qfill, d_key2,
                                           d_val2);
-  hs_hit_order_kernel<<<blocks_for(nq), 256, 0, s>>>(d_qoff, nq, d_hit_count, hit_cap, d_key2, d_val2, d_big, d_q,
-                                                    d_id, d_table, d_dist, out_room);
+  hs_hit_order_kernel<<<blocks_for(nq), 256, 0, s>>>(d_qoff, nq, d_hit_count, hit_cap, d_key2, d_val2, d_big,
+                                                    d_qlist, d_q, d_id, d_table, d_dist, out_room);
+  // (blocks that find their list empty leave at once: a batch of few hits pays two empty launches)
+  const unsigned cu = (unsigned)std::max(n_cu, 1);
+  hs_hit_order_block_kernel<1024u><<<std::min(nq, cu * 8u), 256, 0, s>>>(d_qoff, nq, d_hit_count, hit_cap, 0u, d_key2,
+                                                                       d_val2, d_qlist, d_q, d_id, d_table, d_dist,
+                                                                       out_room);
+  hs_hit_order_block_kernel<HS_ORDER_BLOCK_MAX><<<std::min(nq, cu * 2u), 256, 0, s>>>(
+      d_qoff, nq, d_hit_count, hit_cap, 1u, d_key2, d_val2, d_qlist, d_q, d_id, d_table, d_dist, out_room);
   return hipGetLastError();
 }
 

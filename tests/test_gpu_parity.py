@@ -727,26 +727,34 @@ def test_probe_grouping_by_counting_sort_and_by_probe_sort(oracle, monkeypatch, 
             assert np.array_equal(e[key], ref[key])
 
 
-def test_hit_ordering_paths_with_many_hits_per_query(oracle, monkeypatch):
-    """Output order = (query, table of first sight, id) (motif_both_points.cpp:224-245).  Up to 128 hits per
-    query are ordered inside a kernel (hits bucketed by query, no sort); a batch in which some query has
-    more -- and any batch under HS_SORT_HITS=1 -- is radix-sorted on the full key.  A DB with a family
-    of 700 near-identical k-mers (some queries get ~700 hits, most a few) through both against the
-    oracle.  (A segmented sort of the bucketed hits was tried for the hit-heavy case: k = 15 at the C2
-    sizes, 545 hits per query, 38.0 ms against 32.2 for the full-key sort.)"""
+@pytest.mark.parametrize("families", [(700,), (700, 1500), (300, 9000)])
+def test_hit_ordering_paths_with_many_hits_per_query(oracle, monkeypatch, families):
+    """Output order = (query, table of first sight, id) (motif_both_points.cpp:224-245).  The hits are
+    bucketed by query; a query with up to 48 is ordered by one thread, one with up to 1024 / 8192 by a
+    block (bitonic sort in LDS, hs_hit_order_block_kernel); a batch in which some query has more -- and
+    any batch under HS_SORT_HITS=1 -- is radix-sorted on the full key.  A DB with families of
+    near-identical k-mers (queries inside a family of m get ~m hits, most others a few: 700 -> the small
+    blocks, 1500 -> the large ones, 9000 -> the fallback) through all of them against the oracle."""
     k, K, L, W, R, n, nq = 25, 4, 5, 150.0, 40.0, 20011, 903
     a, b = synth.make_planes(k, K, L, W, seed=75)
     codes = synth.make_db(n, k, seed=76)
     rng = np.random.default_rng(77)
-    fam = np.repeat(codes[:1], 700, axis=0)
-    fam[np.arange(700), rng.integers(0, k, size=700)] = rng.integers(0, 20, size=700, dtype=np.uint8)
-    codes[1000:1700] = fam
+    at, nfq = 1000, 0
+    for fi, m in enumerate(families):
+        fam = np.repeat(codes[fi:fi + 1], m, axis=0)
+        fam[np.arange(m), rng.integers(0, k, size=m)] = rng.integers(0, 20, size=m, dtype=np.uint8)
+        codes[at:at + m] = fam
+        at += m
     centers, _ = synth.make_queries(codes, nq, seed=78, jitter=0.2)
-    centers[:40] = synth.embed(fam[:40])            # 40 queries inside the family
+    at = 1000
+    for m in families:
+        centers[nfq:nfq + 20] = synth.embed(codes[at:at + 20])   # 20 queries inside each family
+        nfq += 20
+        at += m
     want = oracle.search(a, b, W, R, oracle.embed_codes(codes), centers)
     per_q = np.bincount(want["q"], minlength=nq)
-    assert per_q.max() > 500 and np.median(per_q) < 20
-    want_few = oracle.search(a, b, W, R, oracle.embed_codes(codes), centers[40:])
+    assert per_q.max() > 0.7 * max(families) and np.median(per_q) < 20
+    want_few = oracle.search(a, b, W, R, oracle.embed_codes(codes), centers[nfq:])
     for sort_all in (False, True):
         monkeypatch.delenv("HS_SORT_HITS", raising=False)
         if sort_all:
@@ -756,8 +764,8 @@ def test_hit_ordering_paths_with_many_hits_per_query(oracle, monkeypatch):
         for mode in ("auto", "stream"):
             eng.set_verify_mode(mode)
             _assert_hits_equal(eng.query(centers, R), want)
-        # without the family queries every query stays under 128 hits: the in-kernel ordering
-        few = eng.query(centers[40:], R)
+        # without the family queries every query has few hits: the one-thread ordering
+        few = eng.query(centers[nfq:], R)
         _assert_hits_equal(few, want_few)
         eng.close()
 
