@@ -292,7 +292,7 @@ class Workload:
         for _ in range(warmup):
             self.step(hdist, HsError, use_dist)
         acc = dict(verify_ms=0.0, hash_ms=0.0, probe_ms=0.0, fin_ms=0.0, join_ms=0.0, launches=0, join_batches=0,
-                   join_i8=0, retries=0)
+                   join_i8=0, retries=0, recognised=0)
         jstat, qproj, join_rows, cand, hits_local = (0, 0, 0, 0), (0, 0), (128, 0), 0, 0
         gathered = None
         fence()
@@ -309,6 +309,7 @@ class Workload:
             acc["join_ms"] += p["ms_join"]
             acc["join_i8"] += p["join_i8_batches"]
             acc["retries"] += p["join_async_retries"]
+            acc["recognised"] += p["queries_recognised"]
             jstat = (p["join_items"], p["join_pairs"], p["join_pairs_issued"], p["join_items_resident"])
             if p["join_i8_batches"]:
                 join_rows = (int(p["join_row_bytes"]), int(p["join_wide"]))
@@ -525,6 +526,10 @@ def main():
                                    "verify": m["verify_ms"] / steps, "finalize_sort": m["fin_ms"] / steps},
             "candidates_per_query": m["cand"] / args.nq, "hits_per_step_rank0": m["hits_local"],
             "hits_gathered": m["total_hits"],
+            # the synthetic centres are k-mers' points, as the reference's centres files hold: hs_query_dev finds
+            # that out per call (one pass over the [nq][8k] doubles, inside the timed step) and then works from
+            # the residue codes it read off them; HS_NO_RECOGNISE=1 keeps the points path
+            "queries_recognised_as_kmers_per_step": m["recognised"] / steps,
             "index": index,
         }
         nr = min(args.recall_queries, args.nq)

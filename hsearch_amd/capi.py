@@ -46,7 +46,7 @@ class _Profile(C.Structure):
                 ("join_pairs_issued", C.c_uint64), ("join_i8_batches", C.c_uint64),
                 ("hash_values", C.c_uint64), ("hash_flagged", C.c_uint64),
                 ("join_row_bytes", C.c_uint32), ("join_wide", C.c_uint32), ("join_items_resident", C.c_uint64),
-                ("join_async_retries", C.c_uint64)]
+                ("join_async_retries", C.c_uint64), ("queries_recognised", C.c_uint64)]
 
 
 class _IndexInfo(C.Structure):

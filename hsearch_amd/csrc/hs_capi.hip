@@ -91,6 +91,7 @@ struct Knobs {
   bool sort_hits = false;          // HS_SORT_HITS: order hits by the radix sort, not per query
   bool sync_items = false;         // HS_SYNC_ITEMS: read the join's item count back before launching it
   bool no_join_r = false;          // HS_NO_JOIN_R: every segment through the query-streaming join kernel
+  bool no_recognise = false;       // HS_NO_RECOGNISE: centres that are k-mers are not looked for (run_query)
   bool force_join_r = false;       // HS_FORCE_JOIN_R: the query-resident kernel for its class whatever its share
   bool build_sort = false;         // HS_BUILD_SORT: group a table's k-mers by sorting (fingerprint, id) pairs
                                    // (rocPRIM; rounds 1-2) instead of hs_group.hip's table + rank sort
@@ -131,6 +132,7 @@ struct hs_handle {
   // the records once more in four bytes per entry ([L][n]; k <= 25 with 4-column rows: what the
   // query-resident join kernel reads instead of t_rec8 -- it is bound by the bytes it moves per member)
   DevBuf t_rho;
+  DevBuf rec_codes;  // run_query: the residue codes of centres that turned out to be k-mers (+ the counter)
   // member records of the wide rows for k = 21..25 (built when a call's radius first asks for them)
   DevBuf t_rec8w;
   bool rec8w_ready = false;
@@ -419,6 +421,7 @@ void read_knobs(hs_handle* h) {
   kn.sort_hits = on("HS_SORT_HITS");
   kn.sync_items = on("HS_SYNC_ITEMS");
   kn.no_join_r = on("HS_NO_JOIN_R");
+  kn.no_recognise = on("HS_NO_RECOGNISE");
   kn.force_join_r = on("HS_FORCE_JOIN_R");
   kn.build_sort = on("HS_BUILD_SORT");
   if (const char* m = getenv("HS_SEG_MODE")) kn.seg_mode = !strcmp(m, "sparse") ? 1 : !strcmp(m, "dense") ? 2 : 0;
@@ -669,7 +672,7 @@ void hs_destroy(hs_handle* h) {
                     &h->proj_xmeta, &h->slice_ql, &h->qhits, &h->bs_ints2[0], &h->bs_ints2[1], &h->bs_keys2[0],
                     &h->bs_keys2[1], &h->bs_iota2[0], &h->bs_iota2[1], &h->bs_keys_sorted, &h->bs_rle_unique,
                     &h->bs_rle_counts, &h->bs_small, &h->bs_sort_temp, &h->bs_slow_q, &h->all_codes,
-                    &h->subset_ids, &h->qcodes_buf, &h->qembed, &h->seg_res, &h->jconst, &h->t_rho, &h->bs_fptab, &h->bs_blk,
+                    &h->subset_ids, &h->qcodes_buf, &h->qembed, &h->seg_res, &h->jconst, &h->t_rho, &h->rec_codes, &h->bs_fptab, &h->bs_blk,
                     &h->bs_dk, &h->bs_hist, &h->bs_rank};
   for (DevBuf* bf : bufs) bf->release();
   h->sj_host.release();
@@ -2211,11 +2214,11 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
     uint32_t *qcnt = nullptr, *qoff = nullptr, *qfill = nullptr;
     if (order_here) {
       const size_t n1q = (size_t)nq + 1;
-      HS_HIP(h, h->qhits.reserve((5 * n1q + 4) * 4));
+      HS_HIP(h, h->qhits.reserve((6 * n1q + 8) * 4));
       qcnt = h->qhits.as<uint32_t>();
       qoff = qcnt + n1q;
-      qfill = qoff + n1q;  // (and behind it the lists of the queries a block orders: 4 + 2 nq words)
-      HS_HIP(h, hipMemsetAsync(qcnt, 0, (3 * n1q + 4) * 4, h->stream));
+      qfill = qoff + n1q;  // (and behind it the lists of the queries a block orders: 8 + 3 nq words)
+      HS_HIP(h, hipMemsetAsync(qcnt, 0, (3 * n1q + 8) * 4, h->stream));
       if (launches) HS_HIP(h, hipMemsetAsync(d_cnt + 20, 0, 4, h->stream));  // retry: the "too many hits" flag
       HS_HIP(h, h->hit_key2.reserve((size_t)hit_cap * 8));
       HS_HIP(h, h->hit_val2.reserve((size_t)hit_cap * 8));
@@ -2301,7 +2304,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
                                    fin_list, fin_count, prov_cap, h->sorted_ql.as<uint32_t>(),
                                    k, L, r2, h->sqrt_test ? R : (double)NAN, q_base, h->self_first, d_cnt + 1,
                                    hit_cap, h->hit_key.as<uint64_t>(), h->hit_val.as<uint64_t>(), qcnt,
-                                   h->stream));
+                                   h->alphabet, h->stream));
       if (order_here) {
         const size_t n1q_ = (size_t)nq + 1;
         HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, qcnt, qoff, (size_t)nq + 1, h->stream));
@@ -2427,6 +2430,25 @@ static hs_status run_query(hs_handle* h, const double* d_centers, const uint8_t*
   memset(&h->prof, 0, sizeof(h->prof));
   HS_HIP(h, h->counters.reserve(256));
   HS_HIP(h, hipEventRecord(h->ev[8], h->stream));
+  // Centres that are k-mers (every 8 doubles a row of the coordinate table, bit for bit -- what the
+  // reference's centres files hold) run from their residue codes, as hs_query_codes's do: the same
+  // results from k bytes per query where the point rows are 64 k.  One small kernel and one wait per call.
+  if (d_centers && !d_qcodes && nq && h->n && !brute && !h->knobs.no_recognise && h->p.k <= 75) {
+    const size_t cb = ((size_t)nq * h->p.k + 15) & ~(size_t)15;
+    HS_HIP(h, h->rec_codes.reserve(cb + 16));
+    uint32_t* const d_bad = reinterpret_cast<uint32_t*>(h->rec_codes.as<uint8_t>() + cb);
+    HS_HIP(h, hipMemsetAsync(d_bad, 0, 4, h->stream));
+    HS_HIP(h, hs_launch_recognise_kmers(d_centers, nq, h->p.k, h->coords.as<double>(), h->alphabet,
+                                        h->rec_codes.as<uint8_t>(), d_bad, h->stream));
+    uint32_t bad = 1;
+    HS_HIP(h, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, h->stream));
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    if (!bad) {
+      d_qcodes = h->rec_codes.as<uint8_t>();
+      d_centers = nullptr;
+      h->prof.queries_recognised = nq;
+    }
+  }
   uint64_t total = 0;
   if (nq && h->n && !(brute && R < 0)) {
     // queries per batch: bounds the workspace, which grows with nq * L (2^17 at L >= 8; with few

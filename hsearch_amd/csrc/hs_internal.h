@@ -273,6 +273,8 @@ hipError_t hs_launch_gather_packed(const uint4* d_packed_all, const uint32_t* d_
                                    uint64_t n, int PW, uint4* d_out, hipStream_t s);
 hipError_t hs_launch_set_u32(uint32_t* d_p, uint32_t v, hipStream_t s);
 // d_out[i] = d_in[i] if it is a row of the table (< alphabet), else 0 and *d_bad |= 1
+hipError_t hs_launch_recognise_kmers(const double* d_centers, uint64_t nq, int k, const double* d_coords, int alphabet,
+                                     uint8_t* d_out_codes, uint32_t* d_n_unrecognised, hipStream_t s);
 hipError_t hs_launch_check_codes(const uint8_t* d_in, uint64_t n_bytes, int alphabet, uint8_t* d_out,
                                  uint32_t* d_bad, hipStream_t s);
 // windows of length k of every sequence of a residue buffer -> codes [n_windows][k] (+ the buffer
@@ -348,14 +350,14 @@ hipError_t hs_launch_finalize(const hs_tables_dev& tabs, const uint8_t* d_codes,
                               const uint32_t* d_sorted_ql, int k, int L, double r2, double r_sqrt,
                               uint32_t q_base, uint32_t self_first, uint32_t* d_hit_count,
                               uint32_t hit_cap, uint64_t* d_hit_key, uint64_t* d_hit_val,
-                              uint32_t* d_qcnt /* [nq] hits per query, or null */, hipStream_t s);
+                              uint32_t* d_qcnt /* [nq] hits per query, or null */, int alphabet, hipStream_t s);
 // the batch's hits in the reference's order without a sort: bucket by query (d_qoff = exclusive
 // scan of the per-query counts), order every query's few hits, unpack to the outputs (at most
 // out_room of them); *d_big is set when a query has too many hits for that (caller: radix sort)
 hipError_t hs_launch_hit_order(const uint64_t* d_key, const uint64_t* d_val, const uint32_t* d_hit_count,
                                uint32_t hit_cap, uint32_t q_base, uint32_t nq, const uint32_t* d_qoff,
                                uint32_t* d_qfill, uint64_t* d_key2, uint64_t* d_val2, uint32_t* d_big,
-                               uint32_t* d_qlist /* 4 + 2 nq words, the first four zero */,
+                               uint32_t* d_qlist /* 8 + 3 nq words, the first eight zero */,
                                uint32_t* d_q, uint32_t* d_id, uint32_t* d_table, double* d_dist,
                                uint64_t out_room, int n_cu, hipStream_t s);
 // self_first: the queries are the indexed k-mers self_first, self_first + 1, ... themselves (the

@@ -997,6 +997,124 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
   flush_hits();
 }
 
+// hs_finalize_kernel for queries that are k-mers (qcodes given) and alphabets of up to HS_FIN_TABLE_ALPHABET
+// residues: every term of the exact sum is then one of alphabet^2 x 8 values -- (x_r[j] - x_s[j])^2 for a
+// member residue r meeting a query residue s, rounded once at the difference and once at the square as
+// the reference does -- and the kernel looks them up (a 64-byte row of a table in LDS per position) and
+// ADDS them in the reference's order: a third of the double-precision operations and half the LDS reads
+// of fetching both residues' rows, no staging of 64-byte point pieces, no byte copy of the member's
+// residues (they are taken from the packed word by constant shifts).  Hit-heavy batches spend their time
+// here (k = 15 at the C2 sizes: 1.4e8 survivors per batch, 9.4 ms with the two-row form).
+#define HS_FIN_TABLE_ALPHABET 24
+__global__ __launch_bounds__(256) void hs_finalize_codes_kernel(hs_tables_dev tabs,
+                                                                const uint8_t* __restrict__ qcodes,
+                                                                const double* __restrict__ coords, int alphabet,
+                                                                const uint32_t* __restrict__ qstart,
+                                                                const uint32_t* __restrict__ qcount,
+                                                                const uint2* __restrict__ prov,
+                                                                const uint32_t* __restrict__ prov_count,
+                                                                uint32_t prov_cap,
+                                                                const uint32_t* __restrict__ sorted_ql,
+                                                                int k, int L, double r2, double r_sqrt,
+                                                                uint32_t q_base, uint32_t self_first,
+                                                                uint32_t* __restrict__ hit_count, uint32_t hit_cap,
+                                                                uint64_t* __restrict__ hit_key,
+                                                                uint64_t* __restrict__ hit_val,
+                                                                uint32_t* __restrict__ qcnt) {
+  extern __shared__ __attribute__((aligned(16))) double s_sq[];  // [alphabet][alphabet][8]
+  __shared__ uint8_t s_qc[4][64 * 76];  // the survivors' query residues, row stride 76 (k <= 75)
+  constexpr uint32_t HBUF = 128;
+  __shared__ uint64_t s_hk[4][HBUF], s_hv[4][HBUF];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < alphabet * alphabet * 8; e += 256) {
+    const int j = e & 7, rs = e >> 3, r = rs / alphabet, sq = rs - r * alphabet;
+    const double d = __dsub_rn(coords[r * 8 + j], coords[sq * 8 + j]);
+    s_sq[e] = __dmul_rn(d, d);
+  }
+  __syncthreads();
+  const uint32_t n = min(*prov_count, prov_cap);
+  const uint32_t wave_stride = gridDim.x * 4u * 64u;
+  const int PW = (k + 24) / 25;
+  uint32_t n_buf = 0;
+  auto flush_hits = [&]() {
+    if (!n_buf) return;
+    uint32_t gbase = 0;
+    if (lane == 0) gbase = atomicAdd(hit_count, n_buf);
+    gbase = __shfl(gbase, 0);
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = (uint32_t)lane; i < n_buf; i += 64u)
+      if (gbase + i < hit_cap) {
+        hit_key[gbase + i] = s_hk[wave][i];
+        hit_val[gbase + i] = s_hv[wave][i];
+      }
+    __builtin_amdgcn_wave_barrier();
+    n_buf = 0;
+  };
+  uint8_t* const my_qc = &s_qc[wave][lane * 76];
+  for (uint32_t base = (blockIdx.x * 4u + (uint32_t)wave) * 64u; base < n; base += wave_stride) {
+    const uint32_t e = base + (uint32_t)lane;
+    uint32_t ql = e < n ? prov[e].x : 0xffffffffu;
+    const uint32_t pos = e < n ? prov[e].y : 0u;
+    const bool live = ql != 0xffffffffu;
+    if (live && (ql & HS_PROV_INDIRECT)) ql = sorted_ql[ql & ~HS_PROV_INDIRECT];
+    const uint32_t q = live ? ql / (uint32_t)L : 0u;
+    const int l = live ? (int)(ql % (uint32_t)L) : 0;
+    const uint32_t id = live ? tabs.t[l].ids[pos] : 0u;
+    {
+      const uint8_t* qc = qcodes + (uint64_t)q * k;
+      for (int p = 0; p < k; ++p) my_qc[p] = qc[p];
+    }
+    const uint4* pkp = tabs.t[l].packed + (uint64_t)pos * PW;
+    double d2 = 0.0;
+    for (int wd = 0; wd < PW; ++wd) {
+      const uint4 pk = pkp[wd];
+      const uint32_t w[5] = {pk.x, pk.y, pk.z, pk.w, 0u};
+#pragma unroll
+      for (int r = 0; r < 25; ++r) {
+        const int p = 25 * wd + r;
+        if (p < k) {  // (wave-uniform)
+          const int bit = 5 * r, wi = bit >> 5, sh = bit & 31;
+          uint32_t c = w[wi] >> sh;
+          if (sh > 27) c |= w[wi + 1] << (32 - sh);
+          c &= 31u;
+          const double2* row = reinterpret_cast<const double2*>(s_sq + ((int)c * alphabet + (int)my_qc[p]) * 8);
+          // exact left-to-right sum of the rounded squares (PairwiseDistance_square :176-183)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const double2 v = row[j];
+            d2 = __dadd_rn(d2, v.x);
+            d2 = __dadd_rn(d2, v.y);
+          }
+        }
+      }
+    }
+    bool hit = live && ((r_sqrt == r_sqrt) ? (__dsqrt_rn(d2) <= r_sqrt) : (d2 <= r2));
+    if (self_first != HS_NO_SELF && self_first + q_base + q == id) hit = false;
+    if (hit) {  // first-seen rule, as in hs_finalize_kernel
+      bool dup = false;
+      for (int l2 = 0; l2 < l; ++l2) {
+        const uint32_t c2 = qcount[q * L + l2];
+        const uint32_t p2 = tabs.t[l2].pos_of[id];
+        dup = dup || (p2 - qstart[q * L + l2] < c2);
+      }
+      hit = !dup;
+    }
+    const unsigned long long hm = __ballot(hit);
+    if (hm) {
+      const uint32_t cnt = (uint32_t)__popcll(hm);
+      if (n_buf + cnt > HBUF) flush_hits();
+      const uint32_t idx = n_buf + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+      if (hit) {
+        s_hk[wave][idx] = ((uint64_t)(q_base + q) << 37) | ((uint64_t)l << 32) | id;
+        s_hv[wave][idx] = (uint64_t)__double_as_longlong(__dsqrt_rn(d2));
+      }
+      n_buf += cnt;
+      if (hit && qcnt) atomicAdd(&qcnt[q], 1u);
+    }
+  }
+  flush_hits();
+}
+
 // One thread per residue position: the position starts a window iff k residues of its own
 // sequence follow it.  Neighbouring threads write neighbouring rows of the codes array.
 __global__ __launch_bounds__(256) void hs_windows_kernel(const uint8_t* __restrict__ residues,
@@ -1174,10 +1292,13 @@ __global__ __launch_bounds__(256) void hs_bf_finalize_kernel(const uint8_t* __re
 // HS_ORDER_BLOCK_MAX hits) whose queries are ordered by a block each, with a bitonic sort in LDS
 // (hs_hit_order_block_kernel): short k-mers at a loose radius have hundreds of hits per query (k = 15 at
 // the C2 sizes: 545 on average), and the radix sort over the whole list those batches fell back to cost
-// as much as their join.  A query with more than HS_ORDER_BLOCK_MAX hits still raises *big (the caller
-// then falls back to that sort).
+// as much as their join.  A query with more than HS_ORDER_BLOCK_MAX hits goes on a third list: a block of
+// 1024 threads sorts it in chunks of that many words in LDS and merges the chunks through global memory
+// (hs_hit_order_huge_kernel).  Only a query with 2^27 hits or more -- the place no longer fits beside
+// (table, id) in a word -- raises *big (the caller then falls back to the sort over the whole list).
 #define HS_ORDER_MAX 48u
 #define HS_ORDER_BLOCK_MAX 8192u
+#define HS_ORDER_LIST_HEAD 8u   // words in front of the three lists: [0..2] entries, [3..5] work counters
 __global__ __launch_bounds__(256) void hs_hit_place_kernel(const uint64_t* __restrict__ key,
                                                            const uint64_t* __restrict__ val,
                                                            const uint32_t* __restrict__ hit_count,
@@ -1198,8 +1319,8 @@ __global__ __launch_bounds__(256) void hs_hit_place_kernel(const uint64_t* __res
   }
 }
 
-// qlist: [0] queries on the list of the 1024-hit blocks, [1] on the list of the larger blocks, [2], [3]
-// the two lists' work counters, then the lists themselves (nq entries each)
+// qlist: HS_ORDER_LIST_HEAD words, then the three lists (nq entries each): queries of up to 1024 hits, of
+// up to HS_ORDER_BLOCK_MAX, of more
 __global__ __launch_bounds__(256) void hs_hit_order_kernel(const uint32_t* __restrict__ qoff, uint32_t nq,
                                                            const uint32_t* __restrict__ hit_count,
                                                            uint32_t hit_cap, uint64_t* __restrict__ key2,
@@ -1215,13 +1336,13 @@ __global__ __launch_bounds__(256) void hs_hit_order_kernel(const uint32_t* __res
   if (*hit_count > hit_cap) return;  // the batch is repeated with larger buffers anyway
   const uint32_t lo = qoff[q], m = qoff[q + 1] - lo;
   if (!m) return;
-  if (m > HS_ORDER_BLOCK_MAX) {
+  if (m >= (1u << 27)) {
     atomicOr(big, 1u);
     return;
   }
   if (m > HS_ORDER_MAX) {
-    const uint32_t which = m > 1024u ? 1u : 0u;
-    qlist[4 + (size_t)which * nq + atomicAdd(&qlist[which], 1u)] = q;
+    const uint32_t which = m > HS_ORDER_BLOCK_MAX ? 2u : m > 1024u ? 1u : 0u;
+    qlist[HS_ORDER_LIST_HEAD + (size_t)which * nq + atomicAdd(&qlist[which], 1u)] = q;
     return;
   }
   // insertion sort of the query's hits by key (distinct: (table, id) is unique per query)
@@ -1249,9 +1370,10 @@ __global__ __launch_bounds__(256) void hs_hit_order_kernel(const uint32_t* __res
 
 // One block per listed query: its hits' (table, id) -- 37 bits -- with the hit's place in the query's
 // range below them -- 27 bits -- sorted as one 64-bit word in LDS, padded with all-ones words to a
-// power of two; the distance follows through the place.  CAP = 1024 or HS_ORDER_BLOCK_MAX words of LDS.
-template <uint32_t CAP>
-__global__ __launch_bounds__(256) void hs_hit_order_block_kernel(const uint32_t* __restrict__ qoff, uint32_t nq,
+// power of two; the distance follows through the place.  CAP = 1024 or HS_ORDER_BLOCK_MAX words of LDS,
+// NT = 256 or 1024 threads.
+template <uint32_t CAP, uint32_t NT>
+__global__ __launch_bounds__(NT) void hs_hit_order_block_kernel(const uint32_t* __restrict__ qoff, uint32_t nq,
                                                                  const uint32_t* __restrict__ hit_count,
                                                                  uint32_t hit_cap, uint32_t which,
                                                                  const uint64_t* __restrict__ key2,
@@ -1264,25 +1386,25 @@ __global__ __launch_bounds__(256) void hs_hit_order_block_kernel(const uint32_t*
   __shared__ uint64_t sk[CAP];
   if (*hit_count > hit_cap) return;
   const uint32_t n_list = qlist[which];
-  const uint32_t* const list = qlist + 4 + (size_t)which * nq;
+  const uint32_t* const list = qlist + HS_ORDER_LIST_HEAD + (size_t)which * nq;
   const uint32_t tid = threadIdx.x;
   for (;;) {
     __syncthreads();  // (the previous query's words have been written out)
-    if (tid == 0) sk[0] = atomicAdd(&qlist[2 + which], 1u);  // the block's next query, by way of word 0
+    if (tid == 0) sk[0] = atomicAdd(&qlist[3 + which], 1u);  // the block's next query, by way of word 0
     __syncthreads();
     const uint32_t at = (uint32_t)sk[0];
     __syncthreads();
     if (at >= n_list) return;
     const uint32_t q = list[at];
     const uint32_t lo = qoff[q], m = qoff[q + 1] - lo;
-    uint32_t P = 512u;  // (256 threads: every thread has a pair in every step)
+    uint32_t P = 2u * NT;  // (every thread has a pair in every step)
     while (P < m) P <<= 1;
-    for (uint32_t i = tid; i < P; i += 256u)
+    for (uint32_t i = tid; i < P; i += NT)
       sk[i] = i < m ? ((key2[lo + i] & ((1ull << 37) - 1ull)) << 27) | (uint64_t)i : ~0ull;
     __syncthreads();
     for (uint32_t size = 2u; size <= P; size <<= 1) {
       for (uint32_t stride = size >> 1; stride > 0u; stride >>= 1) {
-        for (uint32_t t = tid; t < (P >> 1); t += 256u) {
+        for (uint32_t t = tid; t < (P >> 1); t += NT) {
           const uint32_t i = 2u * t - (t & (stride - 1u));  // the pair's lower index
           const uint32_t j = i + stride;
           const bool up = (i & size) == 0u;
@@ -1296,10 +1418,135 @@ __global__ __launch_bounds__(256) void hs_hit_order_block_kernel(const uint32_t*
       }
     }
     const uint32_t q_abs = (uint32_t)(key2[lo] >> 37);
-    for (uint32_t i = tid; i < m; i += 256u) {
+    for (uint32_t i = tid; i < m; i += NT) {
       const uint64_t o = (uint64_t)lo + i;
       if (o >= out_room) break;
       const uint64_t e = sk[i];
+      const uint64_t ti = e >> 27;
+      out_q[o] = q_abs;
+      if (out_table) out_table[o] = (uint32_t)(ti >> 32) & 31u;
+      out_id[o] = (uint32_t)ti;
+      out_dist[o] = __longlong_as_double((long long)val2[lo + (uint32_t)(e & ((1u << 27) - 1u))]);
+    }
+  }
+}
+
+// Sorting network used below: every comparator ascending (the smaller word to the lower index).  A merge
+// of two sorted runs of size / 2 first compares i with its MIRROR image in the run pair, then halves the
+// stride down to 1.  With all comparators ascending, words past the end of the list behave as +infinity
+// without being stored: a comparator whose upper index is past the end does nothing.
+__device__ __forceinline__ void order_lds_steps(uint64_t* sk, uint32_t n_words, uint32_t size, bool mirror_first,
+                                                uint32_t first_stride, uint32_t tid, uint32_t n_threads) {
+  if (mirror_first) {
+    const uint32_t half = size >> 1;
+    for (uint32_t t = tid; t < (n_words >> 1); t += n_threads) {
+      const uint32_t blk = t / half, off = t - blk * half;
+      const uint32_t i = blk * size + off, j = blk * size + size - 1u - off;
+      const uint64_t a = sk[i], b = sk[j];
+      if (a > b) {
+        sk[i] = b;
+        sk[j] = a;
+      }
+    }
+    __syncthreads();
+  }
+  for (uint32_t stride = first_stride; stride > 0u; stride >>= 1) {
+    for (uint32_t t = tid; t < (n_words >> 1); t += n_threads) {
+      const uint32_t i = 2u * t - (t & (stride - 1u)), j = i + stride;
+      const uint64_t a = sk[i], b = sk[j];
+      if (a > b) {
+        sk[i] = b;
+        sk[j] = a;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// One block of 1024 threads per query of the third list.  scratch: as many words as the hit lists hold (the
+// unbucketed list's keys, free once hs_hit_place_kernel has run); the query's words live at its own
+// range [lo, lo + m) of it.  Chunks of HS_ORDER_BLOCK_MAX words are sorted in LDS; merges of larger runs do
+// their mirror step and their strides >= a chunk in global memory (volatile accesses: the block's own
+// stores must be what its later loads see), the rest chunk by chunk in LDS again.
+__global__ __launch_bounds__(1024) void hs_hit_order_huge_kernel(const uint32_t* __restrict__ qoff, uint32_t nq,
+                                                                 const uint32_t* __restrict__ hit_count,
+                                                                 uint32_t hit_cap, const uint32_t* __restrict__ big,
+                                                                 const uint64_t* __restrict__ key2,
+                                                                 const uint64_t* __restrict__ val2,
+                                                                 uint32_t* __restrict__ qlist,
+                                                                 uint64_t* scratch,
+                                                                 uint32_t* __restrict__ out_q,
+                                                                 uint32_t* __restrict__ out_id,
+                                                                 uint32_t* __restrict__ out_table,
+                                                                 double* __restrict__ out_dist, uint64_t out_room) {
+  constexpr uint32_t CH = HS_ORDER_BLOCK_MAX;
+  __shared__ uint64_t sk[CH];
+  if (*hit_count > hit_cap || *big) return;  // (*big: the whole list is about to be sorted from `scratch`)
+  const uint32_t n_list = qlist[2];
+  const uint32_t* const list = qlist + HS_ORDER_LIST_HEAD + 2u * (size_t)nq;
+  const uint32_t tid = threadIdx.x;
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) sk[0] = atomicAdd(&qlist[5], 1u);
+    __syncthreads();
+    const uint32_t at = (uint32_t)sk[0];
+    __syncthreads();
+    if (at >= n_list) return;
+    const uint32_t q = list[at];
+    const uint32_t lo = qoff[q], m = qoff[q + 1] - lo;
+    volatile uint64_t* const G = scratch + lo;
+    uint32_t P = CH;
+    while (P < m) P <<= 1;
+    // sorted chunks
+    for (uint32_t base = 0; base < m; base += CH) {
+      for (uint32_t i = tid; i < CH; i += 1024u)
+        sk[i] = base + i < m ? ((key2[lo + base + i] & ((1ull << 37) - 1ull)) << 27) | (uint64_t)(base + i) : ~0ull;
+      __syncthreads();
+      for (uint32_t size = 2u; size <= CH; size <<= 1) order_lds_steps(sk, CH, size, true, size >> 2, tid, 1024u);
+      for (uint32_t i = tid; i < CH && base + i < m; i += 1024u) G[base + i] = sk[i];
+      __syncthreads();
+    }
+    // merges of runs of a chunk and more
+    for (uint32_t size = 2u * CH; size <= P; size <<= 1) {
+      const uint32_t half = size >> 1;
+      for (uint32_t t = tid; t < (P >> 1); t += 1024u) {
+        const uint32_t blk = t / half, off = t - blk * half;
+        const uint32_t i = blk * size + off, j = blk * size + size - 1u - off;
+        if (j < m) {
+          const uint64_t a = G[i], b = G[j];
+          if (a > b) {
+            G[i] = b;
+            G[j] = a;
+          }
+        }
+      }
+      __syncthreads();
+      for (uint32_t stride = size >> 2; stride >= CH; stride >>= 1) {
+        for (uint32_t t = tid; t < (P >> 1); t += 1024u) {
+          const uint32_t i = 2u * t - (t & (stride - 1u)), j = i + stride;
+          if (j < m) {
+            const uint64_t a = G[i], b = G[j];
+            if (a > b) {
+              G[i] = b;
+              G[j] = a;
+            }
+          }
+        }
+        __syncthreads();
+      }
+      for (uint32_t base = 0; base < m; base += CH) {
+        for (uint32_t i = tid; i < CH; i += 1024u) sk[i] = base + i < m ? G[base + i] : ~0ull;
+        __syncthreads();
+        order_lds_steps(sk, CH, CH, false, CH >> 1, tid, 1024u);
+        for (uint32_t i = tid; i < CH && base + i < m; i += 1024u) G[base + i] = sk[i];
+        __syncthreads();
+      }
+    }
+    const uint32_t q_abs = (uint32_t)(key2[lo] >> 37);
+    for (uint32_t i = tid; i < m; i += 1024u) {
+      const uint64_t o = (uint64_t)lo + i;
+      if (o >= out_room) break;
+      const uint64_t e = G[i];
       const uint64_t ti = e >> 27;
       out_q[o] = q_abs;
       if (out_table) out_table[o] = (uint32_t)(ti >> 32) & 31u;
@@ -1472,6 +1719,49 @@ hipError_t hs_launch_probe(const hs_tables_dev& tabs, const int32_t* d_qints, ui
   return hipGetLastError();
 }
 
+// Are the centres k-mers?  The reference's usual centres are (KmerToCoordinates, hclust2.cpp:49-62): every
+// group of 8 doubles is then a row of the coordinate table, bit for bit.  One thread per (query, position):
+// the first residue whose row equals the group, or a count of groups that equal none.  A batch of
+// recognised queries runs from the codes (hs_query_codes's path): identical results -- the same doubles
+// enter the same operations -- with k bytes per query in place of 64 k wherever a row is fetched.
+__global__ __launch_bounds__(256) void hs_recognise_kmers_kernel(const double* __restrict__ centers, uint64_t total,
+                                                                 const double* __restrict__ coords, int alphabet,
+                                                                 uint8_t* __restrict__ out_codes,
+                                                                 uint32_t* __restrict__ n_unrecognised) {
+  __shared__ unsigned long long s_rows[HS_ALPHABET_PAD * 8];
+  for (int t = threadIdx.x; t < HS_ALPHABET_PAD * 8; t += 256)
+    s_rows[t] = t < alphabet * 8 ? (unsigned long long)__double_as_longlong(coords[t]) : 0ull;
+  __syncthreads();
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  unsigned long long g[8];
+  const double2* src = reinterpret_cast<const double2*>(centers + t * 8);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const double2 v = src[j];
+    g[2 * j] = (unsigned long long)__double_as_longlong(v.x);
+    g[2 * j + 1] = (unsigned long long)__double_as_longlong(v.y);
+  }
+  int code = -1;
+  for (int c = alphabet - 1; c >= 0; --c) {
+    unsigned long long diff = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) diff |= g[j] ^ s_rows[c * 8 + j];
+    if (!diff) code = c;
+  }
+  out_codes[t] = (uint8_t)(code < 0 ? 0 : code);
+  if (code < 0) atomicAdd(n_unrecognised, 1u);
+}
+
+hipError_t hs_launch_recognise_kmers(const double* d_centers, uint64_t nq, int k, const double* d_coords, int alphabet,
+                                     uint8_t* d_out_codes, uint32_t* d_n_unrecognised, hipStream_t s) {
+  const uint64_t total = nq * (uint64_t)k;
+  if (!total) return hipSuccess;
+  hs_recognise_kmers_kernel<<<blocks_for(total), 256, 0, s>>>(d_centers, total, d_coords, alphabet, d_out_codes,
+                                                             d_n_unrecognised);
+  return hipGetLastError();
+}
+
 hipError_t hs_launch_check_codes(const uint8_t* d_in, uint64_t n_bytes, int alphabet, uint8_t* d_out,
                                  uint32_t* d_bad, hipStream_t s) {
   if (!n_bytes) return hipSuccess;
@@ -1548,8 +1838,12 @@ hipError_t hs_launch_finalize(const hs_tables_dev& tabs, const uint8_t* d_codes,
                               const uint32_t* d_sorted_ql, int k, int L, double r2, double r_sqrt,
                               uint32_t q_base, uint32_t self_first, uint32_t* d_hit_count,
                               uint32_t hit_cap, uint64_t* d_hit_key, uint64_t* d_hit_val, uint32_t* d_qcnt,
-                              hipStream_t s) {
-  if (d_qcodes)  // the queries are indexed k-mers: centre rows from the coordinate table
+                              int alphabet, hipStream_t s) {
+  if (d_qcodes && alphabet <= HS_FIN_TABLE_ALPHABET && k <= 75)  // the queries are k-mers: terms from a table
+    hs_finalize_codes_kernel<<<1024, 256, (size_t)alphabet * alphabet * 64, s>>>(
+        tabs, d_qcodes, d_coords, alphabet, d_qstart, d_qcount, d_prov, d_prov_count, prov_cap, d_sorted_ql, k, L, r2,
+        r_sqrt, q_base, self_first, d_hit_count, hit_cap, d_hit_key, d_hit_val, d_qcnt);
+  else if (d_qcodes)  // ... with a large alphabet: centre rows from the coordinate table
     hs_finalize_kernel<true><<<1024, 256, 0, s>>>(tabs, d_codes, nullptr, d_qcodes, d_coords, d_qstart, d_qcount,
                                                   d_prov, d_prov_count, prov_cap, d_sorted_ql, k, L, r2,
                                                   r_sqrt, q_base, self_first, d_hit_count, hit_cap,
@@ -1564,7 +1858,7 @@ hipError_t hs_launch_finalize(const hs_tables_dev& tabs, const uint8_t* d_codes,
 hipError_t hs_launch_hit_order(const uint64_t* d_key, const uint64_t* d_val, const uint32_t* d_hit_count,
                                uint32_t hit_cap, uint32_t q_base, uint32_t nq, const uint32_t* d_qoff,
                                uint32_t* d_qfill, uint64_t* d_key2, uint64_t* d_val2, uint32_t* d_big,
-                               uint32_t* d_qlist /* 4 + 2 nq words, the first four zero */,
+                               uint32_t* d_qlist /* 8 + 3 nq words, the first eight zero */,
                                uint32_t* d_q, uint32_t* d_id, uint32_t* d_table, double* d_dist,
                                uint64_t out_room, int n_cu, hipStream_t s) {
   if (!nq) return hipSuccess;
@@ -1574,11 +1868,15 @@ hipError_t hs_launch_hit_order(const uint64_t* d_key, const uint64_t* d_val, con
                                                     d_qlist, d_q, d_id, d_table, d_dist, out_room);
   // (blocks that find their list empty leave at once: a batch of few hits pays two empty launches)
   const unsigned cu = (unsigned)std::max(n_cu, 1);
-  hs_hit_order_block_kernel<1024u><<<std::min(nq, cu * 8u), 256, 0, s>>>(d_qoff, nq, d_hit_count, hit_cap, 0u, d_key2,
-                                                                       d_val2, d_qlist, d_q, d_id, d_table, d_dist,
-                                                                       out_room);
-  hs_hit_order_block_kernel<HS_ORDER_BLOCK_MAX><<<std::min(nq, cu * 2u), 256, 0, s>>>(
+  hs_hit_order_block_kernel<1024u, 256u><<<std::min(nq, cu * 8u), 256, 0, s>>>(d_qoff, nq, d_hit_count, hit_cap, 0u,
+                                                                             d_key2, d_val2, d_qlist, d_q, d_id,
+                                                                             d_table, d_dist, out_room);
+  hs_hit_order_block_kernel<HS_ORDER_BLOCK_MAX, 1024u><<<std::min(nq, cu * 2u), 1024, 0, s>>>(
       d_qoff, nq, d_hit_count, hit_cap, 1u, d_key2, d_val2, d_qlist, d_q, d_id, d_table, d_dist, out_room);
+  // (the unbucketed keys are its scratch: nothing reads them again unless *d_big, and then it does not run)
+  hs_hit_order_huge_kernel<<<std::min(nq, cu), 1024, 0, s>>>(d_qoff, nq, d_hit_count, hit_cap, d_big, d_key2, d_val2,
+                                                            d_qlist, const_cast<uint64_t*>(d_key), d_q, d_id, d_table,
+                                                            d_dist, out_room);
   return hipGetLastError();
 }
 

@@ -92,6 +92,8 @@ typedef struct hs_profile {
                                    query-resident kernel (hs_join8r_kernel) */
   uint64_t join_async_retries; /* batches whose join was launched on a capacity hint that turned out too small
                                   (or illegal) and ran a second time: exclude such a call from kernel timings */
+  uint64_t queries_recognised; /* hs_query / hs_query_dev: the call's centres were all k-mers (every 8 doubles a
+                                  row of the coordinate table) and ran from their residue codes: this many */
 } hs_profile;
 
 typedef struct hs_index_info {

@@ -727,14 +727,15 @@ def test_probe_grouping_by_counting_sort_and_by_probe_sort(oracle, monkeypatch, 
             assert np.array_equal(e[key], ref[key])
 
 
-@pytest.mark.parametrize("families", [(700,), (700, 1500), (300, 9000)])
+@pytest.mark.parametrize("families", [(700,), (700, 1500), (300, 9000), (17000,)])
 def test_hit_ordering_paths_with_many_hits_per_query(oracle, monkeypatch, families):
     """Output order = (query, table of first sight, id) (motif_both_points.cpp:224-245).  The hits are
     bucketed by query; a query with up to 48 is ordered by one thread, one with up to 1024 / 8192 by a
-    block (bitonic sort in LDS, hs_hit_order_block_kernel); a batch in which some query has more -- and
-    any batch under HS_SORT_HITS=1 -- is radix-sorted on the full key.  A DB with families of
-    near-identical k-mers (queries inside a family of m get ~m hits, most others a few: 700 -> the small
-    blocks, 1500 -> the large ones, 9000 -> the fallback) through all of them against the oracle."""
+    block (bitonic sort in LDS, hs_hit_order_block_kernel), one with more by a block that sorts chunks in
+    LDS and merges them through global memory (hs_hit_order_huge_kernel); any batch under HS_SORT_HITS=1
+    is radix-sorted on the full key.  A DB with families of near-identical k-mers (queries inside a family
+    of m get ~m hits, most others a few: 700 -> the small blocks, 1500 -> the large ones, 9000 -> two
+    chunks and one merge, 17000 -> three chunks, two merge levels) through all of them against the oracle."""
     k, K, L, W, R, n, nq = 25, 4, 5, 150.0, 40.0, 20011, 903
     a, b = synth.make_planes(k, K, L, W, seed=75)
     codes = synth.make_db(n, k, seed=76)
@@ -753,7 +754,7 @@ def test_hit_ordering_paths_with_many_hits_per_query(oracle, monkeypatch, famili
         at += m
     want = oracle.search(a, b, W, R, oracle.embed_codes(codes), centers)
     per_q = np.bincount(want["q"], minlength=nq)
-    assert per_q.max() > 0.7 * max(families) and np.median(per_q) < 20
+    assert per_q.max() > 0.7 * max(families) and (np.median(per_q) < 20 or sum(families) > n // 4)
     want_few = oracle.search(a, b, W, R, oracle.embed_codes(codes), centers[nfq:])
     for sort_all in (False, True):
         monkeypatch.delenv("HS_SORT_HITS", raising=False)
@@ -768,6 +769,54 @@ def test_hit_ordering_paths_with_many_hits_per_query(oracle, monkeypatch, famili
         few = eng.query(centers[nfq:], R)
         _assert_hits_equal(few, want_few)
         eng.close()
+
+
+@pytest.mark.parametrize("k,K,L,W,R", [(25, 6, 5, 140.0, 42.0), (15, 5, 4, 90.0, 32.0), (39, 6, 3, 260.0, 50.0),
+                                      (60, 4, 3, 400.0, 70.0)])
+def test_centres_that_are_kmers_run_from_their_codes(oracle, monkeypatch, k, K, L, W, R):
+    """hs_query looks at its centres first: when every group of 8 doubles is a row of the coordinate
+    table bit for bit -- the reference's centres are k-mers (KmerToCoordinates, hclust2.cpp:49-62) -- the
+    call runs from the residue codes like hs_query_codes.  Same hits, order, distances and candidate
+    counts as the oracle's and as the same call with the recognition off; one centre moved by one ulp in
+    one coordinate and the whole call stays on the points path; -0.0 for a 0.0 likewise."""
+    n, nq = 15013, 703
+    a, b = synth.make_planes(k, K, L, W, seed=95)
+    codes = synth.make_db(n, k, seed=96)
+    qcodes, _ = synth.make_query_codes(codes, nq, seed=97)
+    centers = synth.embed(qcodes)
+    want = oracle.search(a, b, W, R, oracle.embed_codes(codes), centers)
+    assert len(want["q"]) > 50
+    eng = Engine(k, K, L, W, a, b)
+    eng.index_build(codes)
+    for mode in ("auto", "stream"):
+        eng.set_verify_mode(mode)
+        got = eng.query(centers, R)
+        assert eng.profile()["queries_recognised"] == nq
+        assert np.array_equal(got["cand"], want["cand"])
+        _assert_hits_equal(got, want)
+    eng.set_verify_mode("auto")
+    moved = centers.copy()
+    moved[nq // 2, 8 * (k // 2) + 3] = np.nextafter(moved[nq // 2, 8 * (k // 2) + 3], np.inf)
+    want_moved = oracle.search(a, b, W, R, oracle.embed_codes(codes), moved)
+    got = eng.query(moved, R)
+    assert eng.profile()["queries_recognised"] == 0
+    _assert_hits_equal(got, want_moved)
+    zeros = np.argwhere(centers == 0.0)
+    if len(zeros):
+        neg = centers.copy()
+        neg[zeros[0][0], zeros[0][1]] = -0.0
+        got = eng.query(neg, R)
+        assert eng.profile()["queries_recognised"] == 0
+        _assert_hits_equal(got, want)          # (-0.0 and 0.0 give the same distances and dot products)
+    eng.close()
+    monkeypatch.setenv("HS_NO_RECOGNISE", "1")
+    eng = Engine(k, K, L, W, a, b)
+    eng.index_build(codes)
+    got = eng.query(centers, R)
+    assert eng.profile()["queries_recognised"] == 0
+    assert np.array_equal(got["cand"], want["cand"])
+    _assert_hits_equal(got, want)
+    eng.close()
 
 
 @pytest.mark.parametrize("k,K,L,W,R", [(25, 6, 5, 140.0, 42.0), (15, 5, 4, 90.0, 32.0), (39, 6, 3, 260.0, 50.0),
