@@ -132,6 +132,8 @@ struct hs_handle {
   // the records once more in four bytes per entry ([L][n]; k <= 25 with 4-column rows: what the
   // query-resident join kernel reads instead of t_rec8 -- it is bound by the bytes it moves per member)
   DevBuf t_rho;
+  DevBuf hit_rank;   // query_batch: a hit's number among its query's hits (ordering without a sort)
+  DevBuf qpacked;    // query_batch: queries given as k-mers, packed like the members (exact pass)
   DevBuf rec_codes;  // run_query: the residue codes of centres that turned out to be k-mers (+ the counter)
   // member records of the wide rows for k = 21..25 (built when a call's radius first asks for them)
   DevBuf t_rec8w;
@@ -672,7 +674,7 @@ void hs_destroy(hs_handle* h) {
                     &h->proj_xmeta, &h->slice_ql, &h->qhits, &h->bs_ints2[0], &h->bs_ints2[1], &h->bs_keys2[0],
                     &h->bs_keys2[1], &h->bs_iota2[0], &h->bs_iota2[1], &h->bs_keys_sorted, &h->bs_rle_unique,
                     &h->bs_rle_counts, &h->bs_small, &h->bs_sort_temp, &h->bs_slow_q, &h->all_codes,
-                    &h->subset_ids, &h->qcodes_buf, &h->qembed, &h->seg_res, &h->jconst, &h->t_rho, &h->rec_codes, &h->bs_fptab, &h->bs_blk,
+                    &h->subset_ids, &h->qcodes_buf, &h->qembed, &h->seg_res, &h->jconst, &h->t_rho, &h->rec_codes, &h->qpacked, &h->hit_rank, &h->bs_fptab, &h->bs_blk,
                     &h->bs_dk, &h->bs_hist, &h->bs_rank};
   for (DevBuf* bf : bufs) bf->release();
   h->sj_host.release();
@@ -2000,8 +2002,8 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
   }
   if (!brute) {
     HS_HIP(h, h->qints.reserve((size_t)nq * h->LK * 4));
-    HS_HIP(h, h->qstart.reserve((size_t)nql * 4));
-    HS_HIP(h, h->qcount.reserve((size_t)nql * 4));
+    HS_HIP(h, h->qstart.reserve(((size_t)nql + HS_QRANGE_PAD) * 4));
+    HS_HIP(h, h->qcount.reserve(((size_t)nql + HS_QRANGE_PAD) * 4));
     HS_HIP(h, h->nslices.reserve(((size_t)nql + 1) * 4));
     HS_HIP(h, h->probe_slow.reserve(((size_t)nql + 1) * 4));
     HS_HIP(h, h->slice_off.reserve(((size_t)nql + 1) * 4));
@@ -2222,6 +2224,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
       if (launches) HS_HIP(h, hipMemsetAsync(d_cnt + 20, 0, 4, h->stream));  // retry: the "too many hits" flag
       HS_HIP(h, h->hit_key2.reserve((size_t)hit_cap * 8));
       HS_HIP(h, h->hit_val2.reserve((size_t)hit_cap * 8));
+      HS_HIP(h, h->hit_rank.reserve((size_t)hit_cap * 4));
       HS_HIP(h, h->temp.reserve(hs_scan_u32_temp(n1q) + 256));
     }
     HS_HIP(h, hipEventRecord(h->ev[3], h->stream));
@@ -2299,17 +2302,25 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
         fin_list = h->prov2.as<uint2>();
         fin_count = d_cnt + 4;
       }
+      const uint4* d_qpacked = nullptr;
+      if (d_qcodes && k <= 75) {  // the queries are k-mers: packed like the members, for the exact pass
+        HS_HIP(h, h->qpacked.reserve(std::max<size_t>(16, (size_t)nq * h->PW * 16)));
+        HS_HIP(h, hs_launch_pack(d_qcodes, nq, k, h->alphabet, h->qpacked.as<uint4>(),
+                                 d_cnt + HS_CNT_BAD_QUERY_CODE, h->stream));
+        d_qpacked = h->qpacked.as<uint4>();
+      }
       HS_HIP(h, hs_launch_finalize(h->tabs, h->codes.as<uint8_t>(), d_centers, d_qcodes, h->coords.as<double>(),
                                    h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
                                    fin_list, fin_count, prov_cap, h->sorted_ql.as<uint32_t>(),
                                    k, L, r2, h->sqrt_test ? R : (double)NAN, q_base, h->self_first, d_cnt + 1,
                                    hit_cap, h->hit_key.as<uint64_t>(), h->hit_val.as<uint64_t>(), qcnt,
-                                   h->alphabet, h->stream));
+                                   h->alphabet, d_qpacked, order_here ? h->hit_rank.as<uint32_t>() : nullptr,
+                                   h->stream));
       if (order_here) {
         const size_t n1q_ = (size_t)nq + 1;
         HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, qcnt, qoff, (size_t)nq + 1, h->stream));
         HS_HIP(h, hs_launch_hit_order(h->hit_key.as<uint64_t>(), h->hit_val.as<uint64_t>(), d_cnt + 1, hit_cap,
-                                      q_base, nq, qoff, qfill, h->hit_key2.as<uint64_t>(),
+                                      q_base, nq, qoff, h->hit_rank.as<uint32_t>(), h->hit_key2.as<uint64_t>(),
                                       h->hit_val2.as<uint64_t>(), d_cnt + 20, qfill + n1q_, bout->q, bout->id,
                                       bout->table, bout->dist, bout->room, h->n_cu, h->stream));
       }

@@ -350,13 +350,18 @@ hipError_t hs_launch_finalize(const hs_tables_dev& tabs, const uint8_t* d_codes,
                               const uint32_t* d_sorted_ql, int k, int L, double r2, double r_sqrt,
                               uint32_t q_base, uint32_t self_first, uint32_t* d_hit_count,
                               uint32_t hit_cap, uint64_t* d_hit_key, uint64_t* d_hit_val,
-                              uint32_t* d_qcnt /* [nq] hits per query, or null */, int alphabet, hipStream_t s);
+                              uint32_t* d_qcnt /* [nq] hits per query, or null */, int alphabet,
+                              const uint4* d_qpacked /* the queries as packed k-mers (with d_qcodes), or null */,
+                              uint32_t* d_hit_rank /* with d_qcnt: the hit's number among its query's hits */,
+                              hipStream_t s);
+// hs_finalize's first-seen test reads four words at a time from d_qstart / d_qcount: this many words of padding
+#define HS_QRANGE_PAD 4
 // the batch's hits in the reference's order without a sort: bucket by query (d_qoff = exclusive
 // scan of the per-query counts), order every query's few hits, unpack to the outputs (at most
 // out_room of them); *d_big is set when a query has too many hits for that (caller: radix sort)
 hipError_t hs_launch_hit_order(const uint64_t* d_key, const uint64_t* d_val, const uint32_t* d_hit_count,
                                uint32_t hit_cap, uint32_t q_base, uint32_t nq, const uint32_t* d_qoff,
-                               uint32_t* d_qfill, uint64_t* d_key2, uint64_t* d_val2, uint32_t* d_big,
+                               const uint32_t* d_rank, uint64_t* d_key2, uint64_t* d_val2, uint32_t* d_big,
                                uint32_t* d_qlist /* 8 + 3 nq words, the first eight zero */,
                                uint32_t* d_q, uint32_t* d_id, uint32_t* d_table, double* d_dist,
                                uint64_t out_room, int n_cu, hipStream_t s);

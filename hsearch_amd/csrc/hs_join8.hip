@@ -59,9 +59,10 @@ typedef int intx16 __attribute__((ext_vector_type(16)));
 constexpr int QD = 4;        // table columns used
 constexpr int HS_J8_CONST_AT = 48;  // uint4 index in the int8 table block of the gamma slots' constant factors
 // k-steps of 32 bytes in a row: 4 (k <= 25), 6 (k <= 41), 8 (k <= 50); row = 32 KS bytes = 2 KS pieces
-// wide rows (all 8 coordinates): 6 (k <= 20) or 8 (k <= 25)
+// wide rows (all 8 coordinates): 5 (k <= 16: 128 coordinate bytes + 4 spare + 28 digit slots), 6 (k <= 20)
+// or 8 (k <= 25)
 __host__ __device__ constexpr int ks_of(int k, bool wide = false) {
-  return wide ? (k <= 20 ? 6 : 8) : k <= 25 ? 4 : k <= 41 ? 6 : 8;
+  return wide ? (k <= 16 ? 5 : k <= 20 ? 6 : 8) : k <= 25 ? 4 : k <= 41 ? 6 : 8;
 }
 // survivor slots a wave reserves per counter access: same-address atomics complete at ~ 90 per
 // microsecond, and a hit-heavy launch (k = 15 at the C2 sizes: 1.4e8 survivors in 25 ms) asked for
@@ -490,7 +491,8 @@ __device__ __forceinline__ void build_afrags8_wide(const uint4 pk, const uint4 r
     const uint2 p1_ = sTabW[residue_at<(20 * (S) + 5 < 124 ? 20 * (S) + 5 : 123)>(x, y, z, w)]; \
     A[S] = intx4{(int)p0_.x, (int)p0_.y, (int)p1_.x, (int)p1_.y};         \
   }
-  HS_AW(0) HS_AW(1) HS_AW(2) HS_AW(3) HS_AW(4)
+  HS_AW(0) HS_AW(1) HS_AW(2) HS_AW(3)
+  if constexpr (KS >= 6) { HS_AW(4) }
   if constexpr (KS == 8) { HS_AW(5) HS_AW(6) }
 #undef HS_AW
   constexpr uint32_t C127 = 0x7f7f7f7fu;
@@ -726,8 +728,8 @@ __global__ __launch_bounds__(256, 2) void hs_join8w_kernel(
   // trip between cutting the items and joining them)
   if (n_items_dev) n_items = min(n_items, __builtin_amdgcn_readfirstlane(*n_items_dev));
   static_assert(JT == 4 || JT == 2, "two accumulator groups of JT / 2 row tiles");
-  static_assert(KS == 4 || KS == 6 || KS == 8, "k-steps of a row");
-  static_assert(!WIDE || KS == 6 || KS == 8, "wide rows have 6 or 8 k-steps");
+  static_assert(KS == 4 || (WIDE && KS == 5) || KS == 6 || KS == 8, "k-steps of a row");
+  static_assert(!WIDE || KS == 5 || KS == 6 || KS == 8, "wide rows have 5, 6 or 8 k-steps");
   constexpr int GT = JT / 2;
   constexpr int PW = (KS == 4 || WIDE) ? 1 : 2;  // packed words per member
   __shared__ uint32_t sTab8[32];
@@ -1984,7 +1986,11 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
   const int KS = ks_of(k, wide != 0);
   // k <= 25: the 16x16x64 form by default (HS_JOIN_SHAPE=32 selects the 32x32x32 form)
   static const bool shape32 = getenv("HS_JOIN_SHAPE") && atoi(getenv("HS_JOIN_SHAPE")) == 32;
-  if (wide && KS == 6)  // d_tab8 = the 8-column table here
+  if (wide && KS == 5)  // d_tab8 = the 8-column table here
+    hs_join8w_kernel<2, 5, true><<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_rec_base,
+                                                          (const uint4*)d_c8t, (const uint4*)d_tab8, d_prov_count,
+                                                          prov_cap, d_prov, d_item_counter, G, d_n_items);
+  else if (wide && KS == 6)
     hs_join8w_kernel<2, 6, true><<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_rec_base,
                                                           (const uint4*)d_c8t, (const uint4*)d_tab8, d_prov_count,
                                                           prov_cap, d_prov, d_item_counter, G, d_n_items);
@@ -2055,7 +2061,11 @@ hipError_t hs_launch_thin8(const hs_tables_dev& tabs, const uint4* d_rec_base, u
                            uint2* d_prov, int n_blocks, hipStream_t s) {
   if (!nql) return hipSuccess;
   if (wide) {  // d_tab8 = the 8-column table
-    if (ks_of(k, true) == 6)
+    if (ks_of(k, true) == 5)
+      hs_thin8_kernel<5, true><<<n_blocks, 256, 0, s>>>(tabs.t[0].packed, d_rec_base, n_entries, (const int8_t*)d_c8,
+                                                        (const uint4*)d_tab8, d_qstart, d_qcount, d_slice_off,
+                                                        d_slice_ql, nql, L, k, d_prov_count, prov_cap, d_prov);
+    else if (ks_of(k, true) == 6)
       hs_thin8_kernel<6, true><<<n_blocks, 256, 0, s>>>(tabs.t[0].packed, d_rec_base, n_entries, (const int8_t*)d_c8,
                                                         (const uint4*)d_tab8, d_qstart, d_qcount, d_slice_off,
                                                         d_slice_ql, nql, L, k, d_prov_count, prov_cap, d_prov);

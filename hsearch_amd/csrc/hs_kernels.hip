@@ -778,6 +778,33 @@ __device__ __forceinline__ double exact_dist2(const uint8_t* __restrict__ row,
   return d2;
 }
 
+// First-seen rule (label[], motif_both_points.cpp:233): a hit's id was already reported if an EARLIER
+// table's probed bucket holds it, i.e. if its sorted position in that table falls inside the bucket's
+// range.  These kernels are bound by the ADDRESSES their scattered loads present (a wave instruction with
+// 64 different cache lines occupies the address unit for 64 cycles), so: four tables per step; their four
+// (start, count) words as two 16-byte loads (qstart / qcount carry four words of padding for the last
+// query); one position load per table, each under the lanes that need that table only.
+__device__ __forceinline__ bool seen_in_earlier_table(const hs_tables_dev& tabs, const uint32_t* __restrict__ qstart,
+                                                      const uint32_t* __restrict__ qcount, uint32_t q, int l, int L,
+                                                      uint32_t id, bool hit) {
+  bool dup = false;
+  struct __attribute__((packed, aligned(4))) U4 { uint32_t v[4]; };
+  for (int l0 = 0; l0 < L; l0 += 4) {
+    if (!__ballot(hit && l > l0)) break;  // (wave-uniform)
+    if (hit && l > l0) {
+      const U4 c4 = *reinterpret_cast<const U4*>(qcount + (size_t)q * L + l0);
+      const U4 s4 = *reinterpret_cast<const U4*>(qstart + (size_t)q * L + l0);
+      uint32_t p4[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (l0 + u < l) p4[u] = tabs.t[l0 + u].pos_of[id];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dup = dup || (l0 + u < l && p4[u] - s4.v[u] < c4.v[u]);
+    }
+  }
+  return dup;
+}
+
 // One thread per survivor of the fp32 filter: (1) first-seen dedupe -- the reference reports a DB
 // id in the first table whose bucket holds it (label[] test, motif_both_points.cpp:233); ids are
 // ascending inside a bucket, so membership in an earlier table's bucket is a binary search;
@@ -805,7 +832,8 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
                                                           uint32_t hit_cap,
                                                           uint64_t* __restrict__ hit_key,
                                                           uint64_t* __restrict__ hit_val,
-                                                          uint32_t* __restrict__ qcnt) {
+                                                          uint32_t* __restrict__ qcnt,
+                                                          uint32_t* __restrict__ hit_rank) {
   // One wave = 64 survivors, one per lane.  The exact d2 is a serial fp64 chain per survivor, but
   // its inputs -- 8k doubles of the query's centre row -- are fetched by the WAVE: per position,
   // the 64 rows' 64-byte pieces go through LDS (4 lanes x 16 B per row: every byte fetched is
@@ -817,6 +845,7 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
   __shared__ uint8_t s_code[4][64 * 76];  // the survivors' residue codes, row stride 76 (k <= 75)
   constexpr uint32_t HBUF = 128;          // hits a wave collects before it asks for global slots
   __shared__ uint64_t s_hk[4][HBUF], s_hv[4][HBUF];
+  __shared__ uint32_t s_hr[4][HBUF];  // the hit's arrival number among its query's hits (with qcnt)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int t = tid; t < HS_ALPHABET_PAD * 8; t += 256) s_coords[t] = coords[t];
   __syncthreads();
@@ -835,6 +864,7 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
       if (gbase + i < hit_cap) {
         hit_key[gbase + i] = s_hk[wave][i];
         hit_val[gbase + i] = s_hv[wave][i];
+        if (hit_rank) hit_rank[gbase + i] = s_hr[wave][i];
       }
     __builtin_amdgcn_wave_barrier();
     n_buf = 0;
@@ -968,15 +998,7 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
     // first-seen dedupe (label[], :233): the id was already reported if an EARLIER table's probed
     // bucket holds it, i.e. if its sorted position in that table falls inside the bucket's range
     // (one independent 4-byte load per earlier table)
-    if (hit) {
-      bool dup = false;
-      for (int l2 = 0; l2 < l; ++l2) {
-        const uint32_t c2 = qcount[q * L + l2];
-        const uint32_t p2 = tabs.t[l2].pos_of[id];
-        dup = dup || (p2 - qstart[q * L + l2] < c2);
-      }
-      hit = !dup;
-    }
+    if (__ballot(hit && l > 0)) hit = hit && !seen_in_earlier_table(tabs, qstart, qcount, q, l, L, id, hit);
     // Hits go through a per-wave LDS buffer of HBUF entries and take their global slots when it
     // fills: same-address atomics complete at ~ 90 per microsecond on this part, and with hundreds of
     // hits per query (k = 15 at the C2 sizes: 3.3e6 wave iterations with hits) one counter access
@@ -986,12 +1008,15 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
       const uint32_t cnt = (uint32_t)__popcll(hm);
       if (n_buf + cnt > HBUF) flush_hits();
       const uint32_t idx = n_buf + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+      // hits per query, and this hit's number among them: the ordering pass buckets by query without
+      // another counter (hs_hit_place_kernel)
+      const uint32_t rk = (hit && qcnt) ? atomicAdd(&qcnt[q], 1u) : 0u;
       if (hit) {
         s_hk[wave][idx] = ((uint64_t)(q_base + q) << 37) | ((uint64_t)l << 32) | id;
         s_hv[wave][idx] = (uint64_t)__double_as_longlong(__dsqrt_rn(d2));
+        s_hr[wave][idx] = rk;
       }
       n_buf += cnt;
-      if (hit && qcnt) atomicAdd(&qcnt[q], 1u);  // hits per query: the ordering pass buckets by query
     }
   }
   flush_hits();
@@ -1002,12 +1027,12 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
 // member residue r meeting a query residue s, rounded once at the difference and once at the square as
 // the reference does -- and the kernel looks them up (a 64-byte row of a table in LDS per position) and
 // ADDS them in the reference's order: a third of the double-precision operations and half the LDS reads
-// of fetching both residues' rows, no staging of 64-byte point pieces, no byte copy of the member's
-// residues (they are taken from the packed word by constant shifts).  Hit-heavy batches spend their time
+// of fetching both residues' rows, no staging of 64-byte point pieces, no byte copies of residues (member
+// and query are both 5-bit packed words -- the queries' by hs_pack_kernel -- read by constant shifts).  Hit-heavy batches spend their time
 // here (k = 15 at the C2 sizes: 1.4e8 survivors per batch, 9.4 ms with the two-row form).
 #define HS_FIN_TABLE_ALPHABET 24
 __global__ __launch_bounds__(256) void hs_finalize_codes_kernel(hs_tables_dev tabs,
-                                                                const uint8_t* __restrict__ qcodes,
+                                                                const uint4* __restrict__ qpacked,
                                                                 const double* __restrict__ coords, int alphabet,
                                                                 const uint32_t* __restrict__ qstart,
                                                                 const uint32_t* __restrict__ qcount,
@@ -1020,22 +1045,27 @@ __global__ __launch_bounds__(256) void hs_finalize_codes_kernel(hs_tables_dev ta
                                                                 uint32_t* __restrict__ hit_count, uint32_t hit_cap,
                                                                 uint64_t* __restrict__ hit_key,
                                                                 uint64_t* __restrict__ hit_val,
-                                                                uint32_t* __restrict__ qcnt) {
-  extern __shared__ __attribute__((aligned(16))) double s_sq[];  // [alphabet][alphabet][8]
-  __shared__ uint8_t s_qc[4][64 * 76];  // the survivors' query residues, row stride 76 (k <= 75)
+                                                                uint32_t* __restrict__ qcnt,
+                                                                uint32_t* __restrict__ hit_rank) {
+  // [alphabet][alphabet] rows of 8 doubles at a stride of 10: with 64-byte rows the 16 lanes of one pass of a
+  // 16-byte read meet in 4 bank groups (4-way conflicts on average), with 80-byte rows in 16
+  extern __shared__ __attribute__((aligned(16))) double s_sq[];
   constexpr uint32_t HBUF = 128;
   __shared__ uint64_t s_hk[4][HBUF], s_hv[4][HBUF];
+  __shared__ uint32_t s_hr[4][HBUF];  // the hit's arrival number among its query's hits (with qcnt)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int e = tid; e < alphabet * alphabet * 8; e += 256) {
     const int j = e & 7, rs = e >> 3, r = rs / alphabet, sq = rs - r * alphabet;
     const double d = __dsub_rn(coords[r * 8 + j], coords[sq * 8 + j]);
-    s_sq[e] = __dmul_rn(d, d);
+    s_sq[rs * 10 + j] = __dmul_rn(d, d);
   }
   __syncthreads();
   const uint32_t n = min(*prov_count, prov_cap);
   const uint32_t wave_stride = gridDim.x * 4u * 64u;
   const int PW = (k + 24) / 25;
   uint32_t n_buf = 0;
+  uint32_t pend_rk = 0;  // per lane: the answer of the lane's last counter access, not yet in the buffer ...
+  int pend_idx = -1;     // ... and the buffer entry it belongs to
   auto flush_hits = [&]() {
     if (!n_buf) return;
     uint32_t gbase = 0;
@@ -1046,38 +1076,55 @@ __global__ __launch_bounds__(256) void hs_finalize_codes_kernel(hs_tables_dev ta
       if (gbase + i < hit_cap) {
         hit_key[gbase + i] = s_hk[wave][i];
         hit_val[gbase + i] = s_hv[wave][i];
+        if (hit_rank) hit_rank[gbase + i] = s_hr[wave][i];
       }
     __builtin_amdgcn_wave_barrier();
     n_buf = 0;
   };
-  uint8_t* const my_qc = &s_qc[wave][lane * 76];
-  for (uint32_t base = (blockIdx.x * 4u + (uint32_t)wave) * 64u; base < n; base += wave_stride) {
-    const uint32_t e = base + (uint32_t)lane;
-    uint32_t ql = e < n ? prov[e].x : 0xffffffffu;
-    const uint32_t pos = e < n ? prov[e].y : 0u;
-    const bool live = ql != 0xffffffffu;
-    if (live && (ql & HS_PROV_INDIRECT)) ql = sorted_ql[ql & ~HS_PROV_INDIRECT];
+  // A survivor's loads form a chain -- list entry, probe number (the join kernels name the probe by its
+  // place in segment order), id and packed word, first-seen words: the first two links run ahead (the list
+  // entry of the iteration after next and the probe number of the next one are requested before this
+  // iteration's work).
+  const uint2 dead = make_uint2(0xffffffffu, 0u);
+  auto entry = [&](uint32_t b) { const uint32_t e_ = b + (uint32_t)lane; return (b < n && e_ < n) ? prov[e_] : dead; };
+  auto probe_of = [&](const uint2 raw) {  // (index 0 for the lanes that need none: a load all the same, no branch)
+    const bool ind = raw.x != 0xffffffffu && (raw.x & HS_PROV_INDIRECT);
+    return sorted_ql ? sorted_ql[ind ? (raw.x & ~HS_PROV_INDIRECT) : 0u] : 0u;
+  };
+  const uint32_t base0 = (blockIdx.x * 4u + (uint32_t)wave) * 64u;
+  uint2 raw1 = entry(base0), raw2 = entry(base0 + wave_stride);
+  uint32_t probe1 = probe_of(raw1);
+  for (uint32_t base = base0; base < n; base += wave_stride) {
+    const uint2 raw = raw1;
+    const uint32_t probe = probe1;
+    raw1 = raw2;
+    probe1 = probe_of(raw1);
+    raw2 = entry(base + 2u * wave_stride);
+    const bool live = raw.x != 0xffffffffu;
+    const uint32_t ql = (live && (raw.x & HS_PROV_INDIRECT)) ? probe : raw.x;
+    const uint32_t pos = raw.y;
     const uint32_t q = live ? ql / (uint32_t)L : 0u;
     const int l = live ? (int)(ql % (uint32_t)L) : 0;
     const uint32_t id = live ? tabs.t[l].ids[pos] : 0u;
-    {
-      const uint8_t* qc = qcodes + (uint64_t)q * k;
-      for (int p = 0; p < k; ++p) my_qc[p] = qc[p];
-    }
     const uint4* pkp = tabs.t[l].packed + (uint64_t)pos * PW;
+    const uint4* qkp = qpacked + (uint64_t)q * PW;
     double d2 = 0.0;
     for (int wd = 0; wd < PW; ++wd) {
-      const uint4 pk = pkp[wd];
-      const uint32_t w[5] = {pk.x, pk.y, pk.z, pk.w, 0u};
+      const uint4 pk = pkp[wd], qk = qkp[wd];
+      const uint32_t w[5] = {pk.x, pk.y, pk.z, pk.w, 0u}, wq[5] = {qk.x, qk.y, qk.z, qk.w, 0u};
 #pragma unroll
       for (int r = 0; r < 25; ++r) {
         const int p = 25 * wd + r;
         if (p < k) {  // (wave-uniform)
           const int bit = 5 * r, wi = bit >> 5, sh = bit & 31;
-          uint32_t c = w[wi] >> sh;
-          if (sh > 27) c |= w[wi + 1] << (32 - sh);
+          uint32_t c = w[wi] >> sh, cq = wq[wi] >> sh;
+          if (sh > 27) {
+            c |= w[wi + 1] << (32 - sh);
+            cq |= wq[wi + 1] << (32 - sh);
+          }
           c &= 31u;
-          const double2* row = reinterpret_cast<const double2*>(s_sq + ((int)c * alphabet + (int)my_qc[p]) * 8);
+          cq &= 31u;
+          const double2* row = reinterpret_cast<const double2*>(s_sq + ((int)c * alphabet + (int)cq) * 10);
           // exact left-to-right sum of the rounded squares (PairwiseDistance_square :176-183)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -1090,28 +1137,28 @@ __global__ __launch_bounds__(256) void hs_finalize_codes_kernel(hs_tables_dev ta
     }
     bool hit = live && ((r_sqrt == r_sqrt) ? (__dsqrt_rn(d2) <= r_sqrt) : (d2 <= r2));
     if (self_first != HS_NO_SELF && self_first + q_base + q == id) hit = false;
-    if (hit) {  // first-seen rule, as in hs_finalize_kernel
-      bool dup = false;
-      for (int l2 = 0; l2 < l; ++l2) {
-        const uint32_t c2 = qcount[q * L + l2];
-        const uint32_t p2 = tabs.t[l2].pos_of[id];
-        dup = dup || (p2 - qstart[q * L + l2] < c2);
-      }
-      hit = !dup;
-    }
+    if (__ballot(hit && l > 0)) hit = hit && !seen_in_earlier_table(tabs, qstart, qcount, q, l, L, id, hit);
     const unsigned long long hm = __ballot(hit);
     if (hm) {
+      // (the number the PREVIOUS hit of this lane drew from its query's counter goes to the buffer now: the
+      // counter's answer has had a whole iteration to arrive)
+      if (pend_idx >= 0) s_hr[wave][pend_idx] = pend_rk;
+      pend_idx = -1;
       const uint32_t cnt = (uint32_t)__popcll(hm);
       if (n_buf + cnt > HBUF) flush_hits();
       const uint32_t idx = n_buf + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
       if (hit) {
         s_hk[wave][idx] = ((uint64_t)(q_base + q) << 37) | ((uint64_t)l << 32) | id;
         s_hv[wave][idx] = (uint64_t)__double_as_longlong(__dsqrt_rn(d2));
+        if (qcnt) {
+          pend_rk = atomicAdd(&qcnt[q], 1u);
+          pend_idx = (int)idx;
+        }
       }
       n_buf += cnt;
-      if (hit && qcnt) atomicAdd(&qcnt[q], 1u);
     }
   }
+  if (pend_idx >= 0) s_hr[wave][pend_idx] = pend_rk;
   flush_hits();
 }
 
@@ -1304,14 +1351,14 @@ __global__ __launch_bounds__(256) void hs_hit_place_kernel(const uint64_t* __res
                                                            const uint32_t* __restrict__ hit_count,
                                                            uint32_t hit_cap, uint32_t q_base,
                                                            const uint32_t* __restrict__ qoff,
-                                                           uint32_t* __restrict__ qfill,
+                                                           const uint32_t* __restrict__ rank,
                                                            uint64_t* __restrict__ key2,
                                                            uint64_t* __restrict__ val2) {
   const uint32_t n = min(*hit_count, hit_cap);
   for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
     const uint64_t kk = key[e];
     const uint32_t q = (uint32_t)(kk >> 37) - q_base;
-    const uint32_t slot = qoff[q] + atomicAdd(&qfill[q], 1u);
+    const uint32_t slot = qoff[q] + rank[e];  // (the hit's number among its query's: hs_finalize_kernel)
     if (slot < hit_cap) {
       key2[slot] = kk;
       val2[slot] = val[e];
@@ -1838,32 +1885,32 @@ hipError_t hs_launch_finalize(const hs_tables_dev& tabs, const uint8_t* d_codes,
                               const uint32_t* d_sorted_ql, int k, int L, double r2, double r_sqrt,
                               uint32_t q_base, uint32_t self_first, uint32_t* d_hit_count,
                               uint32_t hit_cap, uint64_t* d_hit_key, uint64_t* d_hit_val, uint32_t* d_qcnt,
-                              int alphabet, hipStream_t s) {
-  if (d_qcodes && alphabet <= HS_FIN_TABLE_ALPHABET && k <= 75)  // the queries are k-mers: terms from a table
-    hs_finalize_codes_kernel<<<1024, 256, (size_t)alphabet * alphabet * 64, s>>>(
-        tabs, d_qcodes, d_coords, alphabet, d_qstart, d_qcount, d_prov, d_prov_count, prov_cap, d_sorted_ql, k, L, r2,
-        r_sqrt, q_base, self_first, d_hit_count, hit_cap, d_hit_key, d_hit_val, d_qcnt);
+                              int alphabet, const uint4* d_qpacked, uint32_t* d_hit_rank, hipStream_t s) {
+  if (d_qpacked && alphabet <= HS_FIN_TABLE_ALPHABET)  // the queries are k-mers: terms from a table
+    hs_finalize_codes_kernel<<<1024, 256, (size_t)alphabet * alphabet * 80, s>>>(
+        tabs, d_qpacked, d_coords, alphabet, d_qstart, d_qcount, d_prov, d_prov_count, prov_cap, d_sorted_ql, k, L, r2,
+        r_sqrt, q_base, self_first, d_hit_count, hit_cap, d_hit_key, d_hit_val, d_qcnt, d_hit_rank);
   else if (d_qcodes)  // ... with a large alphabet: centre rows from the coordinate table
     hs_finalize_kernel<true><<<1024, 256, 0, s>>>(tabs, d_codes, nullptr, d_qcodes, d_coords, d_qstart, d_qcount,
                                                   d_prov, d_prov_count, prov_cap, d_sorted_ql, k, L, r2,
                                                   r_sqrt, q_base, self_first, d_hit_count, hit_cap,
-                                                  d_hit_key, d_hit_val, d_qcnt);
+                                                  d_hit_key, d_hit_val, d_qcnt, d_hit_rank);
   else
     hs_finalize_kernel<false><<<1024, 256, 0, s>>>(tabs, d_codes, d_centers, nullptr, d_coords, d_qstart,
                                                    d_qcount, d_prov, d_prov_count, prov_cap, d_sorted_ql, k, L,
                                                    r2, r_sqrt, q_base, self_first, d_hit_count, hit_cap,
-                                                   d_hit_key, d_hit_val, d_qcnt);
+                                                   d_hit_key, d_hit_val, d_qcnt, d_hit_rank);
   return hipGetLastError();
 }
 hipError_t hs_launch_hit_order(const uint64_t* d_key, const uint64_t* d_val, const uint32_t* d_hit_count,
                                uint32_t hit_cap, uint32_t q_base, uint32_t nq, const uint32_t* d_qoff,
-                               uint32_t* d_qfill, uint64_t* d_key2, uint64_t* d_val2, uint32_t* d_big,
+                               const uint32_t* d_rank, uint64_t* d_key2, uint64_t* d_val2, uint32_t* d_big,
                                uint32_t* d_qlist /* 8 + 3 nq words, the first eight zero */,
                                uint32_t* d_q, uint32_t* d_id, uint32_t* d_table, double* d_dist,
                                uint64_t out_room, int n_cu, hipStream_t s) {
   if (!nq) return hipSuccess;
-  hs_hit_place_kernel<<<256, 256, 0, s>>>(d_key, d_val, d_hit_count, hit_cap, q_base, d_qoff, d_qfill, d_key2,
-                                          d_val2);
+  hs_hit_place_kernel<<<std::max(n_cu, 1) * 8, 256, 0, s>>>(d_key, d_val, d_hit_count, hit_cap, q_base, d_qoff,
+                                                            d_rank, d_key2, d_val2);
   hs_hit_order_kernel<<<blocks_for(nq), 256, 0, s>>>(d_qoff, nq, d_hit_count, hit_cap, d_key2, d_val2, d_big,
                                                     d_qlist, d_q, d_id, d_table, d_dist, out_room);
   // (blocks that find their list empty leave at once: a batch of few hits pays two empty launches)
