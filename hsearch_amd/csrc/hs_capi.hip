@@ -852,7 +852,12 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
           if (e[g][i]) (void)hipEventDestroy(e[g][i]);
       size_t held = 0;
       for (DevBuf* x : b) held += x->cap;
-      if (held > ((size_t)1 << 30))  // keep up to 1 GB of build scratch for the next build
+      // The build scratch stays for the next build while it is small beside the device's memory (1/16 of
+      // it: 2.2 GB at the C2 sizes stay -- freeing them took 2.5 ms of a 23 ms build --, 22 GB at the C3
+      // shape go).
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = (size_t)16 << 30;
+      if (held > total_b / 16)
         for (DevBuf* x : b) x->release();
     }
   } guard = {h, &hash_stream, own_hash_stream, {ev_hashed, ev_free, ev_t}, {2, 2, 4},
