@@ -860,14 +860,19 @@ def test_queries_given_as_residue_codes(oracle, k, K, L, W, R):
     eng.close()
 
 
-def test_queries_as_codes_in_batches_and_custom_table(oracle, monkeypatch):
+@pytest.mark.parametrize("letters", [11, 29])
+def test_queries_as_codes_in_batches_and_custom_table(oracle, monkeypatch, letters):
+    """An alphabet of its own (11 letters: the exact pass takes its terms from the table of rounded
+    squares, hs_finalize_codes_kernel; 29 letters: above HS_FIN_TABLE_ALPHABET, the two-row form of
+    hs_finalize_kernel), several query batches per call, a code outside the alphabet, and the same
+    queries given as points (recognised as k-mers of that table)."""
     k, K, L, W, R, n, nq = 25, 5, 4, 120.0, 44.0, 9001, 777
     rng = np.random.default_rng(90)
-    table = rng.normal(0.0, 6.0, size=(11, 8))                     # an 11-letter alphabet of its own
+    table = rng.normal(0.0, 6.0, size=(letters, 8))                # an alphabet of its own
     a, b = synth.make_planes(k, K, L, W, seed=91)
-    codes = rng.integers(0, 11, size=(n, k), dtype=np.uint8)
+    codes = rng.integers(0, letters, size=(n, k), dtype=np.uint8)
     qcodes = codes[rng.integers(0, n, size=nq)].copy()
-    qcodes[np.arange(nq), rng.integers(0, k, size=nq)] = rng.integers(0, 11, size=nq, dtype=np.uint8)
+    qcodes[np.arange(nq), rng.integers(0, k, size=nq)] = rng.integers(0, letters, size=nq, dtype=np.uint8)
     pts = table[codes].reshape(n, -1)
     centers = table[qcodes].reshape(nq, -1)
     want = oracle.search(a, b, W, R, pts, centers)
@@ -880,8 +885,13 @@ def test_queries_as_codes_in_batches_and_custom_table(oracle, monkeypatch):
         got = eng.query_codes(qcodes, R)
         assert np.array_equal(got["cand"], want["cand"])
         _assert_hits_equal(got, want)
+    eng.set_verify_mode("auto")
+    got = eng.query(centers, R)                                     # the same k-mers as points
+    assert eng.profile()["queries_recognised"] == nq
+    assert np.array_equal(got["cand"], want["cand"])
+    _assert_hits_equal(got, want)
     bad = qcodes.copy()
-    bad[5, 3] = 11                                                  # a row the table does not have
+    bad[5, 3] = letters                                             # a row the table does not have
     from hsearch_amd import capi
     with pytest.raises(capi.HsError):
         eng.query_codes(bad, R)
