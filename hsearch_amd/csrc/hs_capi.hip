@@ -164,7 +164,6 @@ struct hs_handle {
   uint32_t shard_lo = 0, shard_cnt = 0, shard_seed = 0, shard_nb = 0;
   int shard_table = -1;
   DevBuf seg_res;   // cut_items: flags + scan of the segments that go to the query-resident join kernel
-  DevBuf jconst;    // 128 copies of the gamma slots' constant factors (hs_join8r_kernel's fourth lane quarter)
   DevBuf c16s, item_desc, probe_slow, jtab8, slice_ql, qhits;  // qhits: per-query hit counts, offsets, fill
   DevBuf c8b, prov2;  // survivor refinement: second int8 row per query, the refined survivor list
   bool join8_tables_ok = false;  // int8 can carry the coordinate table
@@ -576,18 +575,6 @@ hs_status hs_create(const hs_params* params, const double* a, const double* b, c
   HS_HIP(h, hs_launch_jtables8(h->coords.as<double>(), h->alphabet, h->jtab8.p, h->jtab8.as<float>() + 128,
                                reinterpret_cast<uint32_t*>(h->jtab8.as<char>() + 640),
                                h->jtab8.as<char>() + 1024, h->jtab8.as<char>() + 1536, h->stream));
-  {
-    HS_HIP(h, h->jconst.reserve(2048));
-    uint32_t rep_[128][4];
-    for (int i = 0; i < 128; ++i) {
-      rep_[i][0] = 0x7f7f0000u;  // = tab8[HS_J8_CONST_AT] (hs_jtables8_kernel): bytes ROW-16.. of a member row
-      rep_[i][1] = 0x7f7f7f7fu;
-      rep_[i][2] = 0x7f7f7f7fu;
-      rep_[i][3] = 0x017f7f7fu;
-    }
-    HS_HIP(h, hipMemcpyAsync(h->jconst.p, rep_, 2048, hipMemcpyHostToDevice, h->stream));
-    HS_HIP(h, hipStreamSynchronize(h->stream));  // rep_ goes out of scope
-  }
   uint32_t unsafe8 = 1;
   float scale8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   HS_HIP(h, hipMemcpyAsync(&unsafe8, h->jtab8.as<char>() + 640, 4, hipMemcpyDeviceToHost, h->stream));
@@ -674,7 +661,7 @@ void hs_destroy(hs_handle* h) {
                     &h->proj_xmeta, &h->slice_ql, &h->qhits, &h->bs_ints2[0], &h->bs_ints2[1], &h->bs_keys2[0],
                     &h->bs_keys2[1], &h->bs_iota2[0], &h->bs_iota2[1], &h->bs_keys_sorted, &h->bs_rle_unique,
                     &h->bs_rle_counts, &h->bs_small, &h->bs_sort_temp, &h->bs_slow_q, &h->all_codes,
-                    &h->subset_ids, &h->qcodes_buf, &h->qembed, &h->seg_res, &h->jconst, &h->t_rho, &h->rec_codes, &h->qpacked, &h->hit_rank, &h->bs_fptab, &h->bs_blk,
+                    &h->subset_ids, &h->qcodes_buf, &h->qembed, &h->seg_res, &h->t_rho, &h->rec_codes, &h->qpacked, &h->hit_rank, &h->bs_fptab, &h->bs_blk,
                     &h->bs_dk, &h->bs_hist, &h->bs_rank};
   for (DevBuf* bf : bufs) bf->release();
   h->sj_host.release();
@@ -2096,7 +2083,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
     jm = use_i8 ? hs_join8_members_per_item(k, wide) : HS_JM_BLOCK;
     // k <= 25 with 4-column rows: segments probed by at most HS_JR_MAXQ queries of the batch go to the
     // query-resident kernel (hs_join8r_kernel), as the tail of the item list
-    use_r = use_i8 && !wide && k <= 25 && !h->knobs.no_join_r &&
+    use_r = use_i8 && !wide && k <= 25 && h->alphabet <= HS_JR_MAX_ALPHABET && !h->knobs.no_join_r &&
             (h->knobs.force_join_r || h->resident_share < 0.0 || h->resident_share >= 0.5 || h->resident_age >= 64);
     HS_CHECK(cut_items(h, nql, jm, d_jstats, use_r ? HS_JR_MAXQ : 0u));
     if (use_i8)
@@ -2269,7 +2256,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
         if (use_r)
           HS_HIP(h, hs_launch_join8r(h->item_desc.as<uint4>(), n_items, d_split, h->tabs.t[0].packed,
                                      h->t_rho.as<uint32_t>(),
-                                     h->c16s.p, jtab_rows, h->jconst.p, d_cnt, prov_cap, h->prov.as<uint2>(),
+                                     h->c16s.p, jtab_rows, h->alphabet, d_cnt, prov_cap, h->prov.as<uint2>(),
                                      d_cnt + 33, h->n_cu * h->join_blocks_per_cu, h->pairs_per_item, h->stream));
       }
       else if (n_items)

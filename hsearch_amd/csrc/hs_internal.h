@@ -413,6 +413,8 @@ hipError_t hs_launch_item_split(const uint32_t* d_item_off, const uint32_t* d_re
 // queries of a segment the query-resident join keeps in registers (two 32-query tiles: with three the
 // kernel spills at two waves per SIMD)
 #define HS_JR_MAXQ 64u
+// ... and alphabets of up to this many residues (its pair table has eight copies of 32 x alphabet entries in LDS)
+#define HS_JR_MAX_ALPHABET 24
 // members per work item: 512 (one workgroup tile) for the staged kernels, 128 (one wave) for the
 // wave-independent int8 join
 #define HS_JM_BLOCK 512u
@@ -475,7 +477,7 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
 hipError_t hs_launch_join8r(const uint4* d_desc, uint32_t desc_cap, const uint32_t* d_split,
                             const uint4* d_packed_base, const uint32_t* d_rho_base /* the records in four bytes */,
                             const void* d_c8t,
-                            const void* d_tab8, const void* d_cn_rep, uint32_t* d_prov_count, uint32_t prov_cap,
+                            const void* d_tab8, int alphabet /* <= HS_JR_MAX_ALPHABET */, uint32_t* d_prov_count, uint32_t prov_cap,
                             uint2* d_prov, uint32_t* d_item_counter, int n_blocks, double pairs_per_item,
                             hipStream_t s);
 // bucket-ordered packed copy of one table (k <= 25) + the per-entry 16-byte A-row tails of the

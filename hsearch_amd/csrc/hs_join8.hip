@@ -1332,30 +1332,54 @@ __device__ __forceinline__ void load_btile_r(intx4 (&B)[2][2], const uint4* __re
 // instruction cache).
 // per-lane constants of the operand build (rows 0, 1, 3 | row 2)
 struct J8rLane {
-  uint32_t sh;    // bit of the loaded word the lane's fields start at: 8 j | 0
-  uint32_t s5;    // field -> byte offset of a pair-table entry: shift 5 | the record word carries its offset: 0
-  uint32_t mA;    // 0x7fe0 | 0x7ff0
-  uint32_t rA, rB;  // copy of the pair table (8 (lane & 3)) | the digit table: 0x8000, 0x8008
-  uint32_t m2, rc2, rc3;  // k-step 1: field mask and copy | 0 and the two entries of the constant factors
-  uint32_t mrem;  // 0 | 0x7f
+  uint32_t sh;      // bit of the loaded word the lane's fields start at: 8 j | 0
+  uint32_t o0, o1;  // bit offsets of the first two fields: 0, 10 | 4, 4 (the record word carries |q| there)
+  uint32_t w01;     // ... and their width: 10 | 11
+  uint32_t sl;      // field -> byte offset of its table entry: shift 6 (64-byte entries) | 3 (8-byte entries)
+  uint32_t b0, b1;  // the lane's copy of the pair table | the two digit tables
+  uint32_t w2;      // k-step 1: width of its two fields: 10 | 0 (no field: row 2 reads ...
+  uint32_t b2, b3;  // ... the lane's copy again | the two entries of the constant factors)
+  uint32_t mrem;    // 0 | 0x7f
   bool row2;
 };
-constexpr uint32_t J8R_DIG_AT = 32768u;                  // digit table: 1398 entries of 16 bytes
-// x^ of one residue: 64 dwords (33 used); on a multiple of 256 bytes (addresses are formed with OR)
-constexpr uint32_t J8R_TAB1_AT = (J8R_DIG_AT + 1398u * 16u + 255u) & ~255u;
-constexpr uint32_t J8R_CONST_AT = J8R_TAB1_AT + 256u;    // the constant factors of the gamma slots: 16 bytes
-constexpr uint32_t J8R_LDS_BYTES = J8R_CONST_AT + 16u;
-static_assert((J8R_DIG_AT & 0x7fffu) == 0 && (J8R_TAB1_AT & 0xffu) == 0 && (J8R_CONST_AT & 0xfu) == 0, "OR-formed addresses");
+// LDS of hs_join8r_kernel, for an alphabet of A <= HS_JR_MAX_ALPHABET residues (byte offsets):
+//   [0, 2048 A)      x^ of TWO consecutive residues per lookup: entry r1 << 5 | r0 = {x^(r0), x^(r1)}, 64 bytes
+//                    each = EIGHT copies side by side -- lane l reads copy l & 7.  The 16 lanes of one pass
+//                    of an 8-byte read then meet, copy by copy, in 4 bank groups two at a time (one copy:
+//                    72 % of the LDS cycles were conflicts; four copies: as many conflict cycles as data
+//                    cycles, and the LDS pipe was the busiest unit of the kernel at ~ 70 %)
+//   digit tables     the record digits of every |q| (digit j = clamp(|q| - 127 j, 0, 127), 1398 entries) as
+//                    TWO arrays of 8-byte entries -- {0, digits 0..3} and {digits 4..7, digits 8..10} -- so
+//                    that the 16 lanes of row 2, whose |q| are neighbours, spread over 32 bank pairs and not
+//                    over the 16 that 16-byte entries gave them
+//   x^ of one residue (64 dwords, entry 32 = 0: no residue; on a multiple of 256: its address is formed with OR)
+//   the constant factors of the gamma slots (16 bytes)
+//   per wave: the sign masks of an item's groups that had a survivor, [4][8][64] dwords
+struct J8rLayout {
+  uint32_t dig_at, dig2_at, tab1_at, const_at, mask_at, total;
+};
+__host__ __device__ inline J8rLayout join8r_layout(int alphabet) {
+  J8rLayout l;
+  l.dig_at = 2048u * (uint32_t)alphabet;
+  l.dig2_at = l.dig_at + 1398u * 8u;
+  l.tab1_at = (l.dig2_at + 1398u * 8u + 255u) & ~255u;
+  l.const_at = l.tab1_at + 256u;
+  l.mask_at = l.const_at + 256u;
+  l.total = l.mask_at + 4u * 8u * 64u * 4u;
+  return l;
+}
 
 __device__ __forceinline__ void join8r_lookup(intx4 (&A)[4][2], uint32_t (&XL)[4], const uint4 (&MK)[8], int half,
-                                              const char* sL, const J8rLane& c) {
+                                              const char* sL, uint32_t tab1_at, const J8rLane& c) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const uint4 mk = MK[4 * half + t];
     const uint32_t x0 = __builtin_amdgcn_alignbit(mk.y, mk.x, c.sh), x1 = __builtin_amdgcn_alignbit(mk.z, mk.y, c.sh);
-    const uint32_t a0 = ((x0 << c.s5) & c.mA) | c.rA, a1 = ((x0 >> c.s5) & c.mA) | c.rB;
-    const uint32_t a2 = ((x0 >> 15) & c.m2) | c.rc2, a3 = (__builtin_amdgcn_alignbit(x1, x0, 25) & c.m2) | c.rc3;
-    const uint32_t ax = J8R_TAB1_AT | ((x0 >> 23) & 0xfcu);  // (rows 0, 1, 3: some entry of that table, unused)
+    const uint32_t a0 = (__builtin_amdgcn_ubfe(x0, c.o0, c.w01) << c.sl) + c.b0;
+    const uint32_t a1 = (__builtin_amdgcn_ubfe(x0, c.o1, c.w01) << c.sl) + c.b1;
+    const uint32_t a2 = (__builtin_amdgcn_ubfe(x0, 20u, c.w2) << 6) + c.b2;
+    const uint32_t a3 = (__builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(x1, x0, 30), 0u, c.w2) << 6) + c.b3;
+    const uint32_t ax = tab1_at | ((x0 >> 23) & 0xfcu);  // (rows 0, 1, 3: some entry of that table, unused)
     const uint2 p0 = *reinterpret_cast<const uint2*>(sL + a0), p1 = *reinterpret_cast<const uint2*>(sL + a1);
     const uint2 p2 = *reinterpret_cast<const uint2*>(sL + a2), p3 = *reinterpret_cast<const uint2*>(sL + a3);
     XL[t] = *reinterpret_cast<const uint32_t*>(sL + ax);
@@ -1477,24 +1501,20 @@ __device__ __forceinline__ void join8r_emit(uint32_t gmask, int NT, const uint32
 __global__ __launch_bounds__(256, 2) void hs_join8r_kernel(
     const uint4* __restrict__ desc, const uint32_t* __restrict__ range, uint32_t desc_cap,
     const uint4* __restrict__ packed_base, const uint32_t* __restrict__ rho_base, const uint4* __restrict__ c8t,
-    const uint4* __restrict__ tab8, const uint4* __restrict__ cn_rep, uint32_t* __restrict__ prov_count,
+    const uint4* __restrict__ tab8, int alphabet, uint32_t* __restrict__ prov_count,
     uint32_t prov_cap, uint2* __restrict__ prov, uint32_t* __restrict__ item_counter, uint32_t G) {
   const uint32_t first = __builtin_amdgcn_readfirstlane(range[0]);
   const uint32_t n_items = min(__builtin_amdgcn_readfirstlane(range[1]), desc_cap);  // (absolute) end of the list
-  // LDS tables (byte offsets J8R_*): x^ of TWO consecutive residues per lookup (entry r1 << 5 | r0 =
-  // {x^(r0), x^(r1)}), four copies side by side -- lane l reads copy l & 3 -- so that the 32 lanes of an LDS
-  // access group spread their random entries over four times as many banks (the single copy spent 72 % of
-  // the LDS cycles on conflicts); the record digits of every |q| (digit j = clamp(|q| - 127 j, 0, 127) at
-  // byte 4 + j of the entry); x^ of one residue (entry 32 = 0: no residue); the constant factors.
-  __shared__ __attribute__((aligned(16))) unsigned char sLds[J8R_LDS_BYTES];
-  __shared__ uint32_t sMask[4][8][64];  // per wave: the sign masks of an item's groups that had a survivor
+  extern __shared__ __attribute__((aligned(64))) unsigned char sLds[];  // join8r_layout(alphabet)
+  const J8rLayout lay = join8r_layout(alphabet);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, row = lane >> 4;
   {
-    uint2* sp = reinterpret_cast<uint2*>(sLds);
-    for (int e = tid; e < 4096; e += 256) sp[e] = make_uint2(tab8[(e >> 2) & 31].x, tab8[e >> 7].x);
-    uint4* sd = reinterpret_cast<uint4*>(sLds + J8R_DIG_AT);
+    uint2* sp = reinterpret_cast<uint2*>(sLds);  // entry f = r1 << 5 | r0, copy c at dword pair 8 f + c
+    for (int e = tid; e < alphabet * 32 * 8; e += 256) sp[e] = make_uint2(tab8[(e >> 3) & 31].x, tab8[e >> 8].x);
+    uint2* sd = reinterpret_cast<uint2*>(sLds + lay.dig_at);
+    uint2* sd2 = reinterpret_cast<uint2*>(sLds + lay.dig2_at);
     for (int e = tid; e < 1398; e += 256) {
       uint32_t w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -1502,14 +1522,15 @@ __global__ __launch_bounds__(256, 2) void hs_join8r_kernel(
         const int d = min(127, max(0, e - 127 * j));
         w[(4 + j) >> 2] |= (uint32_t)d << (8 * ((4 + j) & 3));
       }
-      sd[e] = make_uint4(w[0], w[1], w[2], w[3]);
+      sd[e] = make_uint2(w[0], w[1]);
+      sd2[e] = make_uint2(w[2], w[3]);
     }
-    uint32_t* s1 = reinterpret_cast<uint32_t*>(sLds + J8R_TAB1_AT);
+    uint32_t* s1 = reinterpret_cast<uint32_t*>(sLds + lay.tab1_at);
     if (tid < 64) s1[tid] = tid < 32 ? tab8[tid].x : 0u;
-    if (tid == 0) *reinterpret_cast<uint4*>(sLds + J8R_CONST_AT) = tab8[HS_J8_CONST_AT];
+    if (tid == 0) *reinterpret_cast<uint4*>(sLds + lay.const_at) = tab8[HS_J8_CONST_AT];
   }
   __syncthreads();  // the only one: the tables are read-only from here on
-  uint32_t* const smask = &sMask[wave][0][lane];
+  uint32_t* const smask = reinterpret_cast<uint32_t*>(sLds + lay.mask_at) + (wave * 8 * 64 + lane);
   const uint32_t first_dynamic = first + gridDim.x * 4u * G;
   uint32_t item = first + (blockIdx.x * 4u + (uint32_t)wave) * G;
   if (item >= n_items) return;
@@ -1569,15 +1590,18 @@ __global__ __launch_bounds__(256, 2) void hs_join8r_kernel(
   J8rLane lc;
   lc.row2 = row2;
   lc.sh = row2 ? 0u : 8u * jj;
-  lc.s5 = row2 ? 0u : 5u;
-  lc.mA = row2 ? 0x7ff0u : 0x7fe0u;
-  const uint32_t rc = 8u * ((uint32_t)lane & 3u);
-  lc.rA = row2 ? J8R_DIG_AT : rc;
-  lc.rB = row2 ? J8R_DIG_AT + 8u : rc;
-  lc.m2 = row2 ? 0u : 0x7fe0u;
-  lc.rc2 = row2 ? J8R_CONST_AT : rc;
-  lc.rc3 = row2 ? J8R_CONST_AT + 8u : rc;
+  lc.o0 = row2 ? 4u : 0u;
+  lc.o1 = row2 ? 4u : 10u;
+  lc.w01 = row2 ? 11u : 10u;
+  lc.sl = row2 ? 3u : 6u;
+  const uint32_t rc = 8u * ((uint32_t)lane & 7u);
+  lc.b0 = row2 ? lay.dig_at : rc;
+  lc.b1 = row2 ? lay.dig2_at : rc;
+  lc.w2 = row2 ? 0u : 10u;
+  lc.b2 = row2 ? lay.const_at : rc;
+  lc.b3 = row2 ? lay.const_at + 8u : rc;
   lc.mrem = row2 ? 0x7fu : 0u;
+  const uint32_t tab1_at = lay.tab1_at;
   const char* const sPairB = reinterpret_cast<const char*>(sLds);
 #define HS_LOAD_MEMBERS_R(MK, D0)                                                                   \
   {                                                                                                 \
@@ -1623,7 +1647,7 @@ __global__ __launch_bounds__(256, 2) void hs_join8r_kernel(
        them sits here, with nothing younger in flight: the LDS counter has four bits, sixteen younger lookups  \
        could not be told apart from them), send the second half's lookups out, compute the first half */       \
     join8r_finish(AP, XP, MK, 0, lc);                                                                          \
-    join8r_lookup(AQ, XQ, MK, 1, sPairB, lc);                                                                  \
+    join8r_lookup(AQ, XQ, MK, 1, sPairB, tab1_at, lc);                                                                  \
     switch (nct_) {                                                                                            \
       case 1: gm_ = join8r_half<1, 0>(AP, Bq, smask); break;                                                   \
       case 2: gm_ = join8r_half<2, 0>(AP, Bq, smask); break;                                                   \
@@ -1635,7 +1659,7 @@ __global__ __launch_bounds__(256, 2) void hs_join8r_kernel(
     /* second half: complete, send out the NEXT item's first half (its members were requested one item ago;    \
        the same item's when there is none), compute */                                                         \
     join8r_finish(AQ, XQ, MK, 1, lc);                                                                          \
-    join8r_lookup(AP, XP, MKN, 0, sPairB, lc);                                                                 \
+    join8r_lookup(AP, XP, MKN, 0, sPairB, tab1_at, lc);                                                                 \
     switch (nct_) {                                                                                            \
       case 1: gm_ |= join8r_half<1, 1>(AQ, Bq, smask); break;                                                  \
       case 2: gm_ |= join8r_half<2, 1>(AQ, Bq, smask); break;                                                  \
@@ -1657,7 +1681,7 @@ __global__ __launch_bounds__(256, 2) void hs_join8r_kernel(
   }
   intx4 AP[4][2], AQ[4][2];
   uint32_t XP[4], XQ[4];
-  join8r_lookup(AP, XP, mkA, 0, sPairB, lc);  // the first item's first half
+  join8r_lookup(AP, XP, mkA, 0, sPairB, tab1_at, lc);  // the first item's first half
   for (;;) {
     HS_ITEM_STEP(mkA, mkB)
     if (!has_next) break;
@@ -2026,10 +2050,21 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
 // of the gamma slots, 128 times over (2 KB).  *d_item_counter zeroed by the caller.
 hipError_t hs_launch_join8r(const uint4* d_desc, uint32_t desc_cap, const uint32_t* d_split,
                             const uint4* d_packed_base, const uint32_t* d_rho_base, const void* d_c8t,
-                            const void* d_tab8, const void* d_cn_rep, uint32_t* d_prov_count, uint32_t prov_cap,
+                            const void* d_tab8, int alphabet, uint32_t* d_prov_count, uint32_t prov_cap,
                             uint2* d_prov, uint32_t* d_item_counter, int n_blocks, double pairs_per_item,
                             hipStream_t s) {
   if (!desc_cap) return hipSuccess;
+  if (alphabet < 1 || alphabet > HS_JR_MAX_ALPHABET) return hipErrorInvalidValue;  // (the caller routes by it)
+  const J8rLayout lay = join8r_layout(alphabet);
+  {  // more than the 64 KB a kernel may take without asking
+    static int granted = 0;  // largest size asked for so far (one value per process is enough: it only grows)
+    if ((int)lay.total > granted) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hs_join8r_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total);
+      if (e != hipSuccess) return e;
+      granted = (int)lay.total;
+    }
+  }
   // chunks of consecutive items = consecutive member tiles of one bucket (the query rows stay); sized like
   // hs_launch_join8w's, from the previous batch's pairs per item
   static const uint32_t g_env = getenv("HS_JOIN_CHUNK_R") ? (uint32_t)atoi(getenv("HS_JOIN_CHUNK_R")) : 0u;
@@ -2038,9 +2073,9 @@ hipError_t hs_launch_join8r(const uint4* d_desc, uint32_t desc_cap, const uint32
   const uint32_t n_waves = (uint32_t)n_blocks * 4u;
   G = std::max(2u, std::min(G, std::max(2u, desc_cap / (n_waves * 32u))));
   if (g_env) G = g_env;
-  hs_join8r_kernel<<<n_blocks, 256, 0, s>>>(d_desc, d_split, desc_cap, d_packed_base, d_rho_base, (const uint4*)d_c8t,
-                                            (const uint4*)d_tab8, (const uint4*)d_cn_rep, d_prov_count, prov_cap,
-                                            d_prov, d_item_counter, G);
+  hs_join8r_kernel<<<n_blocks, 256, lay.total, s>>>(d_desc, d_split, desc_cap, d_packed_base, d_rho_base,
+                                                    (const uint4*)d_c8t, (const uint4*)d_tab8, alphabet, d_prov_count,
+                                                    prov_cap, d_prov, d_item_counter, G);
   return hipGetLastError();
 }
 
