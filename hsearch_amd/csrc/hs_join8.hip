@@ -59,10 +59,9 @@ typedef int intx16 __attribute__((ext_vector_type(16)));
 constexpr int QD = 4;        // table columns used
 constexpr int HS_J8_CONST_AT = 48;  // uint4 index in the int8 table block of the gamma slots' constant factors
 // k-steps of 32 bytes in a row: 4 (k <= 25), 6 (k <= 41), 8 (k <= 50); row = 32 KS bytes = 2 KS pieces
-// wide rows (all 8 coordinates): 5 (k <= 16: 128 coordinate bytes + 4 spare + 28 digit slots), 6 (k <= 20)
-// or 8 (k <= 25)
+// wide rows (all 8 coordinates): 6 (k <= 20) or 8 (k <= 25)
 __host__ __device__ constexpr int ks_of(int k, bool wide = false) {
-  return wide ? (k <= 16 ? 5 : k <= 20 ? 6 : 8) : k <= 25 ? 4 : k <= 41 ? 6 : 8;
+  return wide ? (k <= 20 ? 6 : 8) : k <= 25 ? 4 : k <= 41 ? 6 : 8;
 }
 // survivor slots a wave reserves per counter access: same-address atomics complete at ~ 90 per
 // microsecond, and a hit-heavy launch (k = 15 at the C2 sizes: 1.4e8 survivors in 25 ms) asked for
@@ -491,8 +490,7 @@ __device__ __forceinline__ void build_afrags8_wide(const uint4 pk, const uint4 r
     const uint2 p1_ = sTabW[residue_at<(20 * (S) + 5 < 124 ? 20 * (S) + 5 : 123)>(x, y, z, w)]; \
     A[S] = intx4{(int)p0_.x, (int)p0_.y, (int)p1_.x, (int)p1_.y};         \
   }
-  HS_AW(0) HS_AW(1) HS_AW(2) HS_AW(3)
-  if constexpr (KS >= 6) { HS_AW(4) }
+  HS_AW(0) HS_AW(1) HS_AW(2) HS_AW(3) HS_AW(4)
   if constexpr (KS == 8) { HS_AW(5) HS_AW(6) }
 #undef HS_AW
   constexpr uint32_t C127 = 0x7f7f7f7fu;
@@ -728,8 +726,8 @@ __global__ __launch_bounds__(256, 2) void hs_join8w_kernel(
   // trip between cutting the items and joining them)
   if (n_items_dev) n_items = min(n_items, __builtin_amdgcn_readfirstlane(*n_items_dev));
   static_assert(JT == 4 || JT == 2, "two accumulator groups of JT / 2 row tiles");
-  static_assert(KS == 4 || (WIDE && KS == 5) || KS == 6 || KS == 8, "k-steps of a row");
-  static_assert(!WIDE || KS == 5 || KS == 6 || KS == 8, "wide rows have 5, 6 or 8 k-steps");
+  static_assert(KS == 4 || KS == 6 || KS == 8, "k-steps of a row");
+  static_assert(!WIDE || KS == 6 || KS == 8, "wide rows have 6 or 8 k-steps");
   constexpr int GT = JT / 2;
   constexpr int PW = (KS == 4 || WIDE) ? 1 : 2;  // packed words per member
   __shared__ uint32_t sTab8[32];
@@ -1268,6 +1266,305 @@ __global__ __launch_bounds__(256, 2) void hs_join8x_kernel(
 #endif
 }
 
+
+// ---- hs_join8xw_kernel: the 16x16x64 form for WIDE rows of 192 bytes (k <= 20, all 8 coordinate columns) ------
+// Same operands, filter value, work items (64 members) and survivor list as hs_join8w_kernel<2, 6, true>; the
+// structure of hs_join8x_kernel: lane (n, q) holds bytes 64 s + 16 q .. + 15 of k-step s = the two positions
+// 8 s + 2 q, 8 s + 2 q + 1 (8 coordinate bytes each) for s = 0, 1 and for s = 2, q < 2; in k-step 2 lane
+// quarter q = 2 carries the member's record (bytes 160..175 of the row) and q = 3 the constant factors of the
+// gamma slots (176..191).  A lane's two positions are ONE ten-bit field of the packed word (bit 40 s + 10 q),
+// and the table holds the 16 bytes of both residues per entry (r1 << 5 | r0: 16 KB of LDS): one 16-byte
+// lookup per k-step, lane and row tile IS the operand register.  EIGHT row tiles per item (128 members: with
+// 64 the query tiles a wave streams from L2 meet half as many members, and at 192 bytes per query row that
+// traffic -- 15 TB/s asked of the L2 at k = 15 -- was the kernel's limit, not the matrix pipe), two
+// accumulator sets of two row tiles that the four row-tile pairs of a query tile take in turn, each pair's
+// sign test in the gaps of the next pair's MFMAs.
+template <int NS>
+__device__ __forceinline__ void load_btile_xn(intx4 (&B)[NS][2], const uint4* __restrict__ c8t, uint32_t row0,
+                                              uint32_t nr, int lane) {
+  // row = 4 NS pieces of 16 bytes; piece 4 s + q of row 16 c + n of a tile with nr rows sits at (4 s + q) nr + row
+  const char* t0 = reinterpret_cast<const char*>(c8t + (uint64_t)row0 * (4u * NS));
+  const uint32_t n = (uint32_t)lane & 15u, q = (uint32_t)lane >> 4;
+  const uint32_t qn = q * nr;
+  const uint32_t o0 = (qn + min(n, nr - 1u)) * 16u, o1 = (qn + min(16u + n, nr - 1u)) * 16u;
+#pragma unroll
+  for (int s2 = 0; s2 < NS; ++s2) {
+    const char* ts = t0 + (uint64_t)nr * 64u * (uint32_t)s2;
+    const uint4 v0 = *reinterpret_cast<const uint4*>(ts + o0), v1 = *reinterpret_cast<const uint4*>(ts + o1);
+    B[s2][0] = intx4{(int)v0.x, (int)v0.y, (int)v0.z, (int)v0.w};
+    B[s2][1] = intx4{(int)v1.x, (int)v1.y, (int)v1.z, (int)v1.w};
+  }
+}
+
+// Survivors in hs_join8xw_kernel.  Short k-mers at a loose radius pass 0.1 % of the pairs through the
+// filter (k = 15 at the C2 sizes: five survivors per 128 x 32 query tile), so nearly every query tile has
+// some.  Emitting them per 16 x 16 tile with ballot loops (emit_survivors_x2: 22.8 ms against 14.3 for the
+// kernel without them) or one by one with scalar code (22.4: ~ 230 cycles of dependent scalar instructions
+// per survivor) both cost as much as the MFMAs; even a branch per row-tile pair that only saved the pair's
+// sign bits when it had a survivor cost 4 ms (18.2 against 14.3).  Here EVERY pair's 16 sign bits per lane
+// go into a 64-bit per-lane mask (bit 16 pair + 8 t + 4 c + i) with straight-line code in the MFMA gaps, and
+// the query tile's survivors are written out ONCE, after its fourth pair: one round per "r-th survivor
+// of a lane".
+// bit 8 t + 4 c + i = 1 where acc[t][c][i] >= 0 (a survivor): 16 v_alignbit, branch-free -- they take the
+// place of the sign AND-tree in the gaps of the next pair's MFMAs
+__device__ __forceinline__ uint32_t sign_mask16(const intx4 (&acc)[2][2]) {
+  uint32_t neg = 0;
+#pragma unroll
+  for (int t = 1; t >= 0; --t)
+#pragma unroll
+    for (int c = 1; c >= 0; --c)
+#pragma unroll
+      for (int i = 3; i >= 0; --i) neg = __builtin_amdgcn_alignbit(neg, (uint32_t)acc[t][c][i], 31);
+  return ~neg & 0xffffu;
+}
+
+
+
+// hs_join8xw_kernel's survivors go through a per-wave LDS buffer of this many entries and take exactly
+// as many slots of the list when it fills.  A store to the list inside the query-tile loop -- in whatever
+// form: its trip count is unknown -- makes the compiler drain vmcnt(0) before the next use of a prefetched
+// query tile (stores count with the loads on this part), once per query tile in a hit-heavy batch: that
+// drain, not the emission's instructions, was the 7 ms every form of it cost.
+constexpr uint32_t JRESW = 256;
+// the wave's buffered survivors to the list: exactly as many slots as there are entries
+__device__ __forceinline__ void drain_survivors_xw(const uint2* sbuf, uint32_t& n_buf, int lane,
+                                                   uint32_t* __restrict__ prov_count, uint32_t prov_cap,
+                                                   uint2* __restrict__ prov) {
+  if (!n_buf) return;
+  uint32_t base = 0;
+  if (lane == 0) base = hs_reserve_survivors(prov_count, n_buf);
+  base = __builtin_amdgcn_readfirstlane(base);
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t i = (uint32_t)lane; i < n_buf; i += 64u)
+    if (base + i < prov_cap) prov[base + i] = sbuf[i];
+  __builtin_amdgcn_wave_barrier();
+  n_buf = 0;
+}
+
+__device__ __forceinline__ void flush_stash_xw(uint64_t& st, uint32_t qc, uint32_t qoff,
+                                               uint32_t wbase, uint32_t M, uint32_t mstart, int lane,
+                                               uint2* sbuf, uint32_t& n_buf,
+                                               uint32_t* __restrict__ prov_count, uint32_t prov_cap,
+                                               uint2* __restrict__ prov) {
+  const uint32_t n = (uint32_t)lane & 15u, q = (uint32_t)lane >> 4;
+  // (one 64-bit value per lane, not a pair of words picked by a branch: that form -- a store through a
+  // selected pointer -- kept the two words in scratch memory)
+  while (__ballot(st != 0)) {
+    uint32_t idx = 0, col = 0;
+    bool pass = false;
+    if (st) {
+      const uint32_t b = (uint32_t)__builtin_ctzll(st);  // the lane's lowest set bit: 16 pair + 8 t + 4 c + i
+      st &= st - 1ull;
+      idx = wbase + 16u * (b >> 3) + 4u * q + (b & 3u);  // row tile 2 pair + t = b >> 3
+      col = qc + 16u * ((b >> 2) & 1u) + n;
+      pass = idx < M;
+    }
+    const unsigned long long m = __ballot(pass);
+    if (m) {
+      const uint32_t cnt = (uint32_t)__popcll(m);
+      if (n_buf + cnt > JRESW) drain_survivors_xw(sbuf, n_buf, lane, prov_count, prov_cap, prov);
+      if (pass)
+        sbuf[n_buf + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] =
+            make_uint2(HS_PROV_INDIRECT | (qoff + col), mstart + idx);
+      n_buf += cnt;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void hs_join8xw_kernel(
+    const uint4* __restrict__ desc, uint32_t n_items, const uint4* __restrict__ packed_base,
+    const uint4* __restrict__ rec_base, const uint4* __restrict__ c8t,
+    const uint4* __restrict__ tabW, uint32_t* __restrict__ prov_count, uint32_t prov_cap,
+    uint2* __restrict__ prov, uint32_t* __restrict__ item_counter, uint32_t G,
+    const uint32_t* __restrict__ n_items_dev) {
+  if (n_items_dev) n_items = min(n_items, __builtin_amdgcn_readfirstlane(*n_items_dev));
+  constexpr int RT = 8;  // row tiles of 16 members per item: 128 members meet every query tile a wave fetches
+  constexpr int NS = 3;  // k-steps of 64 bytes
+  // both residues of a ten-bit field: entry (r1 << 5 | r0) = {x^(r0) columns 0..3, 4..7, x^(r1) 0..3, 4..7}
+  __shared__ uint4 sPairW[1024];
+  __shared__ uint2 sSurv[4][JRESW];  // per wave: survivors on their way to the list
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, q = lane >> 4, up = lane >> 5;
+  uint2* const sbuf = sSurv[wave];
+  uint32_t n_buf = 0;
+  for (int e = tid; e < 1024; e += 256)
+    sPairW[e] = make_uint4(tabW[e & 31].x, tabW[e & 31].y, tabW[e >> 5].x, tabW[e >> 5].y);
+  __syncthreads();  // the only one: the table is read-only from here on
+  const uint32_t first_dynamic = gridDim.x * 4u * G;
+  uint32_t item = (blockIdx.x * 4u + (uint32_t)wave) * G;
+  if (item >= n_items) return;
+  uint32_t next_chunk_v = 0;
+  if (lane == 0) next_chunk_v = atomicAdd(item_counter, G);
+  uint32_t pf_item = item, pf_chunk_end = item + G;
+#define HS_ADVANCE_PF()                                                                  \
+  {                                                                                      \
+    ++pf_item;                                                                           \
+    if (pf_item == pf_chunk_end) {                                                       \
+      pf_item = first_dynamic + __builtin_amdgcn_readfirstlane(next_chunk_v);            \
+      pf_chunk_end = pf_item + G;                                                        \
+      if (lane == 0 && pf_item < n_items) next_chunk_v = atomicAdd(item_counter, G);     \
+    }                                                                                    \
+  }
+  uint4 d0 = uniform4(desc[2 * (uint64_t)item]), d1 = uniform4(desc[2 * (uint64_t)item + 1]);
+  HS_ADVANCE_PF()
+  uint32_t next_item = pf_item;
+  uint4 nd0 = d0, nd1 = d1;
+  if (next_item < n_items) {
+    nd0 = uniform4(desc[2 * (uint64_t)next_item]);
+    nd1 = uniform4(desc[2 * (uint64_t)next_item + 1]);
+  }
+  // lanes 0..31: packed member 16 t + n (both lane quarters the same word); lanes 32..63: its record
+  uint4 mk[RT];
+  constexpr int NB = 2;          // B tiles in flight per wave: the one in use + one prefetched
+  constexpr uint32_t GQ = 32 * NB;
+  intx4 Bq[NB][NS][2];
+#define HS_LOAD_MEMBERS(D0)                                                              \
+  {                                                                                      \
+    const int64_t off_ = (int64_t)(((uint64_t)(D0).y << 32) | (uint64_t)(D0).x);         \
+    const uint4* src_ = (up ? rec_base : packed_base) + off_;                            \
+    const uint32_t idx_ = (D0).w * (16u * RT) + (uint32_t)n;                             \
+    _Pragma("unroll") for (int t = 0; t < RT; ++t)                                       \
+      mk[t] = src_[min(idx_ + 16 * t, (D0).z - 1)];                                      \
+  }
+  const uint32_t skew = ((blockIdx.x * 4u + (uint32_t)wave) * 40503u) & 0xffffu;
+#define HS_N_GROUPS(D1) (((D1).z - (D1).y + GQ - 1u) / GQ)
+#define HS_FIRST_Q(D1) ((D1).y + GQ * ((skew * HS_N_GROUPS(D1)) >> 16))
+#define HS_LOAD_GROUP(ROW, Q0, QEND)                                                             \
+  _Pragma("unroll") for (int u = 0; u < NB; ++u) {                                               \
+    const uint32_t qu_ = (Q0) + 32u * u < (QEND) ? (Q0) + 32u * u : (Q0);                        \
+    load_btile_xn<NS>(Bq[u], c8t, (ROW) + qu_, min(32u, (QEND) - qu_), lane);                    \
+  }
+  HS_LOAD_MEMBERS(d0)
+  {
+    const uint32_t q0 = HS_FIRST_Q(d1);
+    HS_LOAD_GROUP(d1.x, q0, d1.z)
+  }
+  const uint32_t bs = 10u * (uint32_t)q;  // a lane's fields start 10 q bits into each 40-bit stretch
+  while (true) {
+    const uint32_t M = d0.z, mt = d0.w;
+    const uint32_t qoff = d1.x, q_begin = d1.y, q_end = d1.z, mstart = d1.w;
+    const uint32_t wbase = mt * (16u * RT);
+    const bool has_next = next_item < n_items;
+    HS_ADVANCE_PF()  // pf_item = the item after next
+    uint4 nnd0 = nd0, nnd1 = nd1;
+    if (pf_item < n_items) {
+      nnd0 = uniform4(desc[2 * (uint64_t)pf_item]);
+      nnd1 = uniform4(desc[2 * (uint64_t)pf_item + 1]);
+    }
+    // ---- A operands of the item's 128 members
+    intx4 A[RT][NS];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      // the upper half-wave takes the packed word's first three dwords from the lower one (v_permlane32_swap
+      // (a, b) exchanges the upper half of a with the lower half of b); its own registers hold the record
+      const uint32_t x0 = __builtin_amdgcn_permlane32_swap(mk[t].x, mk[t].x, false, false)[0];
+      const uint32_t y0 = __builtin_amdgcn_permlane32_swap(mk[t].y, mk[t].y, false, false)[0];
+      const uint32_t z0 = __builtin_amdgcn_permlane32_swap(mk[t].z, mk[t].z, false, false)[0];
+      const uint32_t x = __funnelshift_r(x0, y0, bs), y = __funnelshift_r(y0, z0, bs);
+      const uint32_t z = __funnelshift_r(z0, mk[t].w, bs);  // (used by the lower half only: its own w)
+      const uint4 p0 = sPairW[x & 1023u], p1 = sPairW[(y >> 8) & 1023u], p2 = sPairW[(z >> 16) & 1023u];
+      A[t][0] = intx4{(int)p0.x, (int)p0.y, (int)p0.z, (int)p0.w};
+      A[t][1] = intx4{(int)p1.x, (int)p1.y, (int)p1.z, (int)p1.w};
+      const intx4 lk = intx4{(int)p2.x, (int)p2.y, (int)p2.z, (int)p2.w};
+      const intx4 rec = intx4{(int)mk[t].x, (int)mk[t].y, (int)mk[t].z, (int)mk[t].w};
+      const intx4 cn = intx4{0x7f7f0000, 0x7f7f7f7f, 0x7f7f7f7f, 0x017f7f7f};  // (build_afrags8_wide, h = 1)
+      A[t][2] = q == 3 ? cn : q == 2 ? rec : lk;
+    }
+    // Two accumulator sets of two row tiles each; a query tile runs four phases (row-tile pairs 0..3)
+    // that alternate between them, each phase's 12 MFMAs beside the sign test of the phase before (the
+    // first phase of a query tile: of the previous tile's last phase).
+    intx4 acc[2][2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) acc[1][t][c] = __builtin_nondeterministic_value(acc[1][t][c]);
+    bool y_live = false;  // (nothing stands in acc[1] at the item's first phase)
+    uint64_t st = 0;  // per lane: the sign bits of the current query tile's four pairs
+    uint32_t prev_qc = q_begin;
+    const uint32_t n_groups = HS_N_GROUPS(d1);
+    uint32_t qc0 = HS_FIRST_Q(d1);
+    auto do_group = [&](uint32_t gi) {
+      uint32_t nrow = qoff, nq0 = qc0 + GQ, nqend = q_end;
+      if (nq0 >= q_end) nq0 = q_begin;
+      if (gi + 1 == n_groups) {
+        nrow = nd1.x;
+        nq0 = HS_FIRST_Q(nd1);
+        nqend = nd1.z;
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const uint32_t qc = qc0 + 32u * (uint32_t)u;
+        intx4 (&B)[NS][2] = Bq[u];
+        if (u == 0 || qc < q_end) {
+#pragma unroll
+          for (int ph = 0; ph < 4; ++ph) {
+            intx4 (&cur)[2][2] = acc[ph & 1];
+            intx4 (&old)[2][2] = acc[(ph & 1) ^ 1];
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2)
+#pragma unroll
+              for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                  cur[t][c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[2 * ph + t][s2], B[s2][c],
+                                                                    s2 ? cur[t][c] : intx4{0, 0, 0, 0}, 0, 0, 0);
+            // the pair before: pair ph - 1 of this query tile, or pair 3 of the previous one (nothing at the
+            // item's very first pair) -- its sign bits into the tile's mask
+            const uint32_t sm = sign_mask16(old);
+            if (ph == 0) st |= y_live ? (uint64_t)sm << 48 : 0ull;
+            if (ph > 0) st |= (uint64_t)sm << (16 * (ph - 1));
+#pragma unroll
+            for (int g = 0; g < 12; ++g) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            }
+            if (ph == 0) {  // the previous query tile is complete: its survivors, if any, go out
+              const uint64_t bad0 = prev_qc + (uint32_t)n < q_end ? 0ull : 0x0f0f0f0f0f0f0f0full;
+              const uint64_t bad1 = prev_qc + 16u + (uint32_t)n < q_end ? 0ull : 0xf0f0f0f0f0f0f0f0ull;
+              st &= ~(bad0 | bad1);
+              if (__ballot(st != 0))
+                flush_stash_xw(st, prev_qc, qoff, wbase, M, mstart, lane, sbuf, n_buf, prov_count, prov_cap, prov);
+            }
+          }
+          y_live = true;
+          prev_qc = qc;
+        }
+        const uint32_t nb = nq0 + 32u * (uint32_t)u < nqend ? nq0 + 32u * (uint32_t)u : nq0;
+        load_btile_xn<NS>(B, c8t, nrow + nb, min(32u, nqend - nb), lane);
+      }
+      qc0 = nq0;
+    };
+    do_group(0);
+    for (uint32_t gi = 1; gi < n_groups; ++gi) do_group(gi);
+    // The next item's members are requested HERE, not beside the operand build as in hs_join8x_kernel: eight
+    // more live 16-byte registers through the query-tile loop were three spilled registers, and scratch
+    // traffic in that loop -- it counts with the query-tile loads -- cost what the emission seemed to
+    // cost (22 ms against 14 without it, whatever its form).  An item of these rows has tens of query tiles.
+    HS_LOAD_MEMBERS(nd0)
+    {  // the item's last pair
+      st |= (uint64_t)sign_mask16(acc[1]) << 48;
+      const uint64_t bad0 = prev_qc + (uint32_t)n < q_end ? 0ull : 0x0f0f0f0f0f0f0f0full;
+      const uint64_t bad1 = prev_qc + 16u + (uint32_t)n < q_end ? 0ull : 0xf0f0f0f0f0f0f0f0ull;
+      st &= ~(bad0 | bad1);
+      if (__ballot(st != 0))
+        flush_stash_xw(st, prev_qc, qoff, wbase, M, mstart, lane, sbuf, n_buf, prov_count, prov_cap, prov);
+    }
+    if (!has_next) break;
+    item = next_item;
+    next_item = pf_item;
+    d0 = nd0;
+    d1 = nd1;
+    nd0 = nnd0;
+    nd1 = nnd1;
+  }
+#undef HS_ADVANCE_PF
+#undef HS_LOAD_GROUP
+#undef HS_N_GROUPS
+#undef HS_LOAD_MEMBERS
+#undef HS_FIRST_Q
+  drain_survivors_xw(sbuf, n_buf, lane, prov_count, prov_cap, prov);
+}
 
 // ------------------------------------------------------------------ join, query-resident form
 // Segments probed by FEW queries of the batch (<= HS_JR_MAXQ = 64: configs[2]'s shape at its swept W
@@ -1966,7 +2263,13 @@ hipError_t hs_launch_qprep8_codes(const uint8_t* d_qcodes, uint32_t nq, int k, i
 }
 
 int hs_join8_row_bytes(int k, int wide) { return 32 * ks_of(k, wide != 0); }
-uint32_t hs_join8_members_per_item(int k, int wide) { return ks_of(k, wide != 0) == 4 ? 128u : 64u; }
+// 128 members where a 16x16x64 kernel runs the items (hs_join8x_kernel, hs_join8r_kernel, hs_join8xw_kernel),
+// 64 for the 32x32x32 forms of the longer rows
+uint32_t hs_join8_members_per_item(int k, int wide) {
+  static const bool shape32 = getenv("HS_JOIN_SHAPE") && atoi(getenv("HS_JOIN_SHAPE")) == 32;
+  const int KS = ks_of(k, wide != 0);
+  return (KS == 4 || (wide && KS == 6 && !shape32)) ? 128u : 64u;
+}
 
 hipError_t hs_launch_gather_c8t(const void* d_c8, const uint32_t* d_sorted_ql, const uint32_t* d_seg_qoff,
                                 uint32_t nql, int L, int k, int wide, void* d_out, hipStream_t s) {
@@ -2010,10 +2313,10 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
   const int KS = ks_of(k, wide != 0);
   // k <= 25: the 16x16x64 form by default (HS_JOIN_SHAPE=32 selects the 32x32x32 form)
   static const bool shape32 = getenv("HS_JOIN_SHAPE") && atoi(getenv("HS_JOIN_SHAPE")) == 32;
-  if (wide && KS == 5)  // d_tab8 = the 8-column table here
-    hs_join8w_kernel<2, 5, true><<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_rec_base,
-                                                          (const uint4*)d_c8t, (const uint4*)d_tab8, d_prov_count,
-                                                          prov_cap, d_prov, d_item_counter, G, d_n_items);
+  if (wide && KS == 6 && !shape32)  // d_tab8 = the 8-column table here
+    hs_join8xw_kernel<<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_rec_base, (const uint4*)d_c8t,
+                                               (const uint4*)d_tab8, d_prov_count, prov_cap, d_prov, d_item_counter,
+                                               G, d_n_items);
   else if (wide && KS == 6)
     hs_join8w_kernel<2, 6, true><<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_rec_base,
                                                           (const uint4*)d_c8t, (const uint4*)d_tab8, d_prov_count,
@@ -2096,11 +2399,7 @@ hipError_t hs_launch_thin8(const hs_tables_dev& tabs, const uint4* d_rec_base, u
                            uint2* d_prov, int n_blocks, hipStream_t s) {
   if (!nql) return hipSuccess;
   if (wide) {  // d_tab8 = the 8-column table
-    if (ks_of(k, true) == 5)
-      hs_thin8_kernel<5, true><<<n_blocks, 256, 0, s>>>(tabs.t[0].packed, d_rec_base, n_entries, (const int8_t*)d_c8,
-                                                        (const uint4*)d_tab8, d_qstart, d_qcount, d_slice_off,
-                                                        d_slice_ql, nql, L, k, d_prov_count, prov_cap, d_prov);
-    else if (ks_of(k, true) == 6)
+    if (ks_of(k, true) == 6)
       hs_thin8_kernel<6, true><<<n_blocks, 256, 0, s>>>(tabs.t[0].packed, d_rec_base, n_entries, (const int8_t*)d_c8,
                                                         (const uint4*)d_tab8, d_qstart, d_qcount, d_slice_off,
                                                         d_slice_ql, nql, L, k, d_prov_count, prov_cap, d_prov);

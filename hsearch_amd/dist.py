@@ -194,16 +194,26 @@ def index_build_sharded(eng, codes, ops, max_seeds=4):
         l0, h0 = shard_bounds(n, r, ops.world)
         counts.append(h0 - l0)
     assert (lo, cnt) == (shard_bounds(n, ops.rank, ops.world)[0], counts[ops.rank])
+    def ready():
+        # The library works on its own stream and returns with it drained; what torch has queued on ITS
+        # stream (zero fills, concatenations, collectives) must be complete before a pointer is handed over.
+        if ops.dev.type == "cuda":
+            torch.cuda.current_stream(ops.dev).synchronize()
+
     for seed in range(max_seeds):
         collided = 0
         for l in range(eng.L):
             fp_block = torch.empty(max(cnt, 1), dtype=torch.int64, device=ops.dev)
+            ready()
             eng.shard_hash(l, seed, fp_block.data_ptr())
             fp_all = ops.allgather_blocks(fp_block[:cnt], counts).contiguous()
+            ready()
             nb = eng.shard_group(l, fp_all.data_ptr())
             tup = torch.zeros(max(nb, 1) * eng.K, dtype=torch.int32, device=ops.dev)
+            ready()
             eng.shard_tuples(l, tup.data_ptr())
             tup_all = ops.allreduce_sum(tup).contiguous()
+            ready()
             collided |= eng.shard_finish(l, tup_all.data_ptr())
         if not ops.allreduce_max_int(collided):
             return eng.shard_end(seed)

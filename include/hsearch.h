@@ -10,7 +10,10 @@
  *     throws; hs_last_error() gives the message of the last failure on a handle;
  *   - the caller owns every buffer it passes in; the library owns device memory behind the handle;
  *   - functions WITHOUT a _dev suffix take HOST pointers and copy over PCIe; the _dev variants
- *     take DEVICE pointers (HBM-resident inputs/outputs) and are what bench.py times;
+ *     take DEVICE pointers (HBM-resident inputs/outputs) and are what bench.py times.  The library
+ *     works on streams of its own and returns with them drained: device buffers a caller hands in must
+ *     be COMPLETE (whatever the caller has queued on its own streams to fill them: finished) at the
+ *     call, and are ready for any stream when it returns;
  *   - output capacity is explicit: when results exceed `cap` the call returns HS_ERR_CAPACITY and
  *     *n_out holds the required capacity (two-call pattern);
  *   - a handle is bound to one GPU and is not thread-safe; use one handle per GPU / process;

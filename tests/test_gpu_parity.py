@@ -1028,14 +1028,17 @@ def test_index_build_with_the_hashing_spread_over_ranks(oracle, tmp_path, world,
             e.shard_hash(l, 0, t.data_ptr())
             fps.append(t[:blocks[r][1]])
         fp_all = torch.cat(fps).contiguous()                      # the all-gather
+        torch.cuda.synchronize()     # (torch's stream is not the library's: its work first, then the pointer)
         nbs = [e.shard_group(l, fp_all.data_ptr()) for e in engs]
         assert len(set(nbs)) == 1
         tups = []
         for e in engs:
             t = torch.zeros(max(nbs[0], 1) * K, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
             e.shard_tuples(l, t.data_ptr())
             tups.append(t)
         tup_all = torch.stack(tups).sum(0).to(torch.int32).contiguous()   # the all-reduce
+        torch.cuda.synchronize()
         assert all(e.shard_finish(l, tup_all.data_ptr()) == 0 for e in engs)
     for r, e in enumerate(engs):
         info = e.shard_end(0)
