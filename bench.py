@@ -13,7 +13,8 @@ sharded (weak scaling: 100 k queries per GPU), hits all-gathered.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel over its HIP-event time
 (events on the library's stream): with the bucket join on (the default) that is hs_join8x_kernel
-(k = 21..25; hs_join8w_kernel for k <= 20 and k = 26..50), an int8 MFMA GEMM of depth 128 (192 for
+(k = 21..25, with hs_join8r_kernel beside it for segments of few probing queries; hs_join8xw_kernel for
+k <= 20; hs_join8w_kernel for k = 26..50), an int8 MFMA GEMM of depth 128 (192 for
 k <= 20 and 26..41, 256 for k <= 50) per (bucket member, probing query) pair, against the dense int8 MFMA peak; with --verify-mode stream (and wherever no join runs) it is hs_verify_kernel, priced by the
 ALGORITHMIC bytes of SURVEY.md 8(d) against 8 TB/s.  `roofline.traffic` = measured HBM bytes per
 launch from profiles/traffic_latest.json, reported only while that file's recorded kernel source
@@ -46,6 +47,8 @@ def join_i8_kernel(row_bytes, wide):
     batch (hs_profile.join_row_bytes = GEMM depth, join_wide): hs_join8.hip."""
     ks = row_bytes // 32
     if wide:
+        if ks == 6 and os.environ.get("HS_JOIN_SHAPE") != "32":
+            return "hs_join8xw_kernel"          # 16x16x64, 128-member work items
         return "hs_join8w_kernel<2,%d,wide>" % ks
     if ks > 4:
         return "hs_join8w_kernel<2,%d>" % ks
