@@ -132,6 +132,7 @@ struct hs_handle {
   // the records once more in four bytes per entry ([L][n]; k <= 25 with 4-column rows: what the
   // query-resident join kernel reads instead of t_rec8 -- it is bound by the bytes it moves per member)
   DevBuf t_rho;
+  DevBuf hit_kv;     // query_batch: the hits bucketed by query, (key, value) side by side
   DevBuf hit_rank;   // query_batch: a hit's number among its query's hits (ordering without a sort)
   DevBuf qpacked;    // query_batch: queries given as k-mers, packed like the members (exact pass)
   DevBuf rec_codes;  // run_query: the residue codes of centres that turned out to be k-mers (+ the counter)
@@ -661,7 +662,7 @@ void hs_destroy(hs_handle* h) {
                     &h->proj_xmeta, &h->slice_ql, &h->qhits, &h->bs_ints2[0], &h->bs_ints2[1], &h->bs_keys2[0],
                     &h->bs_keys2[1], &h->bs_iota2[0], &h->bs_iota2[1], &h->bs_keys_sorted, &h->bs_rle_unique,
                     &h->bs_rle_counts, &h->bs_small, &h->bs_sort_temp, &h->bs_slow_q, &h->all_codes,
-                    &h->subset_ids, &h->qcodes_buf, &h->qembed, &h->seg_res, &h->t_rho, &h->rec_codes, &h->qpacked, &h->hit_rank, &h->bs_fptab, &h->bs_blk,
+                    &h->subset_ids, &h->qcodes_buf, &h->qembed, &h->seg_res, &h->t_rho, &h->rec_codes, &h->qpacked, &h->hit_rank, &h->hit_kv, &h->bs_fptab, &h->bs_blk,
                     &h->bs_dk, &h->bs_hist, &h->bs_rank};
   for (DevBuf* bf : bufs) bf->release();
   h->sj_host.release();
@@ -2214,8 +2215,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
       qfill = qoff + n1q;  // (and behind it the lists of the queries a block orders: 8 + 3 nq words)
       HS_HIP(h, hipMemsetAsync(qcnt, 0, (3 * n1q + 8) * 4, h->stream));
       if (launches) HS_HIP(h, hipMemsetAsync(d_cnt + 20, 0, 4, h->stream));  // retry: the "too many hits" flag
-      HS_HIP(h, h->hit_key2.reserve((size_t)hit_cap * 8));
-      HS_HIP(h, h->hit_val2.reserve((size_t)hit_cap * 8));
+      HS_HIP(h, h->hit_kv.reserve((size_t)hit_cap * 16));
       HS_HIP(h, h->hit_rank.reserve((size_t)hit_cap * 4));
       HS_HIP(h, h->temp.reserve(hs_scan_u32_temp(n1q) + 256));
     }
@@ -2312,8 +2312,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
         const size_t n1q_ = (size_t)nq + 1;
         HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, qcnt, qoff, (size_t)nq + 1, h->stream));
         HS_HIP(h, hs_launch_hit_order(h->hit_key.as<uint64_t>(), h->hit_val.as<uint64_t>(), d_cnt + 1, hit_cap,
-                                      q_base, nq, qoff, h->hit_rank.as<uint32_t>(), h->hit_key2.as<uint64_t>(),
-                                      h->hit_val2.as<uint64_t>(), d_cnt + 20, qfill + n1q_, bout->q, bout->id,
+                                      q_base, nq, qoff, h->hit_rank.as<uint32_t>(), h->hit_kv.p, d_cnt + 20, qfill + n1q_, bout->q, bout->id,
                                       bout->table, bout->dist, bout->room, h->n_cu, h->stream));
       }
     }

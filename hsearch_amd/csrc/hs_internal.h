@@ -361,7 +361,7 @@ hipError_t hs_launch_finalize(const hs_tables_dev& tabs, const uint8_t* d_codes,
 // out_room of them); *d_big is set when a query has too many hits for that (caller: radix sort)
 hipError_t hs_launch_hit_order(const uint64_t* d_key, const uint64_t* d_val, const uint32_t* d_hit_count,
                                uint32_t hit_cap, uint32_t q_base, uint32_t nq, const uint32_t* d_qoff,
-                               const uint32_t* d_rank, uint64_t* d_key2, uint64_t* d_val2, uint32_t* d_big,
+                               const uint32_t* d_rank, void* d_kv /* hit_cap x 16 bytes: (key, value) by query */, uint32_t* d_big,
                                uint32_t* d_qlist /* 8 + 3 nq words, the first eight zero */,
                                uint32_t* d_q, uint32_t* d_id, uint32_t* d_table, double* d_dist,
                                uint64_t out_room, int n_cu, hipStream_t s);

@@ -1031,7 +1031,11 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
 // and query are both 5-bit packed words -- the queries' by hs_pack_kernel -- read by constant shifts).  Hit-heavy batches spend their time
 // here (k = 15 at the C2 sizes: 1.4e8 survivors per batch, 9.4 ms with the two-row form).
 #define HS_FIN_TABLE_ALPHABET 24
-__global__ __launch_bounds__(256) void hs_finalize_codes_kernel(hs_tables_dev tabs,
+// Workgroups of HS_FINC_WAVES waves: the kernel sits on s_waitcnt 87 % of its wave cycles (PMC) -- a chain of
+// scattered loads per survivor -- so what it needs is waves in flight, and the 32 KB term table is per
+// workgroup: 16 waves share one, two workgroups per CU = 32 waves (4 waves per table: 12).
+#define HS_FINC_WAVES 16
+__global__ __launch_bounds__(64 * HS_FINC_WAVES) void hs_finalize_codes_kernel(hs_tables_dev tabs,
                                                                 const uint4* __restrict__ qpacked,
                                                                 const double* __restrict__ coords, int alphabet,
                                                                 const uint32_t* __restrict__ qstart,
@@ -1051,17 +1055,17 @@ __global__ __launch_bounds__(256) void hs_finalize_codes_kernel(hs_tables_dev ta
   // 16-byte read meet in 4 bank groups (4-way conflicts on average), with 80-byte rows in 16
   extern __shared__ __attribute__((aligned(16))) double s_sq[];
   constexpr uint32_t HBUF = 128;
-  __shared__ uint64_t s_hk[4][HBUF], s_hv[4][HBUF];
-  __shared__ uint32_t s_hr[4][HBUF];  // the hit's arrival number among its query's hits (with qcnt)
+  __shared__ uint64_t s_hk[HS_FINC_WAVES][HBUF], s_hv[HS_FINC_WAVES][HBUF];
+  __shared__ uint32_t s_hr[HS_FINC_WAVES][HBUF];  // the hit's arrival number among its query's hits (with qcnt)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int e = tid; e < alphabet * alphabet * 8; e += 256) {
+  for (int e = tid; e < alphabet * alphabet * 8; e += 64 * HS_FINC_WAVES) {
     const int j = e & 7, rs = e >> 3, r = rs / alphabet, sq = rs - r * alphabet;
     const double d = __dsub_rn(coords[r * 8 + j], coords[sq * 8 + j]);
     s_sq[rs * 10 + j] = __dmul_rn(d, d);
   }
   __syncthreads();
   const uint32_t n = min(*prov_count, prov_cap);
-  const uint32_t wave_stride = gridDim.x * 4u * 64u;
+  const uint32_t wave_stride = gridDim.x * (uint32_t)HS_FINC_WAVES * 64u;
   const int PW = (k + 24) / 25;
   uint32_t n_buf = 0;
   uint32_t pend_rk = 0;  // per lane: the answer of the lane's last counter access, not yet in the buffer ...
@@ -1091,7 +1095,7 @@ __global__ __launch_bounds__(256) void hs_finalize_codes_kernel(hs_tables_dev ta
     const bool ind = raw.x != 0xffffffffu && (raw.x & HS_PROV_INDIRECT);
     return sorted_ql ? sorted_ql[ind ? (raw.x & ~HS_PROV_INDIRECT) : 0u] : 0u;
   };
-  const uint32_t base0 = (blockIdx.x * 4u + (uint32_t)wave) * 64u;
+  const uint32_t base0 = (blockIdx.x * (uint32_t)HS_FINC_WAVES + (uint32_t)wave) * 64u;
   uint2 raw1 = entry(base0), raw2 = entry(base0 + wave_stride);
   uint32_t probe1 = probe_of(raw1);
   for (uint32_t base = base0; base < n; base += wave_stride) {
@@ -1352,16 +1356,14 @@ __global__ __launch_bounds__(256) void hs_hit_place_kernel(const uint64_t* __res
                                                            uint32_t hit_cap, uint32_t q_base,
                                                            const uint32_t* __restrict__ qoff,
                                                            const uint32_t* __restrict__ rank,
-                                                           uint64_t* __restrict__ key2,
-                                                           uint64_t* __restrict__ val2) {
+                                                           ulonglong2* __restrict__ kv) {
   const uint32_t n = min(*hit_count, hit_cap);
   for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
     const uint64_t kk = key[e];
     const uint32_t q = (uint32_t)(kk >> 37) - q_base;
     const uint32_t slot = qoff[q] + rank[e];  // (the hit's number among its query's: hs_finalize_kernel)
     if (slot < hit_cap) {
-      key2[slot] = kk;
-      val2[slot] = val[e];
+      kv[slot] = make_ulonglong2(kk, val[e]);  // (key and value side by side: one scattered 16-byte store)
     }
   }
 }
@@ -1370,8 +1372,7 @@ __global__ __launch_bounds__(256) void hs_hit_place_kernel(const uint64_t* __res
 // up to HS_ORDER_BLOCK_MAX, of more
 __global__ __launch_bounds__(256) void hs_hit_order_kernel(const uint32_t* __restrict__ qoff, uint32_t nq,
                                                            const uint32_t* __restrict__ hit_count,
-                                                           uint32_t hit_cap, uint64_t* __restrict__ key2,
-                                                           uint64_t* __restrict__ val2,
+                                                           uint32_t hit_cap, ulonglong2* __restrict__ kv,
                                                            uint32_t* __restrict__ big,
                                                            uint32_t* __restrict__ qlist,
                                                            uint32_t* __restrict__ out_q,
@@ -1379,39 +1380,52 @@ __global__ __launch_bounds__(256) void hs_hit_order_kernel(const uint32_t* __res
                                                            uint32_t* __restrict__ out_table,
                                                            double* __restrict__ out_dist, uint64_t out_room) {
   const uint32_t q = blockIdx.x * 256 + threadIdx.x;
-  if (q >= nq) return;
   if (*hit_count > hit_cap) return;  // the batch is repeated with larger buffers anyway
-  const uint32_t lo = qoff[q], m = qoff[q + 1] - lo;
-  if (!m) return;
+  uint32_t lo = 0, m = 0;
+  if (q < nq) {
+    lo = qoff[q];
+    m = qoff[q + 1] - lo;
+  }
   if (m >= (1u << 27)) {
     atomicOr(big, 1u);
-    return;
+    m = 0;
   }
-  if (m > HS_ORDER_MAX) {
-    const uint32_t which = m > HS_ORDER_BLOCK_MAX ? 2u : m > 1024u ? 1u : 0u;
-    qlist[HS_ORDER_LIST_HEAD + (size_t)which * nq + atomicAdd(&qlist[which], 1u)] = q;
-    return;
+  {  // the queries a block orders go on their lists: one counter access per wave and list (one per query --
+     // 7.7e4 same-address atomics at ~ 90 per microsecond -- was this kernel's whole time in a hit-heavy batch)
+    const int which = m > HS_ORDER_BLOCK_MAX ? 2 : m > 1024u ? 1 : m > HS_ORDER_MAX ? 0 : -1;
+    const int lane = (int)(threadIdx.x & 63);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const unsigned long long mm = __ballot(which == c);
+      if (!mm) continue;
+      uint32_t base = 0;
+      if (lane == (int)__builtin_ctzll(mm)) base = atomicAdd(&qlist[c], (uint32_t)__popcll(mm));
+      base = __shfl(base, (int)__builtin_ctzll(mm));
+      if (which == c)
+        qlist[HS_ORDER_LIST_HEAD + (size_t)c * nq + base + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = q;
+    }
+    if (which >= 0) return;
   }
+  if (!m) return;
   // insertion sort of the query's hits by key (distinct: (table, id) is unique per query)
   for (uint32_t i = 1; i < m; ++i) {
-    const uint64_t kk = key2[lo + i], vv = val2[lo + i];
+    const ulonglong2 cur = kv[lo + i];
+    const uint64_t kk = cur.x;
     uint32_t j = i;
-    while (j > 0 && key2[lo + j - 1] > kk) {
-      key2[lo + j] = key2[lo + j - 1];
-      val2[lo + j] = val2[lo + j - 1];
+    while (j > 0 && kv[lo + j - 1].x > kk) {
+      kv[lo + j] = kv[lo + j - 1];
       --j;
     }
-    key2[lo + j] = kk;
-    val2[lo + j] = vv;
+    kv[lo + j] = cur;
   }
   for (uint32_t i = 0; i < m; ++i) {
     const uint64_t o = (uint64_t)lo + i;
     if (o >= out_room) break;
-    const uint64_t kk = key2[lo + i];
+    const uint64_t kk = kv[lo + i].x;
     out_q[o] = (uint32_t)(kk >> 37);
     if (out_table) out_table[o] = (uint32_t)((kk >> 32) & 31u);
     out_id[o] = (uint32_t)kk;
-    out_dist[o] = __longlong_as_double((long long)val2[lo + i]);
+    out_dist[o] = __longlong_as_double((long long)kv[lo + i].y);
   }
 }
 
@@ -1423,8 +1437,7 @@ template <uint32_t CAP, uint32_t NT>
 __global__ __launch_bounds__(NT) void hs_hit_order_block_kernel(const uint32_t* __restrict__ qoff, uint32_t nq,
                                                                  const uint32_t* __restrict__ hit_count,
                                                                  uint32_t hit_cap, uint32_t which,
-                                                                 const uint64_t* __restrict__ key2,
-                                                                 const uint64_t* __restrict__ val2,
+                                                                 const ulonglong2* __restrict__ kv,
                                                                  uint32_t* __restrict__ qlist,
                                                                  uint32_t* __restrict__ out_q,
                                                                  uint32_t* __restrict__ out_id,
@@ -1435,19 +1448,24 @@ __global__ __launch_bounds__(NT) void hs_hit_order_block_kernel(const uint32_t* 
   const uint32_t n_list = qlist[which];
   const uint32_t* const list = qlist + HS_ORDER_LIST_HEAD + (size_t)which * nq;
   const uint32_t tid = threadIdx.x;
-  for (;;) {
+  // The short queries are dealt to the blocks in turn (a shared work counter is one same-address atomic per
+  // query, ~ 90 per microsecond: with 6e4 of them it showed); the long ones, few and of very different
+  // lengths, are drawn from a counter.
+  for (uint32_t at = blockIdx.x;; at += gridDim.x) {
     __syncthreads();  // (the previous query's words have been written out)
-    if (tid == 0) sk[0] = atomicAdd(&qlist[3 + which], 1u);  // the block's next query, by way of word 0
-    __syncthreads();
-    const uint32_t at = (uint32_t)sk[0];
-    __syncthreads();
+    if (CAP > 1024u) {
+      if (tid == 0) sk[0] = atomicAdd(&qlist[3 + which], 1u);  // the block's next query, by way of word 0
+      __syncthreads();
+      at = (uint32_t)sk[0];
+      __syncthreads();
+    }
     if (at >= n_list) return;
     const uint32_t q = list[at];
     const uint32_t lo = qoff[q], m = qoff[q + 1] - lo;
     uint32_t P = 2u * NT;  // (every thread has a pair in every step)
     while (P < m) P <<= 1;
     for (uint32_t i = tid; i < P; i += NT)
-      sk[i] = i < m ? ((key2[lo + i] & ((1ull << 37) - 1ull)) << 27) | (uint64_t)i : ~0ull;
+      sk[i] = i < m ? ((kv[lo + i].x & ((1ull << 37) - 1ull)) << 27) | (uint64_t)i : ~0ull;
     __syncthreads();
     for (uint32_t size = 2u; size <= P; size <<= 1) {
       for (uint32_t stride = size >> 1; stride > 0u; stride >>= 1) {
@@ -1464,7 +1482,7 @@ __global__ __launch_bounds__(NT) void hs_hit_order_block_kernel(const uint32_t* 
         __syncthreads();
       }
     }
-    const uint32_t q_abs = (uint32_t)(key2[lo] >> 37);
+    const uint32_t q_abs = (uint32_t)(kv[lo].x >> 37);
     for (uint32_t i = tid; i < m; i += NT) {
       const uint64_t o = (uint64_t)lo + i;
       if (o >= out_room) break;
@@ -1473,7 +1491,7 @@ __global__ __launch_bounds__(NT) void hs_hit_order_block_kernel(const uint32_t* 
       out_q[o] = q_abs;
       if (out_table) out_table[o] = (uint32_t)(ti >> 32) & 31u;
       out_id[o] = (uint32_t)ti;
-      out_dist[o] = __longlong_as_double((long long)val2[lo + (uint32_t)(e & ((1u << 27) - 1u))]);
+      out_dist[o] = __longlong_as_double((long long)kv[lo + (uint32_t)(e & ((1u << 27) - 1u))].y);
     }
   }
 }
@@ -1518,8 +1536,7 @@ __device__ __forceinline__ void order_lds_steps(uint64_t* sk, uint32_t n_words, 
 __global__ __launch_bounds__(1024) void hs_hit_order_huge_kernel(const uint32_t* __restrict__ qoff, uint32_t nq,
                                                                  const uint32_t* __restrict__ hit_count,
                                                                  uint32_t hit_cap, const uint32_t* __restrict__ big,
-                                                                 const uint64_t* __restrict__ key2,
-                                                                 const uint64_t* __restrict__ val2,
+                                                                 const ulonglong2* __restrict__ kv,
                                                                  uint32_t* __restrict__ qlist,
                                                                  uint64_t* scratch,
                                                                  uint32_t* __restrict__ out_q,
@@ -1547,7 +1564,7 @@ __global__ __launch_bounds__(1024) void hs_hit_order_huge_kernel(const uint32_t*
     // sorted chunks
     for (uint32_t base = 0; base < m; base += CH) {
       for (uint32_t i = tid; i < CH; i += 1024u)
-        sk[i] = base + i < m ? ((key2[lo + base + i] & ((1ull << 37) - 1ull)) << 27) | (uint64_t)(base + i) : ~0ull;
+        sk[i] = base + i < m ? ((kv[lo + base + i].x & ((1ull << 37) - 1ull)) << 27) | (uint64_t)(base + i) : ~0ull;
       __syncthreads();
       for (uint32_t size = 2u; size <= CH; size <<= 1) order_lds_steps(sk, CH, size, true, size >> 2, tid, 1024u);
       for (uint32_t i = tid; i < CH && base + i < m; i += 1024u) G[base + i] = sk[i];
@@ -1589,7 +1606,7 @@ __global__ __launch_bounds__(1024) void hs_hit_order_huge_kernel(const uint32_t*
         __syncthreads();
       }
     }
-    const uint32_t q_abs = (uint32_t)(key2[lo] >> 37);
+    const uint32_t q_abs = (uint32_t)(kv[lo].x >> 37);
     for (uint32_t i = tid; i < m; i += 1024u) {
       const uint64_t o = (uint64_t)lo + i;
       if (o >= out_room) break;
@@ -1598,7 +1615,7 @@ __global__ __launch_bounds__(1024) void hs_hit_order_huge_kernel(const uint32_t*
       out_q[o] = q_abs;
       if (out_table) out_table[o] = (uint32_t)(ti >> 32) & 31u;
       out_id[o] = (uint32_t)ti;
-      out_dist[o] = __longlong_as_double((long long)val2[lo + (uint32_t)(e & ((1u << 27) - 1u))]);
+      out_dist[o] = __longlong_as_double((long long)kv[lo + (uint32_t)(e & ((1u << 27) - 1u))].y);
     }
   }
 }
@@ -1887,7 +1904,7 @@ hipError_t hs_launch_finalize(const hs_tables_dev& tabs, const uint8_t* d_codes,
                               uint32_t hit_cap, uint64_t* d_hit_key, uint64_t* d_hit_val, uint32_t* d_qcnt,
                               int alphabet, const uint4* d_qpacked, uint32_t* d_hit_rank, hipStream_t s) {
   if (d_qpacked && alphabet <= HS_FIN_TABLE_ALPHABET)  // the queries are k-mers: terms from a table
-    hs_finalize_codes_kernel<<<1024, 256, (size_t)alphabet * alphabet * 80, s>>>(
+    hs_finalize_codes_kernel<<<512, 64 * HS_FINC_WAVES, (size_t)alphabet * alphabet * 80, s>>>(
         tabs, d_qpacked, d_coords, alphabet, d_qstart, d_qcount, d_prov, d_prov_count, prov_cap, d_sorted_ql, k, L, r2,
         r_sqrt, q_base, self_first, d_hit_count, hit_cap, d_hit_key, d_hit_val, d_qcnt, d_hit_rank);
   else if (d_qcodes)  // ... with a large alphabet: centre rows from the coordinate table
@@ -1904,24 +1921,25 @@ hipError_t hs_launch_finalize(const hs_tables_dev& tabs, const uint8_t* d_codes,
 }
 hipError_t hs_launch_hit_order(const uint64_t* d_key, const uint64_t* d_val, const uint32_t* d_hit_count,
                                uint32_t hit_cap, uint32_t q_base, uint32_t nq, const uint32_t* d_qoff,
-                               const uint32_t* d_rank, uint64_t* d_key2, uint64_t* d_val2, uint32_t* d_big,
+                               const uint32_t* d_rank, void* d_kv /* hit_cap x 16 bytes */, uint32_t* d_big,
                                uint32_t* d_qlist /* 8 + 3 nq words, the first eight zero */,
                                uint32_t* d_q, uint32_t* d_id, uint32_t* d_table, double* d_dist,
                                uint64_t out_room, int n_cu, hipStream_t s) {
   if (!nq) return hipSuccess;
+  ulonglong2* const kv = reinterpret_cast<ulonglong2*>(d_kv);
   hs_hit_place_kernel<<<std::max(n_cu, 1) * 8, 256, 0, s>>>(d_key, d_val, d_hit_count, hit_cap, q_base, d_qoff,
-                                                            d_rank, d_key2, d_val2);
-  hs_hit_order_kernel<<<blocks_for(nq), 256, 0, s>>>(d_qoff, nq, d_hit_count, hit_cap, d_key2, d_val2, d_big,
+                                                            d_rank, kv);
+  hs_hit_order_kernel<<<blocks_for(nq), 256, 0, s>>>(d_qoff, nq, d_hit_count, hit_cap, kv, d_big,
                                                     d_qlist, d_q, d_id, d_table, d_dist, out_room);
   // (blocks that find their list empty leave at once: a batch of few hits pays two empty launches)
   const unsigned cu = (unsigned)std::max(n_cu, 1);
   hs_hit_order_block_kernel<1024u, 256u><<<std::min(nq, cu * 8u), 256, 0, s>>>(d_qoff, nq, d_hit_count, hit_cap, 0u,
-                                                                             d_key2, d_val2, d_qlist, d_q, d_id,
+                                                                             kv, d_qlist, d_q, d_id,
                                                                              d_table, d_dist, out_room);
   hs_hit_order_block_kernel<HS_ORDER_BLOCK_MAX, 1024u><<<std::min(nq, cu * 2u), 1024, 0, s>>>(
-      d_qoff, nq, d_hit_count, hit_cap, 1u, d_key2, d_val2, d_qlist, d_q, d_id, d_table, d_dist, out_room);
+      d_qoff, nq, d_hit_count, hit_cap, 1u, kv, d_qlist, d_q, d_id, d_table, d_dist, out_room);
   // (the unbucketed keys are its scratch: nothing reads them again unless *d_big, and then it does not run)
-  hs_hit_order_huge_kernel<<<std::min(nq, cu), 1024, 0, s>>>(d_qoff, nq, d_hit_count, hit_cap, d_big, d_key2, d_val2,
+  hs_hit_order_huge_kernel<<<std::min(nq, cu), 1024, 0, s>>>(d_qoff, nq, d_hit_count, hit_cap, d_big, kv,
                                                             d_qlist, const_cast<uint64_t*>(d_key), d_q, d_id, d_table,
                                                             d_dist, out_room);
   return hipGetLastError();
