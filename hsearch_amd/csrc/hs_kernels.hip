@@ -789,17 +789,20 @@ __device__ __forceinline__ bool seen_in_earlier_table(const hs_tables_dev& tabs,
                                                       uint32_t id, bool hit) {
   bool dup = false;
   struct __attribute__((packed, aligned(4))) U4 { uint32_t v[4]; };
-  for (int l0 = 0; l0 < L; l0 += 4) {
-    if (!__ballot(hit && l > l0)) break;  // (wave-uniform)
-    if (hit && l > l0) {
+  // steps of 1, 3, 4, 4, ... tables: a pair that shares a bucket in one table mostly shares table 0's too, and
+  // a hit found there needs no further look (every look is a cache line of pos_of from HBM)
+  int w = 1;
+  for (int l0 = 0; l0 < L; l0 += w, w = l0 == 1 ? 3 : 4) {
+    if (!__ballot(hit && l > l0 && !dup)) break;  // (wave-uniform)
+    if (hit && l > l0 && !dup) {
       const U4 c4 = *reinterpret_cast<const U4*>(qcount + (size_t)q * L + l0);
       const U4 s4 = *reinterpret_cast<const U4*>(qstart + (size_t)q * L + l0);
       uint32_t p4[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if (l0 + u < l) p4[u] = tabs.t[l0 + u].pos_of[id];
+        if (u < w && l0 + u < l) p4[u] = tabs.t[l0 + u].pos_of[id];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) dup = dup || (l0 + u < l && p4[u] - s4.v[u] < c4.v[u]);
+      for (int u = 0; u < 4; ++u) dup = dup || (u < w && l0 + u < l && p4[u] - s4.v[u] < c4.v[u]);
     }
   }
   return dup;
