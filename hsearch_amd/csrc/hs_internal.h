@@ -354,6 +354,38 @@ hipError_t hs_launch_finalize(const hs_tables_dev& tabs, const uint8_t* d_codes,
                               const uint4* d_qpacked /* the queries as packed k-mers (with d_qcodes), or null */,
                               uint32_t* d_hit_rank /* with d_qcnt: the hit's number among its query's hits */,
                               hipStream_t s);
+#ifdef __HIPCC__
+// First-seen rule (label[], motif_both_points.cpp:233): a hit's id was already reported if an EARLIER
+// table's probed bucket holds it, i.e. if its sorted position in that table falls inside the bucket's
+// range.  These kernels are bound by the ADDRESSES their scattered loads present (a wave instruction with
+// 64 different cache lines occupies the address unit for 64 cycles), so: four tables per step; their four
+// (start, count) words as two 16-byte loads (qstart / qcount carry four words of padding for the last
+// query); one position load per table, each under the lanes that need that table only.
+__device__ __forceinline__ bool seen_in_earlier_table(const hs_tables_dev& tabs, const uint32_t* __restrict__ qstart,
+                                                      const uint32_t* __restrict__ qcount, uint32_t q, int l, int L,
+                                                      uint32_t id, bool hit) {
+  bool dup = false;
+  struct __attribute__((packed, aligned(4))) U4 { uint32_t v[4]; };
+  // steps of 1, 3, 4, 4, ... tables: a pair that shares a bucket in one table mostly shares table 0's too, and
+  // a hit found there needs no further look (every look is a cache line of pos_of from HBM)
+  int w = 1;
+  for (int l0 = 0; l0 < L; l0 += w, w = l0 == 1 ? 3 : 4) {
+    if (!__ballot(hit && l > l0 && !dup)) break;  // (wave-uniform)
+    if (hit && l > l0 && !dup) {
+      const U4 c4 = *reinterpret_cast<const U4*>(qcount + (size_t)q * L + l0);
+      const U4 s4 = *reinterpret_cast<const U4*>(qstart + (size_t)q * L + l0);
+      uint32_t p4[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (u < w && l0 + u < l) p4[u] = tabs.t[l0 + u].pos_of[id];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dup = dup || (u < w && l0 + u < l && p4[u] - s4.v[u] < c4.v[u]);
+    }
+  }
+  return dup;
+}
+#endif
+
 // hs_finalize's first-seen test reads four words at a time from d_qstart / d_qcount: this many words of padding
 #define HS_QRANGE_PAD 4
 // the batch's hits in the reference's order without a sort: bucket by query (d_qoff = exclusive

@@ -2155,6 +2155,8 @@ __global__ __launch_bounds__(256) void hs_refine8_kernel(hs_tables_dev tabs,
     const bool live = ql != 0xffffffffu;  // unused slot of a wave's reserved block
     if (live && (ql & HS_PROV_INDIRECT)) ql = sorted_ql[ql & ~HS_PROV_INDIRECT];
     bool pass = false;
+    uint32_t fs_q = 0, fs_id = 0;
+    int fs_l = 0;
     if (live) {
       const uint32_t q = ql / (uint32_t)L, l = ql % (uint32_t)L;
       const uint4 pk = tabs.t[l].packed[(uint64_t)pos * PW];
@@ -2196,18 +2198,14 @@ __global__ __launch_bounds__(256) void hs_refine8_kernel(hs_tables_dev tabs,
       const double lhs = (double)nx + cq, rhs = 2.0 * (uA + uB);
       // margin: fp32 sums of the row norms (k x 6e-8 relative) and the roundings of this line
       pass = !(lhs > rhs + 1e-5 * ((double)nx + fabs(cq) + 1.0));
-      // first-seen rule (label[], motif_both_points.cpp:233), which does not depend on the distance:
-      // a pair whose k-mer sits in the probed bucket of an EARLIER table is never reported here
-      if (pass && l) {
-        const uint32_t id = tabs.t[l].ids[pos];
-        bool dup = false;
-        for (uint32_t l2 = 0; l2 < l; ++l2) {
-          const uint32_t p2 = tabs.t[l2].pos_of[id];
-          dup = dup || (p2 - qstart[q * (uint32_t)L + l2] < qcount[q * (uint32_t)L + l2]);
-        }
-        pass = !dup;
-      }
+      fs_q = q;
+      fs_l = (int)l;
+      if (pass && l) fs_id = tabs.t[l].ids[pos];
     }
+    // first-seen rule (label[], motif_both_points.cpp:233), which does not depend on the distance: a pair
+    // whose k-mer sits in the probed bucket of an EARLIER table is never reported here (the whole wave calls:
+    // the tables are looked at a few at a time, for the lanes that still need them)
+    if (__ballot(pass && fs_l > 0)) pass = pass && !seen_in_earlier_table(tabs, qstart, qcount, fs_q, fs_l, L, fs_id, pass);
     // block-level compaction: one access to the global counter per block and round (same-address
     // atomics deliver ~90 per microsecond: one per wave and round took longer than the arithmetic)
     if (pass) s_keep[atomicAdd(&s_n, 1u)] = make_uint2(ql, pos);
