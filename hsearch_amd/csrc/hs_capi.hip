@@ -125,7 +125,7 @@ struct hs_handle {
   uint32_t key_seed = 0;
   DevBuf codes, packed_all;
   DevBuf t_dirkey[HS_MAX_L], t_dirstart[HS_MAX_L], t_dirtuple[HS_MAX_L], t_ids[HS_MAX_L];
-  DevBuf t_dirjump[HS_MAX_L];
+  DevBuf t_dirjump;  // the jump tables of all directories, one allocation (a table's at its own offset)
   // bucket-ordered packed copies of all tables in ONE allocation ([L][n][PW]), and the int8 join's
   // per-entry records ([L][n], k <= 50 only) at the same entry numbers
   DevBuf t_packed, t_rec8;
@@ -402,7 +402,10 @@ hs_status hash_dispatch(hs_handle* h, const uint8_t* d_codes, const double* d_pt
 hs_status hash_account(hs_handle* h, uint64_t n, int F, int set) {
   if (!use_projection(h) || !n || n >= (1ull << 31)) return HS_OK;
   uint32_t c[2] = {0, 0};
-  HS_HIP(h, hipMemcpy(c, h->proj_cnt.as<uint32_t>() + 2 * set, 8, hipMemcpyDeviceToHost));
+  // (on the handle's stream, which the callers have just drained: a plain hipMemcpy goes through the
+  // process's default stream, whose first use cost 6.8 ms of a first build's 30)
+  HS_HIP(h, hipMemcpyAsync(c, h->proj_cnt.as<uint32_t>() + 2 * set, 8, hipMemcpyDeviceToHost, h->stream));
+  HS_HIP(h, hipStreamSynchronize(h->stream));
   h->prof.hash_values += n * (uint64_t)F;
   h->prof.hash_flagged += c[1];
   return HS_OK;
@@ -666,9 +669,9 @@ void hs_destroy(hs_handle* h) {
                     &h->bs_dk, &h->bs_hist, &h->bs_rank};
   for (DevBuf* bf : bufs) bf->release();
   h->sj_host.release();
+  h->t_dirjump.release();
   for (int l = 0; l < HS_MAX_L; ++l) {
     h->t_dirkey[l].release();
-    h->t_dirjump[l].release();
     h->t_dirstart[l].release();
     h->t_dirtuple[l].release();
     h->t_ids[l].release();
@@ -793,6 +796,41 @@ static hs_status cut_items(hs_handle* h, uint32_t nql, uint32_t jm, unsigned lon
   HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, items_ord, h->item_off.as<uint32_t>(), n1,
                                   h->stream));
   HS_HIP(h, hs_launch_item_split(h->item_off.as<uint32_t>(), res_pos, nql, h->seg_n.as<uint32_t>() + 2, h->stream));
+  return HS_OK;
+}
+
+// The allocations of a build whose sizes follow from n alone, made while the packing kernel (and the copy
+// of the codes before it) still runs: an allocation costs ~ 0.3 ms whatever its size, and a first build
+// makes two dozen of them -- with the GPU idle, they were 6.5 of its 30 ms at the C2 sizes.  build_tables
+// reserves the same buffers again (no-ops then).
+static hs_status reserve_build_buffers(hs_handle* h) {
+  const uint64_t n = h->n;
+  const int K = (int)h->p.K, L = (int)h->p.L, k = (int)h->p.k, PW = h->PW;
+  for (int i = 0; i < 2; ++i) {
+    HS_HIP(h, h->bs_ints2[i].reserve(std::max<size_t>(16, (size_t)n * K * 4)));
+    HS_HIP(h, h->bs_keys2[i].reserve(std::max<size_t>(16, (size_t)n * 8)));
+    HS_HIP(h, h->bs_iota2[i].reserve(std::max<size_t>(16, (size_t)n * 4)));
+  }
+  HS_HIP(h, h->bs_keys_sorted.reserve(std::max<size_t>(16, (size_t)n * 8)));
+  HS_HIP(h, h->bs_rle_unique.reserve(std::max<size_t>(16, (size_t)n * 8)));
+  HS_HIP(h, h->bs_rle_counts.reserve(std::max<size_t>(16, (size_t)n * 4)));
+  HS_HIP(h, h->bs_small.reserve(64));
+  HS_HIP(h, h->bs_sort_temp.reserve(std::max(std::max(hs_sort_pairs_u64_u32_temp(n), hs_rle_u64_temp(n)),
+                                             hs_scan_u32_temp(n + 1)) + 256));
+  const bool with_rec8 = h->join8_tables_ok && k <= 50;
+  HS_HIP(h, h->t_packed.reserve(((size_t)L * n + HS_JM_WAVE) * PW * 16));
+  if (with_rec8) HS_HIP(h, h->t_rec8.reserve(((size_t)L * n + HS_JM_WAVE) * 16));
+  if (with_rec8 && k <= 25 && !h->wide8) HS_HIP(h, h->t_rho.reserve(((size_t)L * n + HS_JM_WAVE + 4) * 4));
+  HS_HIP(h, h->t_pos.reserve(std::max<size_t>(16, (size_t)L * n * 4)));
+  for (int l = 0; l < L; ++l) HS_HIP(h, h->t_ids[l].reserve(std::max<size_t>(16, (size_t)n * 4)));
+  if (!h->knobs.build_sort && n && n < (1ull << 31)) {
+    const uint32_t C = hs_group_table_slots(n), n_blk = (C + 1023) / 1024, n_tiles = hs_rs_blocks(n);
+    HS_HIP(h, h->bs_fptab.reserve((size_t)C * 16));
+    HS_HIP(h, h->bs_blk.reserve(2 * ((size_t)n_blk + 2) * 4));
+    HS_HIP(h, h->bs_rank.reserve((size_t)n * 4));
+    HS_HIP(h, h->bs_hist.reserve(2 * (size_t)((size_t)256 * n_tiles + 64) * 4));
+    HS_HIP(h, h->bs_slow_q.reserve(((size_t)(1u << 16) + 1) * 4));
+  }
   return HS_OK;
 }
 
@@ -1095,25 +1133,33 @@ static hs_status finish_index(hs_handle* h) {
     base[h->p.L] = (uint32_t)acc;
     h->nb_total = (uint32_t)acc;
     HS_HIP(h, h->dir_base.reserve((HS_MAX_L + 1) * 4));
-    HS_HIP(h, hipMemcpy(h->dir_base.p, base, ((size_t)h->p.L + 1) * 4, hipMemcpyHostToDevice));
+    HS_HIP(h, hipMemcpyAsync(h->dir_base.p, base, ((size_t)h->p.L + 1) * 4, hipMemcpyHostToDevice, h->stream));
+    HS_HIP(h, hipStreamSynchronize(h->stream));  // (base[] is a local)
   }
-  // jump tables of the directories: the top J bits of a fingerprint (2^J >= number of buckets)
+  // jump tables of the directories: the top J bits of a fingerprint (2^J >= number of buckets); one
+  // allocation for all tables (an allocation costs ~ 0.5 ms, whatever its size)
+  size_t jump_words = 0, jump_at[HS_MAX_L];
+  for (uint32_t l = 0; l < h->p.L; ++l) {
+    const uint32_t J = (uint32_t)std::max(1, bit_width_u32((uint32_t)h->info.n_buckets[l]));
+    jump_at[l] = jump_words;
+    jump_words += ((size_t)1 << J) + 2;
+  }
+  HS_HIP(h, h->t_dirjump.reserve(jump_words * 4));
   for (uint32_t l = 0; l < h->p.L; ++l) {
     const uint32_t nb = (uint32_t)h->info.n_buckets[l];
     const uint32_t J = (uint32_t)std::max(1, bit_width_u32(nb));
     const uint32_t n_slots = 1u << J;
-    HS_HIP(h, h->t_dirjump[l].reserve(((size_t)n_slots + 2) * 4));
-    HS_HIP(h, hs_launch_dir_jump(h->t_dirkey[l].as<uint64_t>(), nb, 64 - J, n_slots,
-                                 h->t_dirjump[l].as<uint32_t>(), h->stream));
-    h->tabs.t[l].dir_jump = h->t_dirjump[l].as<uint32_t>();
+    uint32_t* const jump = h->t_dirjump.as<uint32_t>() + jump_at[l];
+    HS_HIP(h, hs_launch_dir_jump(h->t_dirkey[l].as<uint64_t>(), nb, 64 - J, n_slots, jump, h->stream));
+    h->tabs.t[l].dir_jump = jump;
     h->tabs.t[l].jump_shift = 64 - J;
   }
   HS_HIP(h, hipStreamSynchronize(h->stream));
   uint64_t bytes = h->codes.cap + h->packed_all.cap + h->t_packed.cap + h->t_rec8.cap + h->t_rec8w.cap + h->t_rho.cap +
                    h->t_pos.cap;
   for (uint32_t l = 0; l < h->p.L; ++l)
-    bytes += h->t_dirkey[l].cap + h->t_dirstart[l].cap + h->t_dirtuple[l].cap + h->t_ids[l].cap +
-             h->t_dirjump[l].cap;
+    bytes += h->t_dirkey[l].cap + h->t_dirstart[l].cap + h->t_dirtuple[l].cap + h->t_ids[l].cap;
+  bytes += h->t_dirjump.cap;
   h->info.device_bytes = bytes;
   h->built = true;
   return HS_OK;
@@ -1129,6 +1175,7 @@ static hs_status index_build_resident(hs_handle* h, uint64_t n) {
     HS_HIP(h, hipMemsetAsync(h->counters.p, 0, 256, h->stream));
     HS_HIP(h, hs_launch_pack(h->codes.as<uint8_t>(), n, k, h->alphabet, h->packed_all.as<uint4>(),
                              h->counters.as<uint32_t>(), h->stream));
+    HS_CHECK(reserve_build_buffers(h));  // (beside the copy of the codes and the packing kernel)
     uint32_t bad = 0;
     HS_HIP(h, hipMemcpyAsync(&bad, h->counters.p, 4, hipMemcpyDeviceToHost, h->stream));
     HS_HIP(h, hipStreamSynchronize(h->stream));
