@@ -80,13 +80,16 @@ def parse():
     ap.add_argument("--cpu-nq", type=int, default=200, help="query sample of the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify-mode", choices=["auto", "stream", "join", "join16"], default="auto")
-    ap.add_argument("--cpu-ref-n", type=int, default=200_000,
-                    help="DB sample on which the compiled reference (oracle/_ref) is timed beside the port")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the second block (configs[2]'s per-GPU shape: 10^8 25-mers, L=32, K=20)")
     ap.add_argument("--secondary-W", type=float, default=160.0,
                     help="W of the secondary block: profiles/r02_recall_sweep_c3_shape.json picks 152..160")
     ap.add_argument("--secondary-steps", type=int, default=8)
+    ap.add_argument("--secondary-queries", type=int, default=1_000_000,
+                    help="queries of the secondary block in all (sharded over the ranks)")
+    ap.add_argument("--general-steps", type=int, default=5,
+                    help="steps of the `general_centres` measurement (centres that are not k-mers; 0: skip)")
+    ap.add_argument("--general-jitter", type=float, default=0.05)
     ap.add_argument("--pcie-steps", type=int, default=5,
                     help="steps of the PCIe-inclusive measurement of hs_query / hs_query_codes (0: skip)")
     return ap.parse_args()
@@ -120,12 +123,15 @@ def synth_seed_planes():
 
 
 def cpu_baseline(args, a, b, codes, centers):
-    """Reference CPU path on a bounded sample: the first cpu_n DB k-mers (10^6 by default: ~20 s of
-    build + ~6 s of queries on one core), the first cpu_nq queries, same planes.  `value` is the
-    rate MEASURED at that N.  Bucket populations (hence candidates per query) are linear in N, so
-    value x cpu_n / N is an UPPER estimate of the CPU rate at the bench's N (the per-candidate cost
-    grows once the vectors fall out of cache: 417 q/s at N=2*10^5 predicted 83 q/s at 10^6, where
-    35-40 q/s are measured); it is reported as value_scaled_to_bench_n, never as value."""
+    """The reference's CPU path on a bounded sample of the bench workload: the first cpu_n DB k-mers (10^6),
+    the first cpu_nq queries (200), one thread (the reference has no threads).
+    kind "reference": oracle/_ref = the reference's own Search() compiled from its sources where they lie
+    (oracle/Makefile), phases timed from outside (oracle/ref_search_harness.cpp ref_search_timed); its LSH
+    constructor draws its own planes (same distributions).  The restatement (oracle/hs_oracle.cpp, "port",
+    pinned bit-exact to it) is timed beside it on the same sample with the bench's planes, and is `value`
+    only where oracle/_ref has not been built.  `value` is the rate MEASURED at the sample's N; bucket
+    populations are linear in N, so value x cpu_n / N is an UPPER estimate at the bench's N (the cost per
+    candidate grows once the vectors fall out of cache): value_scaled_to_bench_n, never `value`."""
     from oracle import pyoracle as O
     n_s = min(args.cpu_n, codes.shape[0])
     q_s = min(args.cpu_nq, centers.shape[0])
@@ -138,72 +144,47 @@ def cpu_baseline(args, a, b, codes, centers):
     res = ix.query(cq, args.R)               # Search() query loop, :224-245
     t_query = time.perf_counter() - t0
     # EXTENSION: the same query loop over every host core of the box (the reference is
-    # single-threaded; `value` stays the single-thread rate).  More queries so that each thread has some.
+    # single-threaded; `value` stays the single-thread rate).
     n_thr = max(1, len(os.sched_getaffinity(0)))
-    q_mt = min(centers.shape[0], max(q_s, 32 * n_thr))
+    q_mt = min(centers.shape[0], max(q_s, 6 * n_thr))
     t0 = time.perf_counter()
     res_mt = ix.query_mt(centers[:q_mt], args.R, n_thr)
     t_mt = time.perf_counter() - t0
     ix.close()
-    qps_sample = q_s / t_query
-    out = {
-        "value": qps_sample,
-        "unit": "queries/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": ("oracle/hs_oracle.cpp (restatement with the reference's cost structure, pinned "
-                   "bit-exact to the compiled reference) on the first %d DB k-mers and first %d "
-                   "queries of the bench workload, same planes, one thread: %.1f queries/s MEASURED "
-                   "at N=%d (value); index build %.0f k-mers/s; %.1f s of CPU work"
-                   % (n_s, q_s, qps_sample, n_s, n_s / t_build, t_build + t_query)),
-        "measured_qps_at_sample": qps_sample,
-        "value_scaled_to_bench_n": qps_sample * n_s / codes.shape[0],
-        "scaling_note": "value x sample_n / bench N: upper estimate (candidates per query are linear "
-                        "in N, the cost per candidate grows with N)",
-        "sample_n": n_s, "sample_nq": q_s,
-        "build_kmers_per_s": n_s / t_build,
-        "sample_hits": int(len(res["q"])),
-        "sample_seconds": t_build + t_query,
-        "all_cores_extension": {
-            "what": "the same query loop (oracle hso_index_query_mt) over all host threads of the box; not "
-                    "something the single-threaded reference does; the index build stays single-threaded",
-            "threads": n_thr, "sample_nq": int(q_mt), "measured_qps_at_sample": q_mt / t_mt,
-            "value_scaled_to_bench_n": q_mt / t_mt * n_s / codes.shape[0],
-            "hits": int(len(res_mt["q"])), "seconds": t_mt},
-    }
-    if O.have_ref() and args.cpu_ref_n > 0:
-        # the real compiled reference (oracle/_ref) on a smaller sample (its Search() is monolithic:
-        # two full builds per measurement), with the port timed on the same sample beside it.
-        n_r = min(args.cpu_ref_n, n_s)
-        db = db[:n_r]
-        t = time.perf_counter()
-        ixr = O.Index(a, b, args.W, db)
-        tbp = time.perf_counter() - t
-        t = time.perf_counter()
-        ixr.query(cq, args.R)
-        tqp = time.perf_counter() - t
-        ixr.close()
-        # the real compiled reference (oracle/_ref) on that sample.  Its Search() draws its own
-        # planes (same distributions, seeded through the harness) and is monolithic, so it is timed
-        # with zero centers (build only) and with the sample queries, and the difference is the
-        # query loop.  Reported beside the port, which runs the bench's exact planes.
-        import tempfile
-        fd, path = tempfile.mkstemp()
-        os.close(fd)
-        t = time.perf_counter()
-        O.ref_search(synth_seed_planes(), db, cq[:0], args.K, args.L, args.W, args.R, path)
-        tb = time.perf_counter() - t
-        t = time.perf_counter()
-        O.ref_search(synth_seed_planes(), db, cq, args.K, args.L, args.W, args.R, path)
-        tf = time.perf_counter() - t
-        os.unlink(path)
-        tq = max(tf - tb, 1e-9)
-        out["reference_check"] = {
-            "what": "oracle/_ref: the reference's own Search() compiled from its sources, same "
-                    "sample, planes drawn by its own LSH constructor",
-            "sample_n": n_r, "sample_nq": q_s,
-            "measured_qps_at_sample": q_s / tq, "build_kmers_per_s": n_r / tb,
-            "port_qps_same_sample": q_s / tqp, "port_build_kmers_per_s": n_r / tbp}
+    port = {"what": "oracle/hs_oracle.cpp: restatement with the reference's cost structure, pinned bit-exact to the "
+                    "compiled reference; the bench's planes",
+            "queries_per_s": q_s / t_query, "build_kmers_per_s": n_s / t_build, "hits": int(len(res["q"])),
+            "seconds": t_build + t_query}
+    out = {"value": port["queries_per_s"], "unit": "queries/s", "cores": 1, "kind": "port",
+           "sample_n": n_s, "sample_nq": q_s, "build_kmers_per_s": port["build_kmers_per_s"],
+           "sample_seconds": port["seconds"], "port": port}
+    if O.have_ref():
+        seed = synth_seed_planes()
+        tb0, tr0, _ = O.ref_search_timed(seed, db, cq[:0], args.K, args.L, args.W, args.R)
+        tb1, tr1, nh = O.ref_search_timed(seed, db, cq, args.K, args.L, args.W, args.R)
+        tq = max(tr1 - tr0, 1e-9)     # query loop = (query loop + table destruction) - (table destruction alone)
+        out.update({"value": q_s / tq, "kind": "reference", "build_kmers_per_s": n_s / tb1,
+                    "sample_seconds": tb0 + tr0 + tb1 + tr1,
+                    "reference": {"what": "oracle/_ref/libref_search.so: Search() of motif_both_points.cpp:195-250 "
+                                          "compiled from the reference's sources; planes drawn by its own LSH "
+                                          "constructor (seeded); build loop and query loop timed from outside",
+                                  "queries_per_s": q_s / tq, "build_kmers_per_s": n_s / tb1, "hits": nh,
+                                  "seconds_build": [tb0, tb1], "seconds_after_build": [tr0, tr1]}})
+    out["sample"] = ("%s on the first %d DB k-mers and first %d queries of the bench workload, one thread: %.1f "
+                     "queries/s MEASURED at N=%d (value); index build %.0f k-mers/s; %.1f s of CPU work"
+                     % ("oracle/_ref (the reference's own Search(), compiled)" if out["kind"] == "reference"
+                        else "oracle/hs_oracle.cpp (pinned restatement)", n_s, q_s, out["value"], n_s,
+                        out["build_kmers_per_s"], out["sample_seconds"]))
+    out["measured_qps_at_sample"] = out["value"]
+    out["value_scaled_to_bench_n"] = out["value"] * n_s / codes.shape[0]
+    out["scaling_note"] = ("value x sample_n / bench N: upper estimate (candidates per query are linear in N, the "
+                           "cost per candidate grows with N)")
+    out["all_cores_extension"] = {
+        "what": "the restatement's query loop (oracle hso_index_query_mt) over all host threads of the box; not "
+                "something the single-threaded reference does; the index build stays single-threaded",
+        "threads": n_thr, "sample_nq": int(q_mt), "measured_qps_at_sample": q_mt / t_mt,
+        "value_scaled_to_bench_n": q_mt / t_mt * n_s / codes.shape[0],
+        "hits": int(len(res_mt["q"])), "seconds": t_mt}
     return out
 
 
@@ -255,16 +236,33 @@ class Workload:
         k, K, L, W = args.k, args.K, args.L, args.W
         self.a, self.b = synth.make_planes(k, K, L, W)
         self.codes = synth.make_db(args.n, k)
-        self.qcodes, self.src = synth.make_query_codes(self.codes, args.nq, seed=synth.SEED_QUERIES + 1000 * rank)
-        self.centers = synth.embed(self.qcodes)
+        self.synth = synth
         self.eng = Engine(k, K, L, W, self.a, self.b, device=dev_index)
         self.eng.set_verify_mode(args.verify_mode)
         t0 = time.perf_counter()
         self.info = self.eng.index_build(self.codes)
         self.t_build = time.perf_counter() - t0
         self.build_prof = self.eng.profile()
-        self.d_centers = torch.from_numpy(self.centers).to(dev)
-        self.cap = 16 * args.nq + 4096
+        self.q_offset = rank * args.nq
+        self.set_queries(args.nq, synth.SEED_QUERIES + 1000 * rank)
+
+    def set_queries(self, nq, seed, jitter=0.0, q_offset=None):
+        """The rank's resident query batch: nq DB k-mers with 0..4 substitutions, embedded exactly from the
+        table (jitter > 0: Gaussian noise on every coordinate, so that no centre is a k-mer any more)."""
+        synth, torch = self.synth, self.torch
+        self.args = argparse.Namespace(**vars(self.args))
+        self.args.nq = nq
+        if q_offset is not None:
+            self.q_offset = q_offset
+        self.qcodes, self.src = synth.make_query_codes(self.codes, nq, seed=seed)
+        self.centers = synth.embed(self.qcodes)
+        if jitter:
+            self.centers = self.centers + np.random.Generator(np.random.MT19937(seed + 1)).normal(
+                0.0, jitter, size=self.centers.shape)
+        self.d_centers = None
+        self.out = None
+        self.d_centers = torch.from_numpy(np.ascontiguousarray(self.centers)).to(self.dev)
+        self.cap = 16 * nq + 4096
         self.out = self.alloc(self.cap)
 
     def alloc(self, c):
@@ -286,7 +284,7 @@ class Workload:
                     raise
                 self.cap = int(e.needed * 1.25) + 1024
                 self.out = self.alloc(self.cap)
-        gathered = hdist.allgather_hits(o["q"], o["id"], o["table"], o["dist"], nh, q_offset=self.rank * args.nq,
+        gathered = hdist.allgather_hits(o["q"], o["id"], o["table"], o["dist"], nh, q_offset=self.q_offset,
                                         force=use_dist)
         return nh, gathered
 
@@ -446,19 +444,112 @@ class Workload:
         self.out = None
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` typed without a launcher: start one rank per GPU through
+    torch.distributed.run as a CHILD process (this parent has touched neither torch nor HIP), relay rank 0's
+    JSON line and the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def secondary_block(args, world, rank, dev_index, dev, synth, Engine, torch, hdist, HsError, use_dist, fence, dist,
+                    backend):
+    """BASELINE.json configs[2] -- the north star's own target: 10^8 25-mers, L = 32, K = 20, 10^6 queries in
+    all -- as a STRONG-scaling job: the 10^6 queries are sharded over the ranks (10^6 / world per rank, one
+    batch), the index is replicated; value = 10^6 / the slowest rank's time per pass.  At one rank the block
+    also times 125 000 queries per pass: the share of one GPU of eight, the figure earlier rounds reported."""
+    total_q = args.secondary_queries
+    lo, hi = hdist.shard_bounds(total_q, rank, world)
+    a2 = argparse.Namespace(**vars(args))
+    a2.n, a2.L, a2.K, a2.W, a2.nq = 100_000_000, 32, 20, args.secondary_W, hi - lo
+    t0 = time.perf_counter()
+    w2 = Workload(a2, dev_index, dev, rank, synth, Engine, torch, workload_label(a2))
+    w2.q_offset = lo
+    steps = max(args.secondary_steps, 1)
+    m2 = w2.timed(steps, 2, hdist, HsError, use_dist, fence, dist, backend)
+    sec = None
+    if rank == 0:
+        sec = {"what": "BASELINE.json configs[2] (the north-star target: 100M x 25-mers, L=32, K=20, 10^6 queries), "
+                       "strong scaling: the queries sharded over the ranks in contiguous blocks, one batch per rank "
+                       "and pass, index replicated per GPU; W from profiles/r02_recall_sweep_c3_shape.json",
+               "config": {"workload": "configs[2]: 100000000 x 25-mers, L=32 K=20 W=%g R=%g, %d queries in all"
+                                      % (a2.W, a2.R, total_q),
+                          "db_kmers": a2.n, "k": a2.k, "L": a2.L, "K": a2.K, "W": a2.W, "R": a2.R,
+                          "queries_total": total_q, "queries_per_gpu": a2.nq,
+                          "parallelism": "query-sharded x%d (10^6 queries / %d ranks), index replicated" % (world, world)},
+               "value": total_q * steps / m2["dt"], "unit": "queries/s", "n_gpus": world, "scaling": "strong",
+               "steps": steps, "warmup": 2, "ms_per_step": m2["dt"] / steps * 1e3,
+               "roofline": w2.roofline(m2, steps, *secondary_traffic(a2, world)),
+               "phases_ms_per_step": {"hash_queries": m2["hash_ms"] / steps, "probe_segments": m2["probe_ms"] / steps,
+                                      "verify": m2["verify_ms"] / steps, "finalize_sort": m2["fin_ms"] / steps},
+               "candidates_per_query": m2["cand"] / a2.nq, "hits_per_step_rank0": m2["hits_local"],
+               "hits_gathered": m2["total_hits"],
+               "index": w2.index_block()}
+        nr2 = min(args.recall_queries, a2.nq)
+        if nr2 > 0:
+            sec.update(w2.recall(nr2))
+    if world == 1 and total_q > 125_000:
+        # one GPU's share when eight hold the replicated index (what BENCH_r02 / r03 carried as `secondary`)
+        w2.set_queries(125_000, synth.SEED_QUERIES, q_offset=0)
+        m3 = w2.timed(steps, 2, hdist, HsError, use_dist, fence, dist, backend)
+        sec["one_gpu_share_of_eight"] = {
+            "what": "the same index, 125 000 queries per pass: the per-GPU work of the 8-GPU job",
+            "queries_per_gpu": 125_000, "value": 125_000 * steps / m3["dt"], "unit": "queries/s",
+            "ms_per_step": m3["dt"] / steps * 1e3, "roofline": w2.roofline(m3, steps),
+            "phases_ms_per_step": {"hash_queries": m3["hash_ms"] / steps, "probe_segments": m3["probe_ms"] / steps,
+                                   "verify": m3["verify_ms"] / steps, "finalize_sort": m3["fin_ms"] / steps},
+            "candidates_per_query": m3["cand"] / 125_000}
+    if rank == 0:
+        sec["wall_seconds_of_this_block"] = time.perf_counter() - t0
+    w2.close()
+    del w2
+    return sec
+
+
+def secondary_traffic(a2, world):
+    """HBM bytes per launch of the secondary block's dominant kernel from the PMC passes of
+    tools/pmc_secondary.sh (profiles/traffic_secondary.json), while its recorded kernel source hash and
+    shape are this run's."""
+    tpath = os.path.join(ROOT, "profiles", "traffic_secondary.json")
+    if not os.path.exists(tpath):
+        return None, None
+    try:
+        tj = json.load(open(tpath))
+    except Exception:
+        return None, None
+    same = (tj.get("kernel_source_hash") == kernel_source_hash() and tj.get("queries_per_gpu") == a2.nq and
+            tj.get("W") == a2.W)
+    if not same:
+        return None, {"file": "profiles/traffic_secondary.json", "stale": True,
+                      "recorded_hash": tj.get("kernel_source_hash"), "current_hash": kernel_source_hash(),
+                      "recorded_queries_per_gpu": tj.get("queries_per_gpu")}
+    return tj.get("verify_bytes_per_launch"), {"file": "profiles/traffic_secondary.json",
+                                               "kernel_source_hash": tj.get("kernel_source_hash"),
+                                               "taken": tj.get("taken"), "kernels": tj.get("kernels")}
+
+
 def main():
     args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))          # (before anything touches torch or the GPU)
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # stdout carries ONE line, the JSON result: libraries that print there (RCCL announces its
     # version on stdout when the first communicator is created) are sent to stderr for the whole run
     sys.stdout.flush()
     result_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     import torch
     import torch.distributed as dist
     from hsearch_amd import Engine, HsError, synth
@@ -479,6 +570,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    n_ranks_seen = dist.get_world_size() if use_dist else 1
 
     def fence():
         if use_dist:
@@ -520,6 +612,7 @@ def main():
             "value": world * args.nq * steps / m["dt"], "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": m["dt"] / steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "n_ranks_seen": n_ranks_seen,
             "config": {"workload": wl.label,
                        "db_kmers": args.n, "k": k, "L": L, "K": K, "W": W, "R": R,
                        "queries_per_gpu": args.nq, "parallelism": "query-sharded x%d" % world},
@@ -531,7 +624,8 @@ def main():
             "hits_gathered": m["total_hits"],
             # the synthetic centres are k-mers' points, as the reference's centres files hold: hs_query_dev finds
             # that out per call (one pass over the [nq][8k] doubles, inside the timed step) and then works from
-            # the residue codes it read off them; HS_NO_RECOGNISE=1 keeps the points path
+            # the residue codes it read off them; `general_centres` below is the same step for centres that are
+            # NOT k-mers (the points path)
             "queries_recognised_as_kmers_per_step": m["recognised"] / steps,
             "index": index,
         }
@@ -553,53 +647,42 @@ def main():
             line["value_pcie_inclusive"] = wl.pcie_inclusive(args.pcie_steps)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, wl.a, wl.b, wl.codes, wl.centers)
+    if world == 1 and args.general_steps > 0:
+        # centres that are NOT k-mers (the reference's real centres are family centroids,
+        # centerDistanceSmapling.cpp:67-78): the same queries with Gaussian noise on every coordinate, so that
+        # hs_query_dev recognises nothing and every per-query quantity comes from the point rows
+        wl.set_queries(args.nq, synth.SEED_QUERIES + 1000 * rank, jitter=args.general_jitter)
+        mg = wl.timed(args.general_steps, 2, hdist, HsError, use_dist, fence, dist, backend)
+        gs = max(args.general_steps, 1)
+        line["general_centres"] = {
+            "what": "the primary workload's queries + N(0, %g^2) noise per coordinate: no centre is a k-mer, the "
+                    "points path (hs_quant_points / hs_qprep8 / hs_finalize_kernel) runs" % args.general_jitter,
+            "value": args.nq * gs / mg["dt"], "unit": "queries/s", "steps": args.general_steps,
+            "ms_per_step": mg["dt"] / gs * 1e3, "queries_recognised_as_kmers_per_step": mg["recognised"] / gs,
+            "hits_per_step": mg["hits_local"],
+            "phases_ms_per_step": {"hash_queries": mg["hash_ms"] / gs, "probe_segments": mg["probe_ms"] / gs,
+                                   "verify": mg["verify_ms"] / gs, "finalize_sort": mg["fin_ms"] / gs}}
     wl.close()
     del wl
 
-    # ---- the north star's own target as a second block of the same line: BASELINE.json configs[2]'s
-    # per-GPU share (10^8 25-mers, L = 32, K = 20, 10^6 / 8 queries per GPU) at the W its recall sweep
-    # picks (profiles/r02_recall_sweep_c3_shape.json: the smallest W with radius recall >= 0.9 is
-    # 152..160), index replicated per GPU, same timing protocol (fences, max over ranks).  Run when the
-    # primary line is the default workload and the GPU has the room (index: 135 GB).
+    # ---- the north star's own target as a second block of the same line (secondary_block).  Run when the
+    # primary line is the default workload and every rank's GPU has the room (index: 157 GB).
     want_secondary = (not args.no_secondary and args.verify_mode == "auto" and
                       (args.n, args.k, args.K, args.L) == (10_000_000, 25, 16, 8))
     if want_secondary:
         torch.cuda.empty_cache()
         free_b, _total_b = torch.cuda.mem_get_info(dev_index)
-        ok = torch.tensor([1 if free_b >= 150 * (1 << 30) else 0], dtype=torch.int32,
+        ok = torch.tensor([1 if free_b >= 190 * (1 << 30) else 0], dtype=torch.int32,
                           device=dev if (use_dist and backend == "nccl") else "cpu")
         if use_dist:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank or none
         if int(ok.item()):
-            a2 = argparse.Namespace(**vars(args))
-            a2.n, a2.L, a2.K, a2.W, a2.nq = 100_000_000, 32, 20, args.secondary_W, 125_000
-            t0 = time.perf_counter()
-            w2 = Workload(a2, dev_index, dev, rank, synth, Engine, torch, workload_label(a2))
-            m2 = w2.timed(args.secondary_steps, 2, hdist, HsError, use_dist, fence, dist, backend)
+            sec = secondary_block(args, world, rank, dev_index, dev, synth, Engine, torch, hdist, HsError, use_dist,
+                                  fence, dist, backend)
             if rank == 0:
-                s2 = max(args.secondary_steps, 1)
-                sec = {"what": "BASELINE.json configs[2] (the north-star target: 100M x 25-mers, L=32, K=20), one "
-                               "GPU's share of the 10^6 queries per GPU, index replicated; W from "
-                               "profiles/r02_recall_sweep_c3_shape.json",
-                       "config": {"workload": w2.label, "db_kmers": a2.n, "k": a2.k, "L": a2.L, "K": a2.K,
-                                  "W": a2.W, "R": a2.R, "queries_per_gpu": a2.nq,
-                                  "parallelism": "query-sharded x%d" % world},
-                       "value": world * a2.nq * s2 / m2["dt"], "unit": "queries/s", "n_gpus": world,
-                       "steps": args.secondary_steps, "warmup": 2, "ms_per_step": m2["dt"] / s2 * 1e3,
-                       "roofline": w2.roofline(m2, args.secondary_steps),
-                       "phases_ms_per_step": {"hash_queries": m2["hash_ms"] / s2, "probe_segments": m2["probe_ms"] / s2,
-                                              "verify": m2["verify_ms"] / s2, "finalize_sort": m2["fin_ms"] / s2},
-                       "candidates_per_query": m2["cand"] / a2.nq, "hits_per_step_rank0": m2["hits_local"],
-                       "index": w2.index_block()}
-                nr2 = min(args.recall_queries, a2.nq)
-                if nr2 > 0:
-                    sec.update(w2.recall(nr2))
-                sec["wall_seconds_of_this_block"] = time.perf_counter() - t0
                 line["secondary"] = sec
-            w2.close()
-            del w2
         elif rank == 0:
-            line["secondary"] = {"skipped": "less than 150 GB of HBM free on a rank (%.0f GB here)" % (free_b / 2**30)}
+            line["secondary"] = {"skipped": "less than 190 GB of HBM free on a rank (%.0f GB here)" % (free_b / 2**30)}
     if rank == 0:
         print(json.dumps(line), file=result_out, flush=True)
     if use_dist:

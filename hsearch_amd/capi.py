@@ -15,7 +15,7 @@ _STATUS = ["HS_OK", "HS_ERR_INVALID", "HS_ERR_NO_DEVICE", "HS_ERR_HIP", "HS_ERR_
 _ALPHABET = "ARNDCQEGHILKMFPSTWYV"
 
 EXPORTS = ["hs_create", "hs_destroy", "hs_last_error", "hs_get_profile", "hs_get_params", "hs_version",
-           "hs_set_verify_mode", "hs_set_hash_mode", "hs_set_planes", "hs_self_join", "hs_self_join_range", "hs_clustering",
+           "hs_set_verify_mode", "hs_set_hash_mode", "hs_set_option", "hs_wait_event", "hs_set_planes", "hs_self_join", "hs_self_join_range", "hs_clustering",
            "hs_clustering_begin", "hs_clustering_table_edges", "hs_clustering_table_apply",
            "hs_clustering_end",
            "hs_embed_codes", "hs_hash_codes", "hs_hash_points", "hs_key_string", "hs_key_fingerprint",
@@ -225,6 +225,18 @@ class Engine:
         """'auto' | 'exact' | 'mfma' -- how the bucket ints are evaluated (identical results)."""
         self._check(self._lib.hs_set_hash_mode(self._h, {"auto": 0, "exact": 1, "mfma": 2}[mode],
                                                C.c_double(eps_scale)))
+
+    OPTIONS = {"query_batch": 1, "seg_mode": 2, "join_resident": 3, "recognise_kmers": 4, "build_grouping": 5,
+               "wide_rows": 6, "refine8": 7, "self_codes": 8, "thin_filter": 9, "sort_hits": 10, "sync_items": 11,
+               "join_min_q": 12, "join_min_m": 13, "sort_from_bit": 14, "build_serial": 15, "short_segments": 16}
+
+    def set_option(self, name, value):
+        """hs_set_option (include/hsearch.h hs_option): path selection / batch sizing; never changes a result."""
+        self._check(self._lib.hs_set_option(self._h, C.c_int(self.OPTIONS[name]), C.c_int64(int(value))))
+
+    def wait_event(self, event_handle):
+        """hs_wait_event: the library's stream waits for a hipEvent_t (int handle, e.g. torch.cuda.Event.cuda_event)."""
+        self._check(self._lib.hs_wait_event(self._h, C.c_void_p(event_handle)))
 
     def set_planes(self, a, b):
         """A new hash family of the same shape for this handle (hs_set_planes); drops the index."""

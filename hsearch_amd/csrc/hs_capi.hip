@@ -98,6 +98,7 @@ struct Knobs {
   int seg_mode = 0;                // HS_SEG_MODE=sparse|dense: 1 / 2; 0 = by the bucket : probe ratio
   int sort_from_bit = 16;          // HS_SORT_FROM_BIT: lowest fingerprint bit the build's sort looks at
   uint32_t query_batch = 0;        // HS_QUERY_BATCH: queries per batch (0: by L)
+  uint32_t short_segments = 4;     // HS_OPT_SHORT_SEGMENTS: segments of <= this many queries skip the MFMA join
 #ifdef HS_TEST_HOOKS
   uint32_t test_split_above = 0;   // HS_TEST_SPLIT_ABOVE: batches above this size report a survivor overflow
   bool test_group_fallback = false;  // HS_TEST_GROUP_FALLBACK: the build's fingerprint table reports itself full
@@ -191,6 +192,7 @@ struct hs_handle {
   // class's items cost in the streaming kernel) the next batch runs everything through the streaming kernel
   double resident_share = -1.0;
   uint32_t resident_age = 0;     // joined batches since it was measured (measured again every 64)
+  uint32_t resident_nq = 0;      // ... on a batch of this many queries (a batch half / twice that size measures anew)
   int join_blocks_per_cu = 2;                // resident workgroups of hs_join_kernel per CU
   DevBuf jtab, c16, seg_keys, seg_keys_sorted, seg_vals, sorted_ql, seg_key, seg_cnt, seg_qoff,
       seg_items, item_off, seg_n;
@@ -258,6 +260,7 @@ void drop_index(hs_handle* h) {
   h->pairs_per_item = 0.0;
   h->resident_share = -1.0;
   h->resident_age = 0;
+  h->resident_nq = 0;
 }
 
 hs_status ensure_device(hs_handle* h) {
@@ -645,6 +648,71 @@ hs_status hs_set_hash_mode(hs_handle* h, int mode, double eps_scale) {
 hs_status hs_set_verify_mode(hs_handle* h, int mode) {
   if (!h || mode < 0 || mode > 3) return HS_ERR_INVALID;
   h->verify_mode = mode;
+  return HS_OK;
+}
+
+hs_status hs_set_option(hs_handle* h, int option, int64_t value) {
+  if (!h) return HS_ERR_INVALID;
+  Knobs& kn = h->knobs;
+  auto flag = [&](bool* dst, bool invert) -> hs_status {
+    if (value != 0 && value != 1) return fail(h, HS_ERR_INVALID, "hs_set_option: the option takes 0 or 1");
+    *dst = invert ? value == 0 : value == 1;
+    return HS_OK;
+  };
+  switch (option) {
+    case HS_OPT_QUERY_BATCH:
+      if (value < 0 || value >= (1ll << 27)) break;
+      kn.query_batch = (uint32_t)value;
+      return HS_OK;
+    case HS_OPT_SEG_MODE:
+      if (value < 0 || value > 2) break;
+      kn.seg_mode = (int)value;
+      return HS_OK;
+    case HS_OPT_JOIN_RESIDENT:
+      if (value < 0 || value > 2) break;
+      kn.no_join_r = value == 1;
+      kn.force_join_r = value == 2;
+      return HS_OK;
+    case HS_OPT_RECOGNISE_KMERS: return flag(&kn.no_recognise, true);
+    case HS_OPT_BUILD_GROUPING: return flag(&kn.build_sort, false);
+    case HS_OPT_WIDE_ROWS:
+      if (value < 0 || value > 2) break;
+      kn.force_wide = value == 1;
+      kn.no_wide_by_radius = value == 2;
+      return HS_OK;
+    case HS_OPT_REFINE8: return flag(&kn.no_refine8, true);
+    case HS_OPT_SELF_CODES: return flag(&kn.no_self_codes, true);
+    case HS_OPT_THIN_FILTER: return flag(&kn.no_thin8, true);
+    case HS_OPT_SORT_HITS: return flag(&kn.sort_hits, false);
+    case HS_OPT_SYNC_ITEMS: return flag(&kn.sync_items, false);
+    case HS_OPT_JOIN_MIN_Q:
+      if (value < 1 || value > (1ll << 30)) break;
+      h->join_min_q = (uint32_t)value;
+      return HS_OK;
+    case HS_OPT_JOIN_MIN_M:
+      if (value < 1 || value > (1ll << 30)) break;
+      h->join_min_m = (uint32_t)value;
+      return HS_OK;
+    case HS_OPT_SORT_FROM_BIT:
+      if (value < 0 || value > 60) break;
+      kn.sort_from_bit = (int)value;
+      return HS_OK;
+    case HS_OPT_BUILD_SERIAL: return flag(&kn.build_serial, false);
+    case HS_OPT_SHORT_SEGMENTS:
+      if (value < 0 || value > 4) break;
+      kn.short_segments = (uint32_t)value;
+      return HS_OK;
+    default:
+      return fail(h, HS_ERR_INVALID, "hs_set_option: unknown option");
+  }
+  return fail(h, HS_ERR_INVALID, "hs_set_option: value out of range");
+}
+
+hs_status hs_wait_event(hs_handle* h, void* hip_event) {
+  if (!h || !hip_event) return HS_ERR_INVALID;
+  hs_status st = ensure_device(h);
+  if (st) return st;
+  HS_HIP(h, hipStreamWaitEvent(h->stream, reinterpret_cast<hipEvent_t>(hip_event), 0));
   return HS_OK;
 }
 
@@ -2131,6 +2199,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
     jm = use_i8 ? hs_join8_members_per_item(k, wide) : HS_JM_BLOCK;
     // k <= 25 with 4-column rows: segments probed by at most HS_JR_MAXQ queries of the batch go to the
     // query-resident kernel (hs_join8r_kernel), as the tail of the item list
+    if (h->resident_nq && (nq > 2 * h->resident_nq || 2 * nq < h->resident_nq)) h->resident_share = -1.0;
     use_r = use_i8 && !wide && k <= 25 && h->alphabet <= HS_JR_MAX_ALPHABET && !h->knobs.no_join_r &&
             (h->knobs.force_join_r || h->resident_share < 0.0 || h->resident_share >= 0.5 || h->resident_age >= 64);
     HS_CHECK(cut_items(h, nql, jm, d_jstats, use_r ? HS_JR_MAXQ : 0u));
@@ -2445,6 +2514,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
   if (use_i8 && n_items) ++h->resident_age;
   if (use_i8 && n_items && use_r && h->pin_cnt[42]) {
     h->resident_age = 0;
+    h->resident_nq = nq;
     h->resident_share = (double)(h->pin_cnt[42] - h->pin_cnt[41]) / (double)h->pin_cnt[42];
     h->prof.join_items_resident += h->pin_cnt[42] - h->pin_cnt[41];
   }
@@ -2503,7 +2573,21 @@ static hs_status run_query(hs_handle* h, const double* d_centers, const uint8_t*
     // queries per batch: bounds the workspace, which grows with nq * L (2^17 at L >= 8; with few
     // tables -- the one-table indexes of Clustering() -- larger batches, fewer fixed costs)
     uint32_t QB = std::max(1u << 17, std::min(1u << 20, (1u << 20) / h->p.L));
-    if (h->knobs.query_batch) QB = h->knobs.query_batch;  // tests
+    if (nq > QB && !brute && !h->knobs.query_batch) {
+      // More queries than one such batch: as many per batch as a third of the free HBM carries, up to 2^20.
+      // The pairs of a batch are (bucket members) x (queries probing the bucket), so the join's operand reuse
+      // grows with the batch: at 10^8 k-mers x 32 tables a segment sees ~19 of 125 k queries, ~150 of 10^6.
+      // Workspace per query: L x (K + 5 + 18 + 4) words of probe / segment arrays, L x 416 B of gathered
+      // query rows + 32 B per work item (~ 1 per probe at worst), its own rows, 16 x 48 B of survivor lists.
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const size_t per_q = (size_t)h->p.L * (4 * ((size_t)h->p.K + 27) + 416 + 64) + 416 + 3 * (size_t)h->d + 768;
+        const size_t fit = free_b / 3 / per_q;
+        QB = (uint32_t)std::max<size_t>(QB, std::min<size_t>((size_t)1 << 20, fit));
+        QB = std::min(QB, (uint32_t)((1ull << 31) / h->p.L) - 1);  // probe numbers carry a flag in bit 31
+      }
+    }
+    if (h->knobs.query_batch) QB = h->knobs.query_batch;  // hs_set_option(HS_OPT_QUERY_BATCH) / HS_QUERY_BATCH
     uint32_t nqb = 0;
     for (uint64_t q0 = 0; q0 < nq; q0 += nqb) {
       nqb = (uint32_t)std::min<uint64_t>(QB, nq - q0);

@@ -99,6 +99,36 @@ def allgather_hits(q, ids, table, distance, n_hits, q_offset=0, group=None, forc
     return out[0], out[1], out[2], out[3]
 
 
+def table_shard_bounds(L, rank, world):
+    """Tables [lo, hi) held by `rank` when the L tables are partitioned over the ranks in contiguous blocks."""
+    return shard_bounds(L, rank, world)
+
+
+def merge_table_partitioned(q, ids, table, distance):
+    """The merge of the table-partitioned layout (every rank holds a block of the L tables over ALL k-mers and
+    answers ALL queries; `table` already in GLOBAL numbering).  The reference reports an id in the FIRST table
+    whose probed bucket holds it and never looks at it again (label[], motif_both_points.cpp:232-238), and
+    whether it is a hit does not depend on the table (the distance does not): so of the gathered tuples of one
+    (query, id) the one with the smallest table is the reference's line, the others are dropped, and the
+    result is ordered by (query, table, id) = the reference's file order.  int64 tensors (one device) in and
+    out; two sorts of 64-bit keys, no host round trip but the final size."""
+    if q.numel() == 0:
+        return q, ids, table, distance
+    q, ids, table = q.to(torch.int64), ids.to(torch.int64), table.to(torch.int64)
+    # (q, id, table) ascending: the first tuple of every (q, id) run carries the smallest table
+    key = (q << 37) | (ids << 5) | table          # q < 2^27 (hs_query's limit), id < 2^32 would need 38 bits:
+    assert int(ids.max()) < (1 << 32) and int(table.max()) < 32 and int(q.max()) < (1 << 26)
+    key, order = torch.sort(key)
+    pair = key >> 5
+    first = torch.ones_like(pair, dtype=torch.bool)
+    first[1:] = pair[1:] != pair[:-1]
+    keep = order[first]
+    q, ids, table, distance = q[keep], ids[keep], table[keep], distance[keep]
+    key2 = (q << 37) | (table << 32) | ids
+    order2 = torch.argsort(key2)
+    return q[order2], ids[order2], table[order2], distance[order2]
+
+
 def hits_to_numpy(q, ids, table, distance):
     return dict(q=q.cpu().numpy().astype(np.uint32), id=ids.cpu().numpy().astype(np.uint32),
                 table=table.cpu().numpy().astype(np.uint32), dist=distance.cpu().numpy())

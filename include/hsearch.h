@@ -140,6 +140,38 @@ HS_API hs_status hs_set_verify_mode(hs_handle* h, int mode);
  * bound (tests: more values take the recompute path); 1 is the proven bound.  The environment
  * variable HS_HASH_MODE=exact|mfma sets the default of new handles. */
 HS_API hs_status hs_set_hash_mode(hs_handle* h, int mode, double eps_scale);
+/* Path selection and batch sizing of a handle.  No option changes a result: each forces one of several
+ * equivalent paths (the tests run both and compare) or sizes a batch.  Unknown option / value out of range:
+ * HS_ERR_INVALID.  Options that shape the index (HS_OPT_BUILD_GROUPING) take effect at the next build. */
+typedef enum hs_option {
+  HS_OPT_QUERY_BATCH = 1,    /* queries per internal batch of a query call; 0 (default) = by L and free HBM */
+  HS_OPT_SEG_MODE = 2,       /* grouping of the probes by bucket: 0 by the bucket : probe ratio, 1 sort the
+                                probes, 2 counting sort over the bucket slots */
+  HS_OPT_JOIN_RESIDENT = 3,  /* segments with few probing queries through hs_join8r_kernel: 0 by their share of
+                                the previous batches' work items, 1 never, 2 always */
+  HS_OPT_RECOGNISE_KMERS = 4,/* 1 (default): centres that are rows of the coordinate table run from their residue
+                                codes; 0: always as points */
+  HS_OPT_BUILD_GROUPING = 5, /* 0 (default): exact-membership table + radix sort on bucket ranks; 1: radix sort of
+                                (fingerprint, id) pairs */
+  HS_OPT_WIDE_ROWS = 6,      /* int8 rows over all 8 coordinate columns for k = 21..25: 0 by radius, 1 always,
+                                2 never by radius */
+  HS_OPT_REFINE8 = 7,        /* 1 (default): survivors of the 4-column bound pass the 8-column bound first */
+  HS_OPT_SELF_CODES = 8,     /* 1 (default): the self-join runs from residue codes; 0: from embedded centres */
+  HS_OPT_THIN_FILTER = 9,    /* 1 (default): segments below HS_OPT_JOIN_MIN_Q / _M through the int8 per-pair filter;
+                                0: through the streaming filter */
+  HS_OPT_SORT_HITS = 10,     /* 1: order a batch's hits by a radix sort of the whole list, not per query */
+  HS_OPT_SYNC_ITEMS = 11,    /* 1: read the join's work-item count back before launching it */
+  HS_OPT_JOIN_MIN_Q = 12,    /* segments with fewer probing queries ... */
+  HS_OPT_JOIN_MIN_M = 13,    /* ... or fewer members skip the join (default 1 / 1: none do) */
+  HS_OPT_SORT_FROM_BIT = 14, /* HS_OPT_BUILD_GROUPING = 1: lowest fingerprint bit the first sort looks at (0..60) */
+  HS_OPT_BUILD_SERIAL = 15,  /* 1: no overlap of a table's hashing with the previous table's grouping */
+  HS_OPT_SHORT_SEGMENTS = 16 /* segments of at most this many probing queries (0..4, default 4) through the
+                                member-per-lane filter hs_few8_kernel instead of a 16-query MFMA tile */
+} hs_option;
+HS_API hs_status hs_set_option(hs_handle* h, int option, int64_t value);
+/* The library's work after this call starts only once `hip_event` (a hipEvent_t the caller has recorded on a
+ * stream of its own) has completed: the device-side alternative to draining that stream before a _dev call. */
+HS_API hs_status hs_wait_event(hs_handle* h, void* hip_event);
 HS_API const char* hs_version(void);
 
 /* ---- embedding + hashing (rows a2, a4, a5, a6) ----------------------------------------------- */

@@ -374,6 +374,27 @@ def ref_search(seed, db, centers, K, L, W, R, out_path=None):
     return res
 
 
+def ref_search_timed(seed, db, centers, K, L, W, R):
+    """The reference Search() with its two phases timed from outside (ref_search_harness.cpp
+    ref_search_timed): (seconds of the build loop, seconds from the end of the build loop to the return of
+    Search(), number of hits)."""
+    db, centers = _f64(db), _f64(centers)
+    fd, out_path = tempfile.mkstemp(suffix=".hits")
+    os.close(fd)
+    tb, tr = C.c_double(0.0), C.c_double(0.0)
+    rc = ref_search_lib().ref_search_timed(C.c_uint32(seed), C.c_uint32(db.shape[1]), _ptr(db, _dp),
+                                           C.c_uint64(db.shape[0]), _ptr(centers, _dp),
+                                           C.c_uint64(centers.shape[0]), C.c_uint32(K), C.c_uint32(L),
+                                           C.c_double(W), C.c_double(R), out_path.encode(), C.byref(tb),
+                                           C.byref(tr))
+    with open(out_path) as f:
+        n_hits = sum(1 for _ in f)
+    os.unlink(out_path)
+    if rc != 0:
+        raise RuntimeError("ref_search_timed: Search() did not flush once per table")
+    return tb.value, tr.value, n_hits
+
+
 def ref_pairwise_square(db, centers):
     db, centers = _f64(db), _f64(centers)
     out = np.empty((centers.shape[0], db.shape[0]))

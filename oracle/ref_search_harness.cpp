@@ -123,6 +123,51 @@ HS_REF_API int ref_search(uint32_t seed, uint32_t dim, const double* db, uint64_
   return 0;
 }
 
+// Search() once more, with the time at which its build loop ended.  The reference announces every finished
+// table on std::cout and ends the line with std::endl (motif_both_points.cpp:217), i.e. with a flush: a stream
+// buffer that notes the clock at every flush sees the moment the L-th table is done without touching the
+// function.  *t_build_s = entry of Search() .. that moment (the build loop, :206-218), *t_rest_s = that moment
+// .. return of Search() (the query loop :224-245, plus the destruction of the tables, which a call with zero
+// centres measures alone: bench.py subtracts it).
+#include <chrono>
+struct FlushClock : std::streambuf {
+  std::chrono::steady_clock::time_point last;
+  unsigned flushes = 0;
+  int overflow(int c) override { return c; }
+  int sync() override {
+    last = std::chrono::steady_clock::now();
+    ++flushes;
+    return 0;
+  }
+};
+HS_REF_API int ref_search_timed(uint32_t seed, uint32_t dim, const double* db, uint64_t n,
+                                const double* centers, uint64_t q, uint32_t K, uint32_t L, double W,
+                                double R, const char* out_path, double* t_build_s, double* t_rest_s) {
+  DIMENSION = dim;
+  KMERLENGTH = dim / AACoordinateSize;
+  std::vector<Point> kmers(n), cents(q);
+  std::vector<std::string> kn(n), cn(q);
+  for (uint64_t i = 0; i < n; ++i) {
+    kmers[i].data.assign(db + i * dim, db + (i + 1) * dim);
+    kn[i] = std::to_string(i);
+  }
+  for (uint64_t i = 0; i < q; ++i) {
+    cents[i].data.assign(centers + i * dim, centers + (i + 1) * dim);
+    cn[i] = std::to_string(i);
+  }
+  ref_seed_reset(seed);
+  FlushClock fc;
+  std::streambuf* old = std::cout.rdbuf(&fc);
+  const auto t0 = std::chrono::steady_clock::now();
+  Search(kmers, cents, kn, cn, K, L, W, R, std::string(out_path));
+  const auto t1 = std::chrono::steady_clock::now();
+  std::cout.rdbuf(old);
+  if (fc.flushes != L) return 1;  // not the print pattern this timing relies on
+  *t_build_s = std::chrono::duration<double>(fc.last - t0).count();
+  *t_rest_s = std::chrono::duration<double>(t1 - fc.last).count();
+  return 0;
+}
+
 // Same, but split into build and query so bench.py can time the two phases of the reference
 // separately.  The reference has no such split (tables are locals of Search()); this re-runs the
 // reference's own statements for each phase through its public pieces: LSH::HashKey for the build
