@@ -85,6 +85,11 @@ def parse():
     ap.add_argument("--secondary-W", type=float, default=160.0,
                     help="W of the secondary block: profiles/r02_recall_sweep_c3_shape.json picks 152..160")
     ap.add_argument("--secondary-steps", type=int, default=8)
+    ap.add_argument("--force-secondary", action="store_true", help="the secondary block whatever the primary workload")
+    ap.add_argument("--no-secondary-tables", action="store_true",
+                    help="N > 1: skip the table-partitioned form of the secondary block")
+    ap.add_argument("--secondary-db-size", type=int, default=100_000_000,
+                    help="DB k-mers of the secondary block (smaller: rehearsals of the multi-rank path on one GPU)")
     ap.add_argument("--secondary-queries", type=int, default=1_000_000,
                     help="queries of the secondary block in all (sharded over the ranks)")
     ap.add_argument("--general-steps", type=int, default=5,
@@ -469,7 +474,7 @@ def secondary_block(args, world, rank, dev_index, dev, synth, Engine, torch, hdi
     total_q = args.secondary_queries
     lo, hi = hdist.shard_bounds(total_q, rank, world)
     a2 = argparse.Namespace(**vars(args))
-    a2.n, a2.L, a2.K, a2.W, a2.nq = 100_000_000, 32, 20, args.secondary_W, hi - lo
+    a2.n, a2.L, a2.K, a2.W, a2.nq = args.secondary_db_size, 32, 20, args.secondary_W, hi - lo
     t0 = time.perf_counter()
     w2 = Workload(a2, dev_index, dev, rank, synth, Engine, torch, workload_label(a2))
     w2.q_offset = lo
@@ -480,8 +485,9 @@ def secondary_block(args, world, rank, dev_index, dev, synth, Engine, torch, hdi
         sec = {"what": "BASELINE.json configs[2] (the north-star target: 100M x 25-mers, L=32, K=20, 10^6 queries), "
                        "strong scaling: the queries sharded over the ranks in contiguous blocks, one batch per rank "
                        "and pass, index replicated per GPU; W from profiles/r02_recall_sweep_c3_shape.json",
-               "config": {"workload": "configs[2]: 100000000 x 25-mers, L=32 K=20 W=%g R=%g, %d queries in all"
-                                      % (a2.W, a2.R, total_q),
+               "config": {"workload": "%s: %d x 25-mers, L=32 K=20 W=%g R=%g, %d queries in all"
+                                      % ("configs[2]" if (a2.n, total_q) == (100_000_000, 1_000_000) else "custom",
+                                         a2.n, a2.W, a2.R, total_q),
                           "db_kmers": a2.n, "k": a2.k, "L": a2.L, "K": a2.K, "W": a2.W, "R": a2.R,
                           "queries_total": total_q, "queries_per_gpu": a2.nq,
                           "parallelism": "query-sharded x%d (10^6 queries / %d ranks), index replicated" % (world, world)},
@@ -507,11 +513,69 @@ def secondary_block(args, world, rank, dev_index, dev, synth, Engine, torch, hdi
             "phases_ms_per_step": {"hash_queries": m3["hash_ms"] / steps, "probe_segments": m3["probe_ms"] / steps,
                                    "verify": m3["verify_ms"] / steps, "finalize_sort": m3["fin_ms"] / steps},
             "candidates_per_query": m3["cand"] / 125_000}
+    w2.close()
+    codes2, qc_all = w2.codes, None
+    del w2
+    if world > 1 and not args.no_secondary_tables:
+        # the same job in the TABLE-partitioned layout (hsearch_dist.h): every rank a subset of the 32 tables
+        # (dealt by estimated join work) over all 10^8 k-mers and ALL 10^6 queries in one batch; hits with
+        # global table numbers all-gathered, merged by the first-seen rule (smallest table per (query, id))
+        tp = table_partition_block(args, a2, total_q, codes2, world, rank, dev_index, dev, synth, Engine, torch,
+                                   hdist, HsError, use_dist, fence, dist, backend)
+        if rank == 0:
+            sec["table_partition"] = tp
     if rank == 0:
         sec["wall_seconds_of_this_block"] = time.perf_counter() - t0
-    w2.close()
-    del w2
     return sec
+
+
+def table_partition_block(args, a2, total_q, codes, world, rank, dev_index, dev, synth, Engine, torch, hdist, HsError,
+                          use_dist, fence, dist, backend):
+    k, K, L, W, R = a2.k, a2.K, a2.L, a2.W, a2.R
+    a, b = synth.make_planes(k, K, L, W)
+    cost = hdist.table_costs(k, K, L, W, a, b, codes[:32768], device=dev_index)
+    tabs = hdist.assign_tables(cost, L, world)
+    mine = tabs[rank]
+    eng = Engine(k, K, len(mine), W, a[mine], b[mine], device=dev_index)
+    t0 = time.perf_counter()
+    info = eng.index_build(codes)
+    t_build = time.perf_counter() - t0
+    qcodes, _ = synth.make_query_codes(codes, total_q, seed=synth.SEED_QUERIES)     # the same on every rank
+    d_centers = torch.from_numpy(synth.embed(qcodes)).to(dev)
+    cap = [8 * total_q + 4096]
+    out = [dict(q=torch.empty(cap[0], dtype=torch.int32, device=dev), id=torch.empty(cap[0], dtype=torch.int32, device=dev),
+                table=torch.empty(cap[0], dtype=torch.int32, device=dev),
+                dist=torch.empty(cap[0], dtype=torch.float64, device=dev))]
+
+    def step():
+        return hdist.query_table_partitioned(eng, mine, d_centers.data_ptr(), total_q, R, out[0], cap[0], force=use_dist)
+    steps = max(args.secondary_steps, 1)
+    for _ in range(2):
+        merged, nh = step()
+    acc = {}
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        merged, nh = step()
+        p = eng.profile()
+        for f in ("ms_hash", "ms_probe", "ms_verify", "ms_join", "ms_finalize", "ms_total"):
+            acc[f] = acc.get(f, 0.0) + p[f] / steps
+    fence()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    res = {"what": "configs[2] with the TABLES partitioned over the ranks (every rank: its tables of all k-mers, all "
+                   "queries in one batch; all-gather + first-seen merge); same output as the replicated layout",
+           "value": total_q * steps / dt, "unit": "queries/s", "n_gpus": world, "ms_per_step": dt / steps * 1e3,
+           "tables_of_rank0": [int(x) for x in mine], "tables_per_rank": [len(t) for t in tabs],
+           "estimated_cost_share_per_rank": [float(cost[t].sum() / cost.sum()) for t in tabs],
+           "rank0_device_ms_per_step": acc, "rank0_hits_before_merge": int(nh), "hits_after_merge": int(merged[0].numel()),
+           "rank0_index_bytes": info["device_bytes"], "rank0_build_seconds": t_build,
+           "rank0_join_frac_of_int8_peak": (p["join_pairs"] * 256.0 / (acc["ms_join"] * 1e-3) / 5e15) if acc.get("ms_join") else None}
+    eng.close()
+    return res
 
 
 def secondary_traffic(a2, world):
@@ -668,11 +732,12 @@ def main():
     # ---- the north star's own target as a second block of the same line (secondary_block).  Run when the
     # primary line is the default workload and every rank's GPU has the room (index: 157 GB).
     want_secondary = (not args.no_secondary and args.verify_mode == "auto" and
-                      (args.n, args.k, args.K, args.L) == (10_000_000, 25, 16, 8))
+                      ((args.n, args.k, args.K, args.L) == (10_000_000, 25, 16, 8) or args.force_secondary))
     if want_secondary:
         torch.cuda.empty_cache()
         free_b, _total_b = torch.cuda.mem_get_info(dev_index)
-        ok = torch.tensor([1 if free_b >= 190 * (1 << 30) else 0], dtype=torch.int32,
+        need_b = 190 * (1 << 30) * args.secondary_db_size // 100_000_000
+        ok = torch.tensor([1 if free_b >= need_b else 0], dtype=torch.int32,
                           device=dev if (use_dist and backend == "nccl") else "cpu")
         if use_dist:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank or none

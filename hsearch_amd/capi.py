@@ -22,7 +22,7 @@ EXPORTS = ["hs_create", "hs_destroy", "hs_last_error", "hs_get_profile", "hs_get
            "hs_key_strings_equal", "hs_index_build", "hs_index_build_subset", "hs_index_build_windows", "hs_index_shard_begin", "hs_index_shard_hash_dev", "hs_index_shard_group_dev",
            "hs_index_shard_tuples_dev", "hs_index_shard_finish_dev", "hs_index_shard_end", "hs_index_save", "hs_index_load", "hs_index_file_check", "hs_klsh_draw_planes", "hs_klsh_codes",
            "hs_index_info_get", "hs_query", "hs_query_dev", "hs_query_codes", "hs_query_codes_dev", "hs_bruteforce",
-           "hs_bruteforce_topk"]
+           "hs_bruteforce_topk", "hs_merge_first_table_dev"]
 
 
 class HsError(RuntimeError):
@@ -447,6 +447,13 @@ class Engine:
             raise e
         self._check(st)
         return int(n.value)
+
+    def merge_first_table_dev(self, d_q, d_id, d_table, d_dist, n):
+        """hs_merge_first_table_dev (device pointers as ints; in place): the number of tuples kept."""
+        n_out = C.c_uint64(0)
+        self._check(self._lib.hs_merge_first_table_dev(self._h, C.c_void_p(d_q), C.c_void_p(d_id), C.c_void_p(d_table),
+                                                       C.c_void_p(d_dist), C.c_uint64(n), C.byref(n_out)))
+        return int(n_out.value)
 
     # -- a11
     def bruteforce(self, centers, R, cap=None):

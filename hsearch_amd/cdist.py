@@ -10,7 +10,7 @@ from . import capi
 RCCL_LOCAL, LOOPBACK = 0, 1
 EXPORTS = ["hs_comm_create", "hs_comm_unique_id", "hs_comm_create_rank", "hs_comm_destroy", "hs_comm_world",
            "hs_comm_last_error", "hs_shard_bounds", "hs_allgather_hits", "hs_comm_barrier", "hs_comm_query",
-           "hs_comm_query_codes"]
+           "hs_comm_query_codes", "hs_comm_query_tables", "hs_assign_tables"]
 
 _lib = None
 
@@ -33,6 +33,7 @@ def load():
         lib.hs_comm_last_error.restype = C.c_char_p
         lib.hs_comm_last_error.argtypes = [C.c_void_p, C.c_uint32]
         lib.hs_shard_bounds.restype = None
+        lib.hs_assign_tables.restype = None
         _lib = lib
     return _lib
 
@@ -41,6 +42,15 @@ def shard_bounds(n, world, rank):
     lo, hi = C.c_uint64(0), C.c_uint64(0)
     load().hs_shard_bounds(C.c_uint64(n), C.c_uint32(world), C.c_uint32(rank), C.byref(lo), C.byref(hi))
     return lo.value, hi.value
+
+
+def assign_tables(cost, L, world):
+    """hs_assign_tables: owner[l] = rank of table l (longest processing time first by cost; None: equal)."""
+    owner = np.zeros(L, dtype=np.uint32)
+    c = None if cost is None else np.ascontiguousarray(cost, dtype=np.float64)
+    assert c is None or len(c) == L
+    load().hs_assign_tables(_p(c), C.c_uint32(L), C.c_uint32(world), _p(owner))
+    return owner
 
 
 def _p(x):
@@ -134,6 +144,31 @@ class Comm:
             st = fn(self._h, C.c_uint32(rank), engine._h, _p(centers_block), C.c_uint64(nq),
                     C.c_uint32(q_offset), C.c_double(R), _p(hq), _p(hid), _p(ht), _p(hd),
                     C.c_uint64(cap), C.byref(n_total))
+            if st == capi.HS_ERR_CAPACITY:
+                cap = n_total.value
+                continue
+            if st != capi.HS_OK:
+                raise capi.HsError(st, self._lib.hs_comm_last_error(self._h, C.c_uint32(rank)).decode())
+            n = n_total.value
+            return dict(q=hq[:n], id=hid[:n], table=ht[:n], dist=hd[:n])
+
+    def query_tables(self, rank, engine, tables, queries, R, cap=None, codes=False):
+        """hs_comm_query_tables: the table-partitioned layout -- `engine` holds the tables `tables` (global
+        numbers, ascending) over all k-mers, `queries` are ALL queries (points, or residue codes with
+        codes=True); every rank gets the merged hits, the reference's order."""
+        queries = np.ascontiguousarray(queries, dtype=np.uint8 if codes else np.float64)
+        tables = np.ascontiguousarray(tables, dtype=np.uint32)
+        nq = queries.shape[0]
+        cap = int(cap) if cap else max(1024, 64 * nq)
+        while True:
+            hq = np.empty(cap, np.uint32); hid = np.empty(cap, np.uint32); ht = np.empty(cap, np.uint32)
+            hd = np.empty(cap, np.float64)
+            n_total = C.c_uint64(0)
+            st = self._lib.hs_comm_query_tables(self._h, C.c_uint32(rank), engine._h if engine is not None else None,
+                                                _p(tables), C.c_uint32(len(tables)),
+                                                None if codes else _p(queries), _p(queries) if codes else None,
+                                                C.c_uint64(nq), C.c_double(R), _p(hq), _p(hid), _p(ht), _p(hd),
+                                                C.c_uint64(cap), C.byref(n_total))
             if st == capi.HS_ERR_CAPACITY:
                 cap = n_total.value
                 continue

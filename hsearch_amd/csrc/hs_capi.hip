@@ -2710,6 +2710,44 @@ hs_status hs_query_codes(hs_handle* h, const uint8_t* qcodes, uint64_t nq, doubl
   return host_query(h, nullptr, qcodes, nq, R, false, hit_q, hit_id, hit_table, hit_dist, cap, n_hits, cand);
 }
 
+// The merge step of the TABLE-partitioned multi-GPU layout (include/hsearch.h): in place on n gathered tuples.
+hs_status hs_merge_first_table_dev(hs_handle* h, uint32_t* d_q, uint32_t* d_id, uint32_t* d_table, double* d_dist,
+                                   uint64_t n, uint64_t* n_out) {
+  if (!h || !n_out) return HS_ERR_INVALID;
+  *n_out = 0;
+  if (!n) return HS_OK;
+  if (!d_q || !d_id || !d_table || !d_dist) return HS_ERR_INVALID;
+  if (n >= (1ull << 31)) return fail(h, HS_ERR_INVALID, "more than 2^31 - 1 tuples to merge");
+  hs_status st = ensure_device(h);
+  if (st) return st;
+  const uint32_t n32 = (uint32_t)n;
+  HS_HIP(h, h->hit_key.reserve(n * 8));
+  HS_HIP(h, h->hit_val.reserve(n * 8));
+  HS_HIP(h, h->hit_key2.reserve(n * 8));
+  HS_HIP(h, h->hit_val2.reserve(n * 8));
+  HS_HIP(h, h->qhits.reserve(2 * (n + 1) * 4));
+  HS_HIP(h, h->temp.reserve(std::max(hs_sort_pairs_u64_u64_temp(n), hs_scan_u32_temp(n + 1)) + 256));
+  uint64_t *k1 = h->hit_key.as<uint64_t>(), *v1 = h->hit_val.as<uint64_t>();
+  uint64_t *k2 = h->hit_key2.as<uint64_t>(), *v2 = h->hit_val2.as<uint64_t>();
+  uint32_t* flag = h->qhits.as<uint32_t>();
+  uint32_t* pos = flag + (n + 1);
+  HS_HIP(h, hs_launch_merge_key1(d_q, d_id, d_table, d_dist, n32, k1, v1, h->stream));
+  HS_HIP(h, hs_sort_pairs_u64_u64(h->temp.p, h->temp.cap, k1, k2, v1, v2, n, 64, h->stream));
+  HS_HIP(h, hs_launch_merge_flag(k2, n32, flag, h->stream));
+  HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, flag, pos, n + 1, h->stream));
+  HS_HIP(h, hs_launch_merge_compact(k2, v2, pos, n32, k1, v1, h->stream));
+  uint32_t kept = 0;
+  HS_HIP(h, hipMemcpyAsync(&kept, pos + n, 4, hipMemcpyDeviceToHost, h->stream));
+  HS_HIP(h, hipStreamSynchronize(h->stream));
+  if (kept) {
+    HS_HIP(h, hs_sort_pairs_u64_u64(h->temp.p, h->temp.cap, k1, k2, v1, v2, kept, 64, h->stream));
+    HS_HIP(h, hs_launch_unpack_hits(k2, v2, kept, d_q, d_id, d_table, d_dist, h->stream));
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+  }
+  *n_out = kept;
+  return HS_OK;
+}
+
 hs_status hs_bruteforce(hs_handle* h, const double* centers, uint64_t nq, double R, uint32_t* hit_q,
                         uint32_t* hit_id, double* hit_dist, uint64_t cap, uint64_t* n_hits) {
   return host_query(h, centers, nullptr, nq, R, true, hit_q, hit_id, nullptr, hit_dist, cap, n_hits, nullptr);

@@ -94,6 +94,9 @@ struct RankState {
   std::vector<char> host_send;  // loopback: this rank's record
   std::vector<uint32_t> h_q, h_id, h_table;  // loopback with devices: this rank's hits on the host
   std::vector<double> h_dist;
+  std::vector<uint32_t> g_q, g_id, g_table;  // loopback, table partition: all ranks' tuples before the merge
+  std::vector<double> g_dist;
+  DevBuf table_map;                          // table partition: global numbers of the handle's tables
   std::string err;
 };
 
@@ -137,6 +140,13 @@ __global__ __launch_bounds__(256) void hs_unpack_hits_kernel(const char* __restr
   out_id[offset + i] = rid[i];
   if (out_table) out_table[offset + i] = rt[i];
   out_dist[offset + i] = rd[i];
+}
+
+// table partition: the handle numbers its tables 0 .. L_r - 1; map[l] = the table's number among all L
+__global__ __launch_bounds__(256) void hs_map_tables_kernel(uint32_t* __restrict__ table, uint64_t n,
+                                                            const uint32_t* __restrict__ map) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) table[i] = map[table[i]];
 }
 
 void host_pack(const uint32_t* q, const uint32_t* id, const uint32_t* table, const double* dist, uint64_t n,
@@ -375,7 +385,7 @@ void hs_comm_destroy(hs_comm* c) {
       (void)hipSetDevice(r.device);
       if (r.stream) (void)hipStreamSynchronize(r.stream);
       DevBuf* bufs[] = {&r.send, &r.recv, &r.counts, &r.io_centers, &r.io_q, &r.io_id, &r.io_table, &r.io_dist,
-                        &r.all_q, &r.all_id, &r.all_table, &r.all_dist};
+                        &r.all_q, &r.all_id, &r.all_table, &r.all_dist, &r.table_map};
       for (DevBuf* b : bufs) b->release();
       if (r.comm) (void)rccl()->CommDestroy(r.comm);  // (null for the host-memory transport)
       if (r.stream) (void)hipStreamDestroy(r.stream);
@@ -417,10 +427,14 @@ hs_status publish_words(hs_comm* c, uint32_t rank, const uint64_t mine[4], std::
   if (c->per_process && world > 1) {
     RankState& me = c->rs(rank);
     Rccl* R = rccl();
-    HSD_HIP(c, rank, me.counts.reserve((size_t)(world + 1) * 32));  // (reserved at creation: cannot fail here)
+    HSD_HIP(c, rank, me.counts.reserve((size_t)(world + 1) * 32));  // (reserved at creation: a no-op here)
     char* d_mine = static_cast<char*>(me.counts.p) + (size_t)world * 32;
-    HSD_HIP(c, rank, hipMemcpyAsync(d_mine, mine, 32, hipMemcpyHostToDevice, me.stream));
-    HSD_NCCL(c, rank, R->AllGather(d_mine, me.counts.p, 32, ncclChar, me.comm, me.stream));
+    // Once the words are on their way this rank is IN the collective: a failed copy is remembered, the
+    // all-gather is still entered (the peers are in it, or about to be), and the failure is reported after it.
+    const hipError_t e_copy = hipMemcpyAsync(d_mine, mine, 32, hipMemcpyHostToDevice, me.stream);
+    const ncclResult_t e_gather = R->AllGather(d_mine, me.counts.p, 32, ncclChar, me.comm, me.stream);
+    HSD_HIP(c, rank, e_copy);
+    HSD_NCCL(c, rank, e_gather);
     HSD_HIP(c, rank, hipMemcpyAsync(all->data(), me.counts.p, (size_t)world * 32, hipMemcpyDeviceToHost, me.stream));
     HSD_HIP(c, rank, hipStreamSynchronize(me.stream));
     return HS_OK;
@@ -498,17 +512,21 @@ hs_status allgather_impl(hs_comm* c, uint32_t rank, hs_status lst, const uint32_
   hs_status rst = HS_OK;
   if (me.send.reserve(rb) != hipSuccess || me.recv.reserve(rb * world) != hipSuccess)
     rst = rfail(c, rank, HS_ERR_NOMEM, "no memory for the exchange buffers");
+  if (rst == HS_OK) {
+    // this rank's record is packed BEFORE the round below: a launch that fails travels as this rank's status,
+    // and no rank unpacks a record that was never written
+    const unsigned pb = (unsigned)((m + 255) / 256);
+    hs_pack_hits_kernel<<<pb, 256, 0, me.stream>>>(q, id, table, dist, n_local, m, q_offset,
+                                                   static_cast<char*>(me.send.p));
+    const hipError_t pack_err = hipGetLastError();
+    if (pack_err != hipSuccess)
+      rst = rfail(c, rank, HS_ERR_HIP, std::string("hs_pack_hits_kernel: ") + hipGetErrorString(pack_err));
+  }
   const uint64_t ready[4] = {(uint64_t)rst, 0, 0, 0};
   HS_DIST_CHECK(publish_words(c, rank, ready, &all));
   const uint32_t bad2 = first_failed(all, world, 0);
   if (bad2 < world) return peer_failed(c, rank, bad2, all[(size_t)bad2 * 4], rst);
-  const unsigned pb = (unsigned)((m + 255) / 256);
-  hs_pack_hits_kernel<<<pb, 256, 0, me.stream>>>(q, id, table, dist, n_local, m, q_offset,
-                                                 static_cast<char*>(me.send.p));
-  // (a failed launch leaves the record unwritten; the collective is still entered, then reported)
-  const hipError_t pack_err = hipGetLastError();
   HSD_NCCL(c, rank, R->AllGather(me.send.p, me.recv.p, rb, ncclChar, me.comm, me.stream));
-  HSD_HIP(c, rank, pack_err);
   uint64_t off = 0;
   for (uint32_t r = 0; r < world; ++r) {
     if (cnt[r]) {
@@ -542,9 +560,13 @@ hs_status hs_allgather_hits(hs_comm* c, uint32_t rank, const uint32_t* q, const 
 namespace {
 
 // hs_comm_query / hs_comm_query_codes: the block as centres [nq_local][d] or as residue codes [nq_local][k]
+// tables != null: the TABLE-partitioned form -- the handle holds tables[0 .. n_tables) (global numbers,
+// ascending) over all k-mers, the block is ALL queries (q_offset 0), and the gathered tuples are merged
+// (hs_merge_first_table_dev) before they go to the caller's arrays.
 hs_status comm_query_impl(hs_comm* c, uint32_t rank, hs_handle* h, const double* centers, const uint8_t* qcodes,
                           uint64_t nq_local, uint32_t q_offset, double R, uint32_t* hit_q, uint32_t* hit_id,
-                          uint32_t* hit_table, double* hit_dist, uint64_t cap, uint64_t* n_total) {
+                          uint32_t* hit_table, double* hit_dist, uint64_t cap, uint64_t* n_total,
+                          const uint32_t* tables = nullptr, uint32_t n_tables = 0) {
   if (!rank_ok(c, rank) || !n_total) return HS_ERR_INVALID;  // cannot take part at all
   RankState& me = c->rs(rank);
   const bool loop = c->kind == HS_COMM_LOOPBACK;
@@ -570,6 +592,13 @@ hs_status comm_query_impl(hs_comm* c, uint32_t rank, hs_handle* h, const double*
   if (lst == HS_OK && hs_get_params(h, &prm) != HS_OK) keep(HS_ERR_INVALID, "hs_get_params failed");
   if (lst == HS_OK && prm.device != me.device) keep(HS_ERR_INVALID, "the handle is bound to another device than the rank");
   if (lst == HS_OK) hip(hipSetDevice(me.device), "hipSetDevice");
+  if (lst == HS_OK && tables) {
+    bool ok = n_tables == prm.L;
+    for (uint32_t l = 0; ok && l < n_tables; ++l) ok = tables[l] < 32u && (l == 0 || tables[l] > tables[l - 1]);
+    if (!ok) keep(HS_ERR_INVALID, "table partition: as many table numbers as the handle has tables, ascending, < 32");
+    if (ok && hip(me.table_map.reserve(32 * 4), "table map: hipMalloc"))
+      hip(hipMemcpy(me.table_map.p, tables, (size_t)n_tables * 4, hipMemcpyHostToDevice), "table map: hipMemcpy");
+  }
   // this rank's block on its GPU, then the search with HBM-resident outputs
   const uint64_t d = 8ull * prm.k;
   const size_t cbytes = qcodes ? (size_t)nq_local * prm.k : (size_t)nq_local * d * 8;
@@ -598,7 +627,70 @@ hs_status comm_query_impl(hs_comm* c, uint32_t rank, hs_handle* h, const double*
     break;
   }
   if (lst != HS_OK) n_local = 0;
+  if (tables && n_local) {
+    hs_map_tables_kernel<<<(unsigned)((n_local + 255) / 256), 256, 0, me.stream>>>(
+        static_cast<uint32_t*>(me.io_table.p), n_local, static_cast<const uint32_t*>(me.table_map.p));
+    hip(hipGetLastError(), "hs_map_tables_kernel");
+    hip(hipStreamSynchronize(me.stream), "hs_map_tables_kernel");
+    if (lst != HS_OK) n_local = 0;
+  }
   hs_status st;
+  if (loop && tables) {
+    // host-memory transport: this rank's tuples to the host, every rank's into g_*, then the merge on this
+    // rank's device (through the all_* buffers) and the merged list to the caller
+    me.h_q.resize(n_local);
+    me.h_id.resize(n_local);
+    me.h_table.resize(n_local);
+    me.h_dist.resize(n_local);
+    if (n_local) {
+      hip(hipMemcpy(me.h_q.data(), me.io_q.p, n_local * 4, hipMemcpyDeviceToHost), "hits: hipMemcpy");
+      hip(hipMemcpy(me.h_id.data(), me.io_id.p, n_local * 4, hipMemcpyDeviceToHost), "hits: hipMemcpy");
+      hip(hipMemcpy(me.h_table.data(), me.io_table.p, n_local * 4, hipMemcpyDeviceToHost), "hits: hipMemcpy");
+      hip(hipMemcpy(me.h_dist.data(), me.io_dist.p, n_local * 8, hipMemcpyDeviceToHost), "hits: hipMemcpy");
+    }
+    uint64_t gcap = std::max<uint64_t>(me.g_q.size(), 1024);
+    for (;;) {
+      me.g_q.resize(gcap);
+      me.g_id.resize(gcap);
+      me.g_table.resize(gcap);
+      me.g_dist.resize(gcap);
+      st = allgather_impl(c, rank, lst, me.h_q.data(), me.h_id.data(), me.h_table.data(), me.h_dist.data(),
+                          lst == HS_OK ? n_local : 0, 0u, me.g_q.data(), me.g_id.data(), me.g_table.data(),
+                          me.g_dist.data(), gcap, n_total);
+      if (st == HS_ERR_CAPACITY) {  // every rank sees the same total and repeats the exchange
+        gcap = *n_total + 1024;
+        continue;
+      }
+      break;
+    }
+    if (st != HS_OK) return st;
+    const uint64_t ng = *n_total;
+    uint64_t kept = 0;
+    if (ng) {
+      HSD_HIP(c, rank, me.all_q.reserve(ng * 4));
+      HSD_HIP(c, rank, me.all_id.reserve(ng * 4));
+      HSD_HIP(c, rank, me.all_table.reserve(ng * 4));
+      HSD_HIP(c, rank, me.all_dist.reserve(ng * 8));
+      HSD_HIP(c, rank, hipMemcpy(me.all_q.p, me.g_q.data(), ng * 4, hipMemcpyHostToDevice));
+      HSD_HIP(c, rank, hipMemcpy(me.all_id.p, me.g_id.data(), ng * 4, hipMemcpyHostToDevice));
+      HSD_HIP(c, rank, hipMemcpy(me.all_table.p, me.g_table.data(), ng * 4, hipMemcpyHostToDevice));
+      HSD_HIP(c, rank, hipMemcpy(me.all_dist.p, me.g_dist.data(), ng * 8, hipMemcpyHostToDevice));
+    }
+    const hs_status mst = hs_merge_first_table_dev(h, static_cast<uint32_t*>(me.all_q.p), static_cast<uint32_t*>(me.all_id.p),
+                                                   static_cast<uint32_t*>(me.all_table.p), static_cast<double*>(me.all_dist.p),
+                                                   ng, &kept);
+    if (mst != HS_OK) return rfail(c, rank, mst, std::string("hs_merge_first_table_dev: ") + hs_last_error(h));
+    *n_total = kept;
+    if (kept > cap) return rfail(c, rank, HS_ERR_CAPACITY, "hit buffers too small; see *n_total");
+    if (kept) {
+      if (!hit_q || !hit_id || !hit_dist) return HS_ERR_INVALID;
+      HSD_HIP(c, rank, hipMemcpy(hit_q, me.all_q.p, kept * 4, hipMemcpyDeviceToHost));
+      HSD_HIP(c, rank, hipMemcpy(hit_id, me.all_id.p, kept * 4, hipMemcpyDeviceToHost));
+      if (hit_table) HSD_HIP(c, rank, hipMemcpy(hit_table, me.all_table.p, kept * 4, hipMemcpyDeviceToHost));
+      HSD_HIP(c, rank, hipMemcpy(hit_dist, me.all_dist.p, kept * 8, hipMemcpyDeviceToHost));
+    }
+    return HS_OK;
+  }
   if (loop) {
     // ranks with devices over the host-memory transport (two ranks may share a GPU: the protocol of
     // hs_motif_both_points --gpus n on a box with fewer GPUs): this rank's hits to the host, the
@@ -635,6 +727,14 @@ hs_status comm_query_impl(hs_comm* c, uint32_t rank, hs_handle* h, const double*
     break;
   }
   if (st != HS_OK) return st;
+  if (tables) {  // the gathered tuples, merged in place on this rank's GPU
+    uint64_t kept = 0;
+    const hs_status mst = hs_merge_first_table_dev(h, static_cast<uint32_t*>(me.all_q.p), static_cast<uint32_t*>(me.all_id.p),
+                                                   static_cast<uint32_t*>(me.all_table.p), static_cast<double*>(me.all_dist.p),
+                                                   *n_total, &kept);
+    if (mst != HS_OK) return rfail(c, rank, mst, std::string("hs_merge_first_table_dev: ") + hs_last_error(h));
+    *n_total = kept;
+  }
   const uint64_t nt = *n_total;
   if (nt > cap) return rfail(c, rank, HS_ERR_CAPACITY, "hit buffers too small; see *n_total");
   if (nt) {
@@ -656,6 +756,38 @@ hs_status hs_comm_query(hs_comm* c, uint32_t rank, hs_handle* h, const double* c
                         uint32_t* hit_table, double* hit_dist, uint64_t cap, uint64_t* n_total) {
   return comm_query_impl(c, rank, h, centers, nullptr, nq_local, q_offset, R, hit_q, hit_id, hit_table, hit_dist,
                          cap, n_total);
+}
+
+hs_status hs_comm_query_tables(hs_comm* c, uint32_t rank, hs_handle* h, const uint32_t* tables, uint32_t n_tables,
+                               const double* centers, const uint8_t* qcodes, uint64_t nq, double R, uint32_t* hit_q,
+                               uint32_t* hit_id, uint32_t* hit_table, double* hit_dist, uint64_t cap,
+                               uint64_t* n_total) {
+  static const uint32_t none[1] = {0u};
+  // (a rank that cannot name its tables still takes part, as a failed rank: an empty map fails the checks)
+  const bool args_ok = tables && n_tables && (centers || qcodes || !nq) && !(centers && qcodes);
+  return comm_query_impl(c, rank, args_ok ? h : nullptr, centers, qcodes, nq, 0u, R, hit_q, hit_id, hit_table,
+                         hit_dist, cap, n_total, tables ? tables : none, tables ? n_tables : 0u);
+}
+
+void hs_assign_tables(const double* cost, uint32_t L, uint32_t world, uint32_t* owner) {
+  // longest processing time first: tables by falling cost (ties: lower number first), each to the rank with
+  // the least cost so far (ties: lower rank first) -- deterministic, so every rank computes the same map
+  if (!owner || !L || !world) return;
+  std::vector<uint32_t> order(L);
+  for (uint32_t l = 0; l < L; ++l) order[l] = l;
+  if (cost)
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
+  std::vector<double> load(world, 0.0);
+  std::vector<uint32_t> count(world, 0);
+  for (uint32_t i = 0; i < L; ++i) {
+    const uint32_t l = order[i];
+    uint32_t best = 0;
+    for (uint32_t r = 1; r < world; ++r)
+      if (load[r] < load[best] || (load[r] == load[best] && count[r] < count[best])) best = r;
+    owner[l] = best;
+    load[best] += cost ? cost[l] : 1.0;
+    ++count[best];
+  }
 }
 
 hs_status hs_comm_query_codes(hs_comm* c, uint32_t rank, hs_handle* h, const uint8_t* qcodes, uint64_t nq_local,

@@ -400,6 +400,13 @@ hipError_t hs_launch_hit_order(const uint64_t* d_key, const uint64_t* d_val, con
 // self_first: the queries are the indexed k-mers self_first, self_first + 1, ... themselves (the
 // self-join): the pair of a k-mer with itself is not a hit; HS_NO_SELF otherwise
 #define HS_NO_SELF 0xffffffffu
+// merge of the table-partitioned layout (hs_merge_first_table_dev): keys (q, id, table) + the distance bits;
+// run heads of the sorted keys; the heads re-keyed (q, table, id) at their scanned positions
+hipError_t hs_launch_merge_key1(const uint32_t* d_q, const uint32_t* d_id, const uint32_t* d_table, const double* d_dist,
+                                uint32_t n, uint64_t* d_key, uint64_t* d_val, hipStream_t s);
+hipError_t hs_launch_merge_flag(const uint64_t* d_key, uint32_t n, uint32_t* d_flag /* [n + 1] */, hipStream_t s);
+hipError_t hs_launch_merge_compact(const uint64_t* d_key, const uint64_t* d_val, const uint32_t* d_pos /* [n + 1] */,
+                                   uint32_t n, uint64_t* d_key2, uint64_t* d_val2, hipStream_t s);
 hipError_t hs_launch_unpack_hits(const uint64_t* d_key, const uint64_t* d_val, uint32_t n,
                                  uint32_t* d_q, uint32_t* d_id, uint32_t* d_table, double* d_dist,
                                  hipStream_t s);

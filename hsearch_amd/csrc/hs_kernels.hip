@@ -1608,11 +1608,62 @@ __global__ __launch_bounds__(256) void hs_unpack_hits_kernel(const uint64_t* __r
   dist[i] = __longlong_as_double((long long)val[i]);
 }
 
+// ---- merge of the table-partitioned layout (hs_merge_first_table_dev) --------------------------------
+// Every rank holds a block of the L tables over ALL k-mers and answers ALL queries; gathered, one (query, id)
+// pair appears once per rank whose tables hold it in the query's bucket, each time with the smallest of THAT
+// rank's tables.  The reference reports an id in the first table whose probed bucket holds it
+// (motif_both_points.cpp:232-238) -- the smallest table over all ranks -- so: order the tuples by
+// (q, id, table), keep the first of every (q, id) run, order what is kept by (q, table, id).
+__global__ __launch_bounds__(256) void hs_merge_key1_kernel(const uint32_t* __restrict__ q, const uint32_t* __restrict__ id,
+                                                            const uint32_t* __restrict__ table,
+                                                            const double* __restrict__ dist, uint32_t n,
+                                                            uint64_t* __restrict__ key, uint64_t* __restrict__ val) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  key[i] = ((uint64_t)q[i] << 37) | ((uint64_t)id[i] << 5) | (uint64_t)(table[i] & 31u);
+  val[i] = (uint64_t)__double_as_longlong(dist[i]);
+}
+// flag[i] = 1 where a (q, id) run starts; flag[n] = 0 closes the scan
+__global__ __launch_bounds__(256) void hs_merge_flag_kernel(const uint64_t* __restrict__ key, uint32_t n,
+                                                            uint32_t* __restrict__ flag) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i > n) return;
+  flag[i] = (i < n && (i == 0 || (key[i] >> 5) != (key[i - 1] >> 5))) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void hs_merge_compact_kernel(const uint64_t* __restrict__ key,
+                                                               const uint64_t* __restrict__ val,
+                                                               const uint32_t* __restrict__ pos, uint32_t n,
+                                                               uint64_t* __restrict__ key2, uint64_t* __restrict__ val2) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || pos[i + 1] == pos[i]) return;
+  const uint64_t kk = key[i];
+  const uint64_t q = kk >> 37, id = (kk >> 5) & 0xffffffffull, t = kk & 31ull;
+  key2[pos[i]] = (q << 37) | (t << 32) | id;
+  val2[pos[i]] = val[i];
+}
+
 inline unsigned blocks_for(uint64_t n, unsigned per = 256) { return (unsigned)((n + per - 1) / per); }
 
 }  // namespace
 
 // ================================================================================= launchers
+hipError_t hs_launch_merge_key1(const uint32_t* d_q, const uint32_t* d_id, const uint32_t* d_table, const double* d_dist,
+                                uint32_t n, uint64_t* d_key, uint64_t* d_val, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hs_merge_key1_kernel<<<blocks_for(n), 256, 0, s>>>(d_q, d_id, d_table, d_dist, n, d_key, d_val);
+  return hipGetLastError();
+}
+hipError_t hs_launch_merge_flag(const uint64_t* d_key, uint32_t n, uint32_t* d_flag, hipStream_t s) {
+  hs_merge_flag_kernel<<<blocks_for((uint64_t)n + 1), 256, 0, s>>>(d_key, n, d_flag);
+  return hipGetLastError();
+}
+hipError_t hs_launch_merge_compact(const uint64_t* d_key, const uint64_t* d_val, const uint32_t* d_pos, uint32_t n,
+                                   uint64_t* d_key2, uint64_t* d_val2, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hs_merge_compact_kernel<<<blocks_for(n), 256, 0, s>>>(d_key, d_val, d_pos, n, d_key2, d_val2);
+  return hipGetLastError();
+}
+
 hipError_t hs_launch_embed(const uint8_t* d_codes, uint64_t n, int k, const double* d_coords,
                            double* d_out, hipStream_t s) {
   const uint64_t total = n * 8ull * k;

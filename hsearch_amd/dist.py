@@ -116,8 +116,7 @@ def merge_table_partitioned(q, ids, table, distance):
         return q, ids, table, distance
     q, ids, table = q.to(torch.int64), ids.to(torch.int64), table.to(torch.int64)
     # (q, id, table) ascending: the first tuple of every (q, id) run carries the smallest table
-    key = (q << 37) | (ids << 5) | table          # q < 2^27 (hs_query's limit), id < 2^32 would need 38 bits:
-    assert int(ids.max()) < (1 << 32) and int(table.max()) < 32 and int(q.max()) < (1 << 26)
+    key = (q << 37) | (ids << 5) | table          # q < 2^26, id < 2^32, table < 32: 63 bits
     key, order = torch.sort(key)
     pair = key >> 5
     first = torch.ones_like(pair, dtype=torch.bool)
@@ -127,6 +126,47 @@ def merge_table_partitioned(q, ids, table, distance):
     key2 = (q << 37) | (table << 32) | ids
     order2 = torch.argsort(key2)
     return q[order2], ids[order2], table[order2], distance[order2]
+
+
+def table_costs(k, K, L, W, a, b, codes_sample, device=0, coords=None):
+    """Estimated join work of every table, from a sample of the DB's k-mers: the sum over the table's buckets
+    of (sample k-mers in the bucket)^2 -- for queries distributed like the DB, proportional to the (member,
+    query) pairs the table contributes.  One short-lived handle with all L planes (no index) hashes the sample;
+    the host counts.  Deterministic: every rank computes the same numbers from the same sample."""
+    from . import capi
+    eng = capi.Engine(k, K, L, W, a, b, device=device, coords=coords)
+    try:
+        ints = eng.hash_codes(np.ascontiguousarray(codes_sample, dtype=np.uint8))    # [n][L][K]
+    finally:
+        eng.close()
+    cost = np.zeros(L)
+    for l in range(L):
+        rows = np.ascontiguousarray(ints[:, l, :]).view([("", np.int32)] * K).ravel()
+        _, cnt = np.unique(rows, return_counts=True)
+        cost[l] = float((cnt.astype(np.float64) ** 2).sum())
+    return cost
+
+
+def assign_tables(cost, L, world):
+    """Tables of every rank (ascending global numbers) from hs_assign_tables (libhsearch_dist.so): longest
+    processing time first by `cost` (None: round robin)."""
+    from . import cdist
+    owner = cdist.assign_tables(cost, L, world)
+    return [np.nonzero(owner == r)[0].astype(np.int64) for r in range(world)]
+
+
+def query_table_partitioned(eng, tables, d_centers_ptr, nq, R, out, cap, group=None, force=False, codes=False):
+    """One pass of the table-partitioned layout on this rank: `eng` holds the tables `tables` (global numbers,
+    ascending) over all k-mers, the nq queries are ALL queries (the same on every rank); its hits with the
+    tables made global, all-gathered (allgather_hits, q_offset 0), merged (merge_table_partitioned).  `out` =
+    dict of the rank's output tensors q / id / table / dist (cap entries).  Returns the merged (q, id, table,
+    dist) -- every rank the same list, the reference's order -- and the rank's own hit count."""
+    nh = eng.query_dev(d_centers_ptr, nq, R, out["q"].data_ptr(), out["id"].data_ptr(), out["table"].data_ptr(),
+                       out["dist"].data_ptr(), cap, codes=codes)
+    tmap = torch.as_tensor(np.asarray(tables, dtype=np.int64), device=out["table"].device)
+    gtab = tmap[out["table"][:nh].to(torch.int64)].to(torch.int32)
+    gq, gi, gt, gd = allgather_hits(out["q"], out["id"], gtab, out["dist"], nh, q_offset=0, group=group, force=force)
+    return merge_table_partitioned(gq, gi, gt, gd), nh
 
 
 def hits_to_numpy(q, ids, table, distance):

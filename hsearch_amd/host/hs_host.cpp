@@ -114,8 +114,40 @@ struct HandleCloser {
   ~HandleCloser() { hs_destroy(h); }
 };
 
-// how the rank threads exchange hits (SetShardTransport)
+// how the rank threads exchange hits (SetShardTransport) and what a rank holds (SetShardPartition)
 ShardTransport g_shard_transport = kTransportRccl;
+ShardPartition g_shard_partition = kPartitionQueries;
+
+// Cost of every table for the table-partitioned layout, from a sample of the DB's k-mers: the sum over the
+// table's buckets of (sample k-mers in the bucket)^2 -- for queries distributed like the DB, proportional to
+// the (member, query) pairs the table contributes to the join.  One short-lived handle with all L planes (no
+// index) hashes the sample; buckets are told apart by the fingerprint of their K ints (a collision would only
+// nudge an estimate).  Empty on any failure: the caller then deals the tables round robin.
+std::vector<double> TableCosts(hs_params prm, const Planes& planes, const double* coords, const uint8_t* sample,
+                               uint64_t n_sample, int device) {
+  std::vector<double> cost;
+  if (!sample || n_sample < 64) return cost;
+  hs_handle* h = nullptr;
+  prm.device = device;
+  if (hs_create(&prm, planes.a.data(), planes.b.data(), coords, &h) != HS_OK) {
+    hs_destroy(h);
+    return cost;
+  }
+  HandleCloser closer = {h};
+  std::vector<int32_t> ints((size_t)n_sample * prm.L * prm.K);
+  if (hs_hash_codes(h, sample, n_sample, ints.data()) != HS_OK) return cost;
+  cost.assign(prm.L, 0.0);
+  std::vector<uint64_t> fp(n_sample);
+  for (uint32_t l = 0; l < prm.L; ++l) {
+    for (uint64_t i = 0; i < n_sample; ++i) fp[i] = hs_key_fingerprint(&ints[((size_t)i * prm.L + l) * prm.K], prm.K, 0);
+    std::sort(fp.begin(), fp.end());
+    for (uint64_t i = 0, j; i < n_sample; i = j) {
+      for (j = i + 1; j < n_sample && fp[j] == fp[i]; ++j) {}
+      cost[l] += (double)(j - i) * (double)(j - i);
+    }
+  }
+  return cost;
+}
 
 
 // The device part of Search(): index build (through `build`, on a fresh handle) and the query loop,
@@ -128,16 +160,43 @@ ShardTransport g_shard_transport = kTransportRccl;
 int RunSearch(hs_params prm, const Planes& planes, const double* coords,
               const std::function<hs_status(hs_handle*, uint32_t rank)>& build, const double* flat,
               const uint8_t* qcodes, uint64_t nq, double R, const std::vector<int>& devices, bool sharded,
-              SearchHits* out, std::string* err, std::vector<uint64_t>* table_sizes) {
+              SearchHits* out, std::string* err, std::vector<uint64_t>* table_sizes,
+              const uint8_t* db_sample = nullptr, uint64_t n_db_sample = 0) {
   const uint32_t world = (uint32_t)devices.size();
   if (!world) {
     if (err) *err = "no device given";
     return HS_ERR_INVALID;
   }
-  auto open = [&](int device, hs_handle** h, std::string* msg) -> hs_status {
+  // table partition: rank r holds the tables tabs[r] (global numbers, ascending) of ALL k-mers
+  const bool by_tables = sharded && g_shard_partition == kPartitionTables;
+  std::vector<std::vector<uint32_t>> tabs(world);
+  if (by_tables) {
+    if (world > prm.L) {
+      if (err) *err = "table partition: more GPUs than tables";
+      return HS_ERR_INVALID;
+    }
+    const std::vector<double> cost = TableCosts(prm, planes, coords, db_sample, n_db_sample, devices[0]);
+    std::vector<uint32_t> owner(prm.L, 0);
+    hs_assign_tables(cost.empty() ? nullptr : cost.data(), prm.L, world, owner.data());
+    for (uint32_t l = 0; l < prm.L; ++l) tabs[owner[l]].push_back(l);
+    if (table_sizes) table_sizes->assign(prm.L, 0);
+  }
+  const size_t plane_doubles = (size_t)prm.K * 8 * prm.k;
+  auto open = [&](int device, hs_handle** h, std::string* msg, uint32_t rank = 0) -> hs_status {
     hs_params p = prm;
     p.device = device;
-    hs_status st = hs_create(&p, planes.a.data(), planes.b.data(), coords, h);
+    hs_status st;
+    if (by_tables) {
+      std::vector<double> a, b;
+      for (uint32_t l : tabs[rank]) {
+        a.insert(a.end(), planes.a.begin() + (size_t)l * plane_doubles, planes.a.begin() + (size_t)(l + 1) * plane_doubles);
+        b.insert(b.end(), planes.b.begin() + (size_t)l * prm.K, planes.b.begin() + (size_t)(l + 1) * prm.K);
+      }
+      p.L = (uint32_t)tabs[rank].size();
+      st = hs_create(&p, a.data(), b.data(), coords, h);
+    } else {
+      st = hs_create(&p, planes.a.data(), planes.b.data(), coords, h);
+    }
     if (st != HS_OK) {
       *msg = std::string("hs_create: ") + (*h ? hs_last_error(*h) : "no usable gfx950 device");
       hs_destroy(*h);
@@ -198,11 +257,16 @@ int RunSearch(hs_params prm, const Planes& planes, const double* coords,
   std::vector<int> built(world, 0);
   auto rank_main = [&](uint32_t r) {
     hs_handle* h = nullptr;
-    hs_status st = open(devices[r], &h, &msgs[r]);
+    hs_status st = open(devices[r], &h, &msgs[r], r);
     HandleCloser closer = {h};
     if (st == HS_OK) {
       st = build(h, r);
       if (st != HS_OK) msgs[r] = std::string("index build: ") + hs_last_error(h);
+    }
+    if (st == HS_OK && by_tables && table_sizes) {  // (distinct slots per rank)
+      hs_index_info info;
+      if (hs_index_info_get(h, &info) == HS_OK)
+        for (size_t i = 0; i < tabs[r].size(); ++i) (*table_sizes)[tabs[r][i]] = info.n_buckets[i];
     }
     built[r] = st == HS_OK;
     status[r] = st;
@@ -210,7 +274,7 @@ int RunSearch(hs_params prm, const Planes& planes, const double* coords,
     hs_comm_barrier(comm, r);
     for (uint32_t x = 0; x < world; ++x)
       if (!built[x]) return;
-    if (r == 0) sizes(h);
+    if (r == 0 && !by_tables) sizes(h);
     uint64_t lo = 0, hi = 0;
     hs_shard_bounds(nq, world, r, &lo, &hi);
     SearchHits mine;  // ranks other than 0 drop theirs
@@ -227,6 +291,11 @@ int RunSearch(hs_params prm, const Planes& planes, const double* coords,
       if (const char* fr = getenv("HS_TEST_FAIL_RANK"))
         if ((uint32_t)atoi(fr) == r) hq = nullptr;
 #endif
+      if (by_tables)  // every rank passes ALL centres; the merged list comes back (include/hsearch_dist.h)
+        st = hs_comm_query_tables(comm, r, hq, tabs[r].data(), (uint32_t)tabs[r].size(), qcodes ? nullptr : flat, qcodes,
+                                  nq, R, dst->q.data(), dst->id.data(), dst->table.data(), dst->dist.data(), cap,
+                                  &dst->n);
+      else
       st = qcodes ? hs_comm_query_codes(comm, r, hq, qcodes + lo * prm.k, hi - lo, (uint32_t)lo, R, dst->q.data(),
                                         dst->id.data(), dst->table.data(), dst->dist.data(), cap, &dst->n)
                   : hs_comm_query(comm, r, hq, flat + lo * d, hi - lo, (uint32_t)lo, R, dst->q.data(),
@@ -268,6 +337,7 @@ bool FlattenCenters(const std::vector<Point>& centers, uint32_t dim, std::vector
 }  // namespace
 
 void SetShardTransport(ShardTransport t) { g_shard_transport = t; }
+void SetShardPartition(ShardPartition p) { g_shard_partition = p; }
 
 int Search(const std::vector<Point>& kmers, const std::vector<Point>& centers,
            const std::vector<std::string>& kmer_names, const std::vector<std::string>& center_names,
@@ -305,7 +375,7 @@ int SearchSharded(const std::vector<Point>& kmers, const std::vector<Point>& cen
   const int st = RunSearch(prm, planes, table.data(),
                            [&](hs_handle* h, uint32_t) { return hs_index_build(h, codes.data(), kmers.size()); },
                            flat.data(), nullptr, centers.size(), hash_R, devices, use_comm || devices.size() > 1,
-                           &hits, err, table_sizes);
+                           &hits, err, table_sizes, codes.data(), std::min<uint64_t>(kmers.size(), 32768));
   if (st != HS_OK) return st;
   std::ofstream fout(output_file.c_str());
   for (uint64_t i = 0; i < hits.n; ++i)  // :240-241

@@ -66,6 +66,15 @@ int Search(const std::vector<Point>& kmers, const std::vector<Point>& centers,
 // which RCCL refuses (`hs_motif_both_points --transport loopback`).  Process-wide; set before the call.
 enum ShardTransport { kTransportRccl = 0, kTransportLoopback = 1 };
 void SetShardTransport(ShardTransport t);
+// What a rank of the *Sharded() functions holds.  kPartitionQueries (the default): the whole index,
+// replicated, and a contiguous block of the centres.  kPartitionTables: a subset of the L tables over ALL
+// k-mers (tables dealt to the GPUs by an estimate of their join work, hs_assign_tables) and ALL centres; behind
+// the all-gather every rank keeps, per (centre, k-mer), the tuple of the smallest table -- the reference's
+// first-seen rule (motif_both_points.cpp:232-238) -- so the file is the same (include/hsearch_dist.h).  A GPU
+// then holds and builds 1 / n of the table bytes (configs[2]: 23 GB instead of 157 GB) and every bucket meets
+// all centres of the batch at once.  Process-wide; set before the call.
+enum ShardPartition { kPartitionQueries = 0, kPartitionTables = 1 };
+void SetShardPartition(ShardPartition p);
 
 // Search() spread over the GPUs `devices` of this node: one host thread and one handle
 // per GPU, the index replicated (built on every GPU), centre i searched by the rank owning its

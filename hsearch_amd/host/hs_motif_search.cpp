@@ -54,6 +54,7 @@ const Opt kOpts[] = {
     {"seed", 's', "seed of the LSH planes [random_device]", false},
     {"device", 'G', "GPU ordinal (the first one with --gpus) [0]", false},
     {"gpus", 'N', "shard the centres over this many GPUs, hits all-gathered over RCCL [off: one GPU, no communicator]", false},
+    {"partition", 'Y', "with --gpus: queries (every GPU the whole index and a block of the centres, the default) or tables (every GPU a subset of the L tables over all k-mers and all centres; same output)", false},
     {"transport", 'X', "with --gpus: rccl (one rank per GPU, the default) or loopback (host memory between the rank threads, all ranks on --device: the rank protocol on a box with fewer GPUs)", false},
     {"centers-as-points", 'E', "k-mer centres over a FASTA database: send them embedded (8k doubles each) instead of as residue codes [0]", false},
     {"planes", 'p', "read the planes from this file (as written by --planes-out) instead of drawing them", false},
@@ -194,6 +195,12 @@ int main(int argc, const char* argv[]) {
       fprintf(stderr, "ERROR: --gpus must be 1..64\n");
       return EXIT_FAILURE;
     }
+    const bool by_tables = val.count("partition") && val["partition"] == "tables";
+    if (val.count("partition") && !by_tables && val["partition"] != "queries") {
+      fprintf(stderr, "ERROR: --partition must be queries or tables\n");
+      return EXIT_FAILURE;
+    }
+    hsearch::SetShardPartition(by_tables ? hsearch::kPartitionTables : hsearch::kPartitionQueries);
     const bool loopback = val.count("transport") && val["transport"] == "loopback";
     if (val.count("transport") && !loopback && val["transport"] != "rccl") {
       fprintf(stderr, "ERROR: --transport must be rccl or loopback\n");

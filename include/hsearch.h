@@ -239,7 +239,12 @@ HS_API hs_status hs_index_build_windows(hs_handle* h, const uint8_t* residues, u
  * and after the last table <max over ranks of collided over all tables>: if set (two HashKey strings
  * under one fingerprint), start over from table 0 with seed + 1 (hs_index_build tries seeds 0..3); else
  * hs_index_shard_end(h, seed).  The index equals hs_index_build's bit for bit (same file from
- * hs_index_save). */
+ * hs_index_save).
+ * STREAMS: every one of these calls works on the handle's own stream and returns with it drained.  A d_
+ * buffer the caller fills between two calls (the gathered fingerprints, the summed tuples: outputs of the
+ * caller's collectives on the caller's stream) must be COMPLETE when it is handed over -- drain that stream,
+ * or record an event behind the collective and pass it to hs_wait_event(h, event) before the call; buffers
+ * the library writes (d_fp_block, d_tuples) are complete when the call returns. */
 HS_API hs_status hs_index_shard_begin(hs_handle* h, const uint8_t* codes, uint64_t n, uint32_t rank,
                                       uint32_t world, uint64_t* block_lo, uint64_t* block_count);
 HS_API hs_status hs_index_shard_hash_dev(hs_handle* h, uint32_t l, uint32_t seed, uint64_t* d_fp_block);
@@ -298,7 +303,11 @@ HS_API hs_status hs_index_info_get(const hs_handle* h, hs_index_info* out);
 HS_API hs_status hs_query(hs_handle* h, const double* centers, uint64_t nq, double R,
                           uint32_t* hit_q, uint32_t* hit_id, uint32_t* hit_table, double* hit_dist,
                           uint64_t cap, uint64_t* n_hits, uint64_t* cand);
-/* Same with every pointer except n_hits in device memory (HBM-resident queries and hits). */
+/* Same with every pointer except n_hits in device memory (HBM-resident queries and hits).
+ * STREAMS (this and every other _dev entry point): the library works on the handle's own stream.  d_centers
+ * must be complete when the call is made (the caller's producer stream drained, or an event recorded behind
+ * the producer handed to hs_wait_event(h, event) first); the call returns with the library's stream drained,
+ * so the outputs are complete and the inputs may be reused at once, from any stream. */
 HS_API hs_status hs_query_dev(hs_handle* h, const double* d_centers, uint64_t nq, double R,
                               uint32_t* d_hit_q, uint32_t* d_hit_id, uint32_t* d_hit_table,
                               double* d_hit_dist, uint64_t cap, uint64_t* n_hits,
@@ -318,6 +327,17 @@ HS_API hs_status hs_query_codes_dev(hs_handle* h, const uint8_t* d_qcodes, uint6
                                     uint32_t* d_hit_q, uint32_t* d_hit_id, uint32_t* d_hit_table,
                                     double* d_hit_dist, uint64_t cap, uint64_t* n_hits,
                                     uint64_t* d_cand);
+
+/* The merge step of the TABLE-partitioned multi-GPU layout (hsearch_dist.h hs_comm_query_tables): every rank
+ * holds some of the L tables over ALL k-mers and answers ALL queries, so a (query, id) pair is reported by
+ * every rank whose tables hold the id in the query's bucket, each time with the smallest of that rank's
+ * tables (in GLOBAL table numbers).  The reference reports an id in the FIRST table whose probed bucket
+ * holds it and never looks at it again (label[], motif_both_points.cpp:232-238); whether it is a hit does not
+ * depend on the table.  So of the n gathered tuples the one with the smallest table per (query, id) is the
+ * reference's line: this call keeps exactly those, ordered by (query, table, id) -- the reference's file
+ * order -- in place in the first *n_out entries of the four device arrays.  q < 2^27, table < 32. */
+HS_API hs_status hs_merge_first_table_dev(hs_handle* h, uint32_t* d_q, uint32_t* d_id, uint32_t* d_table,
+                                          double* d_dist, uint64_t n, uint64_t* n_out);
 
 /* ---- brute force (row a11) ---------------------------------------------------------------------- */
 

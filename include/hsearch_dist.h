@@ -92,6 +92,30 @@ HS_API hs_status hs_comm_query_codes(hs_comm* c, uint32_t rank, hs_handle* h, co
                                      uint32_t* hit_id, uint32_t* hit_table, double* hit_dist, uint64_t cap,
                                      uint64_t* n_total);
 
+/* ---- the TABLE-partitioned layout -----------------------------------------------------------------
+ * The alternative to query blocks over a replicated index: rank r holds a SUBSET of the L tables over ALL
+ * k-mers (a handle created with the planes of those tables only: L_r = its number of tables) and answers ALL
+ * queries; per rank the same probes and (member, query) pairs as in the replicated layout, but every bucket
+ * meets all queries of the batch at once (the join's operand reuse), and a rank holds -- and builds -- 1/world
+ * of the table bytes.  The exchange is the same all-gather of hit tuples; behind it every rank keeps, per
+ * (query, id), the tuple with the smallest GLOBAL table number: the reference reports an id in the first table
+ * whose probed bucket holds it (label[], motif_both_points.cpp:232-238), and whether it is a hit does not
+ * depend on the table -- so the merged list IS the reference's output (hs_merge_first_table_dev, hsearch.h).
+ *
+ * hs_comm_query_tables: tables[n_tables] = the global numbers of the handle's tables, ascending (n_tables =
+ * the handle's L); centers [nq][d] or qcodes [nq][k] (exactly one non-null) = ALL queries, the same on every
+ * rank.  Returns all hits in HOST buffers in the reference's order, on every rank; *n_total = their number;
+ * cap counts merged hits.  Failure protocol as hs_comm_query.
+ * hs_assign_tables: owner[l] = rank of table l, balanced by cost[l] (longest processing time first; cost NULL:
+ * equal costs = round robin); deterministic.  A useful cost: the sum over a table's buckets of
+ * (k-mers of a DB sample in the bucket)^2 -- proportional to the (member, query) pairs the table's share of
+ * the join meets for queries distributed like the DB. */
+HS_API hs_status hs_comm_query_tables(hs_comm* c, uint32_t rank, hs_handle* h, const uint32_t* tables,
+                                      uint32_t n_tables, const double* centers, const uint8_t* qcodes, uint64_t nq,
+                                      double R, uint32_t* hit_q, uint32_t* hit_id, uint32_t* hit_table,
+                                      double* hit_dist, uint64_t cap, uint64_t* n_total);
+HS_API void hs_assign_tables(const double* cost, uint32_t L, uint32_t world, uint32_t* owner);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,67 @@ def test_sharded_search_allgather_world2():
     assert ok
 
 
+def _table_worker(rank, world, port, ret):
+    """The table-partitioned layout over gloo: rank r searches ALL queries in ITS tables only (the oracle over
+    the planes of those tables), local table numbers are made global, the tuples are all-gathered and merged
+    (per (query, id) the smallest table, order (query, table, id)): the reference's full-L output."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle as O
+    k, K, L, W, R, n, nq = 25, 4, 6, 120.0, 45.0, 4000, 150
+    a, b = synth.make_planes(k, K, L, W)
+    rng = np.random.default_rng(5)
+    codes = synth.make_db(n, k)
+    codes[rng.choice(n, 600, replace=False)] = codes[rng.choice(n, 600)]      # duplicates: pairs found by many tables
+    centers, _ = synth.make_queries(codes, nq, jitter=0.2)
+    # an uneven, interleaved assignment: rank 0 tables {0, 3, 4, 5}, rank 1 tables {1, 2}
+    mine = np.array([[0, 3, 4, 5], [1, 2]][rank])
+    res = O.search(a[mine], b[mine], W, R, O.embed_codes(codes), centers)
+    nh = len(res["q"])
+    def t(x, dt):
+        return torch.from_numpy(x.astype(np.int64)).to(dt)
+    gq, gi, gt, gd = hdist.allgather_hits(t(res["q"], torch.int32), t(res["id"], torch.int32),
+                                          t(mine[res["table"].astype(np.int64)], torch.int32),
+                                          torch.from_numpy(res["dist"]), nh, q_offset=0)
+    mq, mi, mt, md = hdist.merge_table_partitioned(gq, gi, gt, gd)
+    full = O.search(a, b, W, R, O.embed_codes(codes), centers)
+    ok = (np.array_equal(mq.numpy(), full["q"].astype(np.int64)) and
+          np.array_equal(mi.numpy(), full["id"].astype(np.int64)) and
+          np.array_equal(mt.numpy(), full["table"].astype(np.int64)) and
+          np.array_equal(md.numpy(), full["dist"]) and len(full["q"]) > 50 and len(gq) > len(mq) and
+          len(np.unique(full["table"])) > 3)
+    ret.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_table_partitioned_search_world2():
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_table_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(ret.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == {0: True, 1: True}       # every rank ends with the reference's list
+
+
+def test_merge_table_partitioned_small_cases():
+    q = torch.tensor([3, 0, 3, 3, 0, 1], dtype=torch.int64)
+    i = torch.tensor([7, 5, 7, 2, 5, 9], dtype=torch.int64)
+    t = torch.tensor([4, 2, 1, 6, 0, 3], dtype=torch.int64)
+    d = torch.tensor([1.5, 2.5, 1.5, 0.5, 2.5, 9.0], dtype=torch.float64)
+    mq, mi, mt, md = hdist.merge_table_partitioned(q, i, t, d)
+    assert mq.tolist() == [0, 1, 3, 3] and mi.tolist() == [5, 9, 7, 2] and mt.tolist() == [0, 3, 1, 6]
+    assert md.tolist() == [2.5, 9.0, 1.5, 0.5]
+    e = torch.empty(0, dtype=torch.int64)
+    assert hdist.merge_table_partitioned(e, e, e, torch.empty(0, dtype=torch.float64))[0].numel() == 0
+
+
 def _table_edges_oracle(O, a_l, b_l, W, R, pts, active, lo, hi):
     """Edges (i, j) of one clustering table for the active k-mers active[lo:hi] as the i side:
     same bucket of the table built over `active`, i != j, sqrt(d2) <= R (hclust2.cpp:46-60,107-120)."""

@@ -4,6 +4,7 @@ pack kernel -> ncclAllGather -> unpack kernel with device pointers, hs_comm_quer
 query, and the one-process-per-GPU creation path (unique id) -- while the world > 1 layout logic is
 covered on the CPU by tests/test_cdist_cpu.py over the loopback transport."""
 import ctypes as C
+import threading
 
 import numpy as np
 import pytest
@@ -51,6 +52,10 @@ def test_comm_query_equals_plain_query(oracle):
     assert len(want["q"]) > 100
     comm = cdist.Comm(cdist.RCCL_LOCAL, 1, devices=[0])
     got = comm.query(0, eng, centers, 0, R)
+    for f in ("q", "id", "table", "dist"):
+        assert np.array_equal(got[f], want[f]), f
+    # the table-partitioned form with one rank holding every table: pack -> ncclAllGather -> unpack -> merge
+    got = comm.query_tables(0, eng, np.arange(L), centers, R, cap=8)
     for f in ("q", "id", "table", "dist"):
         assert np.array_equal(got[f], want[f]), f
     # a block in the middle of a larger query set: q comes back global
@@ -137,3 +142,106 @@ def test_rank_threads_with_two_live_handles_over_the_loopback(oracle):
         for e in engs:
             e.close()
         comm.close()
+
+
+def test_merge_first_table_on_the_device():
+    """hs_merge_first_table_dev against a numpy statement of the rule: per (query, id) the smallest table,
+    then the order (query, table, id)."""
+    import torch
+    k, K, L, W = 25, 4, 2, 100.0
+    a, b = synth.make_planes(k, K, L, W)
+    eng = Engine(k, K, L, W, a, b)
+    rng = np.random.default_rng(9)
+    n = 200_000
+    q = rng.integers(0, 3000, n).astype(np.uint32)
+    i = rng.integers(0, 500, n).astype(np.uint32)
+    t = rng.integers(0, 32, n).astype(np.uint32)
+    d = (q * 1000.0 + i).astype(np.float64)           # a function of (q, id), as a distance is
+    dev = torch.device("cuda", 0)
+    tq, ti, tt = (torch.from_numpy(x.view(np.int32).copy()).to(dev) for x in (q, i, t))
+    td = torch.from_numpy(d).to(dev)
+    torch.cuda.synchronize()
+    kept = eng.merge_first_table_dev(tq.data_ptr(), ti.data_ptr(), tt.data_ptr(), td.data_ptr(), n)
+    key = (q.astype(np.int64) << 32) | i
+    order = np.lexsort((t, key))
+    first = np.ones(n, bool)
+    first[1:] = key[order][1:] != key[order][:-1]
+    sel = order[first]
+    o2 = np.lexsort((i[sel], t[sel], q[sel]))
+    sel = sel[o2]
+    assert kept == len(sel) and kept < n
+    assert np.array_equal(tq[:kept].cpu().numpy().view(np.uint32), q[sel])
+    assert np.array_equal(ti[:kept].cpu().numpy().view(np.uint32), i[sel])
+    assert np.array_equal(tt[:kept].cpu().numpy().view(np.uint32), t[sel])
+    assert np.array_equal(td[:kept].cpu().numpy(), d[sel])
+    assert eng.merge_first_table_dev(tq.data_ptr(), ti.data_ptr(), tt.data_ptr(), td.data_ptr(), 0) == 0
+    eng.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_table_partitioned_search_equals_one_handle_with_all_tables(world):
+    """The table-partitioned layout (hs_comm_query_tables) with `world` live handles on ONE GPU over the
+    host-memory transport, each holding its subset of the tables over all k-mers: every rank's merged list ==
+    the list of one handle with all tables (hits, table of first sight, order, bit-identical distances), for
+    contiguous and for cost-balanced (interleaved, uneven) table assignments, queries as points and as codes."""
+    k, K, L, W, R, n, nq = 25, 6, 8, 130.0, 45.0, 60_000, 3000
+    a, b = synth.make_planes(k, K, L, W)
+    rng = np.random.default_rng(11)
+    codes = synth.make_db(n, k)
+    codes[rng.choice(n, 5000, replace=False)] = codes[rng.choice(n, 5000)]   # pairs that share buckets in many tables
+    qcodes, _ = synth.make_query_codes(codes, nq)
+    centers = synth.embed(qcodes)
+    one = Engine(k, K, L, W, a, b)
+    one.index_build(codes)
+    want = one.query(centers, R, want_cand=False)
+    one.close()
+    assert len(want["q"]) > 1000 and len(np.unique(want["table"])) > 4
+    cost = np.array([5.0, 1.0, 1.0, 3.0, 1.0, 2.0, 1.0, 1.0])
+    for owner in (np.arange(L) * world // L, cdist.assign_tables(cost, L, world)):
+        tabs = [np.nonzero(owner == r)[0].astype(np.uint32) for r in range(world)]
+        assert sorted(np.concatenate(tabs).tolist()) == list(range(L)) and all(len(t) for t in tabs)
+        engs = []
+        for r in range(world):
+            e = Engine(k, K, len(tabs[r]), W, a[tabs[r]], b[tabs[r]])
+            e.index_build(codes)
+            engs.append(e)
+        comm = cdist.Comm(cdist.LOOPBACK, world, devices=[0] * world)
+        for as_codes in (False, True):
+            got = [None] * world
+            def run(r):
+                got[r] = comm.query_tables(r, engs[r], tabs[r], qcodes if as_codes else centers, R, codes=as_codes)
+            th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+            for t_ in th:
+                t_.start()
+            for t_ in th:
+                t_.join()
+            for r in range(world):
+                for f in ("q", "id", "table", "dist"):
+                    assert np.array_equal(got[r][f], want[f]), (world, r, f, as_codes)
+        # the capacity protocol counts MERGED hits, and a rank without its table list fails everybody
+        st = [None] * world
+        def bad(r):
+            try:
+                comm.query_tables(r, engs[r], tabs[r] if r else tabs[r][::-1].copy(), centers, R)
+                st[r] = capi.HS_OK
+            except capi.HsError as e:
+                st[r] = e.status
+        th = [threading.Thread(target=bad, args=(r,)) for r in range(world)]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        if len(tabs[0]) > 1:
+            assert st[0] == capi.HS_ERR_INVALID and all(x == capi.HS_ERR_PEER for x in st[1:])
+        comm.close()
+        for e in engs:
+            e.close()
+
+
+def test_assign_tables_is_balanced_and_deterministic():
+    cost = np.array([9.0, 1, 1, 1, 8, 1, 1, 1, 7, 1, 1, 1, 1, 1, 1, 1])
+    own = cdist.assign_tables(cost, 16, 4)
+    loads = [cost[own == r].sum() for r in range(4)]
+    assert max(loads) <= 10.0 and sorted(np.bincount(own, minlength=4).tolist())[0] >= 1
+    assert np.array_equal(own, cdist.assign_tables(cost, 16, 4))
+    assert np.array_equal(cdist.assign_tables(None, 8, 4), np.array([0, 1, 2, 3, 0, 1, 2, 3], dtype=np.uint32))

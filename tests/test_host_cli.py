@@ -312,9 +312,20 @@ def test_cli_two_rank_threads_with_live_handles_over_loopback(tmp_path, oracle):
     for n in (1, 2, 3):
         got, so = run("lb%d" % n, "-d", db, "-c", cen, "--gpus", str(n), "--transport", "loopback")
         assert "%d ranks on device 0" % n in so and got == plain
+    # the table-partitioned layout: every rank a subset of the L = 5 tables (dealt by estimated join work) over
+    # all k-mers and ALL centres, merged behind the exchange by the first-seen rule: the same file, and the
+    # same table sizes in the reference's "table size" lines
+    _, so_plain = run("plain2", "-d", db, "-c", cen)
+    for n in (1, 2, 3, 5):
+        got, so = run("tp%d" % n, "-d", db, "-c", cen, "--gpus", str(n), "--transport", "loopback", "--partition", "tables")
+        assert got == plain, n
+        assert [l for l in so.splitlines() if l.startswith("table size")] == \
+            [l for l in so_plain.splitlines() if l.startswith("table size")]
+    r = run("tp6", "-d", db, "-c", cen, "--gpus", "6", "--transport", "loopback", "--partition", "tables", ok=False)
+    assert r.returncode == 1 and "more GPUs than tables" in r.stderr
     fa_plain, _ = run("fa_plain", "-d", fa, "-c", cfa, "--centers-as-points", "1")
     assert len(fa_plain.splitlines()) > 0
-    for extra in ((), ("--centers-as-points", "1")):
+    for extra in ((), ("--centers-as-points", "1"), ("--partition", "tables")):
         got, _ = run("fa_lb2", "-d", fa, "-c", cfa, "--gpus", "2", "--transport", "loopback", *extra)
         assert got == fa_plain
     # a failed rank: everybody stops, nobody hangs (timeout above), the message names the rank

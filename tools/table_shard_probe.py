@@ -28,6 +28,8 @@ ap.add_argument("--K", type=int, default=20)
 ap.add_argument("--W", type=float, default=160.0)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--check", action="store_true")
+ap.add_argument("--balance", action="store_true",
+                help="deal the tables by estimated join work (dist.table_costs + hs_assign_tables) instead of in blocks")
 ap.add_argument("--out", default=None)
 args = ap.parse_args()
 
@@ -77,33 +79,53 @@ def run(eng, out, nq_, steps):
 
 
 ranks = list(range(G)) if args.ranks == "all" else [int(x) for x in args.ranks.split(",")]
+if args.balance:
+    cost = hdist.table_costs(k, K, L, W, a, b, codes[:32768], device=0)
+    tabs = hdist.assign_tables(cost, L, G)
+else:
+    cost = None
+    tabs = [np.arange(r * Lr, (r + 1) * Lr) for r in range(G)]
 per_rank, parts = [], []
 for r in ranks:
-    eng = Engine(k, K, Lr, W, a[r * Lr:(r + 1) * Lr], b[r * Lr:(r + 1) * Lr], device=0)
+    eng = Engine(k, K, len(tabs[r]), W, a[tabs[r]], b[tabs[r]], device=0)
     t0 = time.perf_counter()
     info = eng.index_build(codes)
     t_build = time.perf_counter() - t0
     bp = eng.profile()
     out = alloc(cap)
     nh, res = run(eng, out, nq, args.steps)
-    res.update(rank=r, tables=[r * Lr, (r + 1) * Lr - 1], build_seconds=t_build, build_device_ms=bp["ms_total"],
-               index_bytes=info["device_bytes"])
+    res.update(rank=r, tables=[int(x) for x in tabs[r]], build_seconds=t_build, build_device_ms=bp["ms_total"],
+               index_bytes=info["device_bytes"],
+               estimated_cost_share=float(cost[tabs[r]].sum() / cost.sum()) if cost is not None else None)
     per_rank.append(res)
-    parts.append((out["q"][:nh].clone(), out["id"][:nh].clone(), out["table"][:nh].clone() + r * Lr, out["dist"][:nh].clone()))
+    tmap = torch.as_tensor(np.asarray(tabs[r], dtype=np.int64), device=dev)
+    parts.append((out["q"][:nh].clone(), out["id"][:nh].clone(), tmap[out["table"][:nh].to(torch.int64)], out["dist"][:nh].clone()))
     eng.close()
     del eng, out
     torch.cuda.empty_cache()
     print(json.dumps(res), file=sys.stderr, flush=True)
 
-# the merge, as every rank would run it on the gathered lists
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-mq, mid, mt, md = hdist.merge_table_partitioned(torch.cat([p[0] for p in parts]).to(torch.int64),
-                                                torch.cat([p[1] for p in parts]).to(torch.int64),
-                                                torch.cat([p[2] for p in parts]).to(torch.int64),
-                                                torch.cat([p[3] for p in parts]))
-torch.cuda.synchronize()
-t_merge = time.perf_counter() - t0
+# the merge, as every rank would run it on the gathered lists: torch (bench.py's path) and the library's own
+# (hs_merge_first_table_dev, the C++ host's path); the second call of each is the warm figure
+gq, gi, gt, gd = (torch.cat([p[j] for p in parts]) for j in range(4))
+t_merge = None
+for _ in range(2):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mq, mid, mt, md = hdist.merge_table_partitioned(gq.to(torch.int64), gi.to(torch.int64), gt.to(torch.int64), gd)
+    torch.cuda.synchronize()
+    t_merge = time.perf_counter() - t0
+eng_m = Engine(k, K, 1, W, a[:1], b[:1], device=0)
+t_merge_lib = None
+for _ in range(2):
+    cq, ci, ct, cd = gq.to(torch.int32).clone(), gi.to(torch.int32).clone(), gt.to(torch.int32).clone(), gd.clone()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kept = eng_m.merge_first_table_dev(cq.data_ptr(), ci.data_ptr(), ct.data_ptr(), cd.data_ptr(), len(cq))
+    t_merge_lib = time.perf_counter() - t0
+lib_equal = (kept == len(mq) and bool((cq[:kept].to(torch.int64) == mq).all()) and bool((ci[:kept].to(torch.int64) == mid).all())
+             and bool((ct[:kept].to(torch.int64) == mt).all()) and bool((cd[:kept] == md).all()))
+eng_m.close()
 gathered = int(sum(len(p[0]) for p in parts))
 slowest = max(r["seconds_per_pass"] for r in per_rank)
 result = {"layout": "tables sharded x%d (rank r: tables %dr .. %dr+%d of all k-mers, all queries), emulated on one GPU"
@@ -111,6 +133,8 @@ result = {"layout": "tables sharded x%d (rank r: tables %dr .. %dr+%d of all k-m
           "db_kmers": n, "queries": nq, "L": L, "K": K, "W": W, "ranks_measured": ranks, "per_rank": per_rank,
           "slowest_rank_seconds_per_pass": slowest, "hits_gathered_from_measured_ranks": gathered,
           "hits_after_merge": int(len(mq)), "merge_seconds_on_one_gpu": t_merge,
+          "merge_seconds_hs_merge_first_table_dev": t_merge_lib, "library_merge_equals_torch_merge": lib_equal,
+          "tables_dealt_by_estimated_cost": bool(args.balance),
           "job_queries_per_s_%d_gpus_before_exchange" % G: nq / slowest,
           "job_queries_per_s_%d_gpus_with_merge" % G: nq / (slowest + t_merge)}
 if args.check:
