@@ -236,7 +236,7 @@ def planted_family_recall(args, eng, codes, a, b, device):
 class Workload:
     """One resident index + one resident query batch on this rank, and the timed loop over it."""
 
-    def __init__(self, args, dev_index, dev, rank, synth, Engine, torch, label):
+    def __init__(self, args, dev_index, dev, rank, synth, Engine, torch, label, queries=True):
         self.args, self.dev, self.rank, self.torch, self.label = args, dev, rank, torch, label
         k, K, L, W = args.k, args.K, args.L, args.W
         self.a, self.b = synth.make_planes(k, K, L, W)
@@ -249,17 +249,24 @@ class Workload:
         self.t_build = time.perf_counter() - t0
         self.build_prof = self.eng.profile()
         self.q_offset = rank * args.nq
-        self.set_queries(args.nq, synth.SEED_QUERIES + 1000 * rank)
+        if queries:
+            self.set_queries(args.nq, synth.SEED_QUERIES + 1000 * rank)
 
-    def set_queries(self, nq, seed, jitter=0.0, q_offset=None):
+    def set_queries(self, nq, seed, jitter=0.0, q_offset=None, block_of=None):
         """The rank's resident query batch: nq DB k-mers with 0..4 substitutions, embedded exactly from the
-        table (jitter > 0: Gaussian noise on every coordinate, so that no centre is a k-mer any more)."""
+        table (jitter > 0: Gaussian noise on every coordinate, so that no centre is a k-mer any more).
+        block_of = (total, lo): the batch is the block [lo, lo + nq) of a set of `total` queries drawn with
+        `seed` -- the same set on every rank (strong scaling: one query set, sharded)."""
         synth, torch = self.synth, self.torch
         self.args = argparse.Namespace(**vars(self.args))
         self.args.nq = nq
         if q_offset is not None:
             self.q_offset = q_offset
-        self.qcodes, self.src = synth.make_query_codes(self.codes, nq, seed=seed)
+        if block_of is not None:
+            qc, src = synth.make_query_codes(self.codes, block_of[0], seed=seed)
+            self.qcodes, self.src = qc[block_of[1]:block_of[1] + nq].copy(), src[block_of[1]:block_of[1] + nq].copy()
+        else:
+            self.qcodes, self.src = synth.make_query_codes(self.codes, nq, seed=seed)
         self.centers = synth.embed(self.qcodes)
         if jitter:
             self.centers = self.centers + np.random.Generator(np.random.MT19937(seed + 1)).normal(
@@ -476,8 +483,8 @@ def secondary_block(args, world, rank, dev_index, dev, synth, Engine, torch, hdi
     a2 = argparse.Namespace(**vars(args))
     a2.n, a2.L, a2.K, a2.W, a2.nq = args.secondary_db_size, 32, 20, args.secondary_W, hi - lo
     t0 = time.perf_counter()
-    w2 = Workload(a2, dev_index, dev, rank, synth, Engine, torch, workload_label(a2))
-    w2.q_offset = lo
+    w2 = Workload(a2, dev_index, dev, rank, synth, Engine, torch, workload_label(a2), queries=False)
+    w2.set_queries(hi - lo, synth.SEED_QUERIES, q_offset=lo, block_of=(total_q, lo))   # ONE query set, sharded
     steps = max(args.secondary_steps, 1)
     m2 = w2.timed(steps, 2, hdist, HsError, use_dist, fence, dist, backend)
     sec = None
