@@ -47,12 +47,12 @@ def join_i8_kernel(row_bytes, wide):
     batch (hs_profile.join_row_bytes = GEMM depth, join_wide): hs_join8.hip."""
     ks = row_bytes // 32
     if wide:
-        if ks == 6 and os.environ.get("HS_JOIN_SHAPE") != "32":
+        if ks == 6:
             return "hs_join8xw_kernel"          # 16x16x64, 128-member work items
         return "hs_join8w_kernel<2,%d,wide>" % ks
     if ks > 4:
         return "hs_join8w_kernel<2,%d>" % ks
-    return "hs_join8w_kernel<4,4>" if os.environ.get("HS_JOIN_SHAPE") == "32" else "hs_join8x_kernel"
+    return "hs_join8x_kernel"
 
 
 MFMA_I8_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md: I8 MFMA = 2x the BF16 rate per clock

@@ -188,7 +188,7 @@ class Engine:
     Search() build loop -> index_build; Search() query loop -> query; noLSH Search() -> bruteforce.
     """
 
-    def __init__(self, k, K, L, W, a, b, device=0, coords=None, hooks=False):
+    def __init__(self, k, K, L, W, a, b, device=0, coords=None, hooks=False, options=None):
         self._lib = load(hooks)
         self.k, self.K, self.L, self.W = int(k), int(K), int(L), float(W)
         self.d = 8 * self.k
@@ -211,6 +211,8 @@ class Engine:
                 self._lib.hs_destroy(self._h)
                 self._h = C.c_void_p()
             raise HsError(st, msg or "hs_create failed (is a gfx950 GPU visible?)")
+        for name, value in (options or {}).items():      # hs_set_option, before any index exists
+            self.set_option(name, value)
 
     # -- helpers
     def _check(self, st):
@@ -228,7 +230,7 @@ class Engine:
 
     OPTIONS = {"query_batch": 1, "seg_mode": 2, "join_resident": 3, "recognise_kmers": 4, "build_grouping": 5,
                "wide_rows": 6, "refine8": 7, "self_codes": 8, "thin_filter": 9, "sort_hits": 10, "sync_items": 11,
-               "join_min_q": 12, "join_min_m": 13, "sort_from_bit": 14, "build_serial": 15, "short_segments": 16}
+               "join_min_q": 12, "join_min_m": 13, "sort_from_bit": 14, "build_serial": 15}
 
     def set_option(self, name, value):
         """hs_set_option (include/hsearch.h hs_option): path selection / batch sizing; never changes a result."""

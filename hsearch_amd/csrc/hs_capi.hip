@@ -73,11 +73,10 @@ struct HostBuf {
 enum { EV_COUNT = 12 };
 enum { EV_FORK = 0, EV_JOIN = 1, EVX_COUNT = 2 };
 
-// Environment switches, read ONCE per handle (hs_create -> read_knobs).  None of them changes a result:
-// each forces one of several equivalent paths (the tests run both and compare), sizes a batch, or prints
-// a diagnostic.  HS_VERIFY_MODE / HS_HASH_MODE are the documented defaults of hs_set_verify_mode /
-// hs_set_hash_mode (include/hsearch.h).  Fault injection (HS_TEST_SPLIT_ABOVE) exists only in the test
-// build of the library (-DHS_TEST_HOOKS: libhsearch_amd_hooks.so), never in libhsearch_amd.so.
+// Switches of a handle (hs_set_option, include/hsearch.h; read_knobs for the few that come from the
+// environment).  None of them changes a result: each forces one of several equivalent paths (the tests run
+// both and compare), sizes a batch, or prints a diagnostic.  Fault injection (HS_TEST_SPLIT_ABOVE) exists only
+// in the test build of the library (-DHS_TEST_HOOKS: libhsearch_amd_hooks.so), never in libhsearch_amd.so.
 struct Knobs {
   bool build_serial = false;       // HS_BUILD_SERIAL: no hash / sort overlap in the build (measurement)
   bool build_debug = false;        // HS_BUILD_DEBUG: say when a table is sorted a second time
@@ -98,7 +97,6 @@ struct Knobs {
   int seg_mode = 0;                // HS_SEG_MODE=sparse|dense: 1 / 2; 0 = by the bucket : probe ratio
   int sort_from_bit = 16;          // HS_SORT_FROM_BIT: lowest fingerprint bit the build's sort looks at
   uint32_t query_batch = 0;        // HS_QUERY_BATCH: queries per batch (0: by L)
-  uint32_t short_segments = 4;     // HS_OPT_SHORT_SEGMENTS: segments of <= this many queries skip the MFMA join
 #ifdef HS_TEST_HOOKS
   uint32_t test_split_above = 0;   // HS_TEST_SPLIT_ABOVE: batches above this size report a survivor overflow
   bool test_group_fallback = false;  // HS_TEST_GROUP_FALLBACK: the build's fingerprint table reports itself full
@@ -165,6 +163,7 @@ struct hs_handle {
   bool shard_open = false;
   uint32_t shard_lo = 0, shard_cnt = 0, shard_seed = 0, shard_nb = 0;
   int shard_table = -1;
+  DevBuf seg_of;    // query_batch: the segment of every sorted probe position
   DevBuf seg_res;   // cut_items: flags + scan of the segments that go to the query-resident join kernel
   DevBuf c16s, item_desc, probe_slow, jtab8, slice_ql, qhits;  // qhits: per-query hit counts, offsets, fill
   DevBuf c8b, prov2;  // survivor refinement: second int8 row per query, the refined survivor list
@@ -414,27 +413,23 @@ hs_status hash_account(hs_handle* h, uint64_t n, int F, int set) {
   return HS_OK;
 }
 
+// The environment is read ONCE per handle, for diagnostics and defaults only: HS_BUILD_DEBUG / HS_CLUSTER_TIMING
+// / HS_DEBUG_REFINE (prints), HS_VERIFY_MODE / HS_HASH_MODE (documented defaults of hs_set_verify_mode /
+// hs_set_hash_mode), HS_OPTIONS = "name=value,..." (hs_set_option by name, for the A/B scripts under tools/),
+// and -- test build of the library only -- the fault-injection hooks.  Every path selection is an hs_option.
+const struct { const char* name; int option; } kOptionNames[] = {
+    {"query_batch", HS_OPT_QUERY_BATCH}, {"seg_mode", HS_OPT_SEG_MODE}, {"join_resident", HS_OPT_JOIN_RESIDENT},
+    {"recognise_kmers", HS_OPT_RECOGNISE_KMERS}, {"build_grouping", HS_OPT_BUILD_GROUPING}, {"wide_rows", HS_OPT_WIDE_ROWS},
+    {"refine8", HS_OPT_REFINE8}, {"self_codes", HS_OPT_SELF_CODES}, {"thin_filter", HS_OPT_THIN_FILTER},
+    {"sort_hits", HS_OPT_SORT_HITS}, {"sync_items", HS_OPT_SYNC_ITEMS}, {"join_min_q", HS_OPT_JOIN_MIN_Q},
+    {"join_min_m", HS_OPT_JOIN_MIN_M}, {"sort_from_bit", HS_OPT_SORT_FROM_BIT}, {"build_serial", HS_OPT_BUILD_SERIAL}};
+
 void read_knobs(hs_handle* h) {
   Knobs& kn = h->knobs;
   auto on = [](const char* name) { return getenv(name) != nullptr; };
-  kn.build_serial = on("HS_BUILD_SERIAL");
   kn.build_debug = on("HS_BUILD_DEBUG");
   kn.cluster_timing = on("HS_CLUSTER_TIMING");
   kn.debug_refine = on("HS_DEBUG_REFINE");
-  kn.force_wide = on("HS_FORCE_WIDE");
-  kn.no_wide_by_radius = on("HS_NO_WIDE_BY_RADIUS");
-  kn.no_refine8 = on("HS_NO_REFINE8");
-  kn.no_self_codes = on("HS_NO_SELF_CODES");
-  kn.no_thin8 = on("HS_NO_THIN8");
-  kn.sort_hits = on("HS_SORT_HITS");
-  kn.sync_items = on("HS_SYNC_ITEMS");
-  kn.no_join_r = on("HS_NO_JOIN_R");
-  kn.no_recognise = on("HS_NO_RECOGNISE");
-  kn.force_join_r = on("HS_FORCE_JOIN_R");
-  kn.build_sort = on("HS_BUILD_SORT");
-  if (const char* m = getenv("HS_SEG_MODE")) kn.seg_mode = !strcmp(m, "sparse") ? 1 : !strcmp(m, "dense") ? 2 : 0;
-  if (const char* m = getenv("HS_SORT_FROM_BIT")) kn.sort_from_bit = std::max(0, std::min(60, atoi(m)));
-  if (const char* m = getenv("HS_QUERY_BATCH")) kn.query_batch = (uint32_t)std::max(1, atoi(m));
 #ifdef HS_TEST_HOOKS
   if (const char* m = getenv("HS_TEST_SPLIT_ABOVE")) kn.test_split_above = (uint32_t)std::max(0, atoi(m));
   kn.test_group_fallback = on("HS_TEST_GROUP_FALLBACK");
@@ -448,9 +443,18 @@ void read_knobs(hs_handle* h) {
     if (!strcmp(m, "join")) h->verify_mode = 2;
     if (!strcmp(m, "join16")) h->verify_mode = 3;
   }
-  if (const char* m = getenv("HS_JOIN_MIN_Q")) h->join_min_q = (uint32_t)std::max(1, atoi(m));
-  if (const char* m = getenv("HS_JOIN_MIN_M")) h->join_min_m = (uint32_t)std::max(1, atoi(m));
-  if (const char* m = getenv("HS_JOIN_BLOCKS_PER_CU")) h->join_blocks_per_cu = std::max(1, atoi(m));
+  if (const char* m = getenv("HS_OPTIONS")) {
+    std::string all(m);
+    for (size_t at = 0; at < all.size();) {
+      const size_t end = std::min(all.find(',', at), all.size());
+      const std::string item = all.substr(at, end - at);
+      at = end + 1;
+      const size_t eq = item.find('=');
+      if (eq == std::string::npos) continue;
+      for (const auto& o : kOptionNames)
+        if (item.substr(0, eq) == o.name) (void)hs_set_option(h, o.option, atoll(item.c_str() + eq + 1));
+    }
+  }
 }
 
 }  // namespace
@@ -591,10 +595,8 @@ hs_status hs_create(const hs_params* params, const double* a, const double* b, c
   // Short k-mers: R^2 is not far below the 4-column distance of bucket mates any more (k = 15: the
   // 4-column bound passes 4 % of random pairs), so their rows carry all 8 columns (hs_join8.hip)
   if (getenv("HS_BACKTRACE")) signal(SIGABRT, hs_abort_backtrace);
-  int wide_max_k = 20;
-  if (const char* m = getenv("HS_WIDE_MAX_K")) wide_max_k = std::min(20, atoi(m));
   h->wide8_ok = h->join8_tables_ok && scale8[6] > 0.f;
-  h->wide8 = h->wide8_ok && (int)h->p.k <= wide_max_k;
+  h->wide8 = h->wide8_ok && (int)h->p.k <= 20;  // (hs_set_option(HS_OPT_WIDE_ROWS, 3): never)
   h->join8_scale = (double)scale8[0];
   h->join8_scale_w = (double)scale8[4];
   {  // mean and variance of the 4-column squared distance of two uniformly drawn residues (want_wide)
@@ -675,11 +677,18 @@ hs_status hs_set_option(hs_handle* h, int option, int64_t value) {
       return HS_OK;
     case HS_OPT_RECOGNISE_KMERS: return flag(&kn.no_recognise, true);
     case HS_OPT_BUILD_GROUPING: return flag(&kn.build_sort, false);
-    case HS_OPT_WIDE_ROWS:
-      if (value < 0 || value > 2) break;
+    case HS_OPT_WIDE_ROWS: {
+      if (value < 0 || value > 3) break;
       kn.force_wide = value == 1;
-      kn.no_wide_by_radius = value == 2;
+      kn.no_wide_by_radius = value >= 2;
+      // 3: the 4-column rows for short k-mers too -- the index's member records are built for one form
+      const bool wide8 = h->wide8_ok && (int)h->p.k <= 20 && value != 3;
+      if (wide8 != h->wide8) {
+        drop_index(h);
+        h->wide8 = wide8;
+      }
       return HS_OK;
+    }
     case HS_OPT_REFINE8: return flag(&kn.no_refine8, true);
     case HS_OPT_SELF_CODES: return flag(&kn.no_self_codes, true);
     case HS_OPT_THIN_FILTER: return flag(&kn.no_thin8, true);
@@ -698,10 +707,6 @@ hs_status hs_set_option(hs_handle* h, int option, int64_t value) {
       kn.sort_from_bit = (int)value;
       return HS_OK;
     case HS_OPT_BUILD_SERIAL: return flag(&kn.build_serial, false);
-    case HS_OPT_SHORT_SEGMENTS:
-      if (value < 0 || value > 4) break;
-      kn.short_segments = (uint32_t)value;
-      return HS_OK;
     default:
       return fail(h, HS_ERR_INVALID, "hs_set_option: unknown option");
   }
@@ -733,7 +738,7 @@ void hs_destroy(hs_handle* h) {
                     &h->proj_xmeta, &h->slice_ql, &h->qhits, &h->bs_ints2[0], &h->bs_ints2[1], &h->bs_keys2[0],
                     &h->bs_keys2[1], &h->bs_iota2[0], &h->bs_iota2[1], &h->bs_keys_sorted, &h->bs_rle_unique,
                     &h->bs_rle_counts, &h->bs_small, &h->bs_sort_temp, &h->bs_slow_q, &h->all_codes,
-                    &h->subset_ids, &h->qcodes_buf, &h->qembed, &h->seg_res, &h->t_rho, &h->rec_codes, &h->qpacked, &h->hit_rank, &h->hit_kv, &h->bs_fptab, &h->bs_blk,
+                    &h->subset_ids, &h->qcodes_buf, &h->qembed, &h->seg_res, &h->seg_of, &h->t_rho, &h->rec_codes, &h->qpacked, &h->hit_rank, &h->hit_kv, &h->bs_fptab, &h->bs_blk,
                     &h->bs_dk, &h->bs_hist, &h->bs_rank};
   for (DevBuf* bf : bufs) bf->release();
   h->sj_host.release();
@@ -851,7 +856,7 @@ static hs_status cut_items(hs_handle* h, uint32_t nql, uint32_t jm, unsigned lon
                                 h->sorted_ql.as<uint32_t>(), h->qcount.as<uint32_t>(), nql,
                                 h->join_min_q, h->join_min_m, jm, (int)h->p.L, seg_shift_of(h), max_q_res,
                                 h->seg_items.as<uint32_t>(), d_jstats, h->nslices.as<uint32_t>(),
-                                h->stream));
+                                h->seg_of.as<uint32_t>(), h->stream));
   HS_HIP(h, hipMemsetAsync(big + nql, 0, 4, h->stream));
   if (res) HS_HIP(h, hipMemsetAsync(res + nql, 0, 4, h->stream));
   HS_HIP(h, hipMemsetAsync(items_ord + nql, 0, 4, h->stream));
@@ -2173,6 +2178,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
     HS_HIP(h, h->seg_items.reserve(n1 * 4));
     HS_HIP(h, h->item_off.reserve(n1 * 4));
     HS_HIP(h, h->seg_n.reserve(64));
+    HS_HIP(h, h->seg_of.reserve(n1 * 4));
     HS_HIP(h, h->temp.reserve(std::max(hs_scan_u32_temp(n1), hs_scan_u32_temp((size_t)h->nb_total + 2)) + 256));
     // (the query rows of the join filter were quantised on the side stream, beside hash and probe)
     HS_HIP(h, hipStreamWaitEvent(h->stream, h->evx[EV_JOIN], 0));
@@ -2184,7 +2190,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
                                            h->seg_keys.as<uint32_t>() + n1, h->seg_vals.as<uint32_t>(),
                                            h->bucket_work.as<uint32_t>(), nql, h->sorted_ql.as<uint32_t>(),
                                            h->seg_key.as<uint64_t>(), h->seg_cnt.as<uint32_t>(),
-                                           h->seg_n.as<uint32_t>(), h->stream));
+                                           h->seg_n.as<uint32_t>(), h->seg_of.as<uint32_t>(), h->stream));
     } else
     HS_HIP(h, hs_launch_seg_group(h->tabs, h->dir_base.as<uint32_t>(), L, seg_shift, h->nb_total,
                                   h->bucket_work.as<uint32_t>(),
@@ -2192,7 +2198,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
                                   h->temp.cap, h->seg_keys.as<uint32_t>(),
                                   h->seg_keys.as<uint32_t>() + n1, nql, h->sorted_ql.as<uint32_t>(),
                                   h->seg_key.as<uint64_t>(), h->seg_cnt.as<uint32_t>(),
-                                  h->seg_n.as<uint32_t>(), h->stream));
+                                  h->seg_n.as<uint32_t>(), h->seg_of.as<uint32_t>(), h->stream));
     HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, h->seg_cnt.as<uint32_t>(),
                                     h->seg_qoff.as<uint32_t>(), n1, h->stream));
     // work items: one wave's 128 members for the wave-independent int8 join, 512 otherwise
@@ -2205,7 +2211,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
     HS_CHECK(cut_items(h, nql, jm, d_jstats, use_r ? HS_JR_MAXQ : 0u));
     if (use_i8)
       HS_HIP(h, hs_launch_gather_c8t(h->c16.p, h->sorted_ql.as<uint32_t>(), h->seg_qoff.as<uint32_t>(),
-                                     nql, L, k, wide, h->c16s.p, h->stream));
+                                     h->seg_of.as<uint32_t>(), nql, L, k, wide, h->c16s.p, h->stream));
     else
       HS_HIP(h, hs_launch_gather_c16(h->c16.p, h->sorted_ql.as<uint32_t>(), nql, L, h->c16s.p, h->stream));
   }
@@ -2823,6 +2829,7 @@ hs_status hs_self_join_range(hs_handle* h, uint64_t first, uint64_t count, doubl
     acc.candidates += h->prof.candidates; acc.provisional += h->prof.provisional;
     acc.join_pairs += h->prof.join_pairs; acc.join_pairs_issued += h->prof.join_pairs_issued;
     acc.join_items += h->prof.join_items; acc.join_batches += h->prof.join_batches;
+    acc.join_items_resident += h->prof.join_items_resident;
     acc.verify_launches += h->prof.verify_launches;
     acc.hash_values += h->prof.hash_values; acc.hash_flagged += h->prof.hash_flagged;
     HS_HIP(h, h->sj_host.reserve(std::max<size_t>(64, (nh + nh / 8 + 1024) * 20)));

@@ -322,13 +322,14 @@ hipError_t hs_launch_seg_group_sparse(const hs_tables_dev& tabs, const uint32_t*
                                       const uint32_t* d_qbucket, uint32_t* d_keys_sorted, uint32_t* d_iota,
                                       uint32_t* d_work, uint32_t nql, uint32_t* d_sorted_ql,
                                       uint64_t* d_seg_key, uint32_t* d_seg_cnt, uint32_t* d_n_seg,
+                                      uint32_t* d_seg_of /* [nql]: segment of every sorted probe position */,
                                       hipStream_t s);
 hipError_t hs_launch_seg_group(const hs_tables_dev& tabs, const uint32_t* d_dir_base, int L, int shift,
                                uint32_t nb_total, const uint32_t* d_bucket_count,
                                uint32_t* d_bucket_work /* 3 x (nb_total + 2) */, void* d_temp,
                                size_t temp_bytes, const uint32_t* d_qbucket, const uint32_t* d_qrank,
                                uint32_t nql, uint32_t* d_sorted_ql, uint64_t* d_seg_key,
-                               uint32_t* d_seg_cnt, uint32_t* d_n_seg, hipStream_t s);
+                               uint32_t* d_seg_cnt, uint32_t* d_n_seg, uint32_t* d_seg_of, hipStream_t s);
 // self-join: query q = indexed k-mer first_id + q probes the bucket it sits in (no hash, no directory
 // search); outputs as hs_launch_probe
 hipError_t hs_launch_self_probe(const hs_tables_dev& tabs, uint32_t first_id, uint32_t nq, int L,
@@ -429,7 +430,7 @@ hipError_t hs_launch_seg_route(const uint64_t* d_seg_key, const uint32_t* d_seg_
                                uint32_t max_q_resident /* segments up to this many queries are issued in
                                16-query column tiles (hs_join8r_kernel); 0: none */,
                                uint32_t* d_items, unsigned long long* d_stats, uint32_t* d_nslices,
-                               hipStream_t s);
+                               const uint32_t* d_seg_of, hipStream_t s);
 hipError_t hs_launch_item_desc(const hs_tables_dev& tabs, const uint64_t* d_seg_key,
                                const uint32_t* d_seg_cnt,
                                const uint32_t* d_seg_qoff, const uint32_t* d_item_off, uint32_t n_max,
@@ -490,7 +491,8 @@ hipError_t hs_launch_refine8(const hs_tables_dev& tabs, const uint2* d_prov, con
                              const uint32_t* d_qstart, const uint32_t* d_qcount,
                              uint2* d_out, uint32_t* d_out_count, hipStream_t s);
 hipError_t hs_launch_gather_c8t(const void* d_c8, const uint32_t* d_sorted_ql, const uint32_t* d_seg_qoff,
-                                uint32_t nql, int L, int k, int wide, void* d_out, hipStream_t s);
+                                const uint32_t* d_seg_of, uint32_t nql, int L, int k, int wide, void* d_out,
+                                hipStream_t s);
 // bytes of a quantised int8 row (32 per k-step: 128 for k <= 25, 192 for k <= 41 and for wide rows,
 // 256 for k <= 50) and the members of one work item of the wave-independent int8 join (128 / 64)
 int hs_join8_row_bytes(int k, int wide);

@@ -121,13 +121,19 @@ __global__ void hs_jtables_kernel(const double* __restrict__ coords, int alphabe
 //   the non-empty buckets, in bucket order, are the segments: key = (table << shift) | first sorted
 //   position of the bucket, count = probes.  The pseudo-bucket (probes of no bucket) comes last
 //   with table = L and is routed nowhere.
+// (+ seg_of[p] = segment of sorted position p: what the later per-probe passes index with)
 __global__ __launch_bounds__(256) void hs_seg_scatter_kernel(const uint32_t* __restrict__ qbucket,
                                                              const uint32_t* __restrict__ qrank,
                                                              const uint32_t* __restrict__ bucket_start,
+                                                             const uint32_t* __restrict__ flag_pos,
                                                              uint32_t nql,
-                                                             uint32_t* __restrict__ sorted_ql) {
+                                                             uint32_t* __restrict__ sorted_ql,
+                                                             uint32_t* __restrict__ seg_of) {
   const uint32_t ql = blockIdx.x * 256 + threadIdx.x;
-  if (ql < nql) sorted_ql[bucket_start[qbucket[ql]] + qrank[ql]] = ql;
+  if (ql >= nql) return;
+  const uint32_t gb = qbucket[ql], p = bucket_start[gb] + qrank[ql];
+  sorted_ql[p] = ql;
+  seg_of[p] = flag_pos[gb];
 }
 __global__ __launch_bounds__(256) void hs_seg_flag_kernel(const uint32_t* __restrict__ bucket_count,
                                                           uint32_t n, uint32_t* __restrict__ flag) {
@@ -175,12 +181,14 @@ __global__ __launch_bounds__(256) void hs_seg_emit_sparse_kernel(hs_tables_dev t
                                                                  const uint32_t* __restrict__ head_pos,
                                                                  uint32_t n, uint64_t* __restrict__ seg_key,
                                                                  uint32_t* __restrict__ seg_start,
-                                                                 uint32_t* __restrict__ n_seg) {
+                                                                 uint32_t* __restrict__ n_seg,
+                                                                 uint32_t* __restrict__ seg_of) {
   const uint32_t p = blockIdx.x * 256 + threadIdx.x;
   if (p == 0) {
     *n_seg = head_pos[n];
     seg_start[head_pos[n]] = n;
   }
+  if (p < n) seg_of[p] = head_pos[p] + head[p] - 1u;  // heads before p, p's own included: its segment + 1
   if (p >= n || !head[p]) return;
   const uint32_t g = gb[p];
   int l = 0;
@@ -253,19 +261,13 @@ __global__ __launch_bounds__(256) void hs_seg_route_kernel(const uint64_t* __res
 
 // nslices[ql] = 0 for probes whose segment was routed to the join (they keep their slice count,
 // written by the probe kernel, otherwise).  One thread per sorted probe; segment by binary search.
-__global__ __launch_bounds__(256) void hs_seg_unslice_kernel(const uint32_t* __restrict__ seg_qoff,
-                                                             const uint32_t* __restrict__ n_seg,
+__global__ __launch_bounds__(256) void hs_seg_unslice_kernel(const uint32_t* __restrict__ seg_of,
                                                              const uint32_t* __restrict__ items,
                                                              const uint32_t* __restrict__ sorted_ql,
                                                              uint32_t nql, uint32_t* __restrict__ nslices) {
   const uint32_t p = blockIdx.x * 256 + threadIdx.x;
   if (p >= nql) return;
-  uint32_t lo = 0, hi = *n_seg;  // largest j with seg_qoff[j] <= p
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (seg_qoff[mid] <= p) lo = mid; else hi = mid;
-  }
-  if (items[lo]) nslices[sorted_ql[p]] = 0;
+  if (items[seg_of[p]]) nslices[sorted_ql[p]] = 0;
 }
 
 // Item numbering order of the segments: those with many probing queries first (a stable
@@ -318,6 +320,13 @@ __global__ void hs_item_split_kernel(const uint32_t* __restrict__ item_off, cons
 // One descriptor (2 x uint4) per work item:
 //   { offset of the bucket's first packed member from table 0's packed array (lo, hi), M, tile },
 //   { qoff, q_begin, q_end, first sorted position of the bucket }
+// One thread per item.  The item's segment = the largest position j of `order` with item_off[j] <= item
+// (zero-item positions share their successor's offset, so the last such j owns the item): a block's 256
+// consecutive items mostly span a few hundred positions, so thread 0 finds the block's first position by a
+// binary search over item_off in memory, the block copies the next positions' offsets to LDS, and every
+// thread searches there; a block whose items span more positions than the window holds (a run of zero-item
+// positions inside it) falls back to the search in memory.  (One thread per SEGMENT, writing its items in
+// a loop, was measured slower: 32-byte stores scattered over the descriptor array.)
 __global__ __launch_bounds__(256) void hs_item_desc_kernel(hs_tables_dev tabs,
                                                            const uint64_t* __restrict__ seg_key,
                                                            const uint32_t* __restrict__ seg_cnt,
@@ -330,13 +339,40 @@ __global__ __launch_bounds__(256) void hs_item_desc_kernel(hs_tables_dev tabs,
                                                            const uint32_t* __restrict__ order, int PW,
                                                            const uint32_t* __restrict__ n_items_dev,
                                                            uint4* __restrict__ desc) {
-  const uint32_t item = blockIdx.x * 256 + threadIdx.x;
+  constexpr uint32_t WIN = 768;
+  __shared__ uint32_t s_off[WIN + 1];
+  __shared__ uint32_t s_first;
+  const uint32_t item0 = blockIdx.x * 256, item = item0 + threadIdx.x;
   if (n_items_dev) n_items = min(n_items, *n_items_dev);  // n_items = capacity of desc then
+  if (item0 >= n_items) return;
+  if (threadIdx.x == 0) {
+    uint32_t lo = 0, hi = n_max;  // largest j with item_off[j] <= item0
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (item_off[mid] <= item0) lo = mid; else hi = mid;
+    }
+    s_first = lo;
+  }
+  __syncthreads();
+  const uint32_t first = s_first;
+  for (uint32_t i = threadIdx.x; i <= WIN; i += 256) s_off[i] = first + i <= n_max ? item_off[first + i] : 0xffffffffu;
+  __syncthreads();
   if (item >= n_items) return;
-  uint32_t lo = 0, hi = n_max;  // largest j with item_off[j] <= item (zero-item segments share
-  while (hi - lo > 1) {         // their successor's offset, so the last such j owns the item)
-    const uint32_t mid = (lo + hi) >> 1;
-    if (item_off[mid] <= item) lo = mid; else hi = mid;
+  uint32_t lo;
+  if (s_off[WIN] > item) {  // the item's position lies inside the window
+    uint32_t l = 0, h = WIN;
+    while (h - l > 1) {
+      const uint32_t mid = (l + h) >> 1;
+      if (s_off[mid] <= item) l = mid; else h = mid;
+    }
+    lo = first + l;
+  } else {
+    lo = first;
+    uint32_t hi = n_max;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (item_off[mid] <= item) lo = mid; else hi = mid;
+    }
   }
   const uint32_t seg = order[lo];  // item_off runs over the segments in `order`
   const uint64_t key = seg_key[seg];
@@ -625,7 +661,7 @@ hipError_t hs_launch_seg_group(const hs_tables_dev& tabs, const uint32_t* d_dir_
                                uint32_t* d_bucket_work, void* d_temp, size_t temp_bytes,
                                const uint32_t* d_qbucket, const uint32_t* d_qrank, uint32_t nql,
                                uint32_t* d_sorted_ql, uint64_t* d_seg_key, uint32_t* d_seg_cnt,
-                               uint32_t* d_n_seg, hipStream_t s) {
+                               uint32_t* d_n_seg, uint32_t* d_seg_of, hipStream_t s) {
   if (!nql) return hipSuccess;
   const uint32_t n = nb_total + 1;  // buckets incl. the pseudo one; arrays have n + 1 entries
   uint32_t* start = d_bucket_work;
@@ -633,10 +669,10 @@ hipError_t hs_launch_seg_group(const hs_tables_dev& tabs, const uint32_t* d_dir_
   uint32_t* flag_pos = d_bucket_work + 2 * (size_t)(n + 1);
   hipError_t e = hs_exclusive_scan_u32(d_temp, temp_bytes, d_bucket_count, start, (size_t)n + 1, s);
   if (e != hipSuccess) return e;
-  hs_seg_scatter_kernel<<<blocks_for(nql), 256, 0, s>>>(d_qbucket, d_qrank, start, nql, d_sorted_ql);
   hs_seg_flag_kernel<<<blocks_for((uint64_t)n + 1), 256, 0, s>>>(d_bucket_count, n, flag);
   e = hs_exclusive_scan_u32(d_temp, temp_bytes, flag, flag_pos, (size_t)n + 1, s);
   if (e != hipSuccess) return e;
+  hs_seg_scatter_kernel<<<blocks_for(nql), 256, 0, s>>>(d_qbucket, d_qrank, start, flag_pos, nql, d_sorted_ql, d_seg_of);
   hs_seg_emit_kernel<<<blocks_for(n), 256, 0, s>>>(tabs, d_dir_base, L, shift, d_bucket_count, flag_pos,
                                                    n, d_seg_key, d_seg_cnt, d_n_seg);
   return hipGetLastError();
@@ -647,7 +683,7 @@ hipError_t hs_launch_seg_group_sparse(const hs_tables_dev& tabs, const uint32_t*
                                       const uint32_t* d_qbucket, uint32_t* d_keys_sorted, uint32_t* d_iota,
                                       uint32_t* d_work, uint32_t nql, uint32_t* d_sorted_ql,
                                       uint64_t* d_seg_key, uint32_t* d_seg_cnt, uint32_t* d_n_seg,
-                                      hipStream_t s) {
+                                      uint32_t* d_seg_of, hipStream_t s) {
   if (!nql) return hipSuccess;
   uint32_t* head = d_work;
   uint32_t* head_pos = d_work + ((size_t)nql + 1);
@@ -662,7 +698,7 @@ hipError_t hs_launch_seg_group_sparse(const hs_tables_dev& tabs, const uint32_t*
   e = hs_exclusive_scan_u32(d_temp, temp_bytes, head, head_pos, (size_t)nql + 1, s);
   if (e != hipSuccess) return e;
   hs_seg_emit_sparse_kernel<<<blocks_for(nql), 256, 0, s>>>(tabs, d_dir_base, L, shift, d_keys_sorted, head,
-                                                            head_pos, nql, d_seg_key, seg_start, d_n_seg);
+                                                            head_pos, nql, d_seg_key, seg_start, d_n_seg, d_seg_of);
   hs_seg_counts_kernel<<<blocks_for(nql), 256, 0, s>>>(seg_start, d_n_seg, d_seg_cnt);
   return hipGetLastError();
 }
@@ -672,12 +708,11 @@ hipError_t hs_launch_seg_route(const uint64_t* d_seg_key, const uint32_t* d_seg_
                                const uint32_t* d_sorted_ql, const uint32_t* d_qcount, uint32_t n_max,
                                uint32_t min_q, uint32_t min_m, uint32_t jm, int L, int shift,
                                uint32_t max_q_resident, uint32_t* d_items, unsigned long long* d_stats,
-                               uint32_t* d_nslices, hipStream_t s) {
+                               uint32_t* d_nslices, const uint32_t* d_seg_of, hipStream_t s) {
   hs_seg_route_kernel<<<blocks_for((uint64_t)n_max + 1), 256, 0, s>>>(
       d_seg_key, d_seg_cnt, d_seg_qoff, d_n_seg, d_sorted_ql, d_qcount, n_max, min_q, min_m, jm, L,
       shift, max_q_resident, d_items, d_stats);
-  hs_seg_unslice_kernel<<<blocks_for(n_max), 256, 0, s>>>(d_seg_qoff, d_n_seg, d_items, d_sorted_ql,
-                                                         n_max, d_nslices);
+  hs_seg_unslice_kernel<<<blocks_for(n_max), 256, 0, s>>>(d_seg_of, d_items, d_sorted_ql, n_max, d_nslices);
   return hipGetLastError();
 }
 

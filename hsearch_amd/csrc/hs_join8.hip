@@ -597,22 +597,23 @@ __device__ unsigned long long g_join8_timing[8];
 __global__ __launch_bounds__(256) void hs_gather_c8t_kernel(const int8_t* __restrict__ c8,
                                                             const uint32_t* __restrict__ sorted_ql,
                                                             const uint32_t* __restrict__ seg_qoff,
+                                                            const uint32_t* __restrict__ seg_of,
                                                             uint32_t nql, int L, int pieces,
                                                             uint4* __restrict__ out) {
-  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  // EIGHT lanes per probe, lane g of them moving the pieces g, g + 8, ...: a load instruction of the wave then
+  // reads 8 whole rows (8 cache lines) instead of one piece of 64 different rows (64 lines) -- these kernels
+  // are bound by the lines their loads and stores touch, not by the bytes
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t p = t >> 3, g0 = t & 7u;
   if (p >= nql) return;
-  uint32_t lo = 0, hi = nql + 1;  // largest j with seg_qoff[j] <= p (seg_qoff[nql] == nql > p)
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (seg_qoff[mid] <= p) lo = mid; else hi = mid;
-  }
+  const uint32_t lo = seg_of[p];  // the segment of sorted position p (written when the probes were grouped)
   const uint32_t qoff = seg_qoff[lo], nQ = seg_qoff[lo + 1] - qoff;
   const uint32_t local = p - qoff, tile = local >> 5, j = local & 31u;
   const uint32_t nr = min(32u, nQ - (tile << 5));
   const uint32_t q = sorted_ql[p] / (uint32_t)L;
   const uint4* src = reinterpret_cast<const uint4*>(c8) + (uint64_t)q * pieces;
   uint4* dst = out + (uint64_t)(qoff + (tile << 5)) * pieces + j;
-  for (int g = 0; g < pieces; ++g) dst[(uint32_t)g * nr] = src[g];
+  for (uint32_t g = g0; g < (uint32_t)pieces; g += 8u) dst[g * nr] = src[g];
 }
 
 // No LDS staging and no workgroup barrier: a work item is 128 bucket members x <= 2048 probing
@@ -2264,15 +2265,15 @@ int hs_join8_row_bytes(int k, int wide) { return 32 * ks_of(k, wide != 0); }
 // 128 members where a 16x16x64 kernel runs the items (hs_join8x_kernel, hs_join8r_kernel, hs_join8xw_kernel),
 // 64 for the 32x32x32 forms of the longer rows
 uint32_t hs_join8_members_per_item(int k, int wide) {
-  static const bool shape32 = getenv("HS_JOIN_SHAPE") && atoi(getenv("HS_JOIN_SHAPE")) == 32;
   const int KS = ks_of(k, wide != 0);
-  return (KS == 4 || (wide && KS == 6 && !shape32)) ? 128u : 64u;
+  return (KS == 4 || (wide && KS == 6)) ? 128u : 64u;
 }
 
 hipError_t hs_launch_gather_c8t(const void* d_c8, const uint32_t* d_sorted_ql, const uint32_t* d_seg_qoff,
-                                uint32_t nql, int L, int k, int wide, void* d_out, hipStream_t s) {
+                                const uint32_t* d_seg_of, uint32_t nql, int L, int k, int wide, void* d_out,
+                                hipStream_t s) {
   if (!nql) return hipSuccess;
-  hs_gather_c8t_kernel<<<blocks_for(nql), 256, 0, s>>>((const int8_t*)d_c8, d_sorted_ql, d_seg_qoff, nql,
+  hs_gather_c8t_kernel<<<blocks_for((uint64_t)nql * 8), 256, 0, s>>>((const int8_t*)d_c8, d_sorted_ql, d_seg_qoff, d_seg_of, nql,
                                                        L, 2 * ks_of(k, wide != 0), (uint4*)d_out);
   return hipGetLastError();
 }
@@ -2291,10 +2292,8 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
   // kernel); bigger chunks than that cost balance at the end.  pairs_per_item = the previous
   // batch's average (0: unknown).  Fewer for small launches.
   const uint32_t n_waves = (uint32_t)n_blocks * 4u;
-  static const uint32_t g_env = getenv("HS_JOIN_CHUNK") ? (uint32_t)atoi(getenv("HS_JOIN_CHUNK")) : 0u;
   uint32_t g_max = 8u;
   if (pairs_per_item > 0.0) g_max = (uint32_t)std::max(8.0, std::min(48.0, 7.0e5 / pairs_per_item));
-  if (g_env) g_max = g_env;
   // up to 8: at least 8 chunks per wave; beyond: at least 64 (the balance at the end is paid in
   // chunks: k = 39 at the C2 sizes, 576 items per wave, lost 3 % with chunks of 18)
   const uint32_t g_small = std::min(8u, n_items / (n_waves * 8u));
@@ -2309,25 +2308,20 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
                                                       d_prov_count, prov_cap, d_prov, d_item_counter, G, \
                                                       d_n_items)
   const int KS = ks_of(k, wide != 0);
-  // k <= 25: the 16x16x64 form by default (HS_JOIN_SHAPE=32 selects the 32x32x32 form)
-  static const bool shape32 = getenv("HS_JOIN_SHAPE") && atoi(getenv("HS_JOIN_SHAPE")) == 32;
-  if (wide && KS == 6 && !shape32)  // d_tab8 = the 8-column table here
+  // the 16x16x64 forms where they exist (k <= 25 with 4-column rows, k <= 20 with rows over all 8 columns);
+  // the 32x32x32 form for the longer rows
+  if (wide && KS == 6)  // d_tab8 = the 8-column table here
     hs_join8xw_kernel<<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_rec_base, (const uint4*)d_c8t,
                                                (const uint4*)d_tab8, d_prov_count, prov_cap, d_prov, d_item_counter,
                                                G, d_n_items);
-  else if (wide && KS == 6)
-    hs_join8w_kernel<2, 6, true><<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_rec_base,
-                                                          (const uint4*)d_c8t, (const uint4*)d_tab8, d_prov_count,
-                                                          prov_cap, d_prov, d_item_counter, G, d_n_items);
   else if (wide)
     hs_join8w_kernel<2, 8, true><<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_rec_base,
                                                           (const uint4*)d_c8t, (const uint4*)d_tab8, d_prov_count,
                                                           prov_cap, d_prov, d_item_counter, G, d_n_items);
-  else if (KS == 4 && !shape32)
+  else if (KS == 4)
     hs_join8x_kernel<<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_rec_base, (const uint4*)d_c8t,
                                               (const uint4*)d_tab8, d_prov_count, prov_cap, d_prov,
                                               d_item_counter, G, d_n_items);
-  else if (KS == 4) HS_J8(4, 4);
   else if (KS == 6) HS_J8(2, 6);
   else HS_J8(2, 8);
 #undef HS_J8
@@ -2368,12 +2362,10 @@ hipError_t hs_launch_join8r(const uint4* d_desc, uint32_t desc_cap, const uint32
   }
   // chunks of consecutive items = consecutive member tiles of one bucket (the query rows stay); sized like
   // hs_launch_join8w's, from the previous batch's pairs per item
-  static const uint32_t g_env = getenv("HS_JOIN_CHUNK_R") ? (uint32_t)atoi(getenv("HS_JOIN_CHUNK_R")) : 0u;
   uint32_t G = 16u;
   if (pairs_per_item > 0.0) G = (uint32_t)std::max(8.0, std::min(64.0, 1.4e5 / pairs_per_item * 8.0));
   const uint32_t n_waves = (uint32_t)n_blocks * 4u;
   G = std::max(2u, std::min(G, std::max(2u, desc_cap / (n_waves * 32u))));
-  if (g_env) G = g_env;
   hs_join8r_kernel<<<n_blocks, 256, lay.total, s>>>(d_desc, d_split, desc_cap, d_packed_base, d_rho_base,
                                                     (const uint4*)d_c8t, (const uint4*)d_tab8, alphabet, d_prov_count,
                                                     prov_cap, d_prov, d_item_counter, G);

@@ -154,7 +154,8 @@ typedef enum hs_option {
   HS_OPT_BUILD_GROUPING = 5, /* 0 (default): exact-membership table + radix sort on bucket ranks; 1: radix sort of
                                 (fingerprint, id) pairs */
   HS_OPT_WIDE_ROWS = 6,      /* int8 rows over all 8 coordinate columns for k = 21..25: 0 by radius, 1 always,
-                                2 never by radius */
+                                2 never by radius; 3: 4-column rows for k <= 20 as well (drops the index: the
+                                member records are built for one form) */
   HS_OPT_REFINE8 = 7,        /* 1 (default): survivors of the 4-column bound pass the 8-column bound first */
   HS_OPT_SELF_CODES = 8,     /* 1 (default): the self-join runs from residue codes; 0: from embedded centres */
   HS_OPT_THIN_FILTER = 9,    /* 1 (default): segments below HS_OPT_JOIN_MIN_Q / _M through the int8 per-pair filter;
@@ -164,9 +165,7 @@ typedef enum hs_option {
   HS_OPT_JOIN_MIN_Q = 12,    /* segments with fewer probing queries ... */
   HS_OPT_JOIN_MIN_M = 13,    /* ... or fewer members skip the join (default 1 / 1: none do) */
   HS_OPT_SORT_FROM_BIT = 14, /* HS_OPT_BUILD_GROUPING = 1: lowest fingerprint bit the first sort looks at (0..60) */
-  HS_OPT_BUILD_SERIAL = 15,  /* 1: no overlap of a table's hashing with the previous table's grouping */
-  HS_OPT_SHORT_SEGMENTS = 16 /* segments of at most this many probing queries (0..4, default 4) through the
-                                member-per-lane filter hs_few8_kernel instead of a 16-query MFMA tile */
+  HS_OPT_BUILD_SERIAL = 15   /* 1: no overlap of a table's hashing with the previous table's grouping */
 } hs_option;
 HS_API hs_status hs_set_option(hs_handle* h, int option, int64_t value);
 /* The library's work after this call starts only once `hip_event` (a hipEvent_t the caller has recorded on a

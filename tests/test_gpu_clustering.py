@@ -129,7 +129,7 @@ def test_self_join_edges_match_bruteforce_within_buckets(oracle):
 
 @pytest.mark.parametrize("k,K,L,W,R", [(25, 4, 3, 120.0, 50.0), (39, 6, 4, 200.0, 60.0), (12, 3, 2, 90.0, 30.0),
                                       (25, 4, 3, 120.0, 171.0)])
-def test_self_join_from_codes_equals_embedded_queries(monkeypatch, k, K, L, W, R):
+def test_self_join_from_codes_equals_embedded_queries(k, K, L, W, R):
     """The self-join's two routes -- per-query rows from the residue codes (no centres, no hashing, no
     directory search) and the ordinary query path over embedded centres -- give the same edges, in
     the same order, with the same distances.  R = 171 is past what the int8 filter's digits carry
@@ -139,15 +139,12 @@ def test_self_join_from_codes_equals_embedded_queries(monkeypatch, k, K, L, W, R
     a, b = synth.make_planes(k, K, L, W, seed=3)
     out = []
     for route in ("codes", "centres", "codes-min"):
-        monkeypatch.delenv("HS_NO_SELF_CODES", raising=False)
-        monkeypatch.delenv("HS_JOIN_MIN_Q", raising=False)
-        monkeypatch.delenv("HS_JOIN_MIN_M", raising=False)
+        opts = {}
         if route == "centres":
-            monkeypatch.setenv("HS_NO_SELF_CODES", "1")
+            opts = dict(self_codes=0)
         if route == "codes-min":  # thin segments leave the join: the int8 thin filter serves them
-            monkeypatch.setenv("HS_JOIN_MIN_Q", "3")
-            monkeypatch.setenv("HS_JOIN_MIN_M", "16")
-        eng = Engine(k, K, L, W, a, b)
+            opts = dict(join_min_q=3, join_min_m=16)
+        eng = Engine(k, K, L, W, a, b, options=opts)
         eng.index_build(codes)
         for sq in (False, True):
             out.append((route, sq, eng.self_join(R, sqrt_test=sq), eng.self_join(R, first=100, count=2345, sqrt_test=sq)))

@@ -68,16 +68,12 @@ def test_random_configuration_matches_oracle(oracle, seed):
     import os
     c = _case(seed)
     # every third case with the thin-segment routing on (segments with < 3 probing queries or < 16
-    # members to the per-pair filters hs_thin8_kernel / hs_verify_kernel instead of the join)
-    thin = {"HS_JOIN_MIN_Q": "3", "HS_JOIN_MIN_M": "16"} if seed % 3 == 0 else {}
-    os.environ.update(thin)
-    try:
-        # (HS_TEST_SPLIT_ABOVE in the environment: the library's test build, which has that hook)
-        eng = Engine(c["k"], c["K"], c["L"], c["W"], c["a"], c["b"], coords=c["table"],
-                     hooks=bool(os.environ.get("HS_TEST_SPLIT_ABOVE")))
-    finally:
-        for key in thin:
-            del os.environ[key]
+    # members to the per-pair filters hs_thin8_kernel / hs_verify_kernel instead of the join); every other
+    # remaining case forces the query-resident join kernel for its class
+    opts = dict(join_min_q=3, join_min_m=16) if seed % 3 == 0 else dict(join_resident=2 * (seed % 2))
+    # (HS_TEST_SPLIT_ABOVE in the environment: the library's test build, which has that hook)
+    eng = Engine(c["k"], c["K"], c["L"], c["W"], c["a"], c["b"], coords=c["table"],
+                 hooks=bool(os.environ.get("HS_TEST_SPLIT_ABOVE")), options=opts)
     info = eng.index_build(c["codes"])
     ix = oracle.Index(c["a"], c["b"], c["W"], c["pts"])
     try:

@@ -113,12 +113,12 @@ def test_long_kmers_through_the_int8_join(oracle, k):
 
 
 @pytest.mark.parametrize("k,R", [(5, 20.0), (8, 30.0), (12, 36.0), (15, 40.0), (20, 40.0)])
-def test_short_kmers_through_the_wide_int8_join(oracle, monkeypatch, k, R):
+def test_short_kmers_through_the_wide_int8_join(oracle, k, R):
     """k <= 20 (configs[4]'s k = 15): R^2 is no longer far below the 4-column distance of bucket mates,
     so the int8 rows carry all 8 coordinate columns (6 k-steps, 64-member work items, no refinement
     pass).  Hits, order and distances equal the oracle's in every verify mode, with the thin-segment
-    filter in play (HS_JOIN_MIN_Q/_M) and with the 4-column rows forced (HS_WIDE_MAX_K=0 and
-    HS_NO_WIDE_BY_RADIUS=1).  (How many
+    filter in play (options join_min_q / join_min_m) and with the 4-column rows forced (option wide_rows = 3).
+    (How many
     fewer survivors the wide rows leave at the bench's sizes: tools/regime_sweep.py.)"""
     K, L, W, n, nq = 3, 3, 260.0, 20011, 1203
     a, b = synth.make_planes(k, K, L, W, seed=25)
@@ -128,17 +128,12 @@ def test_short_kmers_through_the_wide_int8_join(oracle, monkeypatch, k, R):
     assert len(want["q"]) > 200
     survivors = {}
     for rows in ("wide", "wide-thin", "narrow"):
-        monkeypatch.delenv("HS_WIDE_MAX_K", raising=False)
-        monkeypatch.delenv("HS_NO_WIDE_BY_RADIUS", raising=False)
-        monkeypatch.delenv("HS_JOIN_MIN_Q", raising=False)
-        monkeypatch.delenv("HS_JOIN_MIN_M", raising=False)
-        if rows == "narrow":  # (without the second switch the radius rule would bring the wide rows back)
-            monkeypatch.setenv("HS_WIDE_MAX_K", "0")
-            monkeypatch.setenv("HS_NO_WIDE_BY_RADIUS", "1")
+        opts = {}
+        if rows == "narrow":  # 4-column rows for every k, whatever the radius
+            opts = dict(wide_rows=3)
         if rows == "wide-thin":
-            monkeypatch.setenv("HS_JOIN_MIN_Q", "3")
-            monkeypatch.setenv("HS_JOIN_MIN_M", "16")
-        eng = Engine(k, K, L, W, a, b)
+            opts = dict(join_min_q=3, join_min_m=16)
+        eng = Engine(k, K, L, W, a, b, options=opts)
         info = eng.index_build(codes)
         assert max(info["max_bucket"]) > 1000
         for mode in ("join", "auto", "join16", "stream"):
@@ -160,11 +155,11 @@ def test_short_kmers_through_the_wide_int8_join(oracle, monkeypatch, k, R):
 
 
 @pytest.mark.parametrize("k,R", [(21, 40.0), (23, 52.0), (25, 58.0)])
-def test_wide_rows_by_radius(oracle, monkeypatch, tmp_path, k, R):
+def test_wide_rows_by_radius(oracle, tmp_path, k, R):
     """k = 21..25: calls whose radius is large for the k-mer length (R^2 within 3 standard deviations of
     the mean 4-column distance of random k-mers; forced for the others) run on 8-k-step rows over all 8
     columns, whose member records are built on first use -- also on an index that came from a file.
-    Same hits as the oracle, as the 4-column rows (HS_NO_WIDE_BY_RADIUS) and as the streaming filter;
+    Same hits as the oracle, as the 4-column rows (option wide_rows = 2) and as the streaming filter;
     calls at a small radius on the same handle keep using the 4-column rows."""
     K, L, W, n, nq = 3, 3, 300.0, 20011, 1203
     a, b = synth.make_planes(k, K, L, W, seed=45)
@@ -177,16 +172,14 @@ def test_wide_rows_by_radius(oracle, monkeypatch, tmp_path, k, R):
     path = str(tmp_path / "idx.bin")
     survivors = {}
     for rows in ("by-radius", "forced", "forced-thin", "narrow", "loaded"):
-        for v in ("HS_FORCE_WIDE", "HS_NO_WIDE_BY_RADIUS", "HS_JOIN_MIN_Q", "HS_JOIN_MIN_M"):
-            monkeypatch.delenv(v, raising=False)
+        opts = {}
         if rows.startswith("forced") or rows == "loaded":
-            monkeypatch.setenv("HS_FORCE_WIDE", "1")
+            opts["wide_rows"] = 1
         if rows == "narrow":
-            monkeypatch.setenv("HS_NO_WIDE_BY_RADIUS", "1")
+            opts["wide_rows"] = 2
         if rows == "forced-thin":
-            monkeypatch.setenv("HS_JOIN_MIN_Q", "3")
-            monkeypatch.setenv("HS_JOIN_MIN_M", "16")
-        eng = Engine(k, K, L, W, a, b)
+            opts.update(join_min_q=3, join_min_m=16)
+        eng = Engine(k, K, L, W, a, b, options=opts)
         if rows == "loaded":
             eng.index_load(path)
         else:
@@ -287,13 +280,7 @@ def test_join_with_many_queries_per_bucket(oracle):
     assert eng.profile()["join_batches"] == 0
     eng.close()
     # thin segments (< 3 probing queries or < 16 members) routed to the per-pair filter instead
-    import os
-    os.environ["HS_JOIN_MIN_Q"] = "3"
-    os.environ["HS_JOIN_MIN_M"] = "16"
-    try:
-        eng = Engine(k, K, L, W, a, b)
-    finally:
-        del os.environ["HS_JOIN_MIN_Q"], os.environ["HS_JOIN_MIN_M"]
+    eng = Engine(k, K, L, W, a, b, options=dict(join_min_q=3, join_min_m=16))
     eng.index_build(codes)
     eng.set_verify_mode("join")
     got = eng.query(centers, R)
@@ -620,22 +607,21 @@ def test_set_planes_rebuild_equals_fresh_handle(oracle):
     eng.close()
 
 
-def test_build_sorts_again_when_partial_fingerprints_interleave(monkeypatch):
+def test_build_sorts_again_when_partial_fingerprints_interleave():
     """From 2^20 k-mers on, the build's radix sort looks at the fingerprints' top 48 bits only; distinct
     fingerprints that agree there would interleave, which hs_check_runs_kernel reports and a second
-    sort on all bits repairs.  HS_SORT_FROM_BIT=56 (8 bits) makes that certain: the index and the hits
-    must be those of the one-pass form (=0) and of the default."""
+    sort on all bits repairs.  Option sort_from_bit = 56 (8 bits) makes that certain: the index and the hits
+    must be those of the one-pass form (= 0) and of the default."""
     k, K, L, W, R, n, nq = 25, 8, 3, 150.0, 45.0, (1 << 20) + 77, 2003
     a, b = synth.make_planes(k, K, L, W, seed=55)
     codes = synth.make_db(n, k, seed=56)
     centers, _ = synth.make_queries(codes, nq, seed=57, jitter=0.2)
     res = {}
-    monkeypatch.setenv("HS_BUILD_SORT", "1")     # the sorting form of the grouping (default: hs_group.hip)
     for from_bit in ("0", "56", None):
-        monkeypatch.delenv("HS_SORT_FROM_BIT", raising=False)
+        opts = dict(build_grouping=1)      # the sorting form of the grouping (default: hs_group.hip)
         if from_bit is not None:
-            monkeypatch.setenv("HS_SORT_FROM_BIT", from_bit)
-        eng = Engine(k, K, L, W, a, b)
+            opts["sort_from_bit"] = int(from_bit)
+        eng = Engine(k, K, L, W, a, b, options=opts)
         info = eng.index_build(codes)
         assert min(info["n_buckets"]) > 300          # far more buckets than 8 bits tell apart
         res[from_bit] = (info["n_buckets"], info["max_bucket"], eng.query(centers, R))
@@ -648,7 +634,7 @@ def test_build_sorts_again_when_partial_fingerprints_interleave(monkeypatch):
 
 
 @pytest.mark.parametrize("n", [(1 << 20) - 1, 1 << 20, (1 << 20) + 1])
-def test_build_at_the_sort_path_boundary(monkeypatch, n):
+def test_build_at_the_sort_path_boundary(n):
     """rocPRIM sorts up to merge_sort_limit = 2^20 items with a merge sort whose comparator for a bit
     range ending at bit 64 is built from 1 << 64 (hs_prims.hip): the build may hand it a range only
     above that size.  Round 2's cut was n >= 2^20, one too early.  Builds at the boundary and either
@@ -661,13 +647,12 @@ def test_build_at_the_sort_path_boundary(monkeypatch, n):
     centers = synth.embed(codes[src])
     res = {}
     for mode in ("0", None, "subset", "group"):
-        monkeypatch.delenv("HS_SORT_FROM_BIT", raising=False)
-        monkeypatch.setenv("HS_BUILD_SORT", "1")     # the sorting form of the grouping, whose boundary this is ...
+        opts = dict(build_grouping=1)      # the sorting form of the grouping, whose boundary this is ...
         if mode == "group":
-            monkeypatch.delenv("HS_BUILD_SORT")      # ... and the default form (hs_group.hip) beside it
+            opts = {}                      # ... and the default form (hs_group.hip) beside it
         if mode == "0":
-            monkeypatch.setenv("HS_SORT_FROM_BIT", "0")
-        eng = Engine(k, K, L, W, a, b)
+            opts["sort_from_bit"] = 0
+        eng = Engine(k, K, L, W, a, b, options=opts)
         info = eng.index_build_subset(codes, None) if mode == "subset" else eng.index_build(codes)
         res[mode] = (info["n_buckets"], info["max_bucket"], eng.query(centers, R))
         eng.close()
@@ -685,7 +670,7 @@ def test_build_at_the_sort_path_boundary(monkeypatch, n):
 
 @pytest.mark.parametrize("k,K,L,W,R", [(25, 6, 5, 120.0, 45.0), (25, 2, 3, 400.0, 42.0), (15, 5, 4, 90.0, 32.0),
                                       (39, 6, 3, 260.0, 50.0)])
-def test_probe_grouping_by_counting_sort_and_by_probe_sort(oracle, monkeypatch, k, K, L, W, R):
+def test_probe_grouping_by_counting_sort_and_by_probe_sort(oracle, k, K, L, W, R):
     """The probes are grouped by bucket in front of the join either by a counting sort over the bucket
     slots or, when buckets far outnumber probes (C3 shape: 1.3e8 slots for 4e6 probes), by a radix sort
     of the probes on their bucket number.  Both forms, forced in turn, give the oracle's hits -- for
@@ -703,13 +688,10 @@ def test_probe_grouping_by_counting_sort_and_by_probe_sort(oracle, monkeypatch, 
     edges = {}
     for mode in ("dense", "sparse"):
         for thin in (False, True):
-            monkeypatch.setenv("HS_SEG_MODE", mode)
-            monkeypatch.delenv("HS_JOIN_MIN_Q", raising=False)
-            monkeypatch.delenv("HS_JOIN_MIN_M", raising=False)
+            opts = dict(seg_mode={"sparse": 1, "dense": 2}[mode])
             if thin:
-                monkeypatch.setenv("HS_JOIN_MIN_Q", "3")
-                monkeypatch.setenv("HS_JOIN_MIN_M", "16")
-            eng = Engine(k, K, L, W, a, b)
+                opts.update(join_min_q=3, join_min_m=16)
+            eng = Engine(k, K, L, W, a, b, options=opts)
             eng.index_build(codes)
             for vm in ("join", "join16") if k <= 25 else ("join",):
                 eng.set_verify_mode(vm)
@@ -728,11 +710,11 @@ def test_probe_grouping_by_counting_sort_and_by_probe_sort(oracle, monkeypatch, 
 
 
 @pytest.mark.parametrize("families", [(700,), (700, 1500), (300, 9000), (17000,)])
-def test_hit_ordering_paths_with_many_hits_per_query(oracle, monkeypatch, families):
+def test_hit_ordering_paths_with_many_hits_per_query(oracle, families):
     """Output order = (query, table of first sight, id) (motif_both_points.cpp:224-245).  The hits are
     bucketed by query; a query with up to 48 is ordered by one thread, one with up to 1024 / 8192 by a
     block (bitonic sort in LDS, hs_hit_order_block_kernel), one with more by a block that sorts chunks in
-    LDS and merges them through global memory (hs_hit_order_huge_kernel); any batch under HS_SORT_HITS=1
+    LDS and merges them through global memory (hs_hit_order_huge_kernel); any batch under option sort_hits = 1
     is radix-sorted on the full key.  A DB with families of near-identical k-mers (queries inside a family
     of m get ~m hits, most others a few: 700 -> the small blocks, 1500 -> the large ones, 9000 -> two
     chunks and one merge, 17000 -> three chunks, two merge levels) through all of them against the oracle."""
@@ -757,10 +739,7 @@ def test_hit_ordering_paths_with_many_hits_per_query(oracle, monkeypatch, famili
     assert per_q.max() > 0.7 * max(families) and (np.median(per_q) < 20 or sum(families) > n // 4)
     want_few = oracle.search(a, b, W, R, oracle.embed_codes(codes), centers[nfq:])
     for sort_all in (False, True):
-        monkeypatch.delenv("HS_SORT_HITS", raising=False)
-        if sort_all:
-            monkeypatch.setenv("HS_SORT_HITS", "1")
-        eng = Engine(k, K, L, W, a, b)      # (a handle reads its environment switches when it is created)
+        eng = Engine(k, K, L, W, a, b, options=dict(sort_hits=1) if sort_all else None)
         eng.index_build(codes)
         for mode in ("auto", "stream"):
             eng.set_verify_mode(mode)
@@ -773,7 +752,7 @@ def test_hit_ordering_paths_with_many_hits_per_query(oracle, monkeypatch, famili
 
 @pytest.mark.parametrize("k,K,L,W,R", [(25, 6, 5, 140.0, 42.0), (15, 5, 4, 90.0, 32.0), (39, 6, 3, 260.0, 50.0),
                                       (60, 4, 3, 400.0, 70.0)])
-def test_centres_that_are_kmers_run_from_their_codes(oracle, monkeypatch, k, K, L, W, R):
+def test_centres_that_are_kmers_run_from_their_codes(oracle, k, K, L, W, R):
     """hs_query looks at its centres first: when every group of 8 doubles is a row of the coordinate
     table bit for bit -- the reference's centres are k-mers (KmerToCoordinates, hclust2.cpp:49-62) -- the
     call runs from the residue codes like hs_query_codes.  Same hits, order, distances and candidate
@@ -809,8 +788,7 @@ def test_centres_that_are_kmers_run_from_their_codes(oracle, monkeypatch, k, K, 
         assert eng.profile()["queries_recognised"] == 0
         _assert_hits_equal(got, want)          # (-0.0 and 0.0 give the same distances and dot products)
     eng.close()
-    monkeypatch.setenv("HS_NO_RECOGNISE", "1")
-    eng = Engine(k, K, L, W, a, b)
+    eng = Engine(k, K, L, W, a, b, options=dict(recognise_kmers=0))
     eng.index_build(codes)
     got = eng.query(centers, R)
     assert eng.profile()["queries_recognised"] == 0
@@ -861,7 +839,7 @@ def test_queries_given_as_residue_codes(oracle, k, K, L, W, R):
 
 
 @pytest.mark.parametrize("letters", [11, 29])
-def test_queries_as_codes_in_batches_and_custom_table(oracle, monkeypatch, letters):
+def test_queries_as_codes_in_batches_and_custom_table(oracle, letters):
     """An alphabet of its own (11 letters: the exact pass takes its terms from the table of rounded
     squares, hs_finalize_codes_kernel; 29 letters: above HS_FIN_TABLE_ALPHABET, the two-row form of
     hs_finalize_kernel), several query batches per call, a code outside the alphabet, and the same
@@ -877,8 +855,7 @@ def test_queries_as_codes_in_batches_and_custom_table(oracle, monkeypatch, lette
     centers = table[qcodes].reshape(nq, -1)
     want = oracle.search(a, b, W, R, pts, centers)
     assert len(want["q"]) > 100
-    monkeypatch.setenv("HS_QUERY_BATCH", "100")
-    eng = Engine(k, K, L, W, a, b, coords=table)
+    eng = Engine(k, K, L, W, a, b, coords=table, options=dict(query_batch=100))
     eng.index_build(codes)
     for mode in ("auto", "stream"):
         eng.set_verify_mode(mode)
@@ -899,14 +876,14 @@ def test_queries_as_codes_in_batches_and_custom_table(oracle, monkeypatch, lette
 
 
 @pytest.mark.parametrize("K,W,nq", [(2, 400.0, 3000), (3, 300.0, 1203), (5, 160.0, 6000), (8, 150.0, 900)])
-def test_query_resident_and_query_streaming_join_kernels(oracle, monkeypatch, K, W, nq):
+def test_query_resident_and_query_streaming_join_kernels(oracle, K, W, nq):
     """k <= 25 with 4-column rows: segments (bucket x the batch's queries probing it) with at most 64
     probing queries go through hs_join8r_kernel (query rows resident in registers, member tiles
     streamed, 16-query column tiles), the others through hs_join8x_kernel (member operands resident,
     query tiles streamed).  Coarse to fine keys give segments of every class -- 1..16, 17..32, 33..48,
     49..64 and more queries; buckets of one member up to thousands, ragged last tiles -- and both
-    routings (default; HS_NO_JOIN_R: everything through the streaming kernel) must give the oracle's
-    candidates, hits, order and distances, also with several query batches per call."""
+    routings (the resident class forced; option join_resident = 1: everything through the streaming kernel)
+    must give the oracle's candidates, hits, order and distances, also with several query batches per call."""
     k, L, R, n = 25, 4, 44.0, 30011
     a, b = synth.make_planes(k, K, L, W, seed=95)
     codes = synth.make_db(n, k, seed=96)
@@ -914,17 +891,11 @@ def test_query_resident_and_query_streaming_join_kernels(oracle, monkeypatch, K,
     want = oracle.search(a, b, W, R, oracle.embed_codes(codes), centers)
     assert len(want["q"]) > 300
     seen = {}
-    for routing in ("default", "no_r", "batches"):
-        monkeypatch.delenv("HS_NO_JOIN_R", raising=False)
-        monkeypatch.delenv("HS_QUERY_BATCH", raising=False)
-        # (by default the resident kernel runs only while its class is the bulk of a batch's items)
-        monkeypatch.setenv("HS_FORCE_JOIN_R", "1")
-        if routing == "no_r":
-            monkeypatch.delenv("HS_FORCE_JOIN_R")
-            monkeypatch.setenv("HS_NO_JOIN_R", "1")
-        if routing == "batches":
-            monkeypatch.setenv("HS_QUERY_BATCH", "257")
-        eng = Engine(k, K, L, W, a, b)
+    # (join_resident=2: by default the resident kernel runs only while its class is the bulk of a batch's items)
+    routings = {"default": dict(join_resident=2), "no_r": dict(join_resident=1),
+                "batches": dict(join_resident=2, query_batch=257)}
+    for routing, opts in routings.items():
+        eng = Engine(k, K, L, W, a, b, options=opts)
         eng.index_build(codes)
         eng.set_verify_mode("join")
         for rep in range(2):          # the second call runs on the first one's capacity hint (no host round trip)
@@ -933,18 +904,19 @@ def test_query_resident_and_query_streaming_join_kernels(oracle, monkeypatch, K,
             _assert_hits_equal(got, want)
         p = eng.profile()
         assert p["join_i8_batches"] > 0 and p["join_pairs"] > 0
-        seen[routing] = (p["join_pairs"], p["join_pairs_issued"])
+        seen[routing] = (p["join_pairs"], p["join_pairs_issued"], p["join_items_resident"])
         eng.close()
     # the same pairs either way; the resident kernel issues 16-query column tiles: no more padding, mostly less
     assert seen["default"][0] == seen["no_r"][0] and seen["default"][1] <= seen["no_r"][1]
+    assert seen["no_r"][2] == 0 and (seen["default"][2] > 0 or K < 5)
 
 
 @pytest.mark.parametrize("k,K,L,W,n", [(25, 16, 4, 200.0, 300007), (25, 4, 3, 0.5, 50021), (15, 3, 5, 60.0, 4099),
                                        (25, 20, 3, 160.0, 1), (39, 6, 2, 260.0, 70001), (25, 1, 2, 1.0e6, 9001)])
-def test_grouping_by_rank_equals_grouping_by_sort(oracle, monkeypatch, tmp_path, k, K, L, W, n):
+def test_grouping_by_rank_equals_grouping_by_sort(oracle, tmp_path, k, K, L, W, n):
     """Index build, SURVEY 8(a) a7: the default grouping (hs_group.hip: table of distinct fingerprints,
     ranks, a radix sort of (rank, id) of its own) against the full-width sort of (fingerprint, id) pairs
-    (HS_BUILD_SORT=1, rounds 1-2): the same index FILE byte for byte -- ids per bucket, directory keys,
+    (option build_grouping = 1, rounds 1-2): the same index FILE byte for byte -- ids per bucket, directory keys,
     boundaries, tuples -- the same bucket statistics, the oracle's table sizes, and the oracle's hits.
     Shapes: many k-mers per bucket, nearly every k-mer its own bucket (W = 0.5: the table fills up and the
     build falls back to sorting), one k-mer, one bucket per table (W = 10^6), two packed words."""
@@ -956,10 +928,7 @@ def test_grouping_by_rank_equals_grouping_by_sort(oracle, monkeypatch, tmp_path,
     want = ix.query(centers, R)
     files = {}
     for form in ("rank", "sort"):
-        monkeypatch.delenv("HS_BUILD_SORT", raising=False)
-        if form == "sort":
-            monkeypatch.setenv("HS_BUILD_SORT", "1")
-        eng = Engine(k, K, L, W, a, b)
+        eng = Engine(k, K, L, W, a, b, options=dict(build_grouping=1) if form == "sort" else None)
         info = eng.index_build(codes)
         assert info["n_buckets"] == ix.table_sizes(), form
         got = eng.query(centers, R)
