@@ -86,7 +86,6 @@ struct Knobs {
   bool no_wide_by_radius = false;  // HS_NO_WIDE_BY_RADIUS: never choose 8-column rows by radius
   bool no_refine8 = false;         // HS_NO_REFINE8: no 8-column refinement of the join's survivors
   bool no_self_codes = false;      // HS_NO_SELF_CODES: self-join from embedded centres, not from codes
-  bool no_thin8 = false;           // HS_NO_THIN8: thin segments through the streaming filter
   bool sort_hits = false;          // HS_SORT_HITS: order hits by the radix sort, not per query
   bool sync_items = false;         // HS_SYNC_ITEMS: read the join's item count back before launching it
   bool no_join_r = false;          // HS_NO_JOIN_R: every segment through the query-streaming join kernel
@@ -165,7 +164,7 @@ struct hs_handle {
   int shard_table = -1;
   DevBuf seg_of;    // query_batch: the segment of every sorted probe position
   DevBuf seg_res;   // cut_items: flags + scan of the segments that go to the query-resident join kernel
-  DevBuf c16s, item_desc, probe_slow, jtab8, slice_ql, qhits;  // qhits: per-query hit counts, offsets, fill
+  DevBuf c16s, item_desc, probe_slow, jtab8, qhits;  // qhits: per-query hit counts, offsets, fill
   DevBuf c8b, prov2;  // survivor refinement: second int8 row per query, the refined survivor list
   bool join8_tables_ok = false;  // int8 can carry the coordinate table
   double join8_scale = 0.0, join8_scale_w = 0.0;  // quantisation scales: 4-column rows, wide rows
@@ -420,7 +419,7 @@ hs_status hash_account(hs_handle* h, uint64_t n, int F, int set) {
 const struct { const char* name; int option; } kOptionNames[] = {
     {"query_batch", HS_OPT_QUERY_BATCH}, {"seg_mode", HS_OPT_SEG_MODE}, {"join_resident", HS_OPT_JOIN_RESIDENT},
     {"recognise_kmers", HS_OPT_RECOGNISE_KMERS}, {"build_grouping", HS_OPT_BUILD_GROUPING}, {"wide_rows", HS_OPT_WIDE_ROWS},
-    {"refine8", HS_OPT_REFINE8}, {"self_codes", HS_OPT_SELF_CODES}, {"thin_filter", HS_OPT_THIN_FILTER},
+    {"refine8", HS_OPT_REFINE8}, {"self_codes", HS_OPT_SELF_CODES},
     {"sort_hits", HS_OPT_SORT_HITS}, {"sync_items", HS_OPT_SYNC_ITEMS}, {"join_min_q", HS_OPT_JOIN_MIN_Q},
     {"join_min_m", HS_OPT_JOIN_MIN_M}, {"sort_from_bit", HS_OPT_SORT_FROM_BIT}, {"build_serial", HS_OPT_BUILD_SERIAL}};
 
@@ -691,7 +690,6 @@ hs_status hs_set_option(hs_handle* h, int option, int64_t value) {
     }
     case HS_OPT_REFINE8: return flag(&kn.no_refine8, true);
     case HS_OPT_SELF_CODES: return flag(&kn.no_self_codes, true);
-    case HS_OPT_THIN_FILTER: return flag(&kn.no_thin8, true);
     case HS_OPT_SORT_HITS: return flag(&kn.sort_hits, false);
     case HS_OPT_SYNC_ITEMS: return flag(&kn.sync_items, false);
     case HS_OPT_JOIN_MIN_Q:
@@ -735,7 +733,7 @@ void hs_destroy(hs_handle* h) {
                     &h->probe_slow, &h->jtab8, &h->c8b, &h->prov2, &h->t_packed, &h->t_rec8, &h->t_rec8w, &h->t_pos, &h->dir_base,
                     &h->bucket_work, &h->proj_aq_all, &h->proj_aq_tab, &h->proj_fn, &h->proj_tab, &h->proj_stats,
                     &h->proj_flags[0], &h->proj_flags[1], &h->proj_flags[2], &h->proj_cnt, &h->proj_xq,
-                    &h->proj_xmeta, &h->slice_ql, &h->qhits, &h->bs_ints2[0], &h->bs_ints2[1], &h->bs_keys2[0],
+                    &h->proj_xmeta, &h->qhits, &h->bs_ints2[0], &h->bs_ints2[1], &h->bs_keys2[0],
                     &h->bs_keys2[1], &h->bs_iota2[0], &h->bs_iota2[1], &h->bs_keys_sorted, &h->bs_rle_unique,
                     &h->bs_rle_counts, &h->bs_small, &h->bs_sort_temp, &h->bs_slow_q, &h->all_codes,
                     &h->subset_ids, &h->qcodes_buf, &h->qembed, &h->seg_res, &h->seg_of, &h->t_rho, &h->rec_codes, &h->qpacked, &h->hit_rank, &h->hit_kv, &h->bs_fptab, &h->bs_blk,
@@ -898,11 +896,10 @@ static hs_status reserve_build_buffers(hs_handle* h) {
   for (int l = 0; l < L; ++l) HS_HIP(h, h->t_ids[l].reserve(std::max<size_t>(16, (size_t)n * 4)));
   if (!h->knobs.build_sort && n && n < (1ull << 31)) {
     const uint32_t C = hs_group_table_slots(n), n_blk = (C + 1023) / 1024, n_tiles = hs_rs_blocks(n);
-    HS_HIP(h, h->bs_fptab.reserve((size_t)C * 16));
+    HS_HIP(h, h->bs_fptab.reserve((size_t)C * 8));
     HS_HIP(h, h->bs_blk.reserve(2 * ((size_t)n_blk + 2) * 4));
     HS_HIP(h, h->bs_rank.reserve((size_t)n * 4));
     HS_HIP(h, h->bs_hist.reserve(2 * (size_t)((size_t)256 * n_tiles + 64) * 4));
-    HS_HIP(h, h->bs_slow_q.reserve(((size_t)(1u << 16) + 1) * 4));
   }
   return HS_OK;
 }
@@ -1025,19 +1022,17 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
     // pass 56 to see the second sort happen.)
     const int from_bit0 = hs_sort_partial_bits_ok((size_t)n) ? h->knobs.sort_from_bit : 0;
     bool grouped = false;   // the table + rank-sort path produced this table's ids and directory
-    const uint32_t slow_cap_g = 1u << 16;
     if (group_by_rank && n) {
       const uint32_t C = hs_group_table_slots(n), n_blk = (C + 1023) / 1024, n_tiles = hs_rs_blocks(n);
-      HS_HIP(h, h->bs_fptab.reserve((size_t)C * 16));   // slots + the slots' full fingerprints
+      HS_HIP(h, h->bs_fptab.reserve((size_t)C * 8));    // the slots: 64-bit fingerprints
       HS_HIP(h, h->bs_blk.reserve(2 * ((size_t)n_blk + 2) * 4));
       HS_HIP(h, h->bs_rank.reserve((size_t)n * 4));
       HS_HIP(h, h->bs_hist.reserve(2 * (size_t)((size_t)256 * n_tiles + 64) * 4));
-      HS_HIP(h, slow_q.reserve(((size_t)slow_cap_g + 1) * 4));
       uint32_t* blk_cnt = h->bs_blk.as<uint32_t>();
       uint32_t* blk_off = blk_cnt + n_blk + 2;
       uint32_t* rank = h->bs_rank.as<uint32_t>();
       HS_HIP(h, hs_launch_group_insert(ints.as<int32_t>(), n, K, seed, h->bs_fptab.as<uint64_t>(), C, rank,
-                                       slow_q.as<uint32_t>(), slow_cap_g, d_small + 1, h->stream));
+                                       d_small + 1, h->stream));
       HS_HIP(h, hs_launch_fp_count(h->bs_fptab.as<uint64_t>(), C, blk_cnt, h->stream));
       HS_HIP(h, hipMemsetAsync(blk_cnt + n_blk, 0, 4, h->stream));
       HS_HIP(h, hs_exclusive_scan_u32(sort_temp.p, sort_temp.cap, blk_cnt, blk_off, (size_t)n_blk + 1, h->stream));
@@ -1050,10 +1045,6 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
 #endif
       if (h->knobs.build_debug && (host2[1] & 48u))
         fprintf(stderr, "table %d: grouping by rank not possible (flag 0x%x), sorting\n", l, host2[1]);
-      if (host2[1] & 1u) {  // one fingerprint, two HashKey strings: the caller tries the next seed
-        *collided = true;
-        return HS_OK;
-      }
       if (!(host2[1] & 48u)) {
         nb = host2[0];
         grouped = true;
@@ -1092,6 +1083,9 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
         HS_HIP(h, hs_launch_dir_start(kin, (uint32_t)n, nb, h->t_dirstart[l].as<uint32_t>(), d_small + 2, h->stream));
         HS_HIP(h, hs_launch_dir_tuples(h->t_dirstart[l].as<uint32_t>(), h->t_ids[l].as<uint32_t>(), ints.as<int32_t>(),
                                        nb, K, h->t_dirtuple[l].as<int32_t>(), h->stream));
+        // the exact-membership proof of every k-mer against its bucket's tuple (flag 1, read with max_count below)
+        HS_HIP(h, hs_launch_group_check(ints.as<int32_t>(), n, K, rank, h->t_dirtuple[l].as<int32_t>(), d_small + 1,
+                                        h->stream));
       } else {
         HS_HIP(h, hipMemsetAsync(d_small, 0, 64, h->stream));
         // the sorting path needs the fingerprints and the ids 0 .. n - 1 as its values
@@ -1164,8 +1158,14 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
     HS_HIP(h, hs_launch_invert_perm(h->t_ids[l].as<uint32_t>(), (uint32_t)n,
                                     h->t_pos.as<uint32_t>() + (size_t)l * n, h->stream));
     HS_HIP(h, hipEventRecord(h->ev[3], h->stream));
-    HS_HIP(h, hipMemcpyAsync(&max_count, d_small + 2, 4, hipMemcpyDeviceToHost, h->stream));
+    uint32_t tail2[2] = {0, 0};  // {collision flag, largest bucket}
+    HS_HIP(h, hipMemcpyAsync(tail2, d_small + 1, 8, hipMemcpyDeviceToHost, h->stream));
     HS_HIP(h, hipStreamSynchronize(h->stream));
+    max_count = tail2[1];
+    if (grouped && (tail2[0] & 1u)) {  // one fingerprint, two HashKey strings: the caller tries the next seed
+      *collided = true;
+      return HS_OK;
+    }
     if (l + 1 < L && serial) HS_CHECK(hash_table(l + 1));
     {
       float ms = 0.f;  // the hash ran on the side stream, possibly beside the previous table's sort
@@ -1299,12 +1299,30 @@ hs_status hs_index_build(hs_handle* h, const uint8_t* codes, uint64_t n) {
 //                              bucket-ordered copies; *collided = one fingerprint, two HashKey strings
 //   <max over ranks of collided: if set, every rank starts over with seed + 1>
 // then hs_index_shard_end.  The index is the one hs_index_build builds, bit for bit.
+// The sharded build's scratch (sorted fingerprints, run lengths, ids, sort space, the block's bucket ints:
+// ~ 40 bytes per k-mer) stays with the handle for the next build while it is small beside the device's
+// memory and is given back otherwise: build_tables' rule (4-5 GB beside a 157 GB index at 10^8 k-mers).
+static void release_large_shard_scratch(hs_handle* h) {
+  DevBuf* b[] = {&h->bs_keys_sorted, &h->bs_rle_unique, &h->bs_rle_counts, &h->bs_iota2[0], &h->bs_sort_temp,
+                 &h->bs_ints2[0]};
+  size_t held = 0, free_b = 0, total_b = 0;
+  for (DevBuf* x : b) held += x->cap;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = (size_t)16 << 30;
+  if (held > total_b / 16)
+    for (DevBuf* x : b) x->release();
+}
+
 hs_status hs_index_shard_begin(hs_handle* h, const uint8_t* codes, uint64_t n, uint32_t rank, uint32_t world,
                                uint64_t* block_lo, uint64_t* block_count) {
   if (!h || (n && !codes) || !world || rank >= world) return HS_ERR_INVALID;
   if (n >= (1ull << 31)) return fail(h, HS_ERR_INVALID, "n must be < 2^31 (ids are 32-bit, as in the reference)");
   hs_status st = ensure_device(h);
   if (st) return st;
+  if (h->shard_open) {  // a sharded build that never reached hs_index_shard_end (a collision on every seed)
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    release_large_shard_scratch(h);
+    h->shard_open = false;
+  }
   drop_index(h);
   h->n = n;
   memset(&h->prof, 0, sizeof(h->prof));
@@ -1473,6 +1491,8 @@ hs_status hs_index_shard_end(hs_handle* h, uint32_t key_seed) {
   hs_status st = ensure_device(h);
   if (st) return st;
   h->shard_open = false;
+  HS_HIP(h, hipStreamSynchronize(h->stream));
+  release_large_shard_scratch(h);
   h->key_seed = key_seed;
   HS_HIP(h, hipEventRecord(h->ev[9], h->stream));
   HS_HIP(h, hipStreamSynchronize(h->stream));
@@ -2028,7 +2048,8 @@ static bool self_codes_ok(const hs_handle* h, double R) {
   const double r2 = R * R, s = wide ? h->join8_scale_w : h->join8_scale, k = (double)h->p.k;
   if (!h->join8_tables_ok || h->p.k > 50 || h->verify_mode == 1 || h->verify_mode == 3 || !(r2 < 30000.0))
     return false;
-  if (h->knobs.no_thin8 || h->knobs.no_self_codes) return false;
+  // (segments routed away from the join go to the streaming filter, which works from the centres)
+  if (h->join_min_q > 1 || h->join_min_m > 1 || h->knobs.no_self_codes) return false;
   // -gamma <= s^2 R^2 / 2 + L1(c^)/2 + 3, L1(c^) <= 127 * 4 k (127 * 8 k with wide rows)
   return s > 0.0 && 0.5 * s * s * r2 + (wide ? 508.0 : 254.0) * k + 3.0 < 127.0 * 127.0 * 13.0;
 }
@@ -2067,7 +2088,9 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
   // the only filters that work without per-query distance tables.
   // how the probes are grouped by bucket in front of the join: a counting sort over the bucket slots,
   // or -- when those far outnumber the probes -- a sort of the probes (HS_SEG_MODE=dense|sparse forces one)
-  bool seg_sparse = (uint64_t)h->nb_total > 4ull * nql;
+  // (measured at the configs[2] shape, 10^6 queries x 32 tables against 1.3e8 bucket slots -- a ratio of 4:
+  // 11.3 ms for the whole probe + segment chain with the sort, 15.0 with the counting sort)
+  bool seg_sparse = (uint64_t)h->nb_total > 2ull * nql;
   if (h->knobs.seg_mode) seg_sparse = h->knobs.seg_mode == 1;
   const bool self_codes = h->self_first != HS_NO_SELF && !brute && use_i8 && self_codes_ok(h, R);
   const uint8_t* d_qcodes =
@@ -2284,20 +2307,10 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
                                     h->item_desc.as<uint4>(), h->stream));
     }
   }
-  // ... with the int8 join, thin segments are filtered by the join's own integer bound on the
-  // vector ALU (hs_thin8_kernel): no per-query distance tables.  It runs BEFORE the join on the same
-  // stream: the join's persistent waves take every register of every SIMD, so nothing runs beside
-  // it anyway -- a kernel launched on a side stream first only delays the join's start (and one
-  // launched later waits for the join's tail)
-  const bool thin8 = !brute && (n_items || from_codes) && n_slices && use_i8 && !h->knobs.no_thin8;
-  // without it (fp16 join, HS_NO_THIN8) the streaming filter and its tables go to the side stream
-  const bool side = !brute && n_items && n_slices && !thin8;
-  if (thin8) {
-    HS_HIP(h, h->slice_ql.reserve((size_t)n_slices * 4));
-    HS_HIP(h, hs_launch_slice_map(h->nslices.as<uint32_t>(), h->slice_off.as<uint32_t>(), nql,
-                                  h->slice_ql.as<uint32_t>(), h->stream));
-  }
-  if ((brute || n_slices) && !thin8) {
+  // segments routed away from the join (HS_OPT_JOIN_MIN_Q / _M; none by default) go through the streaming
+  // filter and its per-query distance tables, on the side stream beside the join
+  const bool side = !brute && n_items && n_slices;
+  if (brute || n_slices) {
     HS_HIP(h, h->tq.reserve((size_t)nq * k * HS_TROW * 4));
     if (!side)
       HS_HIP(h, hs_launch_qtables(d_centers, nq, k, h->coords.as<double>(), h->alphabet,
@@ -2343,11 +2356,6 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
     }
     HS_HIP(h, hipEventRecord(h->ev[3], h->stream));
     if (launches) HS_HIP(h, hipMemsetAsync(d_cnt + 32, 0, 8, h->stream));  // retry: the item counters again
-    if (thin8)
-      HS_HIP(h, hs_launch_thin8(h->tabs, rec8, h->n, h->c16.p, jtab_rows,
-                                h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
-                                h->slice_off.as<uint32_t>(), h->slice_ql.as<uint32_t>(), nql, L, k, wide, d_cnt,
-                                prov_cap, h->prov.as<uint2>(), n_blocks, h->stream));
     if (side) {
       HS_HIP(h, hipEventRecord(h->evx[EV_FORK], h->stream));
       HS_HIP(h, hipStreamWaitEvent(h->stream2, h->evx[EV_FORK], 0));
@@ -2390,7 +2398,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
       HS_HIP(h, hipEventRecord(h->ev[10], h->stream));
       if (side)
         HS_HIP(h, hipStreamWaitEvent(h->stream, h->evx[EV_JOIN], 0));
-      else if (n_slices && !thin8)
+      else if (n_slices)
         HS_HIP(h, hs_launch_verify(h->tabs, h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
                                    h->slice_off.as<uint32_t>(), nql, h->tq.as<float>(), k, L, r2_hi,
                                    d_cnt, prov_cap, h->prov.as<uint2>(), n_blocks, h->stream));

@@ -9,19 +9,18 @@
 //
 // Buckets are FEW (10^5 of 10^7 k-mers at configs[1], 4 10^6 of 10^8 at configs[2]'s shape) and very
 // skewed (the largest holds 6.5 % of the database), so here the fingerprints are never sorted as such:
-//   1. every k-mer's key goes into an open-addressing table, found there by its fingerprint and PROVED
-//      there by its bucket ints against the slot's representative (one 8-byte slot read and one cached
-//      tuple per k-mer in the common case, one CAS per DISTINCT key); the k-mer keeps its slot number;
+//   1. every k-mer's key goes into an open-addressing table of 64-bit fingerprints (one 8-byte slot read per
+//      k-mer in the common case, one CAS per DISTINCT key); the k-mer keeps its slot number;
 //   2. the distinct keys' fingerprints are compacted out of the table and sorted -- nb of them, a small
 //      sort (rocPRIM, on all 64 bits) -- which gives every slot the RANK of its key in the directory;
 //   3. the k-mers carry 32-bit ranks now: a stable LSD radix sort of (rank, id) over ceil(log2 nb) bits,
 //      8 bits per pass, written here (histogram per 4096-element tile, one scan over digits x tiles,
 //      stable scatter through an LDS-staged tile): 2 - 3 passes of 20 bytes per pair;
-//   4. bucket boundaries fall out of the sorted ranks.
-// Bucket membership is exactly the reference's string equality: step 1 lets a k-mer into a slot only
-// when its ints equal the representative's or -- hs_group_insert_slow_kernel -- when the HashKey strings
-// do (aliased tuples share a fingerprint by construction); two strings under one fingerprint are
-// reported and the build repeats with the next seed, as with the sorting form.
+//   4. bucket boundaries fall out of the sorted ranks;
+//   5. every k-mer's bucket ints are compared with its bucket's tuple (hs_group_check_kernel).
+// Bucket membership is exactly the reference's string equality: step 5 accepts a k-mer whose ints equal the
+// bucket's tuple or whose HashKey string does (aliased tuples share a fingerprint by construction); two
+// strings under one fingerprint are reported and the build repeats with the next seed, as with the sorting form.
 // Skew does not matter to any step: the hot key's k-mers read one cached slot, and the LSD passes count
 // digits of ranks.
 #include <hip/hip_runtime.h>
@@ -39,83 +38,66 @@ constexpr uint32_t RS_TILE = 4096;  // elements per block of the radix passes: 2
 
 inline unsigned blocks_for(uint64_t n, unsigned per = 256) { return (unsigned)((n + per - 1) / per); }
 
-// ---- 1. bucket ints -> fingerprint -> slot of an open-addressing table, membership proved on the way ----
-// T[C] (C a power of two >= n, all FP_EMPTY at entry), slot from the fingerprint's top bits, linear
-// probing.  A slot holds (top 32 bits of the fingerprint) << 32 | id of the k-mer that claimed it (its
-// representative).  A k-mer that meets its 32 bits compares its K bucket ints with the representative's:
-// identical (the common case; the hot buckets' representatives stay in cache) = same HashKey string = this
-// is its slot.  Ints that differ -- aliased strings ((1,23) and (12,3) have one string and, by
-// construction, one fingerprint), a fingerprint collision, or just equal top halves -- send the k-mer to
-// the queue of hs_group_insert_slow_kernel, which settles it by the strings themselves.  One pass over
-// the bucket ints does what the fingerprint kernel, the table insert and the membership proof of the
-// first draft did in three (the proof alone moved 160 bytes per k-mer).
-// slot_of[i] = the slot of k-mer i's key (0xffffffff: queued).  slow[0] = queued count, slow[1..] = ids.
+// ---- 1. bucket ints -> fingerprint -> slot of an open-addressing table ---------------------------------
+// T[C] (C a power of two >= n, all FP_EMPTY at entry), slot from the fingerprint's top bits, linear probing.
+// A slot holds the FULL 64-bit fingerprint of its key: a k-mer belongs to the first slot that holds its
+// fingerprint, or claims the first empty one (one CAS per DISTINCT key).  ONE random access per k-mer and no
+// second one that depends on it -- rounds 2-3 kept (32 bits, id of a representative) in the slot and proved
+// the k-mer's membership on the spot against the representative's bucket ints: two DEPENDENT random accesses,
+// 12.7 ms per table at 10^8 k-mers.  A slot never changes once written, so a k-mer first looks at it with a
+// plain (cacheable) load -- the hot buckets' slots are read millions of times -- and only an empty or foreign
+// value sends it to the atomic path.  The membership PROOF (equal fingerprints must mean equal HashKey
+// strings) is a pass of its own once every bucket has its tuple: hs_group_check_kernel.
+// slot_of[i] = the slot of k-mer i's key.  flag |= 16: table full, or a fingerprint equal to the empty marker
+// (the caller groups this table by sorting instead).
 __global__ __launch_bounds__(256) void hs_group_insert_kernel(const int32_t* __restrict__ ints, uint64_t n, int K,
-                                                              uint32_t seed, uint64_t* __restrict__ T,
-                                                              uint64_t* __restrict__ Tfp, uint32_t cmask, int shift,
-                                                              uint32_t* __restrict__ slot_of,
-                                                              uint32_t* __restrict__ slow, uint32_t slow_cap,
+                                                              uint32_t seed, uint64_t* __restrict__ T, uint32_t cmask,
+                                                              int shift, uint32_t* __restrict__ slot_of,
                                                               uint32_t* __restrict__ flag) {
   __shared__ int32_t s_t[HS_MAX_K * 256];  // the thread's K ints, [j][thread]
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int32_t* tg = ints + i * (uint64_t)K;
+  const uint64_t i0 = (uint64_t)blockIdx.x * 256, i = i0 + threadIdx.x;
   int32_t* t = s_t + threadIdx.x;
   if ((K & 3) == 0) {
-    int4 v[HS_MAX_K / 4];
-#pragma unroll
-    for (int j4 = 0; j4 < HS_MAX_K / 4; ++j4)
-      if (4 * j4 < K) v[j4] = reinterpret_cast<const int4*>(tg)[j4];
-#pragma unroll
-    for (int j4 = 0; j4 < HS_MAX_K / 4; ++j4)
-      if (4 * j4 < K) {
-        t[256 * (4 * j4)] = v[j4].x;
-        t[256 * (4 * j4 + 1)] = v[j4].y;
-        t[256 * (4 * j4 + 2)] = v[j4].z;
-        t[256 * (4 * j4 + 3)] = v[j4].w;
-      }
+    // the block's 256 K ints as ONE coalesced stream of 16-byte pieces (a thread reading its own K / 4 pieces
+    // touches lines 4 K bytes apart: 64 lines per load instruction of a wave), transposed through LDS
+    const uint32_t K4 = (uint32_t)K >> 2;
+    const uint64_t n_here = min((uint64_t)256, n - i0);
+    const int4* src = reinterpret_cast<const int4*>(ints + i0 * (uint64_t)K);
+    for (uint32_t f = threadIdx.x; f < (uint32_t)n_here * K4; f += 256) {
+      const int4 v = src[f];
+      const uint32_t r = f / K4, j4 = f - r * K4;
+      s_t[256 * (4 * j4) + r] = v.x;
+      s_t[256 * (4 * j4 + 1) + r] = v.y;
+      s_t[256 * (4 * j4 + 2) + r] = v.z;
+      s_t[256 * (4 * j4 + 3) + r] = v.w;
+    }
+    __syncthreads();
+    if (i >= n) return;
   } else {
+    if (i >= n) return;
+    const int32_t* tg = ints + i * (uint64_t)K;
     for (int j = 0; j < K; ++j) t[256 * j] = tg[j];
   }
   uint64_t hk = hs_key_init(seed);
   for (int j = 0; j < K; ++j) hk = hs_key_put_int(hk, t[256 * j]);
   const uint64_t fp = hs_key_fin(hk);
-  const uint64_t hi = fp >> 32;
-  const uint64_t mine = (hi << 32) | (uint64_t)i;
   uint32_t s = (uint32_t)(fp >> shift) & cmask;
+  if (fp == FP_EMPTY) {  // (2^-64: the marker itself)
+    atomicOr(flag, 16u);
+    slot_of[i] = 0;
+    return;
+  }
   // (bounded: the table is at most as full as distinct keys / k-mers; a chain of thousands means nearly
   // every key is distinct -- a tiny W -- and the build takes the sorting path)
   const uint32_t max_probe = cmask < 4095u ? cmask : 4095u;
   for (uint32_t probe = 0; probe <= max_probe; ++probe) {
-    uint64_t w = __hip_atomic_load(&T[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint64_t w = T[s];  // plain load: a value other than the marker is final
     if (w == FP_EMPTY) {
-      w = atomicCAS(reinterpret_cast<unsigned long long*>(&T[s]), (unsigned long long)FP_EMPTY, (unsigned long long)mine);
-      if (w == FP_EMPTY) {  // claimed: this k-mer represents the key (its full fingerprint for the directory)
-        Tfp[s] = fp;
-        slot_of[i] = s;
-        return;
-      }
+      w = atomicCAS(reinterpret_cast<unsigned long long*>(&T[s]), (unsigned long long)FP_EMPTY, (unsigned long long)fp);
+      if (w == FP_EMPTY) w = fp;  // claimed
     }
-    if ((w >> 32) == hi) {
-      const int32_t* pr = ints + (uint64_t)(uint32_t)w * K;
-      bool same = true;
-      if ((K & 3) == 0) {
-        for (int j4 = 0; 4 * j4 < K; ++j4) {
-          const int4 r = reinterpret_cast<const int4*>(pr)[j4];
-          same = same && r.x == t[256 * (4 * j4)] && r.y == t[256 * (4 * j4 + 1)] && r.z == t[256 * (4 * j4 + 2)] &&
-                 r.w == t[256 * (4 * j4 + 3)];
-        }
-      } else {
-        for (int j = 0; j < K; ++j) same = same && pr[j] == t[256 * j];
-      }
-      if (same) {
-        slot_of[i] = s;
-        return;
-      }
-      // equal top halves, different ints: by the strings, in the slow kernel (which probes again from the start)
-      const uint32_t at = atomicAdd(slow, 1u);
-      if (at < slow_cap) slow[1 + at] = (uint32_t)i;
-      slot_of[i] = 0xffffffffu;
+    if (w == fp) {
+      slot_of[i] = s;
       return;
     }
     s = (s + 1) & cmask;
@@ -124,62 +106,53 @@ __global__ __launch_bounds__(256) void hs_group_insert_kernel(const int32_t* __r
   slot_of[i] = 0;
 }
 
-// The queued k-mers, one thread each, with the whole rule: a slot whose 32 bits match belongs to the
-// k-mer if the HashKey STRINGS are equal; if they differ and the full fingerprints are equal it is a
-// fingerprint collision (flag 1: the caller rebuilds with the next seed); otherwise the probe goes on.
-__global__ __launch_bounds__(256) void hs_group_insert_slow_kernel(const int32_t* __restrict__ ints, int K,
-                                                                   uint32_t seed, uint64_t* __restrict__ T,
-                                                                   uint64_t* __restrict__ Tfp, uint32_t cmask, int shift,
-                                                                   uint32_t* __restrict__ slot_of,
-                                                                   const uint32_t* __restrict__ slow,
-                                                                   uint32_t slow_cap, uint32_t* __restrict__ flag) {
-  const uint32_t total = slow[0];
-  if (total > slow_cap) {  // more than the queue holds (massively aliased keys): the caller falls back
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(flag, 32u);
-    return;
+// The exact-membership proof, in id order: k-mer i was put into the bucket of rank rank_of[i] because its
+// fingerprint is that bucket's; its HashKey string must be the bucket's too (the tuple of the bucket's first
+// member).  Identical ints in the common case (the tuple rows of the hot buckets stay in cache, the k-mer's
+// own ints are read in order); ints that differ are compared as strings -- aliased tuples ((1,23) and (12,3))
+// share string and fingerprint by construction -- and two strings under one fingerprint raise flag |= 1: the
+// caller rebuilds with the next seed.
+__global__ __launch_bounds__(256) void hs_group_check_kernel(const int32_t* __restrict__ ints, uint64_t n, int K,
+                                                             const uint32_t* __restrict__ rank_of,
+                                                             const int32_t* __restrict__ dir_tuple,
+                                                             uint32_t* __restrict__ flag) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int32_t* px = ints + i * (uint64_t)K;
+  const int32_t* py = dir_tuple + (uint64_t)rank_of[i] * K;
+  bool same = true;
+  for (int j = 0; j < K; ++j) same = same && px[j] == py[j];
+  if (same) return;
+  int32_t x[HS_MAX_K], y[HS_MAX_K];
+  for (int j = 0; j < K; ++j) {
+    x[j] = px[j];
+    y[j] = py[j];
   }
-  for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < total; q += gridDim.x * 256) {
-    const uint32_t i = slow[1 + q];
-    int32_t x[HS_MAX_K], y[HS_MAX_K];
-    for (int j = 0; j < K; ++j) x[j] = ints[(uint64_t)i * K + j];
-    const uint64_t fp = hs_key_of(x, K, seed);
-    const uint64_t hi = fp >> 32;
-    const uint64_t mine = (hi << 32) | (uint64_t)i;
-    uint32_t s = (uint32_t)(fp >> shift) & cmask;
-    const uint32_t max_probe = cmask < 4095u ? cmask : 4095u;
-    bool done = false;
-    for (uint32_t probe = 0; probe <= max_probe && !done; ++probe) {
-      uint64_t w = __hip_atomic_load(&T[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (w == FP_EMPTY) {
-        w = atomicCAS(reinterpret_cast<unsigned long long*>(&T[s]), (unsigned long long)FP_EMPTY, (unsigned long long)mine);
-        if (w == FP_EMPTY) {
-          Tfp[s] = fp;
-          slot_of[i] = s;
-          done = true;
-          break;
-        }
-      }
-      if ((w >> 32) == hi) {
-        for (int j = 0; j < K; ++j) y[j] = ints[(uint64_t)(uint32_t)w * K + j];
-        if (hs_key_equal(x, y, K)) {
-          slot_of[i] = s;
-          done = true;
-          break;
-        }
-        if (hs_key_of(y, K, seed) == fp) {  // one fingerprint, two strings
-          atomicOr(flag, 1u);
-          slot_of[i] = s;
-          done = true;
-          break;
-        }
-      }
-      s = (s + 1) & cmask;
-    }
-    if (!done) {
-      atomicOr(flag, 16u);
-      slot_of[i] = 0;
-    }
+  if (!hs_key_equal(x, y, K)) atomicOr(flag, 1u);
+}
+// The same for K a multiple of 4 (the usual 16, 20): one thread per 16-BYTE PIECE of the bucket ints, so that
+// the n K ints are read as one coalesced stream (one thread per k-mer reads K / 4 pieces at a stride of 4 K
+// bytes: every load instruction of a wave touched 64 different lines, 6.4 ms per table at 10^8 k-mers).  A
+// piece that differs from the tuple's sends its thread to the comparison of the whole strings.
+__global__ __launch_bounds__(256) void hs_group_check4_kernel(const int4* __restrict__ ints4, uint64_t n_pieces, int K4,
+                                                              const uint32_t* __restrict__ rank_of,
+                                                              const int4* __restrict__ tuple4,
+                                                              uint32_t* __restrict__ flag) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_pieces) return;
+  const uint64_t i = t / (uint32_t)K4;
+  const uint32_t j4 = (uint32_t)(t - i * (uint32_t)K4);
+  const uint64_t rb = (uint64_t)rank_of[i] * (uint32_t)K4;
+  const int4 x = ints4[t], y = tuple4[rb + j4];
+  if (x.x == y.x && x.y == y.y && x.z == y.z && x.w == y.w) return;
+  int32_t xs[HS_MAX_K], ys[HS_MAX_K];
+  const int32_t* px = reinterpret_cast<const int32_t*>(ints4 + i * (uint32_t)K4);
+  const int32_t* py = reinterpret_cast<const int32_t*>(tuple4 + rb);
+  for (int j = 0; j < 4 * K4; ++j) {
+    xs[j] = px[j];
+    ys[j] = py[j];
   }
+  if (!hs_key_equal(xs, ys, 4 * K4)) atomicOr(flag, 1u);
 }
 
 // ---- 2. distinct keys out of the table ----------------------------------------------------------------
@@ -200,10 +173,9 @@ __global__ __launch_bounds__(256) void hs_fp_count_kernel(const uint64_t* __rest
   if (threadIdx.x == 0) blk_cnt[blockIdx.x] = sw[0] + sw[1] + sw[2] + sw[3];
 }
 
-// dk = the full fingerprint of the slot's key (Tfp, written by the k-mer that claimed the slot), ds = the slot
+// dk = the fingerprint the slot holds, ds = the slot
 __global__ __launch_bounds__(256) void hs_fp_compact_kernel(const uint64_t* __restrict__ T, uint32_t C,
                                                             const uint32_t* __restrict__ blk_off,
-                                                            const uint64_t* __restrict__ Tfp,
                                                             uint64_t* __restrict__ dk, uint32_t* __restrict__ ds) {
   const uint32_t base = blockIdx.x * 1024u;
   __shared__ uint32_t s_run;
@@ -224,7 +196,7 @@ __global__ __launch_bounds__(256) void hs_fp_compact_kernel(const uint64_t* __re
     const uint32_t total = sw[0] + sw[1] + sw[2] + sw[3];
     if (live) {
       const uint32_t o = s_run + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      dk[o] = Tfp[s];
+      dk[o] = v;
       ds[o] = s;
     }
     __syncthreads();
@@ -431,20 +403,27 @@ static uint32_t rs_tiles_per_block(uint64_t n) {
   return (uint32_t)((tiles + nb - 1) / nb);
 }
 
-// d_table: 2 C words -- the slots, then the full fingerprints of the slots' keys
+// d_table: C words, the slots
 hipError_t hs_launch_group_insert(const int32_t* d_ints, uint64_t n, int K, uint32_t seed, uint64_t* d_table,
-                                  uint32_t C, uint32_t* d_slot_of, uint32_t* d_slow, uint32_t slow_cap,
-                                  uint32_t* d_flag, hipStream_t s) {
+                                  uint32_t C, uint32_t* d_slot_of, uint32_t* d_flag, hipStream_t s) {
   hipError_t e = hipMemsetAsync(d_table, 0xff, (size_t)C * 8, s);
-  if (e != hipSuccess) return e;
-  e = hipMemsetAsync(d_slow, 0, 4, s);
   if (e != hipSuccess || !n) return e;
   int log2c = 0;
   while ((1u << log2c) < C) ++log2c;
-  hs_group_insert_kernel<<<blocks_for(n), 256, 0, s>>>(d_ints, n, K, seed, d_table, d_table + C, C - 1, 64 - log2c,
-                                                       d_slot_of, d_slow, slow_cap, d_flag);
-  hs_group_insert_slow_kernel<<<64, 256, 0, s>>>(d_ints, K, seed, d_table, d_table + C, C - 1, 64 - log2c, d_slot_of,
-                                                 d_slow, slow_cap, d_flag);
+  hs_group_insert_kernel<<<blocks_for(n), 256, 0, s>>>(d_ints, n, K, seed, d_table, C - 1, 64 - log2c, d_slot_of,
+                                                       d_flag);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_group_check(const int32_t* d_ints, uint64_t n, int K, const uint32_t* d_rank_of,
+                                 const int32_t* d_dir_tuple, uint32_t* d_flag, hipStream_t s) {
+  if (!n) return hipSuccess;
+  if ((K & 3) == 0)
+    hs_group_check4_kernel<<<blocks_for(n * (uint64_t)(K / 4)), 256, 0, s>>>(
+        reinterpret_cast<const int4*>(d_ints), n * (uint64_t)(K / 4), K / 4, d_rank_of,
+        reinterpret_cast<const int4*>(d_dir_tuple), d_flag);
+  else
+    hs_group_check_kernel<<<blocks_for(n), 256, 0, s>>>(d_ints, n, K, d_rank_of, d_dir_tuple, d_flag);
   return hipGetLastError();
 }
 
@@ -455,7 +434,7 @@ hipError_t hs_launch_fp_count(const uint64_t* d_table, uint32_t C, uint32_t* d_b
 
 hipError_t hs_launch_fp_compact(const uint64_t* d_table, uint32_t C, const uint32_t* d_blk_off, uint64_t* d_dk,
                                 uint32_t* d_ds, hipStream_t s) {
-  hs_fp_compact_kernel<<<(C + 1023) / 1024, 256, 0, s>>>(d_table, C, d_blk_off, d_table + C, d_dk, d_ds);
+  hs_fp_compact_kernel<<<(C + 1023) / 1024, 256, 0, s>>>(d_table, C, d_blk_off, d_dk, d_ds);
   return hipGetLastError();
 }
 

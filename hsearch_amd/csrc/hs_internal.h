@@ -166,17 +166,18 @@ hipError_t hs_rle_u64(void* temp, size_t temp_bytes, const uint64_t* in, uint64_
                       uint32_t* counts_out, uint32_t* runs_out, size_t n, hipStream_t s);
 
 // ---- grouping a table's k-mers by key without sorting fingerprints (hs_group.hip) -----------------
-// bucket ints -> slots of an open-addressing table d_table[2 C] (C = hs_group_table_slots(n) slots, then the
-// slots' full fingerprints), membership
-// proved against the slot's representative: d_slot_of[i] = slot of k-mer i's key.  *d_flag |= 1: a
-// fingerprint collision (one fingerprint, two HashKey strings: rebuild with another seed); 16: the table
-// filled up; 32: more k-mers with aliased keys than the queue d_slow (count + slow_cap ids) holds -- with
-// 16 or 32 the caller takes the sorting path for this table.
+// bucket ints -> slots of an open-addressing table d_table[C] of 64-bit fingerprints (C =
+// hs_group_table_slots(n) slots): d_slot_of[i] = slot of k-mer i's key.  *d_flag |= 16: the table filled up (or
+// a fingerprint equals its empty marker) -- the caller takes the sorting path for this table.
+// hs_launch_group_check, once the buckets have their tuples: the exact-membership proof of every k-mer (its
+// bucket ints against the tuple of the bucket of rank d_rank_of[i]); *d_flag |= 1: one fingerprint, two HashKey
+// strings (rebuild with another seed).
 uint32_t hs_group_table_slots(uint64_t n);
 hipError_t hs_launch_iota_u32(uint32_t* d_out, uint32_t n, hipStream_t s);
 hipError_t hs_launch_group_insert(const int32_t* d_ints, uint64_t n, int K, uint32_t seed, uint64_t* d_table,
-                                  uint32_t C, uint32_t* d_slot_of, uint32_t* d_slow, uint32_t slow_cap,
-                                  uint32_t* d_flag, hipStream_t s);
+                                  uint32_t C, uint32_t* d_slot_of, uint32_t* d_flag, hipStream_t s);
+hipError_t hs_launch_group_check(const int32_t* d_ints, uint64_t n, int K, const uint32_t* d_rank_of,
+                                 const int32_t* d_dir_tuple, uint32_t* d_flag, hipStream_t s);
 // distinct keys per block of 1024 slots; after an exclusive scan of those counts (d_blk_off, with the
 // total at [n_blocks]): the distinct keys' fingerprints d_dk and their slots d_ds in slot order
 hipError_t hs_launch_fp_count(const uint64_t* d_table, uint32_t C, uint32_t* d_blk_cnt, hipStream_t s);
@@ -497,16 +498,6 @@ hipError_t hs_launch_gather_c8t(const void* d_c8, const uint32_t* d_sorted_ql, c
 // 256 for k <= 50) and the members of one work item of the wave-independent int8 join (128 / 64)
 int hs_join8_row_bytes(int k, int wide);
 uint32_t hs_join8_members_per_item(int k, int wide);
-// thin segments with the int8 join on: the join's filter value per (probe, member) pair on the
-// vector ALU (v_dot4_i32_i8), work items = the streaming kernel's (probe, slice) list
-hipError_t hs_launch_thin8(const hs_tables_dev& tabs, const uint4* d_rec_base, uint64_t n_entries,
-                           const void* d_c8, const void* d_tab8, const uint32_t* d_qstart,
-                           const uint32_t* d_qcount, const uint32_t* d_slice_off, const uint32_t* d_slice_ql,
-                           uint32_t nql, int L, int k, int wide, uint32_t* d_prov_count, uint32_t prov_cap,
-                           uint2* d_prov, int n_blocks, hipStream_t s);
-// d_slice_ql[d_slice_off[ql] + s] = ql: the probe of every (probe, slice) work item
-hipError_t hs_launch_slice_map(const uint32_t* d_nslices, const uint32_t* d_slice_off, uint32_t nql,
-                               uint32_t* d_slice_ql, hipStream_t s);
 hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* d_packed_base,
                             const uint4* d_rec_base, const void* d_c8t, const void* d_tab8, int k, int wide,
                             uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov,

@@ -1992,128 +1992,6 @@ __global__ __launch_bounds__(256, 2) void hs_join8r_kernel(
   close_reservation(prov, res_base, res_used, prov_cap, lane);
 }
 
-// Thin segments (too few probing queries or members for MFMA tiles) with the int8 join on: the SAME
-// filter value as the join kernel -- the 128-term integer dot product of the member's A row and the
-// query's row, v_dot4_i32_i8 instead of MFMA -- one member per lane, work item = one (probe, slice
-// of <= HS_SLICE bucket entries) per wave as in the streaming kernel.  Needs no per-query distance
-// tables: with this kernel the side stream's work beside the join is a few tens of microseconds.
-template <int KS, bool WIDE = false>
-__global__ __launch_bounds__(256) void hs_thin8_kernel(const uint4* __restrict__ packed_base,
-                                                       const uint4* __restrict__ rec_base, uint64_t n_entries,
-                                                       const int8_t* __restrict__ c8,
-                                                       const uint4* __restrict__ tab8,
-                                                       const uint32_t* __restrict__ qstart,
-                                                       const uint32_t* __restrict__ qcount,
-                                                       const uint32_t* __restrict__ slice_off,
-                                                       const uint32_t* __restrict__ slice_ql,
-                                                       uint32_t nql, int L, int k,
-                                                       uint32_t* __restrict__ prov_count,
-                                                       uint32_t prov_cap, uint2* __restrict__ prov) {
-  // Work item = one (probe, slice of <= HS_SLICE bucket entries), taken by a GROUP OF 16 LANES: four
-  // items per wave at a time.  Thin segments are mostly tiny buckets (< 16 members) or big buckets
-  // probed by one or two queries; an item is a chain of dependent loads (probe -> bucket range ->
-  // query row -> members), so the kernel's time is that latency times the items per wave -- four
-  // chains per wave in flight instead of one.
-  constexpr int PW = (KS == 4 || WIDE) ? 1 : 2;
-  constexpr int NW = 8 * KS;  // dwords of a row
-  __shared__ uint32_t sTab8[32];
-  __shared__ uint32_t sTabY[WIDE ? 32 : 1];  // WIDE (tab8 = the 8-column table): columns 4..7
-  const int tid = threadIdx.x, lane = tid & 63, sub = lane & 15;
-  if (tid < 32) {
-    sTab8[tid] = tab8[tid].x;
-    if constexpr (WIDE) sTabY[tid] = tab8[tid].y;
-  }
-  __syncthreads();
-  const uint32_t grp = (blockIdx.x * 4u + ((uint32_t)tid >> 6)) * 4u + ((uint32_t)lane >> 4);
-  const uint32_t n_grp = gridDim.x * 16u;
-  const uint32_t total = slice_off[nql];
-  for (uint32_t s = grp; __any(s < total); s += n_grp) {
-    const bool have = s < total;
-    const uint32_t ql = have ? slice_ql[s] : 0u;
-    const uint32_t sl = have ? s - slice_off[ql] : 0u;
-    const uint32_t q = ql / (uint32_t)L, l = ql % (uint32_t)L;
-    const uint32_t start = qstart[ql] + sl * HS_SLICE;
-    const uint32_t cnt = have ? min((uint32_t)HS_SLICE, qcount[ql] - sl * HS_SLICE) : 0u;
-    const uint4* packed = packed_base + (uint64_t)l * n_entries * PW;
-    const uint4* rec = rec_base + (uint64_t)l * n_entries;
-    // the query's row: K index = byte index (hs_qprep8_kernel); the same for the 16 lanes of a group
-    const uint4* qrow = reinterpret_cast<const uint4*>(c8) + (uint64_t)q * (2 * KS);
-    int B[NW];
-#pragma unroll
-    for (int g = 0; g < 2 * KS; ++g) {
-      const uint4 v = qrow[g];
-      B[4 * g] = (int)v.x;
-      B[4 * g + 1] = (int)v.y;
-      B[4 * g + 2] = (int)v.z;
-      B[4 * g + 3] = (int)v.w;
-    }
-    // the last four dwords of a member's row are constants (build_afrags8, h = 1)
-    int qconst = __builtin_amdgcn_sdot4(0x7f7f0000, B[NW - 4], 0, false);
-    qconst = __builtin_amdgcn_sdot4(0x7f7f7f7f, B[NW - 3], qconst, false);
-    qconst = __builtin_amdgcn_sdot4(0x7f7f7f7f, B[NW - 2], qconst, false);
-    qconst = __builtin_amdgcn_sdot4(0x017f7f7f, B[NW - 1], qconst, false);
-    const uint32_t iters = (cnt + 15u) / 16u;
-    for (uint32_t it = 0; __any(it < iters); ++it) {
-      const uint32_t i = it * 16u + (uint32_t)sub;
-      const bool valid = i < cnt;
-      const uint64_t pos = (uint64_t)start + (valid ? i : 0u);
-      const uint4 pk = packed[pos * PW];
-      uint4 pk1 = pk;
-      if constexpr (PW == 2) pk1 = packed[pos * PW + 1];
-      const Stream256 st = stitch<PW>(pk, pk1);
-      const uint4 rc = rec[pos];
-      int acc = qconst;
-      // positions 0 .. 8 KS - 9 by table lookup (those past the k-mer meet zero query bytes)
-#define HS_P(P) if ((P) < NW - 8 && (P) < k) acc = __builtin_amdgcn_sdot4((int)sTab8[stream_at<5 * (P)>(st)], B[(P) < NW ? (P) : 0], acc, false);
-#define HS_P8(P) HS_P(P) HS_P(P + 1) HS_P(P + 2) HS_P(P + 3) HS_P(P + 4) HS_P(P + 5) HS_P(P + 6) HS_P(P + 7)
-      if constexpr (WIDE) {
-        // position P = dwords 2 P (columns 0..3) and 2 P + 1 (columns 4..7) of the row; P < 20 / 25
-#define HS_PW(P)                                                                           \
-  if ((P) < k) {                                                                           \
-    const uint32_t r_ = stream_at<5 * (P)>(st);                                            \
-    acc = __builtin_amdgcn_sdot4((int)sTab8[r_], B[2 * (P)], acc, false);                  \
-    acc = __builtin_amdgcn_sdot4((int)sTabY[r_], B[2 * (P) + 1], acc, false);              \
-  }
-        HS_PW(0) HS_PW(1) HS_PW(2) HS_PW(3) HS_PW(4) HS_PW(5) HS_PW(6) HS_PW(7) HS_PW(8) HS_PW(9)
-        HS_PW(10) HS_PW(11) HS_PW(12) HS_PW(13) HS_PW(14) HS_PW(15) HS_PW(16) HS_PW(17) HS_PW(18) HS_PW(19)
-        if constexpr (KS == 8) { HS_PW(20) HS_PW(21) HS_PW(22) HS_PW(23) HS_PW(24) }
-#undef HS_PW
-      } else {
-      HS_P8(0) HS_P8(8) HS_P8(16)
-      if constexpr (KS > 4) { HS_P8(24) HS_P8(32) }
-      if constexpr (KS > 6) { HS_P8(40) HS_P8(48) }
-      }
-#undef HS_P8
-#undef HS_P
-      acc = __builtin_amdgcn_sdot4((int)rc.x, B[NW - 8], acc, false);  // position 8 KS - 8 + the rho digits
-      acc = __builtin_amdgcn_sdot4((int)rc.y, B[NW - 7], acc, false);
-      acc = __builtin_amdgcn_sdot4((int)rc.z, B[NW - 6], acc, false);
-      acc = __builtin_amdgcn_sdot4((int)rc.w, B[NW - 5], acc, false);
-      const bool pass = valid && acc >= 0;
-      const unsigned long long m = __ballot(pass);
-      if (m) {
-        uint32_t base = 0;
-        if (lane == 0) base = hs_reserve_survivors(prov_count, (uint32_t)__popcll(m));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (pass) {
-          const uint32_t idx = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-          if (idx < prov_cap) prov[idx] = make_uint2(ql, (uint32_t)pos);
-        }
-      }
-    }
-  }
-}
-
-// slice_ql[slice_off[ql] + s] = ql for every slice s of every probe that kept slices
-__global__ __launch_bounds__(256) void hs_slice_map_kernel(const uint32_t* __restrict__ nslices,
-                                                           const uint32_t* __restrict__ slice_off, uint32_t nql,
-                                                           uint32_t* __restrict__ slice_ql) {
-  const uint32_t ql = blockIdx.x * 256 + threadIdx.x;
-  if (ql >= nql) return;
-  const uint32_t ns = nslices[ql], o = slice_off[ql];
-  for (uint32_t s = 0; s < ns; ++s) slice_ql[o + s] = ql;
-}
-
 // Survivors of the 4-column int8 bound, refined with all 8 columns before the exact fp64 decision:
 // d2 = |x|^2 + |c|^2 - 2 (x_A.c_A + x_B.c_B) and, per half, s^2 x.c <= x^.c^ + L1(x^)/2 + L1(c^)/2 +
 // dims/4 + saturation penalty (the join's own inequality), so a pair with d2 <= R^2 satisfies
@@ -2379,42 +2257,6 @@ hipError_t hs_launch_gather_rec8(const uint4* d_packed_all, const uint32_t* d_id
   hs_gather_rec8_kernel<<<blocks_for(n), 256, 0, s>>>(d_packed_all, d_ids_sorted, n, k, hs_packed_words(k), wide,
                                                       (const uint4*)d_tab8, (const uint4*)d_tabW, d_scale,
                                                       d_out_packed, d_out_rec, d_out_rho);
-  return hipGetLastError();
-}
-
-hipError_t hs_launch_thin8(const hs_tables_dev& tabs, const uint4* d_rec_base, uint64_t n_entries,
-                           const void* d_c8, const void* d_tab8, const uint32_t* d_qstart,
-                           const uint32_t* d_qcount, const uint32_t* d_slice_off, const uint32_t* d_slice_ql,
-                           uint32_t nql, int L, int k, int wide, uint32_t* d_prov_count, uint32_t prov_cap,
-                           uint2* d_prov, int n_blocks, hipStream_t s) {
-  if (!nql) return hipSuccess;
-  if (wide) {  // d_tab8 = the 8-column table
-    if (ks_of(k, true) == 6)
-      hs_thin8_kernel<6, true><<<n_blocks, 256, 0, s>>>(tabs.t[0].packed, d_rec_base, n_entries, (const int8_t*)d_c8,
-                                                        (const uint4*)d_tab8, d_qstart, d_qcount, d_slice_off,
-                                                        d_slice_ql, nql, L, k, d_prov_count, prov_cap, d_prov);
-    else
-      hs_thin8_kernel<8, true><<<n_blocks, 256, 0, s>>>(tabs.t[0].packed, d_rec_base, n_entries, (const int8_t*)d_c8,
-                                                        (const uint4*)d_tab8, d_qstart, d_qcount, d_slice_off,
-                                                        d_slice_ql, nql, L, k, d_prov_count, prov_cap, d_prov);
-    return hipGetLastError();
-  }
-#define HS_T8(KS_)                                                                                      \
-  hs_thin8_kernel<KS_><<<n_blocks, 256, 0, s>>>(tabs.t[0].packed, d_rec_base, n_entries, (const int8_t*)d_c8, \
-                                                (const uint4*)d_tab8, d_qstart, d_qcount, d_slice_off,  \
-                                                d_slice_ql, nql, L, k, d_prov_count, prov_cap, d_prov)
-  const int KS = ks_of(k);
-  if (KS == 4) HS_T8(4);
-  else if (KS == 6) HS_T8(6);
-  else HS_T8(8);
-#undef HS_T8
-  return hipGetLastError();
-}
-
-hipError_t hs_launch_slice_map(const uint32_t* d_nslices, const uint32_t* d_slice_off, uint32_t nql,
-                               uint32_t* d_slice_ql, hipStream_t s) {
-  if (!nql) return hipSuccess;
-  hs_slice_map_kernel<<<blocks_for(nql), 256, 0, s>>>(d_nslices, d_slice_off, nql, d_slice_ql);
   return hipGetLastError();
 }
 

@@ -1003,7 +1003,10 @@ __global__ __launch_bounds__(256) void hs_finalize_kernel(hs_tables_dev tabs,
 // of fetching both residues' rows, no staging of 64-byte point pieces, no byte copies of residues (member
 // and query are both 5-bit packed words -- the queries' by hs_pack_kernel -- read by constant shifts).  Hit-heavy batches spend their time
 // here (k = 15 at the C2 sizes: 1.4e8 survivors per batch, 9.4 ms with the two-row form).
-#define HS_FIN_TABLE_ALPHABET 24
+// (21: 80 x 21^2 = 35 KB of terms + 40 KB of per-wave hit buffers = 75 KB per workgroup, two of which share a
+// CU's 160 KB; from 22 letters on only one would fit and the kernel -- which lives on waves in flight -- would
+// lose half of them: those alphabets take the two-row form)
+#define HS_FIN_TABLE_ALPHABET 21
 // Workgroups of HS_FINC_WAVES waves: the kernel sits on s_waitcnt 87 % of its wave cycles (PMC) -- a chain of
 // scattered loads per survivor -- so what it needs is waves in flight, and the 32 KB term table is per
 // workgroup: 16 waves share one, two workgroups per CU = 32 waves (4 waves per table: 12).
@@ -1927,11 +1930,19 @@ hipError_t hs_launch_finalize(const hs_tables_dev& tabs, const uint8_t* d_codes,
                               uint32_t q_base, uint32_t self_first, uint32_t* d_hit_count,
                               uint32_t hit_cap, uint64_t* d_hit_key, uint64_t* d_hit_val, uint32_t* d_qcnt,
                               int alphabet, const uint4* d_qpacked, uint32_t* d_hit_rank, hipStream_t s) {
-  if (d_qpacked && alphabet <= HS_FIN_TABLE_ALPHABET)  // the queries are k-mers: terms from a table
+  if (d_qpacked && alphabet <= HS_FIN_TABLE_ALPHABET) {  // the queries are k-mers: terms from a table
+    static bool lds_granted = false;  // (static + dynamic LDS above 64 KB: ask once per process)
+    if (!lds_granted) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hs_finalize_codes_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         HS_FIN_TABLE_ALPHABET * HS_FIN_TABLE_ALPHABET * 80);
+      if (e != hipSuccess) return e;
+      lds_granted = true;
+    }
     hs_finalize_codes_kernel<<<512, 64 * HS_FINC_WAVES, (size_t)alphabet * alphabet * 80, s>>>(
         tabs, d_qpacked, d_coords, alphabet, d_qstart, d_qcount, d_prov, d_prov_count, prov_cap, d_sorted_ql, k, L, r2,
         r_sqrt, q_base, self_first, d_hit_count, hit_cap, d_hit_key, d_hit_val, d_qcnt, d_hit_rank);
-  else if (d_qcodes)  // ... with a large alphabet: centre rows from the coordinate table
+  } else if (d_qcodes)  // ... with a large alphabet: centre rows from the coordinate table
     hs_finalize_kernel<true><<<1024, 256, 0, s>>>(tabs, d_codes, nullptr, d_qcodes, d_coords, d_qstart, d_qcount,
                                                   d_prov, d_prov_count, prov_cap, d_sorted_ql, k, L, r2,
                                                   r_sqrt, q_base, self_first, d_hit_count, hit_cap,

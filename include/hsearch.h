@@ -158,12 +158,11 @@ typedef enum hs_option {
                                 member records are built for one form) */
   HS_OPT_REFINE8 = 7,        /* 1 (default): survivors of the 4-column bound pass the 8-column bound first */
   HS_OPT_SELF_CODES = 8,     /* 1 (default): the self-join runs from residue codes; 0: from embedded centres */
-  HS_OPT_THIN_FILTER = 9,    /* 1 (default): segments below HS_OPT_JOIN_MIN_Q / _M through the int8 per-pair filter;
-                                0: through the streaming filter */
   HS_OPT_SORT_HITS = 10,     /* 1: order a batch's hits by a radix sort of the whole list, not per query */
   HS_OPT_SYNC_ITEMS = 11,    /* 1: read the join's work-item count back before launching it */
   HS_OPT_JOIN_MIN_Q = 12,    /* segments with fewer probing queries ... */
-  HS_OPT_JOIN_MIN_M = 13,    /* ... or fewer members skip the join (default 1 / 1: none do) */
+  HS_OPT_JOIN_MIN_M = 13,    /* ... or fewer members (and fewer than 512) go to the streaming filter instead of the
+                                join (default 1 / 1: none do) */
   HS_OPT_SORT_FROM_BIT = 14, /* HS_OPT_BUILD_GROUPING = 1: lowest fingerprint bit the first sort looks at (0..60) */
   HS_OPT_BUILD_SERIAL = 15   /* 1: no overlap of a table's hashing with the previous table's grouping */
 } hs_option;

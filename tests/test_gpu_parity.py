@@ -838,11 +838,11 @@ def test_queries_given_as_residue_codes(oracle, k, K, L, W, R):
     eng.close()
 
 
-@pytest.mark.parametrize("letters", [11, 29])
+@pytest.mark.parametrize("letters", [11, 21, 23, 29])
 def test_queries_as_codes_in_batches_and_custom_table(oracle, letters):
-    """An alphabet of its own (11 letters: the exact pass takes its terms from the table of rounded
-    squares, hs_finalize_codes_kernel; 29 letters: above HS_FIN_TABLE_ALPHABET, the two-row form of
-    hs_finalize_kernel), several query batches per call, a code outside the alphabet, and the same
+    """An alphabet of its own (11 and 21 letters: the exact pass takes its terms from the table of rounded
+    squares, hs_finalize_codes_kernel -- 21 is the largest it holds; 23 and 29 letters: above
+    HS_FIN_TABLE_ALPHABET, the two-row form of hs_finalize_kernel), several query batches per call, a code outside the alphabet, and the same
     queries given as points (recognised as k-mers of that table)."""
     k, K, L, W, R, n, nq = 25, 5, 4, 120.0, 44.0, 9001, 777
     rng = np.random.default_rng(90)
