@@ -79,6 +79,7 @@ enum { EV_FORK = 0, EV_JOIN = 1, EVX_COUNT = 2 };
 // in the test build of the library (-DHS_TEST_HOOKS: libhsearch_amd_hooks.so), never in libhsearch_amd.so.
 struct Knobs {
   bool build_serial = false;       // HS_BUILD_SERIAL: no hash / sort overlap in the build (measurement)
+  int join_xcd_run = -1;           // HS_OPT_JOIN_XCD_RUN: chunks per XCD-local run of join items (0 off, -1 auto)
   bool build_debug = false;        // HS_BUILD_DEBUG: say when a table is sorted a second time
   bool cluster_timing = false;     // HS_CLUSTER_TIMING: phase times of hs_self_join_range on stderr
   bool debug_refine = false;       // HS_DEBUG_REFINE: survivor counts per batch on stderr
@@ -421,7 +422,8 @@ const struct { const char* name; int option; } kOptionNames[] = {
     {"recognise_kmers", HS_OPT_RECOGNISE_KMERS}, {"build_grouping", HS_OPT_BUILD_GROUPING}, {"wide_rows", HS_OPT_WIDE_ROWS},
     {"refine8", HS_OPT_REFINE8}, {"self_codes", HS_OPT_SELF_CODES},
     {"sort_hits", HS_OPT_SORT_HITS}, {"sync_items", HS_OPT_SYNC_ITEMS}, {"join_min_q", HS_OPT_JOIN_MIN_Q},
-    {"join_min_m", HS_OPT_JOIN_MIN_M}, {"sort_from_bit", HS_OPT_SORT_FROM_BIT}, {"build_serial", HS_OPT_BUILD_SERIAL}};
+    {"join_min_m", HS_OPT_JOIN_MIN_M}, {"sort_from_bit", HS_OPT_SORT_FROM_BIT}, {"build_serial", HS_OPT_BUILD_SERIAL},
+    {"join_xcd_run", HS_OPT_JOIN_XCD_RUN}};
 
 void read_knobs(hs_handle* h) {
   Knobs& kn = h->knobs;
@@ -705,6 +707,10 @@ hs_status hs_set_option(hs_handle* h, int option, int64_t value) {
       kn.sort_from_bit = (int)value;
       return HS_OK;
     case HS_OPT_BUILD_SERIAL: return flag(&kn.build_serial, false);
+    case HS_OPT_JOIN_XCD_RUN:
+      if (value < -1 || value > 4096 || (value > 0 && (value & (value - 1)))) break;  // a power of two
+      kn.join_xcd_run = (int)value;
+      return HS_OK;
     default:
       return fail(h, HS_ERR_INVALID, "hs_set_option: unknown option");
   }
@@ -2355,7 +2361,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
       HS_HIP(h, h->temp.reserve(hs_scan_u32_temp(n1q) + 256));
     }
     HS_HIP(h, hipEventRecord(h->ev[3], h->stream));
-    if (launches) HS_HIP(h, hipMemsetAsync(d_cnt + 32, 0, 8, h->stream));  // retry: the item counters again
+    if (launches) HS_HIP(h, hipMemsetAsync(d_cnt + 32, 0, 64, h->stream));  // retry: the item counters again
     if (side) {
       HS_HIP(h, hipEventRecord(h->evx[EV_FORK], h->stream));
       HS_HIP(h, hipStreamWaitEvent(h->stream2, h->evx[EV_FORK], 0));
@@ -2378,11 +2384,16 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
         // the head [0, split) of the item list through the query-streaming kernel, the tail through the
         // query-resident one (split == the item count when no segment qualifies or use_r is off)
         const uint32_t* const d_split = h->seg_n.as<uint32_t>() + 2;
+        // XCD-local runs of items where the batch's query tiles do not stay in every XCD's L2 anyway
+        // (d_cnt + 40 .. 47: the per-XCD chunk counters)
+        const uint64_t tile_bytes = (uint64_t)nql * (uint64_t)hs_join8_row_bytes(k, wide);
+        const uint32_t xcd_run = h->knobs.join_xcd_run >= 0 ? (uint32_t)h->knobs.join_xcd_run
+                                                            : (tile_bytes > (64ull << 20) ? 128u : 0u);
         HS_HIP(h, hs_launch_join8w(h->item_desc.as<uint4>(), n_items, h->tabs.t[0].packed,
                                    rec8, h->c16s.p, jtab_rows, k, wide, d_cnt, prov_cap,
                                    h->prov.as<uint2>(), d_cnt + 32, h->n_cu * h->join_blocks_per_cu,
                                    use_r ? d_split : (async_items ? h->item_off.as<uint32_t>() + nql : nullptr),
-                                   h->pairs_per_item, h->stream));
+                                   h->pairs_per_item, xcd_run, h->stream));
         if (use_r)
           HS_HIP(h, hs_launch_join8r(h->item_desc.as<uint4>(), n_items, d_split, h->tabs.t[0].packed,
                                      h->t_rho.as<uint32_t>(),

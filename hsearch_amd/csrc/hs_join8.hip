@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(256, 2) void hs_join8x_kernel(
     const uint4* __restrict__ rec_base, const uint4* __restrict__ c8t,
     const uint4* __restrict__ tab8, uint32_t* __restrict__ prov_count, uint32_t prov_cap,
     uint2* __restrict__ prov, uint32_t* __restrict__ item_counter, uint32_t G,
-    const uint32_t* __restrict__ n_items_dev) {
+    const uint32_t* __restrict__ n_items_dev, uint32_t xcd_run) {
   if (n_items_dev) n_items = min(n_items, __builtin_amdgcn_readfirstlane(*n_items_dev));
   constexpr int RT = 8;  // row tiles of 16 members per wave
   // x^ of TWO consecutive residues per lookup: entry (r1 << 5 | r0) = {x^(r0), x^(r1)} -- 8 KB of LDS,
@@ -1068,20 +1068,52 @@ __global__ __launch_bounds__(256, 2) void hs_join8x_kernel(
   uint64_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
   const uint64_t tstart = tlast;
 #endif
+  // Two ways of dealing the chunks (G consecutive items) to the waves.  xcd_run == 0: the first chunk by
+  // wave number, the rest from ONE counter -- consecutive chunks go to whichever wave asks next, on any XCD.
+  // xcd_run > 0: the chunk sequence is cut into runs of xcd_run chunks, run r belongs to XCD r % 8, and a wave
+  // takes from its own XCD's counter (item_counter[8 + x]); consecutive items are the member tiles of ONE
+  // segment and all of them stream that segment's query tiles, so a run's waves find them in their XCD's L2
+  // instead of every XCD fetching every segment's tiles over the fabric.  A wave whose XCD has run dry
+  // takes from the next XCD's counter (and stays there): the tail is dealt like the single counter's.
+  // (xcd_run = a power of two.  The wave's XCD, the victim and the number of XCDs found dry are wave-uniform
+  // and live in scalar registers: this kernel has no vector register to spare.)
+  const uint32_t xcd_sh = 31u - (uint32_t)__builtin_clz(xcd_run | 1u), xcd_mask = (1u << xcd_sh) - 1u;
+  uint32_t victim = __builtin_amdgcn_s_getreg(6164) & 7u;  // hwreg(HW_REG_XCC_ID, 0, 4)
+  uint32_t tried = 0;
   const uint32_t first_dynamic = gridDim.x * 4u * G;
+  // counter value v (already taken) -> the first item of the chunk it stands for; uniform
+  auto chunk_item = [&](uint32_t v) -> uint32_t {
+    if (!xcd_run) return first_dynamic + v;
+    for (;;) {
+      const uint32_t c = ((((v >> xcd_sh) << 3) + victim) << xcd_sh) + (v & xcd_mask);
+      const uint64_t it = (uint64_t)c * G;
+      if (it < (uint64_t)n_items) return (uint32_t)it;
+      if (++tried == 8u) return 0xf0000000u;  // >= any n_items, and a few increments away from wrapping
+      victim = (victim + 1u) & 7u;
+      uint32_t j = 0;
+      if (lane == 0) j = atomicAdd(item_counter + 8 + victim, 1u);
+      v = __builtin_amdgcn_readfirstlane(j);
+    }
+  };
+#define HS_TAKE_CHUNK() (xcd_run ? atomicAdd(item_counter + 8 + victim, 1u) : atomicAdd(item_counter, G))
   uint32_t item = (blockIdx.x * 4u + (uint32_t)wave) * G;
+  if (xcd_run) {
+    uint32_t first = 0;
+    if (lane == 0) first = HS_TAKE_CHUNK();
+    item = chunk_item(__builtin_amdgcn_readfirstlane(first));
+  }
   if (item >= n_items) return;
   uint32_t res_base = 0, res_used = JRES;
   uint32_t next_chunk_v = 0;
-  if (lane == 0) next_chunk_v = atomicAdd(item_counter, G);
+  if (lane == 0) next_chunk_v = HS_TAKE_CHUNK();
   uint32_t pf_item = item, pf_chunk_end = item + G;
 #define HS_ADVANCE_PF()                                                                  \
   {                                                                                      \
     ++pf_item;                                                                           \
     if (pf_item == pf_chunk_end) {                                                       \
-      pf_item = first_dynamic + __builtin_amdgcn_readfirstlane(next_chunk_v);            \
+      pf_item = chunk_item(__builtin_amdgcn_readfirstlane(next_chunk_v));                \
       pf_chunk_end = pf_item + G;                                                        \
-      if (lane == 0 && pf_item < n_items) next_chunk_v = atomicAdd(item_counter, G);     \
+      if (lane == 0 && pf_item < n_items) next_chunk_v = HS_TAKE_CHUNK();                \
     }                                                                                    \
   }
   uint4 d0 = uniform4(desc[2 * (uint64_t)item]), d1 = uniform4(desc[2 * (uint64_t)item + 1]);
@@ -1254,6 +1286,7 @@ __global__ __launch_bounds__(256, 2) void hs_join8x_kernel(
     nd1 = nnd1;
   }
 #undef HS_ADVANCE_PF
+#undef HS_TAKE_CHUNK
 #undef HS_LOAD_GROUP
 #undef HS_N_GROUPS
 #undef HS_LOAD_MEMBERS
@@ -2160,7 +2193,7 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
                             const uint4* d_rec_base, const void* d_c8t, const void* d_tab8, int k, int wide,
                             uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov,
                             uint32_t* d_item_counter, int n_blocks, const uint32_t* d_n_items,
-                            double pairs_per_item, hipStream_t s) {
+                            double pairs_per_item, uint32_t xcd_run, hipStream_t s) {
   if (!n_items) return hipSuccess;
   // (*d_item_counter is zeroed by the caller, with the batch's other counters)
   // Chunk size = items per access to the global counter.  Same-address atomics complete at only
@@ -2199,7 +2232,7 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
   else if (KS == 4)
     hs_join8x_kernel<<<n_blocks, 256, 0, s>>>(d_desc, n_items, d_packed_base, d_rec_base, (const uint4*)d_c8t,
                                               (const uint4*)d_tab8, d_prov_count, prov_cap, d_prov,
-                                              d_item_counter, G, d_n_items);
+                                              d_item_counter, G, d_n_items, xcd_run);
   else if (KS == 6) HS_J8(2, 6);
   else HS_J8(2, 8);
 #undef HS_J8

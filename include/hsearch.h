@@ -164,7 +164,11 @@ typedef enum hs_option {
   HS_OPT_JOIN_MIN_M = 13,    /* ... or fewer members (and fewer than 512) go to the streaming filter instead of the
                                 join (default 1 / 1: none do) */
   HS_OPT_SORT_FROM_BIT = 14, /* HS_OPT_BUILD_GROUPING = 1: lowest fingerprint bit the first sort looks at (0..60) */
-  HS_OPT_BUILD_SERIAL = 15   /* 1: no overlap of a table's hashing with the previous table's grouping */
+  HS_OPT_BUILD_SERIAL = 15,  /* 1: no overlap of a table's hashing with the previous table's grouping */
+  HS_OPT_JOIN_XCD_RUN = 16   /* hs_join8x_kernel's work items dealt in runs of this many chunks per XCD, each XCD's
+                                waves on their own runs (a run's items stream the same query tiles: one L2 fetches
+                                them instead of eight).  0: one counter for the chip; -1 (default): by the size
+                                of the batch's query-tile array */
 } hs_option;
 HS_API hs_status hs_set_option(hs_handle* h, int option, int64_t value);
 /* The library's work after this call starts only once `hip_event` (a hipEvent_t the caller has recorded on a
