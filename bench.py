@@ -18,14 +18,24 @@ k <= 20; hs_join8w_kernel for k = 26..50), an int8 MFMA GEMM of depth 128 (192 f
 k <= 20 and 26..41, 256 for k <= 50) per (bucket member, probing query) pair, against the dense int8 MFMA peak; with --verify-mode stream (and wherever no join runs) it is hs_verify_kernel, priced by the
 ALGORITHMIC bytes of SURVEY.md 8(d) against 8 TB/s.  `roofline.traffic` = measured HBM bytes per
 launch from profiles/traffic_latest.json, reported only while that file's recorded kernel source
-hash equals the hash of the kernel source this run was built from.  `cpu_baseline` times the
-reference's CPU path (the pinned restatement, oracle/) on a bounded sample of the same workload
-(rank 0, N = 1 only): `value` is the MEASURED rate at the sample's N; the figure scaled to the
-bench's N is reported beside it and labelled as an extrapolation.
+hash equals the hash of the kernel source this run was built from.  `cpu_baseline` (rank 0, N = 1 only)
+times the reference ITSELF -- oracle/_ref, the reference's own translation units compiled by oracle/Makefile
+(kind "reference"; the restatement oracle/ as kind "port" where _ref was not built) -- on a bounded sample of
+the same workload: `value` is the MEASURED rate at the sample's N; the figure scaled to the bench's N is
+reported beside it and labelled as an extrapolation.  `general_centres`: the same step with centres that are
+no k-mers (jittered), the path of the reference's family centroids.
+
+`secondary` (default on where the HBM holds it): BASELINE.json configs[2], the north-star target -- 10^8
+25-mers, L = 32, K = 20, W = 160 from its own recall sweep, 10^6 queries -- as a STRONG-scaling job: one
+query set sharded over the ranks, every rank one batch, the index replicated; `value` = 10^6 / the slowest
+rank's pass.  At N = 1 it also times the 125 000-query pass that is one GPU's share of the 8-GPU job
+(`one_gpu_share_of_eight`); at N > 1 the same job with the TABLES dealt over the ranks instead
+(`table_partition`: every rank all queries on L / N tables, merged by the reference's first-seen rule).
+`python bench.py --gpus N` typed as such starts its own N ranks (torch.distributed.run, 127.0.0.1).
 
 Other BASELINE.json configs through the same script (the label in config.workload follows the
-arguments): configs[2]'s per-GPU share `--db-size 100000000 --L 32 --K 20 --queries 125000`,
-configs[4] `--k 39` / `--k 15`.
+arguments): configs[2]'s per-GPU share `--db-size 100000000 --L 32 --K 20 --W 160 --queries 125000`,
+configs[4] `--k 39` / `--k 15` (tools/bench_mixed_k.py runs the three lengths together).
 """
 import argparse
 import json

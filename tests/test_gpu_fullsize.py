@@ -47,6 +47,18 @@ def test_config2_search_properties():
     assert eng.profile()["join_i8_batches"] > 0
     for f in ("q", "id", "table", "dist", "cand"):
         assert np.array_equal(as_codes[f], res["join"][f]), f
+    # ... and as POINTS that are not looked at for being k-mers (option recognise_kmers = 0): the path of centres
+    # that are no rows of the coordinate table (bench.py's general_centres) on the headline workload
+    eng.set_verify_mode("join")
+    eng.query(centers, R)
+    assert eng.profile()["queries_recognised"] == nq      # (what res["join"] above ran as)
+    eng.set_option("recognise_kmers", 0)
+    as_points = eng.query(centers, R)
+    pp = eng.profile()
+    assert pp["join_i8_batches"] > 0 and pp["queries_recognised"] == 0
+    eng.set_option("recognise_kmers", 1)
+    for f in ("q", "id", "table", "dist", "cand"):
+        assert np.array_equal(as_points[f], res["join"][f]), f
     j, s = res["join"], res["stream"]
     for f in ("q", "id", "table", "dist"):
         assert np.array_equal(res["join16"][f], s[f]), f

@@ -12,12 +12,3 @@ for f in ("ab_chain_1M_dense","ab_chain_1M_sparse","ab_chain_125k"):
     p=json.load(open("gpurun_out/%s.json"%f))
     print(f, round(p["value"]/1e6,2), "Mq/s", round(p["ms_per_step"],2), "ms", {k:round(v,2) for k,v in p["phases_ms_per_step"].items()}, round(p["roofline"]["frac"],3))
 PY
-# the few-queries filter off / on at 125 k (hs_few8_kernel)
-HS_OPTIONS=short_segments=0 $B --queries 125000 > gpurun_out/ab_chain_125k_few0.json 2>/dev/null
-HS_OPTIONS=short_segments=1 $B --queries 125000 > gpurun_out/ab_chain_125k_few1.json 2>/dev/null
-python - <<'PY'
-import json
-for f in ("ab_chain_125k_few0","ab_chain_125k_few1"):
-    p=json.load(open("gpurun_out/%s.json"%f))
-    print(f, round(p["value"]/1e6,2), "Mq/s", round(p["ms_per_step"],2), "ms", {k:round(v,2) for k,v in p["phases_ms_per_step"].items()}, round(p["roofline"]["frac"],3))
-PY

@@ -21,6 +21,10 @@ def main():
     ap.add_argument("--R", type=float, default=40.0)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--general-steps", type=int, default=3,
+                    help="passes per length with centres that are NOT k-mers (jittered: the reference's family "
+                         "centroids' path, hs_finalize_kernel instead of hs_finalize_codes_kernel); 0: skip")
+    ap.add_argument("--general-jitter", type=float, default=0.05)
     args = ap.parse_args()
     import torch
     from hsearch_amd import Engine, HsError, synth
@@ -36,21 +40,25 @@ def main():
         eng.index_build(codes)
         tb = time.perf_counter() - t0
         dc = torch.from_numpy(centers).to(dev)
-        engines.append({"k": k, "eng": eng, "centers": dc, "cap": 0, "out": None, "build_s": tb})
+        dg = None
+        if args.general_steps:
+            general, _ = synth.make_queries(codes, args.nq, seed=synth.SEED_QUERIES, jitter=args.general_jitter)
+            dg = torch.from_numpy(general).to(dev)
+        engines.append({"k": k, "eng": eng, "centers": dc, "general": dg, "cap": 0, "out": None, "build_s": tb})
         del codes
 
     def alloc(c):
         return dict(q=torch.empty(c, dtype=torch.int32, device=dev), id=torch.empty(c, dtype=torch.int32, device=dev),
                     table=torch.empty(c, dtype=torch.int32, device=dev), dist=torch.empty(c, dtype=torch.float64, device=dev))
 
-    def one(e):
+    def one(e, which="centers"):
         if e["out"] is None:
             e["cap"] = 16 * args.nq + 4096
             e["out"] = alloc(e["cap"])
         while True:
             o = e["out"]
             try:
-                return e["eng"].query_dev(e["centers"].data_ptr(), args.nq, args.R, o["q"].data_ptr(),
+                return e["eng"].query_dev(e[which].data_ptr(), args.nq, args.R, o["q"].data_ptr(),
                                           o["id"].data_ptr(), o["table"].data_ptr(), o["dist"].data_ptr(), e["cap"])
             except HsError as err:
                 if getattr(err, "needed", 0) <= e["cap"]:
@@ -76,6 +84,34 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ms_step = dt / args.steps * 1e3
+    general = None
+    if args.general_steps:
+        gper = {}
+        for e in engines:
+            one(e, "general")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.general_steps):
+            for e in engines:
+                nh = one(e, "general")
+                p = e["eng"].profile()
+                d = gper.setdefault(e["k"], {"ms": 0.0, "join_ms": 0.0, "fin_ms": 0.0, "hits": 0, "rec": 0})
+                d["ms"] += p["ms_total"]
+                d["join_ms"] += p["ms_join"]
+                d["fin_ms"] += p["ms_finalize"]
+                d["hits"] = int(nh)
+                d["rec"] = int(p["queries_recognised"])
+        torch.cuda.synchronize()
+        gdt = time.perf_counter() - t0
+        general = {"what": "the same step with centres that are no k-mers (every coordinate jittered by N(0, %g)): "
+                           "embedded rows, hs_finalize_kernel" % args.general_jitter,
+                   "value": len(ks) * args.nq * args.general_steps / gdt, "unit": "queries/s",
+                   "ms_per_step": gdt / args.general_steps * 1e3, "steps": args.general_steps,
+                   "per_length": {str(k): {"device_ms_per_step": v["ms"] / args.general_steps,
+                                           "join_ms_per_step": v["join_ms"] / args.general_steps,
+                                           "finalize_ms_per_step": v["fin_ms"] / args.general_steps,
+                                           "hits_per_step": v["hits"], "queries_recognised_as_kmers": v["rec"]}
+                                  for k, v in gper.items()}}
     line = {
         "metric": "motif queries/sec (LSH probe + verify, index resident in HBM), mixed k-mer lengths",
         "value": len(ks) * args.nq * args.steps / dt, "unit": "queries/s", "n_gpus": 1, "steps": args.steps,
@@ -88,6 +124,7 @@ def main():
                                 "hits_per_step": v["hits"], "candidates_per_query": v["cand"] / args.nq}
                        for k, v in per.items()},
         "index_build_seconds": {str(e["k"]): e["build_s"] for e in engines},
+        "general_centres": general,
     }
     print(json.dumps(line))
     for e in engines:

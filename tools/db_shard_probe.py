@@ -15,7 +15,7 @@ a_ = sys.argv[1:]
 n = int(a_[0]) if len(a_) > 0 else 12_500_000
 nq = int(a_[1]) if len(a_) > 1 else 1_000_000
 batch = int(a_[2]) if len(a_) > 2 else 131072
-os.environ["HS_QUERY_BATCH"] = str(batch)
+os.environ["HS_OPTIONS"] = "query_batch=%d" % batch
 import torch
 from hsearch_amd import Engine, synth
 k, K, L, W, R = 25, 20, 32, 160.0, 40.0
