@@ -553,8 +553,9 @@ __global__ __launch_bounds__(256) void hs_gather_rec8_kernel(const uint4* __rest
                           pack4(d[8], d[9], d[10], d[11]));
   // The same record in FOUR bytes, for hs_join8r_kernel (which is bound by the bytes it reads per member):
   // the digits are a function of q = rho div 127 alone -- digit j = clamp(|q| - 127 j, 0, 127), negated for
-  // q < 0 -- and come from a table there; x^ of the record's position from the residue.  Bits 0..14: 16 |q|
-  // (the byte offset of the digits' table entry), 15: q < 0, 16..22: rho mod 127, 23..30: 4 x that residue.
+  // q < 0 -- and come from a table there; x^ of the record's position from the residue.  Bits 0..10: |q|,
+  // 11: q < 0, 12..18: rho mod 127, 20..25: that residue (32: none), 26..31: zero -- the residue is read as the
+  // TEN-bit field at bit 20 the other rows of the operand build read there (join8r_lookup).
   if (out_rho) {
     int q = (int)rho / 127, rem = (int)rho - q * 127;  // as digits127
     if (rem < 0) {
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(256) void hs_gather_rec8_kernel(const uint4* __rest
       q = -127 * RDIG;
       rem = 0;
     }
-    out_rho[t] = ((uint32_t)abs(q) << 4) | (q < 0 ? 0x8000u : 0u) | ((uint32_t)rem << 16) | (rlast << 25);
+    out_rho[t] = (uint32_t)abs(q) | (q < 0 ? 0x800u : 0u) | ((uint32_t)rem << 12) | (rlast << 20);
   }
 }
 
@@ -1635,10 +1636,13 @@ __device__ __forceinline__ void load_btile_r(intx4 (&B)[2][2], const uint4* __re
   const uint32_t o10 = ((g0 + 1u) * nr + r0) * 16u, o11 = ((g0 + 1u) * nr + r1) * 16u;
   const uint4 v00 = *reinterpret_cast<const uint4*>(t0 + o00), v01 = *reinterpret_cast<const uint4*>(t0 + o01);
   const uint4 v10 = *reinterpret_cast<const uint4*>(t0 + o10), v11 = *reinterpret_cast<const uint4*>(t0 + o11);
-  B[0][0] = intx4{(int)v00.x, (int)v00.y, (int)v00.z, (int)v00.w};
-  B[0][1] = intx4{(int)v01.x, (int)v01.y, (int)v01.z, (int)v01.w};
-  B[1][0] = intx4{(int)v10.x, (int)v10.y, (int)v10.z, (int)v10.w};
-  B[1][1] = intx4{(int)v11.x, (int)v11.y, (int)v11.z, (int)v11.w};
+  // row 2 (the record's position | the gamma slots): dword 0 of the two k-steps change places, as the member
+  // side holds them (join8r_layout)
+  const bool sw = row == 2u;
+  B[0][0] = intx4{(int)(sw ? v10.x : v00.x), (int)v00.y, (int)v00.z, (int)v00.w};
+  B[0][1] = intx4{(int)(sw ? v11.x : v01.x), (int)v01.y, (int)v01.z, (int)v01.w};
+  B[1][0] = intx4{(int)(sw ? v00.x : v10.x), (int)v10.y, (int)v10.z, (int)v10.w};
+  B[1][1] = intx4{(int)(sw ? v01.x : v11.x), (int)v11.y, (int)v11.z, (int)v11.w};
 }
 
 // hs_join8r_kernel works on HALF items: four row tiles (64 members) at a time -- the whole item's
@@ -1663,13 +1667,14 @@ __device__ __forceinline__ void load_btile_r(intx4 (&B)[2][2], const uint4* __re
 // instruction cache).
 // per-lane constants of the operand build (rows 0, 1, 3 | row 2)
 struct J8rLane {
-  uint32_t sh;      // bit of the loaded word the lane's fields start at: 8 j | 0
-  uint32_t o0, o1;  // bit offsets of the first two fields: 0, 10 | 4, 4 (the record word carries |q| there)
+  uint32_t sh;      // bit of the loaded words the lane's fields start at: 8 j | 0
+  uint32_t o0, o1;  // bit offsets of the first two fields: 0, 10 | 0, 0 (the record word carries |q| there)
   uint32_t w01;     // ... and their width: 10 | 11
   uint32_t sl;      // field -> byte offset of its table entry: shift 6 (64-byte entries) | 3 (8-byte entries)
   uint32_t b0, b1;  // the lane's copy of the pair table | the two digit tables
-  uint32_t w2;      // k-step 1: width of its two fields: 10 | 0 (no field: row 2 reads ...
-  uint32_t b2, b3;  // ... the lane's copy again | the two entries of the constant factors)
+  uint32_t w3;      // k-step 1: width of its second field: 10 | 0 (no field: row 2 reads the constant factors)
+  uint32_t b2, b3;  // the lane's copy again | the table of single residues (field = the record's residue), the
+                    // second half of the constant factors
   uint32_t mrem;    // 0 | 0x7f
   bool row2;
 };
@@ -1683,7 +1688,12 @@ struct J8rLane {
 //                    TWO arrays of 8-byte entries -- {0, digits 0..3} and {digits 4..7, digits 8..10} -- so
 //                    that the 16 lanes of row 2, whose |q| are neighbours, spread over 32 bank pairs and not
 //                    over the 16 that 16-byte entries gave them
-//   x^ of one residue (64 dwords, entry 32 = 0: no residue; on a multiple of 256: its address is formed with OR)
+//   x^ of ONE residue: entry r (stride = the pair table's) = {x^(r), second dword of the constant factors},
+//                    33 entries, entry 32 = {0, ..}: no residue.  Row 2 reads it in the slot of k-step 1's first
+//                    pair, so its operand dwords are {factor 0, digits ..} | {x^, factors 1..3}: dword 0 of the
+//                    two k-steps swapped against the layout of the query rows, which load_btile_r swaps back.
+//                    (Until r04 a lookup of its own -- three vector instructions and an LDS read per row tile
+//                    for ALL lanes -- and a select put x^ into k-step 0.)
 //   the constant factors of the gamma slots (16 bytes)
 //   per wave: the sign masks of an item's groups that had a survivor, [4][8][64] dwords
 struct J8rLayout {
@@ -1694,49 +1704,46 @@ __host__ __device__ inline J8rLayout join8r_layout(int alphabet) {
   l.dig_at = 2048u * (uint32_t)alphabet;
   l.dig2_at = l.dig_at + 1398u * 8u;
   l.tab1_at = (l.dig2_at + 1398u * 8u + 255u) & ~255u;
-  l.const_at = l.tab1_at + 256u;
+  l.const_at = l.tab1_at + 33u * 64u;
   l.mask_at = l.const_at + 256u;
   l.total = l.mask_at + 4u * 8u * 64u * 4u;
   return l;
 }
 
-__device__ __forceinline__ void join8r_lookup(intx4 (&A)[4][2], uint32_t (&XL)[4], const uint4 (&MK)[8], int half,
-                                              const char* sL, uint32_t tab1_at, const J8rLane& c) {
+__device__ __forceinline__ void join8r_lookup(intx4 (&A)[4][2], const uint2 (&MK)[8], int half, const char* sL,
+                                              const J8rLane& c) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const uint4 mk = MK[4 * half + t];
-    const uint32_t x0 = __builtin_amdgcn_alignbit(mk.y, mk.x, c.sh), x1 = __builtin_amdgcn_alignbit(mk.z, mk.y, c.sh);
+    const uint2 mk = MK[4 * half + t];  // dwords j, j + 1 of the packed word (rows 0, 1, 3) | the record (row 2)
+    // the lane's stream: bits 0..31, and 32 .. 63 - sh of which 32..39 are needed
+    const uint32_t x0 = __builtin_amdgcn_alignbit(mk.y, mk.x, c.sh), x1 = mk.y >> c.sh;
     const uint32_t a0 = (__builtin_amdgcn_ubfe(x0, c.o0, c.w01) << c.sl) + c.b0;
     const uint32_t a1 = (__builtin_amdgcn_ubfe(x0, c.o1, c.w01) << c.sl) + c.b1;
-    const uint32_t a2 = (__builtin_amdgcn_ubfe(x0, 20u, c.w2) << 6) + c.b2;
-    const uint32_t a3 = (__builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(x1, x0, 30), 0u, c.w2) << 6) + c.b3;
-    const uint32_t ax = tab1_at | ((x0 >> 23) & 0xfcu);  // (rows 0, 1, 3: some entry of that table, unused)
+    const uint32_t a2 = (__builtin_amdgcn_ubfe(x0, 20u, 10u) << 6) + c.b2;
+    const uint32_t a3 = (__builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(x1, x0, 30), 0u, c.w3) << 6) + c.b3;
     const uint2 p0 = *reinterpret_cast<const uint2*>(sL + a0), p1 = *reinterpret_cast<const uint2*>(sL + a1);
     const uint2 p2 = *reinterpret_cast<const uint2*>(sL + a2), p3 = *reinterpret_cast<const uint2*>(sL + a3);
-    XL[t] = *reinterpret_cast<const uint32_t*>(sL + ax);
     A[t][0] = intx4{(int)p0.x, (int)p0.y, (int)p1.x, (int)p1.y};
     A[t][1] = intx4{(int)p2.x, (int)p2.y, (int)p3.x, (int)p3.y};
   }
 }
 
 // the lookups have arrived (this is where the wave waits for them): row 2's k-step 0 is the digit
-// pattern of |q| it looked up; it becomes the member's record with x^ of the record's position in its
-// first dword, rho mod 127 in its last byte, and the digits negated should q be negative
-__device__ __forceinline__ void join8r_finish(intx4 (&A)[4][2], const uint32_t (&XL)[4], const uint4 (&MK)[8], int half,
-                                              const J8rLane& c) {
+// pattern of |q| it looked up (first dword: the first constant factor); it becomes the member's record
+// with rho mod 127 in its last byte, and the digits negated should q be negative
+__device__ __forceinline__ void join8r_finish(intx4 (&A)[4][2], const uint2 (&MK)[8], int half, const J8rLane& c) {
   uint32_t any_neg = 0;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const uint32_t w = MK[4 * half + t].x;
-    A[t][0][0] = c.row2 ? (int)XL[t] : A[t][0][0];
-    A[t][0][3] = (int)((((w >> 16) & c.mrem) << 24) | (uint32_t)A[t][0][3]);
+    A[t][0][3] = (int)((((w >> 12) & c.mrem) << 24) | (uint32_t)A[t][0][3]);
     any_neg |= w;
   }
-  if (__ballot(c.row2 && (any_neg & 0x8000u))) {  // a negative rho: a k-mer of very small norm (rare)
+  if (__ballot(c.row2 && (any_neg & 0x800u))) {  // a negative rho: a k-mer of very small norm (rare)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const uint32_t w = MK[4 * half + t].x;
-      if (c.row2 && (w & 0x8000u)) {
+      if (c.row2 && (w & 0x800u)) {
         // -b per byte for digits b in 0..127: ((~v & 0x7f7f7f7f) + 0x01010101) ^ 0x80808080
         const uint32_t y = (uint32_t)A[t][0][1], z = (uint32_t)A[t][0][2], u = (uint32_t)A[t][0][3];
         A[t][0][1] = (int)((((~y) & 0x7f7f7f7fu) + 0x01010101u) ^ 0x80808080u);
@@ -1846,8 +1853,9 @@ __global__ __launch_bounds__(256, 2) void hs_join8r_kernel(
     for (int e = tid; e < alphabet * 32 * 8; e += 256) sp[e] = make_uint2(tab8[(e >> 3) & 31].x, tab8[e >> 8].x);
     uint2* sd = reinterpret_cast<uint2*>(sLds + lay.dig_at);
     uint2* sd2 = reinterpret_cast<uint2*>(sLds + lay.dig2_at);
+    const uint4 cf = tab8[HS_J8_CONST_AT];  // the constant factors of the gamma slots
     for (int e = tid; e < 1398; e += 256) {
-      uint32_t w[4] = {0u, 0u, 0u, 0u};
+      uint32_t w[4] = {cf.x, 0u, 0u, 0u};
 #pragma unroll
       for (int j = 0; j < 11; ++j) {
         const int d = min(127, max(0, e - 127 * j));
@@ -1856,9 +1864,8 @@ __global__ __launch_bounds__(256, 2) void hs_join8r_kernel(
       sd[e] = make_uint2(w[0], w[1]);
       sd2[e] = make_uint2(w[2], w[3]);
     }
-    uint32_t* s1 = reinterpret_cast<uint32_t*>(sLds + lay.tab1_at);
-    if (tid < 64) s1[tid] = tid < 32 ? tab8[tid].x : 0u;
-    if (tid == 0) *reinterpret_cast<uint4*>(sLds + lay.const_at) = tab8[HS_J8_CONST_AT];
+    if (tid < 33) *reinterpret_cast<uint2*>(sLds + lay.tab1_at + 64 * tid) = make_uint2(tid < 32 ? tab8[tid].x : 0u, cf.y);
+    if (tid == 0) *reinterpret_cast<uint4*>(sLds + lay.const_at) = cf;
   }
   __syncthreads();  // the only one: the tables are read-only from here on
   uint32_t* const smask = reinterpret_cast<uint32_t*>(sLds + lay.mask_at) + (wave * 8 * 64 + lane);
@@ -1910,8 +1917,9 @@ __global__ __launch_bounds__(256, 2) void hs_join8r_kernel(
   // 64-bit base per lane and item, eight loads at immediate offsets.  No clamping at a bucket's ragged
   // end: the rows past it read the next bucket's entries (the arrays are padded by 128 entries) and
   // are masked when survivors are emitted.
-  // row 0, 1, 3: j = 0, 1, 2 -- positions 8 j .. 8 j + 7 start at bit 40 j of the packed word: dword j, bit 8 j;
-  // row 2: the member's four-byte record (16 bytes are loaded from it onward: the next members' words, unused)
+  // row 0, 1, 3: j = 0, 1, 2 -- positions 8 j .. 8 j + 7 start at bit 40 j of the packed word: dword j, bit 8 j
+  // (eight bytes from dword j on; loading from BYTE 5 j instead, so that no lane shifts anything into place,
+  // works and measured 1 % slower: unaligned loads); row 2: the member's four-byte record (and the next one's)
   const bool row2 = row == 2;
   const uint32_t jj = row == 3 ? 2u : (uint32_t)row;
   const char* const lane_base = row2 ? reinterpret_cast<const char*>(rho_base) + 4 * n
@@ -1921,26 +1929,25 @@ __global__ __launch_bounds__(256, 2) void hs_join8r_kernel(
   J8rLane lc;
   lc.row2 = row2;
   lc.sh = row2 ? 0u : 8u * jj;
-  lc.o0 = row2 ? 4u : 0u;
-  lc.o1 = row2 ? 4u : 10u;
+  lc.o0 = 0u;
+  lc.o1 = row2 ? 0u : 10u;
   lc.w01 = row2 ? 11u : 10u;
   lc.sl = row2 ? 3u : 6u;
   const uint32_t rc = 8u * ((uint32_t)lane & 7u);
   lc.b0 = row2 ? lay.dig_at : rc;
   lc.b1 = row2 ? lay.dig2_at : rc;
-  lc.w2 = row2 ? 0u : 10u;
-  lc.b2 = row2 ? lay.const_at : rc;
+  lc.w3 = row2 ? 0u : 10u;
+  lc.b2 = row2 ? lay.tab1_at : rc;
   lc.b3 = row2 ? lay.const_at + 8u : rc;
   lc.mrem = row2 ? 0x7fu : 0u;
-  const uint32_t tab1_at = lay.tab1_at;
   const char* const sPairB = reinterpret_cast<const char*>(sLds);
 #define HS_LOAD_MEMBERS_R(MK, D0)                                                                   \
   {                                                                                                 \
     const int64_t e0_ = (int64_t)(((uint64_t)(D0).y << 32) | (uint64_t)(D0).x) + (int64_t)(D0).w * 128; \
     const char* p_ = lane_base + (e0_ << lane_shift);                                               \
-    _Pragma("unroll") for (int t = 0; t < 8; ++t) MK[t] = *reinterpret_cast<const uint4*>(p_ + lane_step * t); \
+    _Pragma("unroll") for (int t = 0; t < 8; ++t) MK[t] = *reinterpret_cast<const uint2*>(p_ + lane_step * t); \
   }
-  uint4 mkA[8], mkB[8];
+  uint2 mkA[8], mkB[8];
   intx4 Bq[2][2][2];
   HS_LOAD_MEMBERS_R(mkA, d0)
   HS_LOAD_MEMBERS_R(mkB, nd0)
@@ -1977,8 +1984,8 @@ __global__ __launch_bounds__(256, 2) void hs_join8r_kernel(
     /* AP holds the lookups of this item's first half, issued one half-step ago: complete it (the wait for     \
        them sits here, with nothing younger in flight: the LDS counter has four bits, sixteen younger lookups  \
        could not be told apart from them), send the second half's lookups out, compute the first half */       \
-    join8r_finish(AP, XP, MK, 0, lc);                                                                          \
-    join8r_lookup(AQ, XQ, MK, 1, sPairB, tab1_at, lc);                                                                  \
+    join8r_finish(AP, MK, 0, lc);                                                                          \
+    join8r_lookup(AQ, MK, 1, sPairB, lc);                                                                  \
     switch (nct_) {                                                                                            \
       case 1: gm_ = join8r_half<1, 0>(AP, Bq, smask); break;                                                   \
       case 2: gm_ = join8r_half<2, 0>(AP, Bq, smask); break;                                                   \
@@ -1986,11 +1993,11 @@ __global__ __launch_bounds__(256, 2) void hs_join8r_kernel(
       default: gm_ = join8r_half<4, 0>(AP, Bq, smask); break;                                                  \
     }                                                                                                          \
     /* MK's first half is consumed: the first half of the members of the item after next */                    \
-    _Pragma("unroll") for (int t = 0; t < 4; ++t) MK[t] = *reinterpret_cast<const uint4*>(nm_ + lane_step * t); \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) MK[t] = *reinterpret_cast<const uint2*>(nm_ + lane_step * t); \
     /* second half: complete, send out the NEXT item's first half (its members were requested one item ago;    \
        the same item's when there is none), compute */                                                         \
-    join8r_finish(AQ, XQ, MK, 1, lc);                                                                          \
-    join8r_lookup(AP, XP, MKN, 0, sPairB, tab1_at, lc);                                                                 \
+    join8r_finish(AQ, MK, 1, lc);                                                                          \
+    join8r_lookup(AP, MKN, 0, sPairB, lc);                                                                 \
     switch (nct_) {                                                                                            \
       case 1: gm_ |= join8r_half<1, 1>(AQ, Bq, smask); break;                                                  \
       case 2: gm_ |= join8r_half<2, 1>(AQ, Bq, smask); break;                                                  \
@@ -1998,7 +2005,7 @@ __global__ __launch_bounds__(256, 2) void hs_join8r_kernel(
       default: gm_ |= join8r_half<4, 1>(AQ, Bq, smask); break;                                                 \
     }                                                                                                          \
     /* ... and the second half */                                                                              \
-    _Pragma("unroll") for (int t = 4; t < 8; ++t) MK[t] = *reinterpret_cast<const uint4*>(nm_ + lane_step * t); \
+    _Pragma("unroll") for (int t = 4; t < 8; ++t) MK[t] = *reinterpret_cast<const uint2*>(nm_ + lane_step * t); \
     if (gm_)                                                                                                   \
       join8r_emit(gm_, (int)((nct_ + 1u) >> 1), smask, qoff, nQ, wbase, M, mstart, lane, res_base, res_used,   \
                   prov_count, prov_cap, prov);                                                                 \
@@ -2011,8 +2018,7 @@ __global__ __launch_bounds__(256, 2) void hs_join8r_kernel(
     nd1 = nnd1;                                                                                                \
   }
   intx4 AP[4][2], AQ[4][2];
-  uint32_t XP[4], XQ[4];
-  join8r_lookup(AP, XP, mkA, 0, sPairB, tab1_at, lc);  // the first item's first half
+  join8r_lookup(AP, mkA, 0, sPairB, lc);  // the first item's first half
   for (;;) {
     HS_ITEM_STEP(mkA, mkB)
     if (!has_next) break;
