@@ -68,9 +68,13 @@ def test_random_configuration_matches_oracle(oracle, seed):
     import os
     c = _case(seed)
     # every third case with the thin-segment routing on (segments with < 3 probing queries or < 16
-    # members to the per-pair filters hs_thin8_kernel / hs_verify_kernel instead of the join); every other
-    # remaining case forces the query-resident join kernel for its class
+    # members to the streaming filter hs_verify_kernel instead of the join); every other remaining case forces
+    # the query-resident join kernel for its class; every fourth case takes its centres as POINTS even where
+    # they are k-mers (recognise_kmers = 0: hs_qprep8_kernel, hs_finalize_kernel, hs_qtables -- half of the
+    # cases have centres that would otherwise run from their residue codes)
     opts = dict(join_min_q=3, join_min_m=16) if seed % 3 == 0 else dict(join_resident=2 * (seed % 2))
+    if seed % 4 == 1:
+        opts["recognise_kmers"] = 0
     # (HS_TEST_SPLIT_ABOVE in the environment: the library's test build, which has that hook)
     eng = Engine(c["k"], c["K"], c["L"], c["W"], c["a"], c["b"], coords=c["table"],
                  hooks=bool(os.environ.get("HS_TEST_SPLIT_ABOVE")), options=opts)
@@ -82,6 +86,7 @@ def test_random_configuration_matches_oracle(oracle, seed):
         for mode in ("auto", "stream", "join", "join16"):
             eng.set_verify_mode(mode)
             got = eng.query(c["centers"], c["R"])
+            assert seed % 4 != 1 or eng.profile()["queries_recognised"] == 0
             assert np.array_equal(got["cand"], want["cand"]), (mode, c["what"])
             for key in ("q", "id", "table", "dist"):
                 assert np.array_equal(got[key], want[key]), (mode, key, c["what"])
