@@ -80,6 +80,7 @@ enum { EV_FORK = 0, EV_JOIN = 1, EVX_COUNT = 2 };
 struct Knobs {
   bool build_serial = false;       // HS_BUILD_SERIAL: no hash / sort overlap in the build (measurement)
   int join_xcd_run = -1;           // HS_OPT_JOIN_XCD_RUN: chunks per XCD-local run of join items (0 off, -1 auto)
+  bool no_probe_records = false;   // HS_OPT_PROBE_RECORDS = 0: the probe reads the directory arrays, not the records
   bool build_debug = false;        // HS_BUILD_DEBUG: say when a table is sorted a second time
   bool cluster_timing = false;     // HS_CLUSTER_TIMING: phase times of hs_self_join_range on stderr
   bool debug_refine = false;       // HS_DEBUG_REFINE: survivor counts per batch on stderr
@@ -125,6 +126,7 @@ struct hs_handle {
   DevBuf codes, packed_all;
   DevBuf t_dirkey[HS_MAX_L], t_dirstart[HS_MAX_L], t_dirtuple[HS_MAX_L], t_ids[HS_MAX_L];
   DevBuf t_dirjump;  // the jump tables of all directories, one allocation (a table's at its own offset)
+  DevBuf t_dirrec;   // the directory records of all tables (hs_table_dev::dir_rec), 64 bytes per bucket
   // bucket-ordered packed copies of all tables in ONE allocation ([L][n][PW]), and the int8 join's
   // per-entry records ([L][n], k <= 50 only) at the same entry numbers
   DevBuf t_packed, t_rec8;
@@ -423,7 +425,7 @@ const struct { const char* name; int option; } kOptionNames[] = {
     {"refine8", HS_OPT_REFINE8}, {"self_codes", HS_OPT_SELF_CODES},
     {"sort_hits", HS_OPT_SORT_HITS}, {"sync_items", HS_OPT_SYNC_ITEMS}, {"join_min_q", HS_OPT_JOIN_MIN_Q},
     {"join_min_m", HS_OPT_JOIN_MIN_M}, {"sort_from_bit", HS_OPT_SORT_FROM_BIT}, {"build_serial", HS_OPT_BUILD_SERIAL},
-    {"join_xcd_run", HS_OPT_JOIN_XCD_RUN}};
+    {"join_xcd_run", HS_OPT_JOIN_XCD_RUN}, {"probe_records", HS_OPT_PROBE_RECORDS}};
 
 void read_knobs(hs_handle* h) {
   Knobs& kn = h->knobs;
@@ -707,6 +709,7 @@ hs_status hs_set_option(hs_handle* h, int option, int64_t value) {
       kn.sort_from_bit = (int)value;
       return HS_OK;
     case HS_OPT_BUILD_SERIAL: return flag(&kn.build_serial, false);
+    case HS_OPT_PROBE_RECORDS: return flag(&kn.no_probe_records, true);
     case HS_OPT_JOIN_XCD_RUN:
       if (value < -1 || value > 4096 || (value > 0 && (value & (value - 1)))) break;  // a power of two
       kn.join_xcd_run = (int)value;
@@ -747,6 +750,7 @@ void hs_destroy(hs_handle* h) {
   for (DevBuf* bf : bufs) bf->release();
   h->sj_host.release();
   h->t_dirjump.release();
+  h->t_dirrec.release();
   for (int l = 0; l < HS_MAX_L; ++l) {
     h->t_dirkey[l].release();
     h->t_dirstart[l].release();
@@ -1197,6 +1201,14 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
   return HS_OK;
 }
 
+// the tables as the probe kernel gets them: without the directory records when the option says so
+static hs_tables_dev probe_tabs(const hs_handle* h) {
+  hs_tables_dev t = h->tabs;
+  if (h->knobs.no_probe_records)
+    for (int l = 0; l < HS_MAX_L; ++l) t.t[l].dir_rec = nullptr;
+  return t;
+}
+
 // Common end of hs_index_build* and hs_index_load: info, global bucket numbering, byte count.
 static hs_status finish_index(hs_handle* h) {
   h->info.n = h->n;
@@ -1233,9 +1245,31 @@ static hs_status finish_index(hs_handle* h) {
     h->tabs.t[l].dir_jump = jump;
     h->tabs.t[l].jump_shift = 64 - J;
   }
+  // directory records (hs_dir_records_kernel): one 64-byte line per bucket for the probe, where the tuples fit
+  for (uint32_t l = 0; l < h->p.L; ++l) h->tabs.t[l].dir_rec = nullptr;
+  if (h->p.K <= HS_REC_MAX_K && h->nb_total) {
+    HS_HIP(h, h->t_dirrec.reserve((size_t)h->nb_total * 64));
+    HS_HIP(h, h->counters.reserve(256));
+    uint32_t* const d_wide = h->counters.as<uint32_t>() + 32;  // one flag per table (L <= 32)
+    HS_HIP(h, hipMemsetAsync(d_wide, 0, HS_MAX_L * 4, h->stream));
+    uint64_t at = 0;
+    for (uint32_t l = 0; l < h->p.L; ++l) {
+      const uint32_t nb = (uint32_t)h->info.n_buckets[l];
+      uint4* const rec = h->t_dirrec.as<uint4>() + 4 * at;
+      HS_HIP(h, hs_launch_dir_records(h->t_dirkey[l].as<uint64_t>(), h->t_dirstart[l].as<uint32_t>(),
+                                      h->t_dirtuple[l].as<int32_t>(), nb, (int)h->p.K, rec, d_wide + l, h->stream));
+      h->tabs.t[l].dir_rec = rec;
+      at += nb;
+    }
+    uint32_t wide[HS_MAX_L];
+    HS_HIP(h, hipMemcpyAsync(wide, d_wide, HS_MAX_L * 4, hipMemcpyDeviceToHost, h->stream));
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    for (uint32_t l = 0; l < h->p.L; ++l)
+      if (wide[l]) h->tabs.t[l].dir_rec = nullptr;  // a bucket int outside 16 bits: this table keeps the arrays
+  }
   HS_HIP(h, hipStreamSynchronize(h->stream));
   uint64_t bytes = h->codes.cap + h->packed_all.cap + h->t_packed.cap + h->t_rec8.cap + h->t_rec8w.cap + h->t_rho.cap +
-                   h->t_pos.cap;
+                   h->t_pos.cap + h->t_dirrec.cap;
   for (uint32_t l = 0; l < h->p.L; ++l)
     bytes += h->t_dirkey[l].cap + h->t_dirstart[l].cap + h->t_dirtuple[l].cap + h->t_ids[l].cap;
   bytes += h->t_dirjump.cap;
@@ -2183,7 +2217,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
                                      h->dir_base.as<uint32_t>(), h->nb_total, bucket_count, qbucket, qrank,
                                      h->stream));
     else
-      HS_HIP(h, hs_launch_probe(h->tabs, h->qints.as<int32_t>(), nq, K, L, h->key_seed,
+      HS_HIP(h, hs_launch_probe(probe_tabs(h), h->qints.as<int32_t>(), nq, K, L, h->key_seed,
                                 h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
                                 h->nslices.as<uint32_t>(), d_cand,
                                 reinterpret_cast<unsigned long long*>(d_cnt + 2),
@@ -2293,7 +2327,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
       use_join = false;
       n_items = 0;
       HS_HIP(h, hipMemsetAsync(d_cnt + 2, 0, 8, h->stream));
-      HS_HIP(h, hs_launch_probe(h->tabs, h->qints.as<int32_t>(), nq, K, L, h->key_seed,
+      HS_HIP(h, hs_launch_probe(probe_tabs(h), h->qints.as<int32_t>(), nq, K, L, h->key_seed,
                                 h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
                                 h->nslices.as<uint32_t>(), d_cand,
                                 reinterpret_cast<unsigned long long*>(d_cnt + 2),

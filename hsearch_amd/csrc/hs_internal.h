@@ -131,6 +131,9 @@ struct hs_table_dev {
   const uint32_t* ids;       // [n] DB ids in bucket order (ascending inside a bucket)
   const uint32_t* pos_of;    // [n] inverse of ids: sorted position of DB id i in this table
   const uint32_t* dir_jump;  // [2^J + 1] first directory entry whose fingerprint's top J bits are >= the slot
+  const uint4* dir_rec;      // [nb][4] or null: one 64-byte line per bucket with all a probe reads of it --
+                             // {fingerprint, start, count} and the K <= HS_REC_MAX_K bucket ints as int16
+                             // (null: K larger, an int outside 16 bits, or the option is off)
   uint32_t nb;
   uint32_t jump_shift;       // 64 - J
 };
@@ -299,6 +302,10 @@ hipError_t hs_launch_validate_table(const uint32_t* d_ids, uint32_t n, uint32_t*
                                     const int32_t* d_dir_tuple, uint32_t nb, int K, uint32_t seed,
                                     uint32_t* d_flag, uint32_t* d_max_bucket, hipStream_t s);
 // jump[t] = first directory entry with (key >> shift) >= t, t = 0 .. n_slots (jump[n_slots] = nb)
+#define HS_REC_MAX_K 24
+// rec[b] = {key[b], start[b], start[b + 1] - start[b]; int16 tuple[b][0..K)}; *d_flag |= 1 where an int does not fit
+hipError_t hs_launch_dir_records(const uint64_t* d_dir_key, const uint32_t* d_dir_start, const int32_t* d_dir_tuple,
+                                 uint32_t nb, int K, uint4* d_rec, uint32_t* d_flag, hipStream_t s);
 hipError_t hs_launch_dir_jump(const uint64_t* d_dir_key, uint32_t nb, uint32_t shift, uint32_t n_slots,
                               uint32_t* d_jump, hipStream_t s);
 hipError_t hs_launch_max_u32(const uint32_t* d_in, uint32_t n, uint32_t* d_out, hipStream_t s);

@@ -393,6 +393,39 @@ __global__ __launch_bounds__(256) void hs_probe_kernel(hs_tables_dev tabs,
     // one directory entry to look at, instead of log2(nb) dependent round trips
     const uint32_t slot = (uint32_t)(key >> tb.jump_shift);
     uint32_t lo = tb.dir_jump[slot], hi = tb.dir_jump[slot + 1];
+    if (tb.dir_rec) {
+      // one line per candidate bucket of the slot (about one): all four pieces of the first are asked for
+      // together; the fingerprints ascend, so the walk stops at the first one that is not smaller
+      bool found = false;
+      uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
+      for (; lo < hi; ++lo) {
+        const uint4* r = tb.dir_rec + 4 * (uint64_t)lo;
+        r0 = r[0];
+        r1 = r[1];
+        r2 = r[2];
+        r3 = r[3];
+        const uint64_t kr = ((uint64_t)r0.y << 32) | r0.x;
+        if (kr >= key) {
+          found = kr == key;
+          break;
+        }
+      }
+      if (found) {
+        const uint32_t w[12] = {r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+        bool same = true;
+#pragma unroll
+        for (int j = 0; j < HS_REC_MAX_K; ++j)
+          if (j < K) same = same && t[256 * j] == (int32_t)(int16_t)(w[j >> 1] >> (16 * (j & 1)));
+        if (same) {
+          start = r0.z;
+          count = r0.w;
+          if (dir_base) gb = dir_base[l] + lo;
+        } else {
+          slow[1 + atomicAdd(slow, 1u)] = ql;
+          ranked = false;
+        }
+      }
+    } else {
     while (lo < hi) {
       const uint32_t mid = (lo + hi) >> 1;
       if (tb.dir_key[mid] < key) lo = mid + 1; else hi = mid;
@@ -422,6 +455,7 @@ __global__ __launch_bounds__(256) void hs_probe_kernel(hs_tables_dev tabs,
         ranked = false;
       }
     }
+    }  // (no directory records)
     qstart[ql] = start;
     qcount[ql] = count;
     nslices[ql] = (count + HS_SLICE - 1) / HS_SLICE;
@@ -1220,6 +1254,37 @@ __global__ __launch_bounds__(256) void hs_dir_jump_kernel(const uint64_t* __rest
   for (uint32_t t = first; t <= cur; ++t) jump[t] = (uint32_t)i;
 }
 
+// Directory records: what a probe needs of a bucket -- fingerprint, boundaries, the tuple of the exact check --
+// in one 64-byte line instead of four arrays (fingerprints, boundaries, 4 K bytes of tuple: 5-6 scattered
+// 64-byte sectors per probe, the probe kernel's whole cost at configs[2]'s 3.2e7 probes per batch).
+__global__ __launch_bounds__(256) void hs_dir_records_kernel(const uint64_t* __restrict__ key,
+                                                             const uint32_t* __restrict__ start,
+                                                             const int32_t* __restrict__ tuple, uint32_t nb, int K,
+                                                             uint4* __restrict__ rec, uint32_t* __restrict__ flag) {
+  const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= nb) return;
+  const uint64_t kb = key[b];
+  const uint32_t s0 = start[b];
+  uint32_t w[12];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) w[j] = 0;
+  bool wide = false;
+  const int32_t* t = tuple + (uint64_t)b * K;
+#pragma unroll
+  for (int j = 0; j < HS_REC_MAX_K; ++j)
+    if (j < K) {
+      const int32_t v = t[j];
+      wide = wide || v != (int32_t)(int16_t)v;
+      w[j >> 1] |= ((uint32_t)v & 0xffffu) << (16 * (j & 1));
+    }
+  if (wide) atomicOr(flag, 1u);
+  uint4* r = rec + 4 * (uint64_t)b;
+  r[0] = make_uint4((uint32_t)kb, (uint32_t)(kb >> 32), s0, start[b + 1] - s0);
+  r[1] = make_uint4(w[0], w[1], w[2], w[3]);
+  r[2] = make_uint4(w[4], w[5], w[6], w[7]);
+  r[3] = make_uint4(w[8], w[9], w[10], w[11]);
+}
+
 __global__ __launch_bounds__(256) void hs_invert_perm_kernel(const uint32_t* __restrict__ perm,
                                                              uint32_t n, uint32_t* __restrict__ out) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -1996,6 +2061,13 @@ hipError_t hs_launch_klsh(const uint8_t* d_classes, const uint64_t* d_seq_start,
   const unsigned blocks = (unsigned)std::min<uint64_t>((n_seq + 3) / 4, 1u << 16);
   hs_klsh_kernel<<<blocks, 256, 0, s>>>(d_classes, d_seq_start, n_seq, d_w, d_b, d_t, bits, d_codes,
                                         d_uncertain);
+  return hipGetLastError();
+}
+
+hipError_t hs_launch_dir_records(const uint64_t* d_dir_key, const uint32_t* d_dir_start, const int32_t* d_dir_tuple,
+                                 uint32_t nb, int K, uint4* d_rec, uint32_t* d_flag, hipStream_t s) {
+  if (!nb) return hipSuccess;
+  hs_dir_records_kernel<<<blocks_for(nb), 256, 0, s>>>(d_dir_key, d_dir_start, d_dir_tuple, nb, K, d_rec, d_flag);
   return hipGetLastError();
 }
 

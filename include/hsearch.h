@@ -165,6 +165,9 @@ typedef enum hs_option {
                                 join (default 1 / 1: none do) */
   HS_OPT_SORT_FROM_BIT = 14, /* HS_OPT_BUILD_GROUPING = 1: lowest fingerprint bit the first sort looks at (0..60) */
   HS_OPT_BUILD_SERIAL = 15,  /* 1: no overlap of a table's hashing with the previous table's grouping */
+  HS_OPT_PROBE_RECORDS = 17, /* 1 (default): a probe reads one 64-byte directory record per bucket (fingerprint,
+                                boundaries, the bucket ints as int16) where the index has them -- K <= 24 and
+                                every bucket int of the table within 16 bits; 0: the directory arrays */
   HS_OPT_JOIN_XCD_RUN = 16   /* hs_join8x_kernel's work items dealt in runs of this many chunks per XCD, each XCD's
                                 waves on their own runs (a run's items stream the same query tiles: one L2 fetches
                                 them instead of eight).  0: one counter for the chip; -1 (default): by the size

@@ -355,6 +355,35 @@ def test_aliased_key_strings_share_a_bucket(oracle):
     eng.close()
 
 
+@pytest.mark.parametrize("k,K,L,W,n", [(25, 20, 4, 160.0, 60011), (25, 24, 2, 90.0, 9001), (25, 2, 2, 1.0, 30000),
+                                       (15, 3, 3, 0.004, 5003), (25, 28, 2, 300.0, 4001), (39, 16, 3, 212.0, 20011)])
+def test_probe_reads_directory_records_or_the_arrays(oracle, k, K, L, W, n):
+    """Probe, SURVEY 8(a) a8: by default the probe reads ONE 64-byte directory record per candidate bucket
+    (fingerprint, boundaries, the bucket ints as int16: hs_dir_records_kernel) and falls back to the directory
+    arrays where a table has none -- K > 24 (here K = 28), a bucket int outside 16 bits (W = 0.004: ints of
+    +-10^5) -- or the option probe_records = 0 says so.  Every form gives the oracle's candidates and hits;
+    aliased key strings (K = 2, W = 1: a found fingerprint whose tuple differs goes to the slow queue) included."""
+    R = 45.0
+    a, b = synth.make_planes(k, K, L, W, seed=131)
+    codes = synth.make_db(n, k, seed=132)
+    centers, _ = synth.make_queries(codes, 700, seed=133, jitter=0.01)
+    pts = oracle.embed_codes(codes)
+    ix = oracle.Index(a, b, W, pts)
+    want = ix.query(centers, R)
+    if W < 0.01:
+        assert np.abs(oracle.hash_all(a, b, W, pts)).max() > 40000
+    for records in (1, 0):
+        eng = Engine(k, K, L, W, a, b, options=dict(probe_records=records))
+        info = eng.index_build(codes)
+        assert info["n_buckets"] == ix.table_sizes()
+        for rep in range(2):
+            got = eng.query(centers, R)
+            assert np.array_equal(got["cand"], want["cand"]), (records, rep)
+            _assert_hits_equal(got, want)
+        eng.close()
+    ix.close()
+
+
 def test_edge_cases(oracle):
     k, K, L, W, R = 25, 4, 3, 100.0, 40.0
     a, b = synth.make_planes(k, K, L, W)
