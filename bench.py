@@ -30,7 +30,9 @@ no k-mers (jittered), the path of the reference's family centroids.
 query set sharded over the ranks, every rank one batch, the index replicated; `value` = 10^6 / the slowest
 rank's pass.  At N = 1 it also times the 125 000-query pass that is one GPU's share of the 8-GPU job
 (`one_gpu_share_of_eight`); at N > 1 the same job with the TABLES dealt over the ranks instead
-(`table_partition`: every rank all queries on L / N tables, merged by the reference's first-seen rule).
+(`table_partition`: every rank all queries on L / N tables, merged by the reference's first-seen rule) and with
+the BUCKETS shared among the ranks of the replicated index (`bucket_partition`: every rank all queries and 1 / N
+of the probes, the same merge; at N = 1 `one_gpu_share_of_eight_bucket_partition` times part 0 of 8).
 `python bench.py --gpus N` typed as such starts its own N ranks (torch.distributed.run, 127.0.0.1).
 
 Other BASELINE.json configs through the same script (the label in config.workload follows the
@@ -520,6 +522,24 @@ def secondary_block(args, world, rank, dev_index, dev, synth, Engine, torch, hdi
         if nr2 > 0:
             sec.update(w2.recall(nr2))
     if world == 1 and total_q > 125_000:
+        # ... and one GPU's share when eight hold the replicated index and share the BUCKETS (hs_set_bucket_partition:
+        # every rank all 10^6 queries, 1/8 of the probes): part 0 of 8 on this handle
+        w2.eng.set_bucket_partition(0, 8)
+        try:
+            m4 = w2.timed(steps, 2, hdist, HsError, use_dist, fence, dist, backend)
+        finally:
+            w2.eng.set_bucket_partition(0, 1)
+        sec["one_gpu_share_of_eight_bucket_partition"] = {
+            "what": "the same index and ALL queries, the buckets of part 0 of 8 (hs_set_bucket_partition): the per-GPU "
+                    "pass of the 8-GPU job in the bucket-partitioned layout, before the exchange (all-gather + "
+                    "first-seen merge of ~ 1.1 hits per query).  The eight parts take the same time within 5 % "
+                    "(profiles/r04_bucket_sharding_emulation.json)",
+            "queries": total_q, "ms_per_step": m4["dt"] / steps * 1e3,
+            "job_queries_per_s_if_all_eight_ranks_take_this_long": total_q * steps / m4["dt"],
+            "roofline": w2.roofline(m4, steps),
+            "phases_ms_per_step": {"hash_queries": m4["hash_ms"] / steps, "probe_segments": m4["probe_ms"] / steps,
+                                   "verify": m4["verify_ms"] / steps, "finalize_sort": m4["fin_ms"] / steps},
+            "hits_of_this_part": m4["hits_local"]}
         # one GPU's share when eight hold the replicated index (what BENCH_r02 / r03 carried as `secondary`)
         w2.set_queries(125_000, synth.SEED_QUERIES, q_offset=0)
         m3 = w2.timed(steps, 2, hdist, HsError, use_dist, fence, dist, backend)
@@ -530,6 +550,13 @@ def secondary_block(args, world, rank, dev_index, dev, synth, Engine, torch, hdi
             "phases_ms_per_step": {"hash_queries": m3["hash_ms"] / steps, "probe_segments": m3["probe_ms"] / steps,
                                    "verify": m3["verify_ms"] / steps, "finalize_sort": m3["fin_ms"] / steps},
             "candidates_per_query": m3["cand"] / 125_000}
+    if world > 1 and not args.no_secondary_tables:
+        # the same job with the BUCKETS shared among the ranks (hsearch_dist.h): index replicated (this handle),
+        # every rank ALL 10^6 queries in one batch and 1 / world of the probes; all-gather + first-seen merge
+        bp = bucket_partition_block(args, a2, total_q, w2, world, rank, dev, synth, torch, hdist, use_dist, fence, dist,
+                                    backend)
+        if rank == 0:
+            sec["bucket_partition"] = bp
     w2.close()
     codes2, qc_all = w2.codes, None
     del w2
@@ -544,6 +571,41 @@ def secondary_block(args, world, rank, dev_index, dev, synth, Engine, torch, hdi
     if rank == 0:
         sec["wall_seconds_of_this_block"] = time.perf_counter() - t0
     return sec
+
+
+def bucket_partition_block(args, a2, total_q, w2, world, rank, dev, synth, torch, hdist, use_dist, fence, dist, backend):
+    eng, R = w2.eng, a2.R
+    qcodes, _ = synth.make_query_codes(w2.codes, total_q, seed=synth.SEED_QUERIES)     # the same on every rank
+    d_centers = torch.from_numpy(synth.embed(qcodes)).to(dev)
+    cap = 8 * total_q + 4096
+    out = dict(q=torch.empty(cap, dtype=torch.int32, device=dev), id=torch.empty(cap, dtype=torch.int32, device=dev),
+               table=torch.empty(cap, dtype=torch.int32, device=dev), dist=torch.empty(cap, dtype=torch.float64, device=dev))
+
+    def step():
+        return hdist.query_bucket_partitioned(eng, rank, world, d_centers.data_ptr(), total_q, R, out, cap, force=use_dist)
+    steps = max(args.secondary_steps, 1)
+    for _ in range(2):
+        merged, nh = step()
+    acc = {}
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        merged, nh = step()
+        p = eng.profile()
+        for f in ("ms_hash", "ms_probe", "ms_verify", "ms_join", "ms_finalize", "ms_total"):
+            acc[f] = acc.get(f, 0.0) + p[f] / steps
+    fence()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return {"what": "configs[2] with the BUCKETS shared among the ranks (index replicated, every rank all queries in "
+                    "one batch and the probes of its part: hs_set_bucket_partition; all-gather + first-seen merge); "
+                    "same output as the query-sharded layout",
+            "value": total_q * steps / dt, "unit": "queries/s", "n_gpus": world, "ms_per_step": dt / steps * 1e3,
+            "rank0_device_ms_per_step": acc, "rank0_hits_before_merge": int(nh), "hits_after_merge": int(merged[0].numel()),
+            "rank0_join_frac_of_int8_peak": (p["join_pairs"] * 256.0 / (acc["ms_join"] * 1e-3) / 5e15) if acc.get("ms_join") else None}
 
 
 def table_partition_block(args, a2, total_q, codes, world, rank, dev_index, dev, synth, Engine, torch, hdist, HsError,

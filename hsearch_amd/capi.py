@@ -15,7 +15,7 @@ _STATUS = ["HS_OK", "HS_ERR_INVALID", "HS_ERR_NO_DEVICE", "HS_ERR_HIP", "HS_ERR_
 _ALPHABET = "ARNDCQEGHILKMFPSTWYV"
 
 EXPORTS = ["hs_create", "hs_destroy", "hs_last_error", "hs_get_profile", "hs_get_params", "hs_version",
-           "hs_set_verify_mode", "hs_set_hash_mode", "hs_set_option", "hs_wait_event", "hs_set_planes", "hs_self_join", "hs_self_join_range", "hs_clustering",
+           "hs_set_verify_mode", "hs_set_hash_mode", "hs_set_option", "hs_set_bucket_partition", "hs_wait_event", "hs_set_planes", "hs_self_join", "hs_self_join_range", "hs_clustering",
            "hs_clustering_begin", "hs_clustering_table_edges", "hs_clustering_table_apply",
            "hs_clustering_end",
            "hs_embed_codes", "hs_hash_codes", "hs_hash_points", "hs_key_string", "hs_key_fingerprint",
@@ -236,6 +236,10 @@ class Engine:
     def set_option(self, name, value):
         """hs_set_option (include/hsearch.h hs_option): path selection / batch sizing; never changes a result."""
         self._check(self._lib.hs_set_option(self._h, C.c_int(self.OPTIONS[name]), C.c_int64(int(value))))
+
+    def set_bucket_partition(self, part, n_parts):
+        """hs_set_bucket_partition: the handle's searches probe only the buckets of `part` of `n_parts` (1: all)."""
+        self._check(self._lib.hs_set_bucket_partition(self._h, C.c_uint32(part), C.c_uint32(n_parts)))
 
     def wait_event(self, event_handle):
         """hs_wait_event: the library's stream waits for a hipEvent_t (int handle, e.g. torch.cuda.Event.cuda_event)."""

@@ -10,7 +10,7 @@ from . import capi
 RCCL_LOCAL, LOOPBACK = 0, 1
 EXPORTS = ["hs_comm_create", "hs_comm_unique_id", "hs_comm_create_rank", "hs_comm_destroy", "hs_comm_world",
            "hs_comm_last_error", "hs_shard_bounds", "hs_allgather_hits", "hs_comm_barrier", "hs_comm_query",
-           "hs_comm_query_codes", "hs_comm_query_tables", "hs_assign_tables"]
+           "hs_comm_query_codes", "hs_comm_query_tables", "hs_comm_query_buckets", "hs_assign_tables"]
 
 _lib = None
 
@@ -169,6 +169,29 @@ class Comm:
                                                 None if codes else _p(queries), _p(queries) if codes else None,
                                                 C.c_uint64(nq), C.c_double(R), _p(hq), _p(hid), _p(ht), _p(hd),
                                                 C.c_uint64(cap), C.byref(n_total))
+            if st == capi.HS_ERR_CAPACITY:
+                cap = n_total.value
+                continue
+            if st != capi.HS_OK:
+                raise capi.HsError(st, self._lib.hs_comm_last_error(self._h, C.c_uint32(rank)).decode())
+            n = n_total.value
+            return dict(q=hq[:n], id=hid[:n], table=ht[:n], dist=hd[:n])
+
+    def query_buckets(self, rank, engine, queries, R, cap=None, codes=False):
+        """hs_comm_query_buckets: the bucket-partitioned layout -- every rank's `engine` holds the whole index,
+        `queries` are ALL queries (points, or residue codes with codes=True), rank r searches the buckets of
+        part r of world; every rank gets the merged hits, the reference's order."""
+        queries = np.ascontiguousarray(queries, dtype=np.uint8 if codes else np.float64)
+        nq = queries.shape[0]
+        cap = int(cap) if cap else max(1024, 64 * nq)
+        while True:
+            hq = np.empty(cap, np.uint32); hid = np.empty(cap, np.uint32); ht = np.empty(cap, np.uint32)
+            hd = np.empty(cap, np.float64)
+            n_total = C.c_uint64(0)
+            st = self._lib.hs_comm_query_buckets(self._h, C.c_uint32(rank), engine._h if engine is not None else None,
+                                                 None if codes else _p(queries), _p(queries) if codes else None,
+                                                 C.c_uint64(nq), C.c_double(R), _p(hq), _p(hid), _p(ht), _p(hd),
+                                                 C.c_uint64(cap), C.byref(n_total))
             if st == capi.HS_ERR_CAPACITY:
                 cap = n_total.value
                 continue

@@ -127,6 +127,9 @@ struct hs_handle {
   DevBuf t_dirkey[HS_MAX_L], t_dirstart[HS_MAX_L], t_dirtuple[HS_MAX_L], t_ids[HS_MAX_L];
   DevBuf t_dirjump;  // the jump tables of all directories, one allocation (a table's at its own offset)
   DevBuf t_dirrec;   // the directory records of all tables (hs_table_dev::dir_rec), 64 bytes per bucket
+  DevBuf part_work;  // bucket partition: flags, positions, compacted (bucket, probe) pairs of a batch
+  DevBuf t_giant;    // the fingerprints of every table's giant buckets (hs_table_dev::giant_key), ascending
+  uint32_t bucket_part = 0, bucket_parts = 1;  // hs_set_bucket_partition
   // bucket-ordered packed copies of all tables in ONE allocation ([L][n][PW]), and the int8 join's
   // per-entry records ([L][n], k <= 50 only) at the same entry numbers
   DevBuf t_packed, t_rec8;
@@ -656,6 +659,15 @@ hs_status hs_set_verify_mode(hs_handle* h, int mode) {
   return HS_OK;
 }
 
+hs_status hs_set_bucket_partition(hs_handle* h, uint32_t part, uint32_t n_parts) {
+  if (!h) return HS_ERR_INVALID;
+  if (!n_parts || part >= n_parts || n_parts > 65536u)
+    return fail(h, HS_ERR_INVALID, "hs_set_bucket_partition: part < n_parts, 1 <= n_parts <= 65536");
+  h->bucket_part = part;
+  h->bucket_parts = n_parts;
+  return HS_OK;
+}
+
 hs_status hs_set_option(hs_handle* h, int option, int64_t value) {
   if (!h) return HS_ERR_INVALID;
   Knobs& kn = h->knobs;
@@ -751,6 +763,8 @@ void hs_destroy(hs_handle* h) {
   h->sj_host.release();
   h->t_dirjump.release();
   h->t_dirrec.release();
+  h->part_work.release();
+  h->t_giant.release();
   for (int l = 0; l < HS_MAX_L; ++l) {
     h->t_dirkey[l].release();
     h->t_dirstart[l].release();
@@ -1202,10 +1216,13 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
 }
 
 // the tables as the probe kernel gets them: without the directory records when the option says so
-static hs_tables_dev probe_tabs(const hs_handle* h) {
+static hs_tables_dev probe_tabs(const hs_handle* h, uint32_t q_first) {
   hs_tables_dev t = h->tabs;
+  t.q_first = q_first;
   if (h->knobs.no_probe_records)
     for (int l = 0; l < HS_MAX_L; ++l) t.t[l].dir_rec = nullptr;
+  t.part = h->self_first == HS_NO_SELF ? h->bucket_part : 0u;  // (searches only, not the self-joins)
+  t.n_parts = h->self_first == HS_NO_SELF ? h->bucket_parts : 1u;
   return t;
 }
 
@@ -1244,6 +1261,32 @@ static hs_status finish_index(hs_handle* h) {
     HS_HIP(h, hs_launch_dir_jump(h->t_dirkey[l].as<uint64_t>(), nb, 64 - J, n_slots, jump, h->stream));
     h->tabs.t[l].dir_jump = jump;
     h->tabs.t[l].jump_shift = 64 - J;
+  }
+  // the giant buckets of every table (bucket partition: shared among the parts by query, hs_probe_part)
+  {
+    constexpr uint32_t GCAP = 1024;  // per table: buckets of > n / 1024 members number < 1024
+    HS_HIP(h, h->t_giant.reserve((size_t)HS_MAX_L * GCAP * 8));
+    HS_HIP(h, h->counters.reserve(256));
+    uint32_t* const d_ng = h->counters.as<uint32_t>() + 32;
+    HS_HIP(h, hipMemsetAsync(d_ng, 0, HS_MAX_L * 4, h->stream));
+    const uint32_t thr = hs_giant_threshold(h->n);
+    for (uint32_t l = 0; l < h->p.L; ++l)
+      HS_HIP(h, hs_launch_giant_buckets(h->t_dirkey[l].as<uint64_t>(), h->t_dirstart[l].as<uint32_t>(),
+                                        (uint32_t)h->info.n_buckets[l], thr, h->t_giant.as<uint64_t>() + (size_t)l * GCAP,
+                                        GCAP, d_ng + l, h->stream));
+    uint32_t ng[HS_MAX_L];
+    std::vector<uint64_t> keys((size_t)HS_MAX_L * GCAP);
+    HS_HIP(h, hipMemcpyAsync(ng, d_ng, HS_MAX_L * 4, hipMemcpyDeviceToHost, h->stream));
+    HS_HIP(h, hipMemcpyAsync(keys.data(), h->t_giant.p, keys.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HS_HIP(h, hipStreamSynchronize(h->stream));
+    for (uint32_t l = 0; l < h->p.L; ++l) {
+      if (ng[l] > GCAP) return fail(h, HS_ERR_STATE, "more giant buckets in a table than its list holds");
+      std::sort(keys.begin() + (size_t)l * GCAP, keys.begin() + (size_t)l * GCAP + ng[l]);
+      h->tabs.t[l].giant_key = h->t_giant.as<uint64_t>() + (size_t)l * GCAP;
+      h->tabs.t[l].n_giant = ng[l];
+    }
+    HS_HIP(h, hipMemcpyAsync(h->t_giant.p, keys.data(), keys.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HS_HIP(h, hipStreamSynchronize(h->stream));  // (keys is a local)
   }
   // directory records (hs_dir_records_kernel): one 64-byte line per bucket for the probe, where the tuples fit
   for (uint32_t l = 0; l < h->p.L; ++l) h->tabs.t[l].dir_rec = nullptr;
@@ -2131,6 +2174,11 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
   // (measured at the configs[2] shape, 10^6 queries x 32 tables against 1.3e8 bucket slots -- a ratio of 4:
   // 11.3 ms for the whole probe + segment chain with the sort, 15.0 with the counting sort)
   bool seg_sparse = (uint64_t)h->nb_total > 2ull * nql;
+  // bucket partition: 1/n_parts of the probes find their bucket; those are compacted before the grouping,
+  // which then is the sort of the probes whatever the number of buckets
+  const bool parted = h->bucket_parts > 1 && h->self_first == HS_NO_SELF;  // (searches only, not the self-joins)
+  if (parted) seg_sparse = true;
+  uint32_t nqs = nql;  // probes the grouping works on (bucket partition: the ones that found a bucket)
   if (h->knobs.seg_mode) seg_sparse = h->knobs.seg_mode == 1;
   const bool self_codes = h->self_first != HS_NO_SELF && !brute && use_i8 && self_codes_ok(h, R);
   const uint8_t* d_qcodes =
@@ -2217,7 +2265,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
                                      h->dir_base.as<uint32_t>(), h->nb_total, bucket_count, qbucket, qrank,
                                      h->stream));
     else
-      HS_HIP(h, hs_launch_probe(probe_tabs(h), h->qints.as<int32_t>(), nq, K, L, h->key_seed,
+      HS_HIP(h, hs_launch_probe(probe_tabs(h, q_base), h->qints.as<int32_t>(), nq, K, L, h->key_seed,
                                 h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
                                 h->nslices.as<uint32_t>(), d_cand,
                                 reinterpret_cast<unsigned long long*>(d_cnt + 2),
@@ -2248,12 +2296,28 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
     HS_HIP(h, hipMemsetAsync(h->seg_cnt.p, 0, n1 * 4, h->stream));
     if (seg_sparse) {
       HS_HIP(h, h->temp.reserve(std::max(hs_sort_pairs_u32_u32_temp(nql), hs_scan_u32_temp(n1)) + 256));
+      const uint32_t* keys_in = h->seg_keys.as<uint32_t>();
+      const uint32_t* probes_in = nullptr;
+      if (parted) {
+        HS_HIP(h, h->part_work.reserve(4 * n1 * 4));
+        uint32_t* const pw = h->part_work.as<uint32_t>();
+        HS_HIP(h, hs_launch_found_probes(h->seg_keys.as<uint32_t>(), nql, h->nb_total, h->temp.p, h->temp.cap, pw,
+                                         pw + n1, pw + 2 * n1, pw + 3 * n1, h->stream));
+        uint32_t n_found = 0;
+        HS_HIP(h, hipMemcpyAsync(&n_found, pw + n1 + nql, 4, hipMemcpyDeviceToHost, h->stream));
+        HS_HIP(h, hipStreamSynchronize(h->stream));
+        if (n_found) {  // (none at all: the batch goes on as one of probes that found nothing)
+          nqs = n_found;
+          keys_in = pw + 2 * n1;
+          probes_in = pw + 3 * n1;
+        }
+      }
       HS_HIP(h, hs_launch_seg_group_sparse(h->tabs, h->dir_base.as<uint32_t>(), L, seg_shift, h->nb_total,
-                                           h->temp.p, h->temp.cap, h->seg_keys.as<uint32_t>(),
+                                           h->temp.p, h->temp.cap, keys_in,
                                            h->seg_keys.as<uint32_t>() + n1, h->seg_vals.as<uint32_t>(),
-                                           h->bucket_work.as<uint32_t>(), nql, h->sorted_ql.as<uint32_t>(),
+                                           h->bucket_work.as<uint32_t>(), nqs, h->sorted_ql.as<uint32_t>(),
                                            h->seg_key.as<uint64_t>(), h->seg_cnt.as<uint32_t>(),
-                                           h->seg_n.as<uint32_t>(), h->seg_of.as<uint32_t>(), h->stream));
+                                           h->seg_n.as<uint32_t>(), h->seg_of.as<uint32_t>(), h->stream, probes_in));
     } else
     HS_HIP(h, hs_launch_seg_group(h->tabs, h->dir_base.as<uint32_t>(), L, seg_shift, h->nb_total,
                                   h->bucket_work.as<uint32_t>(),
@@ -2263,7 +2327,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
                                   h->seg_key.as<uint64_t>(), h->seg_cnt.as<uint32_t>(),
                                   h->seg_n.as<uint32_t>(), h->seg_of.as<uint32_t>(), h->stream));
     HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, h->seg_cnt.as<uint32_t>(),
-                                    h->seg_qoff.as<uint32_t>(), n1, h->stream));
+                                    h->seg_qoff.as<uint32_t>(), (size_t)nqs + 1, h->stream));
     // work items: one wave's 128 members for the wave-independent int8 join, 512 otherwise
     jm = use_i8 ? hs_join8_members_per_item(k, wide) : HS_JM_BLOCK;
     // k <= 25 with 4-column rows: segments probed by at most HS_JR_MAXQ queries of the batch go to the
@@ -2271,12 +2335,12 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
     if (h->resident_nq && (nq > 2 * h->resident_nq || 2 * nq < h->resident_nq)) h->resident_share = -1.0;
     use_r = use_i8 && !wide && k <= 25 && h->alphabet <= HS_JR_MAX_ALPHABET && !h->knobs.no_join_r &&
             (h->knobs.force_join_r || h->resident_share < 0.0 || h->resident_share >= 0.5 || h->resident_age >= 64);
-    HS_CHECK(cut_items(h, nql, jm, d_jstats, use_r ? HS_JR_MAXQ : 0u));
+    HS_CHECK(cut_items(h, nqs, jm, d_jstats, use_r ? HS_JR_MAXQ : 0u));
     if (use_i8)
       HS_HIP(h, hs_launch_gather_c8t(h->c16.p, h->sorted_ql.as<uint32_t>(), h->seg_qoff.as<uint32_t>(),
-                                     h->seg_of.as<uint32_t>(), nql, L, k, wide, h->c16s.p, h->stream));
+                                     h->seg_of.as<uint32_t>(), nqs, L, k, wide, h->c16s.p, h->stream));
     else
-      HS_HIP(h, hs_launch_gather_c16(h->c16.p, h->sorted_ql.as<uint32_t>(), nql, L, h->c16s.p, h->stream));
+      HS_HIP(h, hs_launch_gather_c16(h->c16.p, h->sorted_ql.as<uint32_t>(), nqs, L, h->c16s.p, h->stream));
   }
   if (!brute) {
     HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, h->nslices.as<uint32_t>(),
@@ -2293,7 +2357,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
       n_slices = 0;
     } else if (use_join) {
       HS_HIP(h, hipMemcpyAsync(&unsafe, d_unsafe, 4, hipMemcpyDeviceToHost, h->stream));
-      HS_HIP(h, hipMemcpyAsync(&n_items, h->item_off.as<uint32_t>() + nql, 4, hipMemcpyDeviceToHost,
+      HS_HIP(h, hipMemcpyAsync(&n_items, h->item_off.as<uint32_t>() + nqs, 4, hipMemcpyDeviceToHost,
                                h->stream));
     }
     if (!async_items) {
@@ -2310,14 +2374,14 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
       use_i8 = false;
       HS_HIP(h, hipMemsetAsync(d_unsafe, 0, 4, h->stream));
       HS_HIP(h, hs_launch_qprep(d_centers, nq, k, r2, h->c16.p, d_unsafe, h->stream));
-      HS_HIP(h, hs_launch_gather_c16(h->c16.p, h->sorted_ql.as<uint32_t>(), nql, L, h->c16s.p, h->stream));
+      HS_HIP(h, hs_launch_gather_c16(h->c16.p, h->sorted_ql.as<uint32_t>(), nqs, L, h->c16s.p, h->stream));
       HS_HIP(h, hipMemcpyAsync(&unsafe, d_unsafe, 4, hipMemcpyDeviceToHost, h->stream));
       if (jm != HS_JM_BLOCK) {  // the fp16 kernel works on 512-member items: cut the segments again
         jm = HS_JM_BLOCK;
         use_r = false;
         HS_HIP(h, hipMemsetAsync(d_jstats, 0, 16, h->stream));
-        HS_CHECK(cut_items(h, nql, jm, d_jstats, 0u));
-        HS_HIP(h, hipMemcpyAsync(&n_items, h->item_off.as<uint32_t>() + nql, 4, hipMemcpyDeviceToHost,
+        HS_CHECK(cut_items(h, nqs, jm, d_jstats, 0u));
+        HS_HIP(h, hipMemcpyAsync(&n_items, h->item_off.as<uint32_t>() + nqs, 4, hipMemcpyDeviceToHost,
                                  h->stream));
       }
       HS_HIP(h, hipStreamSynchronize(h->stream));
@@ -2327,7 +2391,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
       use_join = false;
       n_items = 0;
       HS_HIP(h, hipMemsetAsync(d_cnt + 2, 0, 8, h->stream));
-      HS_HIP(h, hs_launch_probe(probe_tabs(h), h->qints.as<int32_t>(), nq, K, L, h->key_seed,
+      HS_HIP(h, hs_launch_probe(probe_tabs(h, q_base), h->qints.as<int32_t>(), nq, K, L, h->key_seed,
                                 h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
                                 h->nslices.as<uint32_t>(), d_cand,
                                 reinterpret_cast<unsigned long long*>(d_cnt + 2),
@@ -2340,10 +2404,10 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
     if (n_items) {
       HS_HIP(h, h->item_desc.reserve((size_t)n_items * 32));
       HS_HIP(h, hs_launch_item_desc(h->tabs, h->seg_key.as<uint64_t>(), h->seg_cnt.as<uint32_t>(),
-                                    h->seg_qoff.as<uint32_t>(), h->item_off.as<uint32_t>(), nql,
+                                    h->seg_qoff.as<uint32_t>(), h->item_off.as<uint32_t>(), nqs,
                                     h->sorted_ql.as<uint32_t>(), h->qcount.as<uint32_t>(), n_items, jm,
                                     seg_shift, h->seg_vals.as<uint32_t>(), h->PW,
-                                    async_items ? h->item_off.as<uint32_t>() + nql : nullptr,
+                                    async_items ? h->item_off.as<uint32_t>() + nqs : nullptr,
                                     h->item_desc.as<uint4>(), h->stream));
     }
   }
@@ -2420,13 +2484,13 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
         const uint32_t* const d_split = h->seg_n.as<uint32_t>() + 2;
         // XCD-local runs of items where the batch's query tiles do not stay in every XCD's L2 anyway
         // (d_cnt + 40 .. 47: the per-XCD chunk counters)
-        const uint64_t tile_bytes = (uint64_t)nql * (uint64_t)hs_join8_row_bytes(k, wide);
+        const uint64_t tile_bytes = (uint64_t)nqs * (uint64_t)hs_join8_row_bytes(k, wide);
         const uint32_t xcd_run = h->knobs.join_xcd_run >= 0 ? (uint32_t)h->knobs.join_xcd_run
                                                             : (tile_bytes > (64ull << 20) ? 128u : 0u);
         HS_HIP(h, hs_launch_join8w(h->item_desc.as<uint4>(), n_items, h->tabs.t[0].packed,
                                    rec8, h->c16s.p, jtab_rows, k, wide, d_cnt, prov_cap,
                                    h->prov.as<uint2>(), d_cnt + 32, h->n_cu * h->join_blocks_per_cu,
-                                   use_r ? d_split : (async_items ? h->item_off.as<uint32_t>() + nql : nullptr),
+                                   use_r ? d_split : (async_items ? h->item_off.as<uint32_t>() + nqs : nullptr),
                                    h->pairs_per_item, xcd_run, h->stream));
         if (use_r)
           HS_HIP(h, hs_launch_join8r(h->item_desc.as<uint4>(), n_items, d_split, h->tabs.t[0].packed,
@@ -2496,7 +2560,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
     if (proj_stats)
       HS_HIP(h, hipMemcpyAsync(host_proj, h->proj_cnt.as<uint32_t>() + 4, 8, hipMemcpyDeviceToHost, h->stream));
     if (async_items)
-      HS_HIP(h, hipMemcpyAsync(&n_items_real, h->item_off.as<uint32_t>() + nql, 4, hipMemcpyDeviceToHost,
+      HS_HIP(h, hipMemcpyAsync(&n_items_real, h->item_off.as<uint32_t>() + nqs, 4, hipMemcpyDeviceToHost,
                                h->stream));
     if (use_join && use_i8 && n_items)  // [41] first item of the few-query class, [42] items (cut_items)
       HS_HIP(h, hipMemcpyAsync(h->pin_cnt + 41, h->seg_n.as<uint32_t>() + 2, 8, hipMemcpyDeviceToHost, h->stream));

@@ -562,14 +562,16 @@ namespace {
 // hs_comm_query / hs_comm_query_codes: the block as centres [nq_local][d] or as residue codes [nq_local][k]
 // tables != null: the TABLE-partitioned form -- the handle holds tables[0 .. n_tables) (global numbers,
 // ascending) over all k-mers, the block is ALL queries (q_offset 0), and the gathered tuples are merged
-// (hs_merge_first_table_dev) before they go to the caller's arrays.
+// (hs_merge_first_table_dev) before they go to the caller's arrays.  buckets: the BUCKET-partitioned form -- all
+// tables, all queries, the handle restricted to the rank's part of the buckets for the call; merged the same way.
 hs_status comm_query_impl(hs_comm* c, uint32_t rank, hs_handle* h, const double* centers, const uint8_t* qcodes,
                           uint64_t nq_local, uint32_t q_offset, double R, uint32_t* hit_q, uint32_t* hit_id,
                           uint32_t* hit_table, double* hit_dist, uint64_t cap, uint64_t* n_total,
-                          const uint32_t* tables = nullptr, uint32_t n_tables = 0) {
+                          const uint32_t* tables = nullptr, uint32_t n_tables = 0, bool buckets = false) {
   if (!rank_ok(c, rank) || !n_total) return HS_ERR_INVALID;  // cannot take part at all
   RankState& me = c->rs(rank);
   const bool loop = c->kind == HS_COMM_LOOPBACK;
+  const bool merge = tables != nullptr || buckets;
   // Everything up to the exchange can fail on this rank alone: the failure is kept in `lst` and carried
   // INTO the exchange (with no hits), where every rank learns of it -- never an early return that would
   // leave the other ranks waiting at a rendezvous or inside ncclAllGather.
@@ -606,6 +608,8 @@ hs_status comm_query_impl(hs_comm* c, uint32_t rank, hs_handle* h, const double*
   if (lst == HS_OK && hip(me.io_centers.reserve(std::max<size_t>(16, cbytes)), "centres: hipMalloc") && cbytes)
     hip(hipMemcpy(me.io_centers.p, src, cbytes, hipMemcpyHostToDevice), "centres: hipMemcpy");
   uint64_t lcap = std::max<uint64_t>(me.io_q.cap / 4, std::max<uint64_t>(1024, 16 * nq_local)), n_local = 0;
+  if (lst == HS_OK && buckets && hs_set_bucket_partition(h, rank, (uint32_t)c->world) != HS_OK)
+    keep(HS_ERR_INVALID, std::string("hs_set_bucket_partition: ") + hs_last_error(h));
   while (lst == HS_OK) {
     if (!hip(me.io_q.reserve(lcap * 4), "hits: hipMalloc") || !hip(me.io_id.reserve(lcap * 4), "hits: hipMalloc") ||
         !hip(me.io_table.reserve(lcap * 4), "hits: hipMalloc") || !hip(me.io_dist.reserve(lcap * 8), "hits: hipMalloc"))
@@ -626,6 +630,7 @@ hs_status comm_query_impl(hs_comm* c, uint32_t rank, hs_handle* h, const double*
     if (st != HS_OK) keep(st, std::string("hs_query_dev: ") + hs_last_error(h));
     break;
   }
+  if (buckets && h) (void)hs_set_bucket_partition(h, 0, 1);  // the handle answers for all buckets again
   if (lst != HS_OK) n_local = 0;
   if (tables && n_local) {
     hs_map_tables_kernel<<<(unsigned)((n_local + 255) / 256), 256, 0, me.stream>>>(
@@ -635,7 +640,7 @@ hs_status comm_query_impl(hs_comm* c, uint32_t rank, hs_handle* h, const double*
     if (lst != HS_OK) n_local = 0;
   }
   hs_status st;
-  if (loop && tables) {
+  if (loop && merge) {
     // host-memory transport: this rank's tuples to the host, every rank's into g_*, then the merge on this
     // rank's device (through the all_* buffers) and the merged list to the caller
     me.h_q.resize(n_local);
@@ -727,7 +732,7 @@ hs_status comm_query_impl(hs_comm* c, uint32_t rank, hs_handle* h, const double*
     break;
   }
   if (st != HS_OK) return st;
-  if (tables) {  // the gathered tuples, merged in place on this rank's GPU
+  if (merge) {  // the gathered tuples, merged in place on this rank's GPU
     uint64_t kept = 0;
     const hs_status mst = hs_merge_first_table_dev(h, static_cast<uint32_t*>(me.all_q.p), static_cast<uint32_t*>(me.all_id.p),
                                                    static_cast<uint32_t*>(me.all_table.p), static_cast<double*>(me.all_dist.p),
@@ -767,6 +772,15 @@ hs_status hs_comm_query_tables(hs_comm* c, uint32_t rank, hs_handle* h, const ui
   const bool args_ok = tables && n_tables && (centers || qcodes || !nq) && !(centers && qcodes);
   return comm_query_impl(c, rank, args_ok ? h : nullptr, centers, qcodes, nq, 0u, R, hit_q, hit_id, hit_table,
                          hit_dist, cap, n_total, tables ? tables : none, tables ? n_tables : 0u);
+}
+
+hs_status hs_comm_query_buckets(hs_comm* c, uint32_t rank, hs_handle* h, const double* centers, const uint8_t* qcodes,
+                                uint64_t nq, double R, uint32_t* hit_q, uint32_t* hit_id, uint32_t* hit_table,
+                                double* hit_dist, uint64_t cap, uint64_t* n_total) {
+  // (a bad argument list still joins the exchange, as a failed rank)
+  const bool args_ok = (centers || qcodes || !nq) && !(centers && qcodes);
+  return comm_query_impl(c, rank, args_ok ? h : nullptr, centers, qcodes, nq, 0u, R, hit_q, hit_id, hit_table,
+                         hit_dist, cap, n_total, nullptr, 0u, true);
 }
 
 void hs_assign_tables(const double* cost, uint32_t L, uint32_t world, uint32_t* owner) {

@@ -678,21 +678,52 @@ hipError_t hs_launch_seg_group(const hs_tables_dev& tabs, const uint32_t* d_dir_
   return hipGetLastError();
 }
 
+// Bucket partition: most probes of a batch find nothing (their bucket belongs to another part).  The ones
+// that did, in probe order: flag -> exclusive scan -> (bucket, probe) pairs; the grouping then sorts and walks
+// those alone (d_pos[nql] = their number).
+__global__ __launch_bounds__(256) void hs_found_flags_kernel(const uint32_t* __restrict__ qbucket, uint32_t nql,
+                                                             uint32_t nb_total, uint32_t* __restrict__ flag) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i <= nql) flag[i] = i < nql && qbucket[i] != nb_total;
+}
+__global__ __launch_bounds__(256) void hs_found_scatter_kernel(const uint32_t* __restrict__ qbucket, uint32_t nql,
+                                                               uint32_t nb_total, const uint32_t* __restrict__ pos,
+                                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ probes) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nql) return;
+  const uint32_t gb = qbucket[i];
+  if (gb == nb_total) return;
+  keys[pos[i]] = gb;
+  probes[pos[i]] = i;
+}
+hipError_t hs_launch_found_probes(const uint32_t* d_qbucket, uint32_t nql, uint32_t nb_total, void* d_temp,
+                                  size_t temp_bytes, uint32_t* d_flag, uint32_t* d_pos, uint32_t* d_keys,
+                                  uint32_t* d_probes, hipStream_t s) {
+  if (!nql) return hipSuccess;
+  hs_found_flags_kernel<<<blocks_for((uint64_t)nql + 1), 256, 0, s>>>(d_qbucket, nql, nb_total, d_flag);
+  hipError_t e = hs_exclusive_scan_u32(d_temp, temp_bytes, d_flag, d_pos, (size_t)nql + 1, s);
+  if (e != hipSuccess) return e;
+  hs_found_scatter_kernel<<<blocks_for(nql), 256, 0, s>>>(d_qbucket, nql, nb_total, d_pos, d_keys, d_probes);
+  return hipGetLastError();
+}
+
+// d_probes_in == null: the probes are 0 .. nql - 1 (d_iota is filled with them); else the nql probe numbers
+// that belong to the keys d_qbucket[0 .. nql) (hs_launch_found_probes)
 hipError_t hs_launch_seg_group_sparse(const hs_tables_dev& tabs, const uint32_t* d_dir_base, int L, int shift,
                                       uint32_t nb_total, void* d_temp, size_t temp_bytes,
                                       const uint32_t* d_qbucket, uint32_t* d_keys_sorted, uint32_t* d_iota,
                                       uint32_t* d_work, uint32_t nql, uint32_t* d_sorted_ql,
                                       uint64_t* d_seg_key, uint32_t* d_seg_cnt, uint32_t* d_n_seg,
-                                      uint32_t* d_seg_of, hipStream_t s) {
+                                      uint32_t* d_seg_of, hipStream_t s, const uint32_t* d_probes_in) {
   if (!nql) return hipSuccess;
   uint32_t* head = d_work;
   uint32_t* head_pos = d_work + ((size_t)nql + 1);
   uint32_t* seg_start = d_work + 2 * ((size_t)nql + 1);
   int bits = 1;
   while (bits < 32 && (nb_total >> bits)) ++bits;  // bucket numbers are <= nb_total
-  hs_iota_kernel<<<blocks_for(nql), 256, 0, s>>>(nql, d_iota);
-  hipError_t e = hs_sort_pairs_u32_u32(d_temp, temp_bytes, d_qbucket, d_keys_sorted, d_iota, d_sorted_ql, nql,
-                                       bits, s);
+  if (!d_probes_in) hs_iota_kernel<<<blocks_for(nql), 256, 0, s>>>(nql, d_iota);
+  hipError_t e = hs_sort_pairs_u32_u32(d_temp, temp_bytes, d_qbucket, d_keys_sorted, d_probes_in ? d_probes_in : d_iota,
+                                       d_sorted_ql, nql, bits, s);
   if (e != hipSuccess) return e;
   hs_seg_heads_kernel<<<blocks_for((uint64_t)nql + 1), 256, 0, s>>>(d_keys_sorted, nql, head);
   e = hs_exclusive_scan_u32(d_temp, temp_bytes, head, head_pos, (size_t)nql + 1, s);

@@ -392,7 +392,22 @@ __global__ __launch_bounds__(256) void hs_probe_kernel(hs_tables_dev tabs,
     // fingerprints are uniform: their top J bits (2^J >= nb) index a jump table that leaves about
     // one directory entry to look at, instead of log2(nb) dependent round trips
     const uint32_t slot = (uint32_t)(key >> tb.jump_shift);
-    uint32_t lo = tb.dir_jump[slot], hi = tb.dir_jump[slot + 1];
+    uint32_t lo = 0, hi = 0;
+    // (bucket partition: a probe of another part is not looked for -- as if the table did not have the bucket)
+    bool mine = true;
+    if (tabs.n_parts > 1u) {
+      uint32_t glo = 0, ghi = tb.n_giant;
+      while (glo < ghi) {
+        const uint32_t mid = (glo + ghi) >> 1;
+        if (tb.giant_key[mid] < key) glo = mid + 1; else ghi = mid;
+      }
+      const bool giant = glo < tb.n_giant && tb.giant_key[glo] == key;
+      mine = hs_probe_part(key, giant, tabs.q_first + ql / (uint32_t)L, tabs.n_parts) == tabs.part;
+    }
+    if (mine) {
+      lo = tb.dir_jump[slot];
+      hi = tb.dir_jump[slot + 1];
+    }
     if (tb.dir_rec) {
       // one line per candidate bucket of the slot (about one): all four pieces of the first are asked for
       // together; the fingerprints ascend, so the walk stops at the first one that is not smaller
@@ -430,7 +445,7 @@ __global__ __launch_bounds__(256) void hs_probe_kernel(hs_tables_dev tabs,
       const uint32_t mid = (lo + hi) >> 1;
       if (tb.dir_key[mid] < key) lo = mid + 1; else hi = mid;
     }
-    if (lo < tb.nb && tb.dir_key[lo] == key) {
+    if (mine && lo < tb.nb && tb.dir_key[lo] == key) {
       const int32_t* u = tb.dir_tuple + (uint64_t)lo * K;
       bool same = true;
       if ((K & 3) == 0) {
@@ -2061,6 +2076,22 @@ hipError_t hs_launch_klsh(const uint8_t* d_classes, const uint64_t* d_seq_start,
   const unsigned blocks = (unsigned)std::min<uint64_t>((n_seq + 3) / 4, 1u << 16);
   hs_klsh_kernel<<<blocks, 256, 0, s>>>(d_classes, d_seq_start, n_seq, d_w, d_b, d_t, bits, d_codes,
                                         d_uncertain);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void hs_giant_buckets_kernel(const uint64_t* __restrict__ key,
+                                                               const uint32_t* __restrict__ start, uint32_t nb,
+                                                               uint32_t threshold, uint64_t* __restrict__ out,
+                                                               uint32_t cap, uint32_t* __restrict__ count) {
+  const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= nb || start[b + 1] - start[b] <= threshold) return;
+  const uint32_t at = atomicAdd(count, 1u);
+  if (at < cap) out[at] = key[b];
+}
+hipError_t hs_launch_giant_buckets(const uint64_t* d_dir_key, const uint32_t* d_dir_start, uint32_t nb,
+                                   uint32_t threshold, uint64_t* d_out, uint32_t cap, uint32_t* d_count, hipStream_t s) {
+  if (!nb) return hipSuccess;
+  hs_giant_buckets_kernel<<<blocks_for(nb), 256, 0, s>>>(d_dir_key, d_dir_start, nb, threshold, d_out, cap, d_count);
   return hipGetLastError();
 }
 

@@ -169,6 +169,24 @@ def query_table_partitioned(eng, tables, d_centers_ptr, nq, R, out, cap, group=N
     return merge_table_partitioned(gq, gi, gt, gd), nh
 
 
+def query_bucket_partitioned(eng, rank, world, d_centers_ptr, nq, R, out, cap, group=None, force=False, codes=False):
+    """One pass of the bucket-partitioned layout on this rank: `eng` holds the WHOLE index (replicated), the nq
+    queries are ALL queries (the same on every rank), and the rank searches only the buckets of part `rank` of
+    `world` (hs_set_bucket_partition: a function of the bucket's key fingerprint); its hits (tables already
+    global) are all-gathered (q_offset 0) and merged by the first-seen rule (merge_table_partitioned: the same
+    rule -- per (query, id) the smallest table).  Returns the merged (q, id, table, dist) -- every rank the same
+    list, the reference's order -- and the rank's own hit count."""
+    eng.set_bucket_partition(rank, world)
+    try:
+        nh = eng.query_dev(d_centers_ptr, nq, R, out["q"].data_ptr(), out["id"].data_ptr(), out["table"].data_ptr(),
+                           out["dist"].data_ptr(), cap, codes=codes)
+    finally:
+        eng.set_bucket_partition(0, 1)
+    gq, gi, gt, gd = allgather_hits(out["q"], out["id"], out["table"], out["dist"], nh, q_offset=0, group=group,
+                                    force=force)
+    return merge_table_partitioned(gq, gi, gt, gd), nh
+
+
 def hits_to_numpy(q, ids, table, distance):
     return dict(q=q.cpu().numpy().astype(np.uint32), id=ids.cpu().numpy().astype(np.uint32),
                 table=table.cpu().numpy().astype(np.uint32), dist=distance.cpu().numpy())

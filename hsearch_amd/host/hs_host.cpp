@@ -169,6 +169,7 @@ int RunSearch(hs_params prm, const Planes& planes, const double* coords,
   }
   // table partition: rank r holds the tables tabs[r] (global numbers, ascending) of ALL k-mers
   const bool by_tables = sharded && g_shard_partition == kPartitionTables;
+  const bool by_buckets = sharded && g_shard_partition == kPartitionBuckets;
   std::vector<std::vector<uint32_t>> tabs(world);
   if (by_tables) {
     if (world > prm.L) {
@@ -295,6 +296,9 @@ int RunSearch(hs_params prm, const Planes& planes, const double* coords,
         st = hs_comm_query_tables(comm, r, hq, tabs[r].data(), (uint32_t)tabs[r].size(), qcodes ? nullptr : flat, qcodes,
                                   nq, R, dst->q.data(), dst->id.data(), dst->table.data(), dst->dist.data(), cap,
                                   &dst->n);
+      else if (by_buckets)  // the same, every rank with the whole index and its part of the buckets
+        st = hs_comm_query_buckets(comm, r, hq, qcodes ? nullptr : flat, qcodes, nq, R, dst->q.data(), dst->id.data(),
+                                   dst->table.data(), dst->dist.data(), cap, &dst->n);
       else
       st = qcodes ? hs_comm_query_codes(comm, r, hq, qcodes + lo * prm.k, hi - lo, (uint32_t)lo, R, dst->q.data(),
                                         dst->id.data(), dst->table.data(), dst->dist.data(), cap, &dst->n)

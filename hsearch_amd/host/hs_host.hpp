@@ -72,8 +72,11 @@ void SetShardTransport(ShardTransport t);
 // the all-gather every rank keeps, per (centre, k-mer), the tuple of the smallest table -- the reference's
 // first-seen rule (motif_both_points.cpp:232-238) -- so the file is the same (include/hsearch_dist.h).  A GPU
 // then holds and builds 1 / n of the table bytes (configs[2]: 23 GB instead of 157 GB) and every bucket meets
-// all centres of the batch at once.  Process-wide; set before the call.
-enum ShardPartition { kPartitionQueries = 0, kPartitionTables = 1 };
+// all centres of the batch at once.  kPartitionBuckets: the whole index, replicated, and ALL centres; the GPUs
+// share the BUCKETS (hs_set_bucket_partition: a function of the bucket's key fingerprint, giant buckets shared
+// by centre) and the lists are merged by the same rule -- 1 / n of the probes and pairs per GPU, every bucket
+// with all the centres there are, even parts whatever the tables look like.  Process-wide; set before the call.
+enum ShardPartition { kPartitionQueries = 0, kPartitionTables = 1, kPartitionBuckets = 2 };
 void SetShardPartition(ShardPartition p);
 
 // Search() spread over the GPUs `devices` of this node: one host thread and one handle

@@ -54,7 +54,7 @@ const Opt kOpts[] = {
     {"seed", 's', "seed of the LSH planes [random_device]", false},
     {"device", 'G', "GPU ordinal (the first one with --gpus) [0]", false},
     {"gpus", 'N', "shard the centres over this many GPUs, hits all-gathered over RCCL [off: one GPU, no communicator]", false},
-    {"partition", 'Y', "with --gpus: queries (every GPU the whole index and a block of the centres, the default) or tables (every GPU a subset of the L tables over all k-mers and all centres; same output)", false},
+    {"partition", 'Y', "with --gpus: queries (every GPU the whole index and a block of the centres, the default), tables (every GPU a subset of the L tables over all k-mers and all centres) or buckets (every GPU the whole index, all centres and its share of the buckets); same output", false},
     {"transport", 'X', "with --gpus: rccl (one rank per GPU, the default) or loopback (host memory between the rank threads, all ranks on --device: the rank protocol on a box with fewer GPUs)", false},
     {"centers-as-points", 'E', "k-mer centres over a FASTA database: send them embedded (8k doubles each) instead of as residue codes [0]", false},
     {"planes", 'p', "read the planes from this file (as written by --planes-out) instead of drawing them", false},
@@ -196,11 +196,13 @@ int main(int argc, const char* argv[]) {
       return EXIT_FAILURE;
     }
     const bool by_tables = val.count("partition") && val["partition"] == "tables";
-    if (val.count("partition") && !by_tables && val["partition"] != "queries") {
-      fprintf(stderr, "ERROR: --partition must be queries or tables\n");
+    const bool by_buckets = val.count("partition") && val["partition"] == "buckets";
+    if (val.count("partition") && !by_tables && !by_buckets && val["partition"] != "queries") {
+      fprintf(stderr, "ERROR: --partition must be queries, tables or buckets\n");
       return EXIT_FAILURE;
     }
-    hsearch::SetShardPartition(by_tables ? hsearch::kPartitionTables : hsearch::kPartitionQueries);
+    hsearch::SetShardPartition(by_tables ? hsearch::kPartitionTables
+                                         : by_buckets ? hsearch::kPartitionBuckets : hsearch::kPartitionQueries);
     const bool loopback = val.count("transport") && val["transport"] == "loopback";
     if (val.count("transport") && !loopback && val["transport"] != "rccl") {
       fprintf(stderr, "ERROR: --transport must be rccl or loopback\n");

@@ -174,6 +174,20 @@ typedef enum hs_option {
                                 of the batch's query-tile array */
 } hs_option;
 HS_API hs_status hs_set_option(hs_handle* h, int option, int64_t value);
+/* Bucket partition -- unlike the options above this CHANGES what a query call returns.  With n_parts > 1 the
+ * searches of this handle (hs_query*, not the self-joins) probe only the buckets that fall to `part` of
+ * `n_parts` (a fixed function of the bucket's key fingerprint, the same on every handle with the same key
+ * seed; for the few buckets of more than max(4096, n / 1024) members a function of the fingerprint AND of the
+ * query's number in the call, so that a giant bucket's queries are shared among the parts instead of the bucket
+ * landing on one of them): the loop over tables and buckets of motif_both_points.cpp:224-238 cut by BUCKET.
+ * Every (query, table) probe belongs to exactly one part -- provided every part is given the same queries in
+ * the same order --, so the union over the parts of the hits is the full call's hits plus
+ * later-table sightings of ids an earlier table of another part already had: hs_merge_first_table_dev (per
+ * (query, id) the smallest table, order (query, table, id)) of the parts' lists IS the full call's output.  n
+ * GPUs with the index replicated and ALL queries on every GPU then share the buckets instead of the queries:
+ * each meets 1/n of the probes with all the queries there are per bucket (hs_comm_query_buckets in
+ * include/hsearch_dist.h).  n_parts = 1 (part 0): everything, the default. */
+HS_API hs_status hs_set_bucket_partition(hs_handle* h, uint32_t part, uint32_t n_parts);
 /* The library's work after this call starts only once `hip_event` (a hipEvent_t the caller has recorded on a
  * stream of its own) has completed: the device-side alternative to draining that stream before a _dev call. */
 HS_API hs_status hs_wait_event(hs_handle* h, void* hip_event);

@@ -116,6 +116,21 @@ HS_API hs_status hs_comm_query_tables(hs_comm* c, uint32_t rank, hs_handle* h, c
                                       double* hit_dist, uint64_t cap, uint64_t* n_total);
 HS_API void hs_assign_tables(const double* cost, uint32_t L, uint32_t world, uint32_t* owner);
 
+/* ---- the BUCKET-partitioned layout ----------------------------------------------------------------
+ * Index replicated as in hs_comm_query, but the ranks share the BUCKETS instead of the queries: every rank
+ * answers ALL queries in the buckets that fall to it (hs_set_bucket_partition(h, rank, world), hsearch.h: a
+ * function of the bucket's key fingerprint -- and of the query for the few giant buckets --, so the parts are
+ * even whatever the tables look like), the tuples
+ * are all-gathered and merged by the same first-seen rule as above.  Per rank 1/world of the probes, members
+ * and (member, query) pairs, with every bucket meeting all the queries of the job at once -- the operand reuse
+ * query blocks lose as the ranks multiply (motif_both_points.cpp:224-238's loops cut by bucket, not by query).
+ * Arguments and results as hs_comm_query_tables (centers or qcodes = ALL queries, the same on every rank; the
+ * handle holds all L tables); the handle's partition is set for the call and back to "everything" after it. */
+HS_API hs_status hs_comm_query_buckets(hs_comm* c, uint32_t rank, hs_handle* h, const double* centers,
+                                       const uint8_t* qcodes, uint64_t nq, double R, uint32_t* hit_q,
+                                       uint32_t* hit_id, uint32_t* hit_table, double* hit_dist, uint64_t cap,
+                                       uint64_t* n_total);
+
 #ifdef __cplusplus
 }
 #endif

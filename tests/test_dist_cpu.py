@@ -126,6 +126,69 @@ def test_table_partitioned_search_world2():
     assert got == {0: True, 1: True}       # every rank ends with the reference's list
 
 
+def _bucket_worker(rank, world, port, ret):
+    """The bucket-partitioned layout over gloo: the ranks share the BUCKETS.  Rank r's list = for every table the
+    hits of the (query, bucket) probes that fall to it -- here by a hash of the bucket's int tuple, and for one
+    big bucket per table by a hash of tuple AND query (the library's rule for giant buckets) --, reduced inside
+    the rank by the first-seen rule over ITS probes, as a handle with hs_set_bucket_partition reports them; the
+    tuples are all-gathered and merged (merge_table_partitioned): the reference's full output."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle as O
+    k, K, L, W, R, n, nq = 25, 3, 6, 150.0, 45.0, 4000, 150
+    a, b = synth.make_planes(k, K, L, W)
+    rng = np.random.default_rng(6)
+    codes = synth.make_db(n, k)
+    codes[rng.choice(n, 600, replace=False)] = codes[rng.choice(n, 600)]      # duplicates: pairs found by many tables
+    centers, _ = synth.make_queries(codes, nq, jitter=0.2)
+    pts = O.embed_codes(codes)
+    qints = O.hash_all(a, b, W, centers)                        # [nq][L][K] bucket ints of every probe
+    dints = O.hash_all(a, b, W, pts)
+    mine_q, mine_i, mine_t, mine_d = [], [], [], []
+    for l in range(L):
+        one = O.search(a[l:l + 1], b[l:l + 1], W, R, pts, centers)       # table l alone: all its hits
+        tuples, counts = np.unique(dints[:, l, :], axis=0, return_counts=True)
+        giant = tuple(tuples[np.argmax(counts)])
+        def part(q):
+            t = tuple(int(v) for v in qints[q, l])
+            return hash((t, int(q)) if t == giant else t) % world
+        keep = np.array([part(int(q)) == rank for q in one["q"]], dtype=bool)
+        mine_q.append(one["q"][keep]); mine_i.append(one["id"][keep]); mine_d.append(one["dist"][keep])
+        mine_t.append(np.full(int(keep.sum()), l))
+    mq, mi, mt, md = (np.concatenate(x) for x in (mine_q, mine_i, mine_t, mine_d))
+    def t64(x):
+        return torch.from_numpy(np.asarray(x).astype(np.int64))
+    # inside the rank: per (query, id) the first table among its own probes
+    lq, li, lt, ld = hdist.merge_table_partitioned(t64(mq), t64(mi), t64(mt), torch.from_numpy(md))
+    nh = len(lq)
+    gq, gi, gt, gd = hdist.allgather_hits(lq.to(torch.int32), li.to(torch.int32), lt.to(torch.int32), ld, nh, q_offset=0)
+    fq, fi, ft, fd = hdist.merge_table_partitioned(gq, gi, gt, gd)
+    full = O.search(a, b, W, R, pts, centers)
+    ok = (np.array_equal(fq.numpy(), full["q"].astype(np.int64)) and
+          np.array_equal(fi.numpy(), full["id"].astype(np.int64)) and
+          np.array_equal(ft.numpy(), full["table"].astype(np.int64)) and
+          np.array_equal(fd.numpy(), full["dist"]) and len(full["q"]) > 50 and len(gq) > len(fq) and 0 < nh < len(full["q"]))
+    ret.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucket_partitioned_search_world2():
+    os.environ["PYTHONHASHSEED"] = "0"      # (the workers' stand-in for the fingerprint is Python's hash of a tuple of ints)
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(ret.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == {0: True, 1: True}       # every rank ends with the reference's list
+
+
 def test_merge_table_partitioned_small_cases():
     q = torch.tensor([3, 0, 3, 3, 0, 1], dtype=torch.int64)
     i = torch.tensor([7, 5, 7, 2, 5, 9], dtype=torch.int64)

@@ -238,6 +238,80 @@ def test_table_partitioned_search_equals_one_handle_with_all_tables(world):
             e.close()
 
 
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_bucket_partitioned_search_equals_the_unpartitioned_search(world):
+    """The bucket-partitioned layout: the index replicated, every rank ALL queries in ITS part of the buckets
+    (hs_set_bucket_partition: a function of the bucket's key fingerprint).  (1) On one handle: the parts' lists
+    are disjoint in (query, table) probes, every part is a sub-list of what the tables hold, no part is empty,
+    and the parts' union merged by hs_merge_first_table_dev is the unpartitioned list -- hits, table of first
+    sight, order, bit-identical distances; the partition is switched off again by (0, 1).  (2) hs_comm_query_buckets
+    with `world` live handles on ONE GPU over the host-memory transport: every rank ends with that list, queries
+    as points and as residue codes."""
+    k, K, L, W, R, n, nq = 25, 6, 8, 130.0, 45.0, 60_000, 3000
+    a, b = synth.make_planes(k, K, L, W)
+    rng = np.random.default_rng(12)
+    codes = synth.make_db(n, k)
+    codes[rng.choice(n, 5000, replace=False)] = codes[rng.choice(n, 5000)]   # pairs that share buckets in many tables
+    qcodes, _ = synth.make_query_codes(codes, nq)
+    centers = synth.embed(qcodes)
+    one = Engine(k, K, L, W, a, b)
+    one.index_build(codes)
+    want = one.query(centers, R)
+    assert len(want["q"]) > 1000 and len(np.unique(want["table"])) > 4
+    parts = []
+    cand = np.zeros_like(want["cand"])
+    for r in range(world):
+        one.set_bucket_partition(r, world)
+        got = one.query(centers, R)
+        assert len(got["q"]) > 0
+        assert np.all((got["cand"] == 0) | (cand == 0))        # a (query, table) probe belongs to ONE part
+        cand += got["cand"]
+        parts.append(got)
+    assert np.array_equal(cand, want["cand"])                    # ... and to some part
+    with pytest.raises(capi.HsError):
+        one.set_bucket_partition(world, world)
+    one.set_bucket_partition(0, 1)
+    again = one.query(centers, R)
+    for f in ("q", "id", "table", "dist", "cand"):
+        assert np.array_equal(again[f], want[f]), f
+    gq, gi, gt, gd = (np.concatenate([p_[f] for p_ in parts]) for f in ("q", "id", "table", "dist"))
+    assert len(gq) >= len(want["q"])
+    import torch
+    dev = torch.device("cuda", 0)
+    tq, ti, tt, td = (torch.from_numpy(x.astype(np.int32) if x.dtype != np.float64 else x).to(dev) for x in (gq, gi, gt, gd))
+    kept = one.merge_first_table_dev(tq.data_ptr(), ti.data_ptr(), tt.data_ptr(), td.data_ptr(), len(gq))
+    assert kept == len(want["q"])
+    assert np.array_equal(tq[:kept].cpu().numpy().astype(np.uint32), want["q"])
+    assert np.array_equal(ti[:kept].cpu().numpy().astype(np.uint32), want["id"])
+    assert np.array_equal(tt[:kept].cpu().numpy().astype(np.uint32), want["table"])
+    assert np.array_equal(td[:kept].cpu().numpy(), want["dist"])
+    one.close()
+    engs = []
+    for r in range(world):
+        e = Engine(k, K, L, W, a, b)
+        e.index_build(codes)
+        engs.append(e)
+    comm = cdist.Comm(cdist.LOOPBACK, world, devices=[0] * world)
+    for as_codes in (False, True):
+        res = [None] * world
+        def run(r):
+            res[r] = comm.query_buckets(r, engs[r], qcodes if as_codes else centers, R, codes=as_codes)
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        for r in range(world):
+            for f in ("q", "id", "table", "dist"):
+                assert np.array_equal(res[r][f], want[f]), (world, r, f, as_codes)
+    # the handles answer for all buckets again after the call
+    back = engs[0].query(centers, R, want_cand=False)
+    assert np.array_equal(back["id"], want["id"])
+    comm.close()
+    for e in engs:
+        e.close()
+
+
 def test_assign_tables_is_balanced_and_deterministic():
     cost = np.array([9.0, 1, 1, 1, 8, 1, 1, 1, 7, 1, 1, 1, 1, 1, 1, 1])
     own = cdist.assign_tables(cost, 16, 4)

@@ -323,9 +323,18 @@ def test_cli_two_rank_threads_with_live_handles_over_loopback(tmp_path, oracle):
             [l for l in so_plain.splitlines() if l.startswith("table size")]
     r = run("tp6", "-d", db, "-c", cen, "--gpus", "6", "--transport", "loopback", "--partition", "tables", ok=False)
     assert r.returncode == 1 and "more GPUs than tables" in r.stderr
+    # the bucket-partitioned layout: every rank the whole index, ALL centres and its share of the buckets
+    # (hs_comm_query_buckets), merged by the same rule: the same file, with more ranks than tables too
+    for n in (1, 2, 3, 6):
+        got, so = run("bp%d" % n, "-d", db, "-c", cen, "--gpus", str(n), "--transport", "loopback", "--partition", "buckets")
+        assert got == plain, n
+        assert [l for l in so.splitlines() if l.startswith("table size")] == \
+            [l for l in so_plain.splitlines() if l.startswith("table size")]
+    r = run("pbad", "-d", db, "-c", cen, "--gpus", "2", "--transport", "loopback", "--partition", "members", ok=False)
+    assert r.returncode == 1 and "--partition" in r.stderr
     fa_plain, _ = run("fa_plain", "-d", fa, "-c", cfa, "--centers-as-points", "1")
     assert len(fa_plain.splitlines()) > 0
-    for extra in ((), ("--centers-as-points", "1"), ("--partition", "tables")):
+    for extra in ((), ("--centers-as-points", "1"), ("--partition", "tables"), ("--partition", "buckets")):
         got, _ = run("fa_lb2", "-d", fa, "-c", cfa, "--gpus", "2", "--transport", "loopback", *extra)
         assert got == fa_plain
     # a failed rank: everybody stops, nobody hangs (timeout above), the message names the rank
