@@ -274,6 +274,17 @@ def test_bucket_partitioned_search_equals_the_unpartitioned_search(world):
     again = one.query(centers, R)
     for f in ("q", "id", "table", "dist", "cand"):
         assert np.array_equal(again[f], want[f]), f
+    # a part does not depend on how the call is cut into batches (a giant bucket's queries are dealt by their
+    # number in the CALL) nor on the verify path (streaming filter: no grouping of the probes at all)
+    small = Engine(k, K, L, W, a, b, options=dict(query_batch=301))
+    small.index_build(codes)
+    for r, mode in ((0, "auto"), (world - 1, "stream")):
+        small.set_bucket_partition(r, world)
+        small.set_verify_mode(mode)
+        got = small.query(centers, R)
+        for f in ("q", "id", "table", "dist", "cand"):
+            assert np.array_equal(got[f], parts[r][f]), (r, mode, f)
+    small.close()
     gq, gi, gt, gd = (np.concatenate([p_[f] for p_ in parts]) for f in ("q", "id", "table", "dist"))
     assert len(gq) >= len(want["q"])
     import torch
