@@ -58,6 +58,10 @@ def test_comm_query_equals_plain_query(oracle):
     got = comm.query_tables(0, eng, np.arange(L), centers, R, cap=8)
     for f in ("q", "id", "table", "dist"):
         assert np.array_equal(got[f], want[f]), f
+    # ... and the bucket-partitioned form with one rank = every bucket: the same pipeline over RCCL
+    got = comm.query_buckets(0, eng, centers, R, cap=8)
+    for f in ("q", "id", "table", "dist"):
+        assert np.array_equal(got[f], want[f]), f
     # a block in the middle of a larger query set: q comes back global
     got = comm.query(0, eng, centers[300:500], 300, R, cap=8)       # and the capacity retry
     sel = (want["q"] >= 300) & (want["q"] < 500)
