@@ -861,8 +861,10 @@ static inline int seg_shift_of(const hs_handle* h) {
 // max_q_res > 0: segments with at most that many probing queries form the item list's tail, whose bounds
 // go to seg_n[2..3] (hs_join8r_kernel's share).
 static hs_status cut_items(hs_handle* h, uint32_t nql, uint32_t jm, unsigned long long* d_jstats,
-                           uint32_t max_q_res) {
+                           uint32_t max_q_res, uint32_t n_probes) {
   const size_t n1 = (size_t)nql + 1;
+  // every segment with a member goes to the join (the default): no probe keeps a slice for the streaming filter
+  const bool all_joined = h->join_min_q == 1 && h->join_min_m == 1;
   uint32_t* big = h->seg_keys.as<uint32_t>();
   uint32_t* big_pos = big + n1;
   uint32_t* order = h->seg_vals.as<uint32_t>();
@@ -877,8 +879,9 @@ static hs_status cut_items(hs_handle* h, uint32_t nql, uint32_t jm, unsigned lon
                                 h->seg_qoff.as<uint32_t>(), h->seg_n.as<uint32_t>(),
                                 h->sorted_ql.as<uint32_t>(), h->qcount.as<uint32_t>(), nql,
                                 h->join_min_q, h->join_min_m, jm, (int)h->p.L, seg_shift_of(h), max_q_res,
-                                h->seg_items.as<uint32_t>(), d_jstats, h->nslices.as<uint32_t>(),
+                                h->seg_items.as<uint32_t>(), d_jstats, all_joined ? nullptr : h->nslices.as<uint32_t>(),
                                 h->seg_of.as<uint32_t>(), h->stream));
+  if (all_joined) HS_HIP(h, hipMemsetAsync(h->nslices.p, 0, (size_t)n_probes * 4, h->stream));
   HS_HIP(h, hipMemsetAsync(big + nql, 0, 4, h->stream));
   if (res) HS_HIP(h, hipMemsetAsync(res + nql, 0, 4, h->stream));
   HS_HIP(h, hipMemsetAsync(items_ord + nql, 0, 4, h->stream));
@@ -2335,7 +2338,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
     if (h->resident_nq && (nq > 2 * h->resident_nq || 2 * nq < h->resident_nq)) h->resident_share = -1.0;
     use_r = use_i8 && !wide && k <= 25 && h->alphabet <= HS_JR_MAX_ALPHABET && !h->knobs.no_join_r &&
             (h->knobs.force_join_r || h->resident_share < 0.0 || h->resident_share >= 0.5 || h->resident_age >= 64);
-    HS_CHECK(cut_items(h, nqs, jm, d_jstats, use_r ? HS_JR_MAXQ : 0u));
+    HS_CHECK(cut_items(h, nqs, jm, d_jstats, use_r ? HS_JR_MAXQ : 0u, nql));
     if (use_i8)
       HS_HIP(h, hs_launch_gather_c8t(h->c16.p, h->sorted_ql.as<uint32_t>(), h->seg_qoff.as<uint32_t>(),
                                      h->seg_of.as<uint32_t>(), nqs, L, k, wide, h->c16s.p, h->stream));
@@ -2380,7 +2383,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
         jm = HS_JM_BLOCK;
         use_r = false;
         HS_HIP(h, hipMemsetAsync(d_jstats, 0, 16, h->stream));
-        HS_CHECK(cut_items(h, nqs, jm, d_jstats, 0u));
+        HS_CHECK(cut_items(h, nqs, jm, d_jstats, 0u, nql));
         HS_HIP(h, hipMemcpyAsync(&n_items, h->item_off.as<uint32_t>() + nqs, 4, hipMemcpyDeviceToHost,
                                  h->stream));
       }

@@ -743,7 +743,10 @@ hipError_t hs_launch_seg_route(const uint64_t* d_seg_key, const uint32_t* d_seg_
   hs_seg_route_kernel<<<blocks_for((uint64_t)n_max + 1), 256, 0, s>>>(
       d_seg_key, d_seg_cnt, d_seg_qoff, d_n_seg, d_sorted_ql, d_qcount, n_max, min_q, min_m, jm, L,
       shift, max_q_resident, d_items, d_stats);
-  hs_seg_unslice_kernel<<<blocks_for(n_max), 256, 0, s>>>(d_seg_of, d_items, d_sorted_ql, n_max, d_nslices);
+  // (d_nslices == null: every segment with a member goes to the join -- min_q = min_m = 1 -- and the caller
+  // clears the slice counts of ALL probes with one memset instead of this kernel's scattered stores)
+  if (d_nslices)
+    hs_seg_unslice_kernel<<<blocks_for(n_max), 256, 0, s>>>(d_seg_of, d_items, d_sorted_ql, n_max, d_nslices);
   return hipGetLastError();
 }
 
