@@ -2346,8 +2346,12 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
       HS_HIP(h, hs_launch_gather_c16(h->c16.p, h->sorted_ql.as<uint32_t>(), nqs, L, h->c16s.p, h->stream));
   }
   if (!brute) {
-    HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, h->nslices.as<uint32_t>(),
-                                    h->slice_off.as<uint32_t>(), (size_t)nql + 1, h->stream));
+    // (every segment joined -- the default --: all slice counts are zero by now, and so is their scan)
+    if (use_join && h->join_min_q == 1 && h->join_min_m == 1)
+      HS_HIP(h, hipMemsetAsync(h->slice_off.p, 0, ((size_t)nql + 1) * 4, h->stream));
+    else
+      HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, h->nslices.as<uint32_t>(),
+                                      h->slice_off.as<uint32_t>(), (size_t)nql + 1, h->stream));
     // No host round trip when the int8 join takes every segment and the previous batch left a
     // capacity hint: the item count stays on the device (item_off[nql]); join legality and the
     // capacity are checked with the batch's final read-back, a violation repeats the batch the

@@ -1107,13 +1107,18 @@ __global__ __launch_bounds__(256, 2) void hs_join8x_kernel(
   uint32_t res_base = 0, res_used = JRES;
   uint32_t next_chunk_v = 0;
   if (lane == 0) next_chunk_v = HS_TAKE_CHUNK();
-  uint32_t pf_item = item, pf_chunk_end = item + G;
+  // A chunk ENDS at the last item there is: the wave leaves its loop at the first item number past the end,
+  // and with XCD-local runs the chunk after the one that straddles the end of the list may well be a valid one
+  // of another XCD's -- a wave that walked the straddling chunk's empty tail took that chunk (and the one
+  // behind it, ahead of time) and left with both unprocessed whenever the tail was shorter than its look-ahead
+  // of two items (G = 48 at 7 121 711 items: 96 items of 7 million never joined, a hit or two in a million lost).
+  uint32_t pf_item = item, pf_chunk_end = min(item + G, n_items);
 #define HS_ADVANCE_PF()                                                                  \
   {                                                                                      \
     ++pf_item;                                                                           \
     if (pf_item == pf_chunk_end) {                                                       \
       pf_item = chunk_item(__builtin_amdgcn_readfirstlane(next_chunk_v));                \
-      pf_chunk_end = pf_item + G;                                                        \
+      pf_chunk_end = pf_item < n_items ? min(pf_item + G, n_items) : pf_item + G;        \
       if (lane == 0 && pf_item < n_items) next_chunk_v = HS_TAKE_CHUNK();                \
     }                                                                                    \
   }
