@@ -231,7 +231,7 @@ class Engine:
     OPTIONS = {"query_batch": 1, "seg_mode": 2, "join_resident": 3, "recognise_kmers": 4, "build_grouping": 5,
                "wide_rows": 6, "refine8": 7, "self_codes": 8, "sort_hits": 10, "sync_items": 11,
                "join_min_q": 12, "join_min_m": 13, "sort_from_bit": 14, "build_serial": 15,
-               "join_xcd_run": 16, "probe_records": 17}
+               "join_xcd_run": 16, "probe_records": 17, "join_chunk": 18}
 
     def set_option(self, name, value):
         """hs_set_option (include/hsearch.h hs_option): path selection / batch sizing; never changes a result."""

@@ -81,6 +81,7 @@ struct Knobs {
   bool build_serial = false;       // HS_BUILD_SERIAL: no hash / sort overlap in the build (measurement)
   int join_xcd_run = -1;           // HS_OPT_JOIN_XCD_RUN: chunks per XCD-local run of join items (0 off, -1 auto)
   bool no_probe_records = false;   // HS_OPT_PROBE_RECORDS = 0: the probe reads the directory arrays, not the records
+  uint32_t join_chunk = 0;         // HS_OPT_JOIN_CHUNK: items per counter access of hs_join8x_kernel (0: by itself)
   bool build_debug = false;        // HS_BUILD_DEBUG: say when a table is sorted a second time
   bool cluster_timing = false;     // HS_CLUSTER_TIMING: phase times of hs_self_join_range on stderr
   bool debug_refine = false;       // HS_DEBUG_REFINE: survivor counts per batch on stderr
@@ -428,7 +429,8 @@ const struct { const char* name; int option; } kOptionNames[] = {
     {"refine8", HS_OPT_REFINE8}, {"self_codes", HS_OPT_SELF_CODES},
     {"sort_hits", HS_OPT_SORT_HITS}, {"sync_items", HS_OPT_SYNC_ITEMS}, {"join_min_q", HS_OPT_JOIN_MIN_Q},
     {"join_min_m", HS_OPT_JOIN_MIN_M}, {"sort_from_bit", HS_OPT_SORT_FROM_BIT}, {"build_serial", HS_OPT_BUILD_SERIAL},
-    {"join_xcd_run", HS_OPT_JOIN_XCD_RUN}, {"probe_records", HS_OPT_PROBE_RECORDS}};
+    {"join_xcd_run", HS_OPT_JOIN_XCD_RUN}, {"probe_records", HS_OPT_PROBE_RECORDS},
+    {"join_chunk", HS_OPT_JOIN_CHUNK}};
 
 void read_knobs(hs_handle* h) {
   Knobs& kn = h->knobs;
@@ -722,6 +724,10 @@ hs_status hs_set_option(hs_handle* h, int option, int64_t value) {
       return HS_OK;
     case HS_OPT_BUILD_SERIAL: return flag(&kn.build_serial, false);
     case HS_OPT_PROBE_RECORDS: return flag(&kn.no_probe_records, true);
+    case HS_OPT_JOIN_CHUNK:
+      if (value != 0 && (value < 2 || value > 64)) break;
+      kn.join_chunk = (uint32_t)value;
+      return HS_OK;
     case HS_OPT_JOIN_XCD_RUN:
       if (value < -1 || value > 4096 || (value > 0 && (value & (value - 1)))) break;  // a power of two
       kn.join_xcd_run = (int)value;
@@ -2498,7 +2504,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
                                    rec8, h->c16s.p, jtab_rows, k, wide, d_cnt, prov_cap,
                                    h->prov.as<uint2>(), d_cnt + 32, h->n_cu * h->join_blocks_per_cu,
                                    use_r ? d_split : (async_items ? h->item_off.as<uint32_t>() + nqs : nullptr),
-                                   h->pairs_per_item, xcd_run, h->stream));
+                                   h->pairs_per_item, xcd_run, h->stream, h->knobs.join_chunk));
         if (use_r)
           HS_HIP(h, hs_launch_join8r(h->item_desc.as<uint4>(), n_items, d_split, h->tabs.t[0].packed,
                                      h->t_rho.as<uint32_t>(),

@@ -535,7 +535,7 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
                             const uint4* d_rec_base, const void* d_c8t, const void* d_tab8, int k, int wide,
                             uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov,
                             uint32_t* d_item_counter, int n_blocks, const uint32_t* d_n_items,
-                            double pairs_per_item, uint32_t xcd_run, hipStream_t s);
+                            double pairs_per_item, uint32_t xcd_run, hipStream_t s, uint32_t chunk = 0);
 // the item list's tail [d_split[0], d_split[1]) (segments with <= HS_JR_MAXQ probing queries; k <= 25,
 // 4-column rows) through the query-resident form; d_cn_rep = 128 copies of the gamma slots' constant
 // factors (HS_J8_CONST bytes); the packed / record arrays must be readable 128 entries past their end

@@ -2204,7 +2204,7 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
                             const uint4* d_rec_base, const void* d_c8t, const void* d_tab8, int k, int wide,
                             uint32_t* d_prov_count, uint32_t prov_cap, uint2* d_prov,
                             uint32_t* d_item_counter, int n_blocks, const uint32_t* d_n_items,
-                            double pairs_per_item, uint32_t xcd_run, hipStream_t s) {
+                            double pairs_per_item, uint32_t xcd_run, hipStream_t s, uint32_t chunk) {
   if (!n_items) return hipSuccess;
   // (*d_item_counter is zeroed by the caller, with the batch's other counters)
   // Chunk size = items per access to the global counter.  Same-address atomics complete at only
@@ -2219,7 +2219,7 @@ hipError_t hs_launch_join8w(const uint4* d_desc, uint32_t n_items, const uint4* 
   // up to 8: at least 8 chunks per wave; beyond: at least 64 (the balance at the end is paid in
   // chunks: k = 39 at the C2 sizes, 576 items per wave, lost 3 % with chunks of 18)
   const uint32_t g_small = std::min(8u, n_items / (n_waves * 8u));
-  const uint32_t G = std::max(2u, std::min(g_max, std::max(g_small, n_items / (n_waves * 64u))));
+  const uint32_t G = chunk ? chunk : std::max(2u, std::min(g_max, std::max(g_small, n_items / (n_waves * 64u))));
   // k <= 25: JT = 4 row tiles per wave (128 members), 4 k-steps, 2 waves per SIMD.  (JT = 2 at 4
   // waves per SIMD, with work items of 64 members, was measured 1.7x slower there: twice the B-tile
   // traffic and per-item work.)  k > 25: 64 members per wave over 6 or 8 k-steps -- the operands of

@@ -168,6 +168,8 @@ typedef enum hs_option {
   HS_OPT_PROBE_RECORDS = 17, /* 1 (default): a probe reads one 64-byte directory record per bucket (fingerprint,
                                 boundaries, the bucket ints as int16) where the index has them -- K <= 24 and
                                 every bucket int of the table within 16 bits; 0: the directory arrays */
+  HS_OPT_JOIN_CHUNK = 18,    /* work items a wave of hs_join8x_kernel takes per access to the item counters (2..64);
+                                0 (default): from the previous batch's pairs per item */
   HS_OPT_JOIN_XCD_RUN = 16   /* hs_join8x_kernel's work items dealt in runs of this many chunks per XCD, each XCD's
                                 waves on their own runs (a run's items stream the same query tiles: one L2 fetches
                                 them instead of eight).  0: one counter for the chip; -1 (default): by the size

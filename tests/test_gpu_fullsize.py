@@ -186,12 +186,19 @@ def test_config3_shape_properties():
     again = eng.query_codes(qcodes_all, R, cap=4 * nq_all, want_cand=False)
     for f in ("q", "id", "table", "dist"):
         assert np.array_equal(again[f], big[f]), f
-    for xr in (1, 1024, 0):   # ... nor the length of the XCD-local runs the join's work items are dealt in
+    # ... nor the length of the XCD-local runs the join's work items are dealt in, nor the chunk size -- chosen so
+    # that the chunk straddling the end of hs_join8x_kernel's share of the items has an empty tail of ONE or TWO
+    # items, the case that lost chunks
+    pr = eng.profile()
+    share = pr["join_items"] - pr["join_items_resident"]
+    chunks = [g for g in range(8, 65) if (-share) % g in (1, 2)][:3] + [0]
+    assert len(chunks) >= 2
+    for xr, g in [(1, chunks[0]), (128, chunks[0]), (1024, chunks[1]), (0, chunks[0]), (-1, chunks[-2]), (-1, 0)]:
         eng.set_option("join_xcd_run", xr)
+        eng.set_option("join_chunk", g)
         other = eng.query_codes(qcodes_all, R, cap=4 * nq_all, want_cand=False)
         for f in ("q", "id", "table", "dist"):
-            assert np.array_equal(other[f], big[f]), (xr, f)
-    eng.set_option("join_xcd_run", -1)
+            assert np.array_equal(other[f], big[f]), (xr, g, f)
     bq, bi, bt = big["q"].astype(np.int64), big["id"].astype(np.int64), big["table"].astype(np.int64)
     assert np.all(np.diff((bq << 40) | (bt << 32) | bi) > 0)
     sel = np.random.default_rng(1).choice(len(bq), size=20000, replace=False)
