@@ -75,6 +75,8 @@ def test_random_configuration_matches_oracle(oracle, seed):
     opts = dict(join_min_q=3, join_min_m=16) if seed % 3 == 0 else dict(join_resident=2 * (seed % 2))
     if seed % 4 == 1:
         opts["recognise_kmers"] = 0
+    if seed % 5 == 2:      # hs_join8x_kernel's items in XCD-local runs of one chunk of 2..4 items (on by itself only for big batches)
+        opts.update(join_xcd_run=1, join_chunk=2 + seed % 3)
     # (HS_TEST_SPLIT_ABOVE in the environment: the library's test build, which has that hook)
     eng = Engine(c["k"], c["K"], c["L"], c["W"], c["a"], c["b"], coords=c["table"],
                  hooks=bool(os.environ.get("HS_TEST_SPLIT_ABOVE")), options=opts)

@@ -925,7 +925,10 @@ def test_query_resident_and_query_streaming_join_kernels(oracle, K, W, nq):
     # batches) -- with this few items most XCDs find their runs dry at once and take from their neighbours'
     routings = {"default": dict(join_resident=2), "no_r": dict(join_resident=1),
                 "batches": dict(join_resident=2, query_batch=257),
-                "no_r_xcd_runs": dict(join_resident=1, join_xcd_run=1), "xcd_runs": dict(join_resident=2, join_xcd_run=4)}
+                "no_r_xcd_runs": dict(join_resident=1, join_xcd_run=1), "xcd_runs": dict(join_resident=2, join_xcd_run=4),
+                # chunks of two / three work items per counter access: item lists that end one or two short of a chunk
+                "no_r_xcd_runs_chunk3": dict(join_resident=1, join_xcd_run=2, join_chunk=3),
+                "xcd_runs_chunk2": dict(join_resident=2, join_xcd_run=1, join_chunk=2)}
     for routing, opts in routings.items():
         eng = Engine(k, K, L, W, a, b, options=opts)
         eng.index_build(codes)
@@ -942,6 +945,7 @@ def test_query_resident_and_query_streaming_join_kernels(oracle, K, W, nq):
     assert seen["default"][0] == seen["no_r"][0] and seen["default"][1] <= seen["no_r"][1]
     assert seen["no_r"][2] == 0 and (seen["default"][2] > 0 or K < 5)
     assert seen["no_r_xcd_runs"] == seen["no_r"] and seen["xcd_runs"] == seen["default"]
+    assert seen["no_r_xcd_runs_chunk3"] == seen["no_r"] and seen["xcd_runs_chunk2"] == seen["default"]
 
 
 @pytest.mark.parametrize("k,K,L,W,n", [(25, 16, 4, 200.0, 300007), (25, 4, 3, 0.5, 50021), (15, 3, 5, 60.0, 4099),
