@@ -948,6 +948,38 @@ def test_query_resident_and_query_streaming_join_kernels(oracle, K, W, nq):
     assert seen["no_r_xcd_runs_chunk3"] == seen["no_r"] and seen["xcd_runs_chunk2"] == seen["default"]
 
 
+def test_join_work_items_dealt_in_any_chunks_and_runs():
+    """hs_join8x_kernel hands its work items to persistent waves in chunks (option join_chunk) from one counter
+    or from one counter per XCD in runs of join_xcd_run chunks; a wave stops when it meets an item number past the
+    end of the list.  Whatever the chunk size, the run length and the length of the list's last, partial chunk --
+    here every tail length comes up: the item count is fixed, the chunk sizes run from 2 to 64 -- the same hits.
+    A few hundred thousand items: every wave of the grid takes many chunks, the XCDs run dry at different times
+    and take from each other.  (r04: a wave that walked an empty tail shorter than its look-ahead left with two
+    valid chunks of another XCD unprocessed.)"""
+    k, K, L, W, R, n, nq = 25, 6, 4, 170.0, 42.0, 8_000_003, 80_000
+    a, b = synth.make_planes(k, K, L, W, seed=141)
+    codes = synth.make_db(n, k, seed=142)
+    qcodes, _ = synth.make_query_codes(codes, nq, seed=143)
+    eng = Engine(k, K, L, W, a, b)
+    eng.index_build(codes)
+    ref, items = None, None
+    for resident in (1, 2):          # everything through hs_join8x_kernel | its share beside hs_join8r_kernel's
+        eng.set_option("join_resident", resident)
+        for xr in (0, 1, 8, 128):
+            for g in (0, 2, 3, 5, 7, 12, 17, 31, 48, 64):
+                eng.set_option("join_xcd_run", xr)
+                eng.set_option("join_chunk", g)
+                got = eng.query_codes(qcodes, R, want_cand=False)
+                p = eng.profile()
+                if ref is None:
+                    ref = got
+                    assert len(ref["q"]) > 10_000 and p["join_items"] > 100_000
+                assert p["join_i8_batches"] == 1
+                for f in ("q", "id", "table", "dist"):
+                    assert np.array_equal(got[f], ref[f]), (resident, xr, g, f)
+    eng.close()
+
+
 @pytest.mark.parametrize("k,K,L,W,n", [(25, 16, 4, 200.0, 300007), (25, 4, 3, 0.5, 50021), (15, 3, 5, 60.0, 4099),
                                        (25, 20, 3, 160.0, 1), (39, 6, 2, 260.0, 70001), (25, 1, 2, 1.0e6, 9001)])
 def test_grouping_by_rank_equals_grouping_by_sort(oracle, tmp_path, k, K, L, W, n):
