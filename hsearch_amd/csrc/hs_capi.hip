@@ -1225,9 +1225,12 @@ static hs_status build_tables(hs_handle* h, uint32_t seed, bool* collided) {
 }
 
 // the tables as the probe kernel gets them: without the directory records when the option says so
-static hs_tables_dev probe_tabs(const hs_handle* h, uint32_t q_first) {
+static hs_tables_dev probe_tabs(const hs_handle* h, uint32_t q_first, const uint32_t* probe_list = nullptr,
+                                uint32_t n_list = 0) {
   hs_tables_dev t = h->tabs;
   t.q_first = q_first;
+  t.probe_list = probe_list;
+  t.n_list = n_list;
   if (h->knobs.no_probe_records)
     for (int l = 0; l < HS_MAX_L; ++l) t.t[l].dir_rec = nullptr;
   t.part = h->self_first == HS_NO_SELF ? h->bucket_part : 0u;  // (searches only, not the self-joins)
@@ -1280,7 +1283,7 @@ static hs_status finish_index(hs_handle* h) {
     HS_HIP(h, hipMemsetAsync(d_ng, 0, HS_MAX_L * 4, h->stream));
     const uint32_t thr = hs_giant_threshold(h->n);
     for (uint32_t l = 0; l < h->p.L; ++l)
-      HS_HIP(h, hs_launch_giant_buckets(h->t_dirkey[l].as<uint64_t>(), h->t_dirstart[l].as<uint32_t>(),
+      HS_HIP(h, hs_launch_giant_buckets(h->t_dirtuple[l].as<int32_t>(), (int)h->p.K, h->t_dirstart[l].as<uint32_t>(),
                                         (uint32_t)h->info.n_buckets[l], thr, h->t_giant.as<uint64_t>() + (size_t)l * GCAP,
                                         GCAP, d_ng + l, h->stream));
     uint32_t ng[HS_MAX_L];
@@ -2188,6 +2191,8 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
   const bool parted = h->bucket_parts > 1 && h->self_first == HS_NO_SELF;  // (searches only, not the self-joins)
   if (parted) seg_sparse = true;
   uint32_t nqs = nql;  // probes the grouping works on (bucket partition: the ones that found a bucket)
+  const uint32_t* owned_list = nullptr;  // bucket partition: the probes of this part, ascending (device)
+  uint32_t n_owned = 0;
   if (h->knobs.seg_mode) seg_sparse = h->knobs.seg_mode == 1;
   const bool self_codes = h->self_first != HS_NO_SELF && !brute && use_i8 && self_codes_ok(h, R);
   const uint8_t* d_qcodes =
@@ -2273,13 +2278,29 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
                                      reinterpret_cast<unsigned long long*>(d_cnt + 2),
                                      h->dir_base.as<uint32_t>(), h->nb_total, bucket_count, qbucket, qrank,
                                      h->stream));
-    else
-      HS_HIP(h, hs_launch_probe(probe_tabs(h, q_base), h->qints.as<int32_t>(), nq, K, L, h->key_seed,
+    else {
+      // bucket partition with a join ahead: the part's own probes (by their bucket ints alone) are listed first,
+      // and only those -- 1 / n_parts of the batch -- pay for a fingerprint and a walk of the directory
+      if (parted && use_join) {
+        const size_t n1 = (size_t)nql + 1;
+        HS_HIP(h, h->part_work.reserve(5 * n1 * 4));
+        uint32_t* const pw = h->part_work.as<uint32_t>();
+        HS_HIP(h, hs_launch_part_owned(probe_tabs(h, q_base), h->qints.as<int32_t>(), nq, K, L, h->nb_total, pw,
+                                       h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(), h->nslices.as<uint32_t>(),
+                                       d_cand, qbucket, h->stream));
+        HS_HIP(h, hs_exclusive_scan_u32(h->temp.p, h->temp.cap, pw, pw + n1, n1, h->stream));
+        HS_HIP(h, hs_launch_flagged_list(pw, pw + n1, nql, pw + 4 * n1, h->stream));
+        HS_HIP(h, hipMemcpyAsync(&n_owned, pw + n1 + nql, 4, hipMemcpyDeviceToHost, h->stream));
+        HS_HIP(h, hipStreamSynchronize(h->stream));
+        owned_list = pw + 4 * n1;
+      }
+      HS_HIP(h, hs_launch_probe(probe_tabs(h, q_base, owned_list, n_owned), h->qints.as<int32_t>(), nq, K, L, h->key_seed,
                                 h->qstart.as<uint32_t>(), h->qcount.as<uint32_t>(),
                                 h->nslices.as<uint32_t>(), d_cand,
                                 reinterpret_cast<unsigned long long*>(d_cnt + 2),
                                 h->probe_slow.as<uint32_t>(), h->dir_base.as<uint32_t>(), h->nb_total,
                                 bucket_count, qbucket, qrank, h->stream));
+    }
   }
   unsigned long long* d_jstats = reinterpret_cast<unsigned long long*>(d_cnt + 10);
   uint32_t n_items = 0, n_slices = 1, jm = HS_JM_BLOCK;
@@ -2308,12 +2329,15 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
       const uint32_t* keys_in = h->seg_keys.as<uint32_t>();
       const uint32_t* probes_in = nullptr;
       if (parted) {
-        HS_HIP(h, h->part_work.reserve(4 * n1 * 4));
+        HS_HIP(h, h->part_work.reserve(5 * n1 * 4));
         uint32_t* const pw = h->part_work.as<uint32_t>();
-        HS_HIP(h, hs_launch_found_probes(h->seg_keys.as<uint32_t>(), nql, h->nb_total, h->temp.p, h->temp.cap, pw,
-                                         pw + n1, pw + 2 * n1, pw + 3 * n1, h->stream));
+        const uint32_t n_cand = owned_list ? n_owned : nql;  // (the part's own probes, listed ahead of the probe kernel)
         uint32_t n_found = 0;
-        HS_HIP(h, hipMemcpyAsync(&n_found, pw + n1 + nql, 4, hipMemcpyDeviceToHost, h->stream));
+        if (n_cand) {
+          HS_HIP(h, hs_launch_found_probes(h->seg_keys.as<uint32_t>(), n_cand, h->nb_total, h->temp.p, h->temp.cap, pw,
+                                           pw + n1, pw + 2 * n1, pw + 3 * n1, h->stream, owned_list));
+          HS_HIP(h, hipMemcpyAsync(&n_found, pw + n1 + n_cand, 4, hipMemcpyDeviceToHost, h->stream));
+        }
         HS_HIP(h, hipStreamSynchronize(h->stream));
         if (n_found) {  // (none at all: the batch goes on as one of probes that found nothing)
           nqs = n_found;

@@ -131,8 +131,8 @@ struct hs_table_dev {
   const uint32_t* ids;       // [n] DB ids in bucket order (ascending inside a bucket)
   const uint32_t* pos_of;    // [n] inverse of ids: sorted position of DB id i in this table
   const uint32_t* dir_jump;  // [2^J + 1] first directory entry whose fingerprint's top J bits are >= the slot
-  const uint64_t* giant_key; // [n_giant] ascending fingerprints of the buckets with more than HS_GIANT members
-  uint32_t n_giant;          // (bucket partition: those are shared among the parts by QUERY, hs_probe_part)
+  const uint64_t* giant_key; // [n_giant] ascending TUPLE HASHES (hs_tuple_hash of the bucket ints) of the buckets with
+  uint32_t n_giant;          // more than hs_giant_threshold members (bucket partition: shared among the parts by QUERY)
   const uint4* dir_rec;      // [nb][4] or null: one 64-byte line per bucket with all a probe reads of it --
                              // {fingerprint, start, count} and the K <= HS_REC_MAX_K bucket ints as int16
                              // (null: K larger, an int outside 16 bits, or the option is off)
@@ -143,17 +143,32 @@ struct hs_tables_dev {
   hs_table_dev t[HS_MAX_L];
   // bucket partition (hs_set_bucket_partition): the probe kernel looks only for the (query, bucket) probes
   // that fall to `part` of `n_parts` (hs_probe_part); n_parts <= 1: all of them.  q_first: number, in the
-  // call, of the batch's first query.
+  // call, of the batch's first query.  probe_list != null: the kernel probes these n_list (query, table) pairs
+  // only -- the part's own, found ahead of it (hs_launch_part_owned).
   uint32_t part, n_parts, q_first;
+  const uint32_t* probe_list;
+  uint32_t n_list;
 };
-// The part a probe belongs to, of n_parts: a function of the bucket's fingerprint -- every rank the same
-// answer, the parts even whatever the tables look like -- and, for the few GIANT buckets alone, of the query's
-// number in the call as well: a table's largest buckets each hold per cents of all (member, query) pairs
-// (configs[2]: 600 buckets of > 10^5 members hold half of them), and whole they would land on the parts like
-// rocks; shared by query every part gets its n-th of each.
-__host__ __device__ inline uint32_t hs_probe_part(uint64_t key, bool giant, uint32_t q, uint32_t n_parts) {
-  if (giant) key ^= (uint64_t)(q + 1u) * 0x9e3779b97f4a7c15ull;
-  return (uint32_t)(((key >> 20) & 0xffffffffull) % n_parts);
+// A cheap hash of a probe's K bucket ints (t[0], t[stride], ...): what decides the part of a probe.  (Not the
+// key fingerprint: that one walks the decimal characters of every int, ~ 10 x the instructions, and seven
+// probes in eight of a batch belong to other parts.  Tuples whose key STRINGS coincide may fall to different
+// parts -- each probe still belongs to exactly one.)
+__host__ __device__ inline uint64_t hs_tuple_hash(const int32_t* t, int K, int stride) {
+  uint64_t h = 0x243f6a8885a308d3ull;
+  for (int j = 0; j < K; ++j) {
+    h = (h ^ (uint32_t)t[(size_t)j * stride]) * 0x9e3779b97f4a7c15ull;
+    h ^= h >> 29;
+  }
+  return h;
+}
+// The part a probe belongs to, of n_parts: a function of its bucket ints -- every rank the same answer, the
+// parts even whatever the tables look like -- and, for the few GIANT buckets alone, of the query's number in
+// the call as well: a table's largest buckets each hold per cents of all (member, query) pairs (configs[2]:
+// 600 buckets of > 10^5 members hold half of them), and whole they would land on the parts like rocks; shared
+// by query every part gets its n-th of each.
+__host__ __device__ inline uint32_t hs_probe_part(uint64_t tuple_hash, bool giant, uint32_t q, uint32_t n_parts) {
+  if (giant) tuple_hash ^= (uint64_t)(q + 1u) * 0x9e3779b97f4a7c15ull;
+  return (uint32_t)(((tuple_hash >> 20) & 0xffffffffull) % n_parts);
 }
 // more members than this make a bucket a giant (n = k-mers of the index)
 static inline uint32_t hs_giant_threshold(uint64_t n) { return (uint32_t)(n / 1024 > 4096 ? n / 1024 : 4096); }
@@ -318,10 +333,19 @@ hipError_t hs_launch_validate_table(const uint32_t* d_ids, uint32_t n, uint32_t*
                                     const uint32_t* d_dir_start, const uint64_t* d_dir_key,
                                     const int32_t* d_dir_tuple, uint32_t nb, int K, uint32_t seed,
                                     uint32_t* d_flag, uint32_t* d_max_bucket, hipStream_t s);
-// the fingerprints of the buckets with more than `threshold` members, unordered: d_out[atomicAdd(d_count, 1)]
+// the tuple hashes of the buckets with more than `threshold` members, unordered: d_out[atomicAdd(d_count, 1)]
 // while the count stays below cap (the count keeps running: the caller sees an overflow)
-hipError_t hs_launch_giant_buckets(const uint64_t* d_dir_key, const uint32_t* d_dir_start, uint32_t nb,
+hipError_t hs_launch_giant_buckets(const int32_t* d_dir_tuple, int K, const uint32_t* d_dir_start, uint32_t nb,
                                    uint32_t threshold, uint64_t* d_out, uint32_t cap, uint32_t* d_count, hipStream_t s);
+// Bucket partition, ahead of the probe: d_flag[ql] = 1 where probe ql = (query, table) belongs to tabs.part (by
+// its bucket ints alone: no fingerprint, no directory); the outputs of the probe kernel are cleared for the
+// others (d_qbucket[ql] = nb_total: found nothing).  d_flag[nq * L] = 0.
+hipError_t hs_launch_part_owned(const hs_tables_dev& tabs, const int32_t* d_qints, uint32_t nq, int K, int L,
+                                uint32_t nb_total, uint32_t* d_flag, uint32_t* d_qstart, uint32_t* d_qcount,
+                                uint32_t* d_nslices, uint64_t* d_cand_out, uint32_t* d_qbucket, hipStream_t s);
+// d_list[d_pos[i]] = i where d_flag[i] (d_pos = exclusive scan of d_flag)
+hipError_t hs_launch_flagged_list(const uint32_t* d_flag, const uint32_t* d_pos, uint32_t n, uint32_t* d_list,
+                                  hipStream_t s);
 #define HS_REC_MAX_K 24
 // rec[b] = {key[b], start[b], start[b + 1] - start[b]; int16 tuple[b][0..K)}; *d_flag |= 1 where an int does not fit
 hipError_t hs_launch_dir_records(const uint64_t* d_dir_key, const uint32_t* d_dir_start, const int32_t* d_dir_tuple,
@@ -353,11 +377,12 @@ hipError_t hs_launch_seg_group_sparse(const hs_tables_dev& tabs, const uint32_t*
                                       uint64_t* d_seg_key, uint32_t* d_seg_cnt, uint32_t* d_n_seg,
                                       uint32_t* d_seg_of /* [nql]: segment of every sorted probe position */,
                                       hipStream_t s, const uint32_t* d_probes_in = nullptr);
-// bucket partition: the probes that found a bucket (d_qbucket[i] != nb_total), in probe order, as (bucket,
-// probe) pairs d_keys / d_probes; d_pos[nql] = their number.  d_flag, d_pos: nql + 1 words.
+// bucket partition: the probes that found a bucket (d_qbucket[ql] != nb_total), in probe order, as (bucket,
+// probe) pairs d_keys / d_probes; d_pos[nql] = their number.  d_flag, d_pos: nql + 1 words.  d_list != null: only
+// the nql probes d_list[0 .. nql) (ascending) are looked at.
 hipError_t hs_launch_found_probes(const uint32_t* d_qbucket, uint32_t nql, uint32_t nb_total, void* d_temp,
                                   size_t temp_bytes, uint32_t* d_flag, uint32_t* d_pos, uint32_t* d_keys,
-                                  uint32_t* d_probes, hipStream_t s);
+                                  uint32_t* d_probes, hipStream_t s, const uint32_t* d_list = nullptr);
 hipError_t hs_launch_seg_group(const hs_tables_dev& tabs, const uint32_t* d_dir_base, int L, int shift,
                                uint32_t nb_total, const uint32_t* d_bucket_count,
                                uint32_t* d_bucket_work /* 3 x (nb_total + 2) */, void* d_temp,

@@ -681,29 +681,33 @@ hipError_t hs_launch_seg_group(const hs_tables_dev& tabs, const uint32_t* d_dir_
 // Bucket partition: most probes of a batch find nothing (their bucket belongs to another part).  The ones
 // that did, in probe order: flag -> exclusive scan -> (bucket, probe) pairs; the grouping then sorts and walks
 // those alone (d_pos[nql] = their number).
-__global__ __launch_bounds__(256) void hs_found_flags_kernel(const uint32_t* __restrict__ qbucket, uint32_t nql,
+// (list != null: the n candidates are the probes list[0 .. n), ascending; else the probes 0 .. n - 1)
+__global__ __launch_bounds__(256) void hs_found_flags_kernel(const uint32_t* __restrict__ qbucket,
+                                                             const uint32_t* __restrict__ list, uint32_t n,
                                                              uint32_t nb_total, uint32_t* __restrict__ flag) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i <= nql) flag[i] = i < nql && qbucket[i] != nb_total;
+  if (i <= n) flag[i] = i < n && qbucket[list ? list[i] : i] != nb_total;
 }
-__global__ __launch_bounds__(256) void hs_found_scatter_kernel(const uint32_t* __restrict__ qbucket, uint32_t nql,
+__global__ __launch_bounds__(256) void hs_found_scatter_kernel(const uint32_t* __restrict__ qbucket,
+                                                               const uint32_t* __restrict__ list, uint32_t n,
                                                                uint32_t nb_total, const uint32_t* __restrict__ pos,
                                                                uint32_t* __restrict__ keys, uint32_t* __restrict__ probes) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= nql) return;
-  const uint32_t gb = qbucket[i];
+  if (i >= n) return;
+  const uint32_t ql = list ? list[i] : i;
+  const uint32_t gb = qbucket[ql];
   if (gb == nb_total) return;
   keys[pos[i]] = gb;
-  probes[pos[i]] = i;
+  probes[pos[i]] = ql;
 }
 hipError_t hs_launch_found_probes(const uint32_t* d_qbucket, uint32_t nql, uint32_t nb_total, void* d_temp,
                                   size_t temp_bytes, uint32_t* d_flag, uint32_t* d_pos, uint32_t* d_keys,
-                                  uint32_t* d_probes, hipStream_t s) {
+                                  uint32_t* d_probes, hipStream_t s, const uint32_t* d_list) {
   if (!nql) return hipSuccess;
-  hs_found_flags_kernel<<<blocks_for((uint64_t)nql + 1), 256, 0, s>>>(d_qbucket, nql, nb_total, d_flag);
+  hs_found_flags_kernel<<<blocks_for((uint64_t)nql + 1), 256, 0, s>>>(d_qbucket, d_list, nql, nb_total, d_flag);
   hipError_t e = hs_exclusive_scan_u32(d_temp, temp_bytes, d_flag, d_pos, (size_t)nql + 1, s);
   if (e != hipSuccess) return e;
-  hs_found_scatter_kernel<<<blocks_for(nql), 256, 0, s>>>(d_qbucket, nql, nb_total, d_pos, d_keys, d_probes);
+  hs_found_scatter_kernel<<<blocks_for(nql), 256, 0, s>>>(d_qbucket, d_list, nql, nb_total, d_pos, d_keys, d_probes);
   return hipGetLastError();
 }
 

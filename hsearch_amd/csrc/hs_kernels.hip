@@ -358,7 +358,9 @@ __global__ __launch_bounds__(256) void hs_probe_kernel(hs_tables_dev tabs,
   // the K bucket ints of a probe are fetched with 16-byte loads, all in flight at once, and parked
   // in LDS (s_t[j][thread]: conflict-free), instead of K loads one after the other.
   __shared__ int32_t s_t[HS_MAX_K * 256];
-  const uint32_t ql = blockIdx.x * 256 + threadIdx.x;
+  // (bucket partition with the part's probes listed ahead of the kernel: one thread per list entry)
+  const uint32_t slot_ = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t ql = tabs.probe_list ? (slot_ < tabs.n_list ? tabs.probe_list[slot_] : 0xffffffffu) : slot_;
   uint32_t count = 0, start = 0;
   // grouping of the probes by bucket (for the bucket join): global bucket number and arrival rank;
   // nb_total = the pseudo-bucket of probes that found none
@@ -385,25 +387,27 @@ __global__ __launch_bounds__(256) void hs_probe_kernel(hs_tables_dev tabs,
     } else {
       for (int j = 0; j < K; ++j) t[256 * j] = tg[j];
     }
+    const hs_table_dev& tb = tabs.t[l];
+    // (bucket partition: a probe of another part is not looked for -- as if the table did not have the bucket;
+    // with a probe list the part's own probes were picked ahead of this kernel, by the same rule)
+    bool mine = true;
+    if (tabs.n_parts > 1u && !tabs.probe_list) {
+      const uint64_t th = hs_tuple_hash(t, K, 256);
+      uint32_t glo = 0, ghi = tb.n_giant;
+      while (glo < ghi) {
+        const uint32_t mid = (glo + ghi) >> 1;
+        if (tb.giant_key[mid] < th) glo = mid + 1; else ghi = mid;
+      }
+      const bool giant = glo < tb.n_giant && tb.giant_key[glo] == th;
+      mine = hs_probe_part(th, giant, tabs.q_first + ql / (uint32_t)L, tabs.n_parts) == tabs.part;
+    }
     uint64_t hk = hs_key_init(seed);
     for (int j = 0; j < K; ++j) hk = hs_key_put_int(hk, t[256 * j]);
     const uint64_t key = hs_key_fin(hk);
-    const hs_table_dev& tb = tabs.t[l];
     // fingerprints are uniform: their top J bits (2^J >= nb) index a jump table that leaves about
     // one directory entry to look at, instead of log2(nb) dependent round trips
     const uint32_t slot = (uint32_t)(key >> tb.jump_shift);
     uint32_t lo = 0, hi = 0;
-    // (bucket partition: a probe of another part is not looked for -- as if the table did not have the bucket)
-    bool mine = true;
-    if (tabs.n_parts > 1u) {
-      uint32_t glo = 0, ghi = tb.n_giant;
-      while (glo < ghi) {
-        const uint32_t mid = (glo + ghi) >> 1;
-        if (tb.giant_key[mid] < key) glo = mid + 1; else ghi = mid;
-      }
-      const bool giant = glo < tb.n_giant && tb.giant_key[glo] == key;
-      mine = hs_probe_part(key, giant, tabs.q_first + ql / (uint32_t)L, tabs.n_parts) == tabs.part;
-    }
     if (mine) {
       lo = tb.dir_jump[slot];
       hi = tb.dir_jump[slot + 1];
@@ -1881,7 +1885,8 @@ hipError_t hs_launch_probe(const hs_tables_dev& tabs, const int32_t* d_qints, ui
     e = hipMemsetAsync(d_bucket_count, 0, ((size_t)nb_total + 2) * 4, s);
     if (e != hipSuccess) return e;
   }
-  hs_probe_kernel<<<blocks_for((uint64_t)nq * L), 256, 0, s>>>(
+  if (tabs.probe_list && !tabs.n_list) return hipSuccess;  // (a part without a probe in this batch)
+  hs_probe_kernel<<<blocks_for(tabs.probe_list ? (uint64_t)tabs.n_list : (uint64_t)nq * L), 256, 0, s>>>(
       tabs, d_qints, nq, K, L, seed, d_qstart, d_qcount, d_nslices, d_cand_out, d_cand_total, d_slow,
       d_dir_base, nb_total, d_bucket_count, d_qbucket, d_qrank);
   hs_probe_slow_kernel<<<64, 256, 0, s>>>(tabs, d_qints, K, L, seed, d_qstart, d_qcount, d_nslices,
@@ -2079,19 +2084,102 @@ hipError_t hs_launch_klsh(const uint8_t* d_classes, const uint64_t* d_seq_start,
   return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void hs_giant_buckets_kernel(const uint64_t* __restrict__ key,
+__global__ __launch_bounds__(256) void hs_giant_buckets_kernel(const int32_t* __restrict__ tuple, int K,
                                                                const uint32_t* __restrict__ start, uint32_t nb,
                                                                uint32_t threshold, uint64_t* __restrict__ out,
                                                                uint32_t cap, uint32_t* __restrict__ count) {
   const uint32_t b = blockIdx.x * 256 + threadIdx.x;
   if (b >= nb || start[b + 1] - start[b] <= threshold) return;
   const uint32_t at = atomicAdd(count, 1u);
-  if (at < cap) out[at] = key[b];
+  if (at < cap) out[at] = hs_tuple_hash(tuple + (uint64_t)b * K, K, 1);
 }
-hipError_t hs_launch_giant_buckets(const uint64_t* d_dir_key, const uint32_t* d_dir_start, uint32_t nb,
+hipError_t hs_launch_giant_buckets(const int32_t* d_dir_tuple, int K, const uint32_t* d_dir_start, uint32_t nb,
                                    uint32_t threshold, uint64_t* d_out, uint32_t cap, uint32_t* d_count, hipStream_t s) {
   if (!nb) return hipSuccess;
-  hs_giant_buckets_kernel<<<blocks_for(nb), 256, 0, s>>>(d_dir_key, d_dir_start, nb, threshold, d_out, cap, d_count);
+  hs_giant_buckets_kernel<<<blocks_for(nb), 256, 0, s>>>(d_dir_tuple, K, d_dir_start, nb, threshold, d_out, cap, d_count);
+  return hipGetLastError();
+}
+
+// Bucket partition, first pass over a batch's probes: whose is it?  From the bucket ints alone (hs_tuple_hash:
+// ~ 1/10 of the fingerprint's instructions); a probe of another part gets the outputs of a probe that found
+// nothing.  The part's own probes then go through hs_probe_kernel as a list (1 / n_parts of the batch).
+__global__ __launch_bounds__(256) void hs_part_owned_kernel(hs_tables_dev tabs, const int32_t* __restrict__ qints,
+                                                            uint32_t nq, int K, int L, uint32_t nb_total,
+                                                            uint32_t* __restrict__ flag, uint32_t* __restrict__ qstart,
+                                                            uint32_t* __restrict__ qcount, uint32_t* __restrict__ nslices,
+                                                            uint64_t* __restrict__ cand_out,
+                                                            uint32_t* __restrict__ qbucket) {
+  const uint32_t ql = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t nql = nq * (uint32_t)L;
+  if (ql > nql) return;
+  if (ql == nql) {
+    flag[ql] = 0;
+    return;
+  }
+  const int l = (int)(ql % (uint32_t)L);
+  const int32_t* tg = qints + (uint64_t)ql * K;
+  uint64_t th;
+  if ((K & 3) == 0) {  // 16-byte loads, all in flight at once
+    int4 v[HS_MAX_K / 4];
+#pragma unroll
+    for (int j4 = 0; j4 < HS_MAX_K / 4; ++j4)
+      if (4 * j4 < K) v[j4] = reinterpret_cast<const int4*>(tg)[j4];
+    int32_t t[HS_MAX_K];
+#pragma unroll
+    for (int j4 = 0; j4 < HS_MAX_K / 4; ++j4)
+      if (4 * j4 < K) {
+        t[4 * j4] = v[j4].x;
+        t[4 * j4 + 1] = v[j4].y;
+        t[4 * j4 + 2] = v[j4].z;
+        t[4 * j4 + 3] = v[j4].w;
+      }
+    uint64_t h = 0x243f6a8885a308d3ull;
+#pragma unroll
+    for (int j = 0; j < HS_MAX_K; ++j)
+      if (j < K) {
+        h = (h ^ (uint32_t)t[j]) * 0x9e3779b97f4a7c15ull;
+        h ^= h >> 29;
+      }
+    th = h;
+  } else {
+    th = hs_tuple_hash(tg, K, 1);
+  }
+  const hs_table_dev& tb = tabs.t[l];
+  uint32_t glo = 0, ghi = tb.n_giant;
+  while (glo < ghi) {
+    const uint32_t mid = (glo + ghi) >> 1;
+    if (tb.giant_key[mid] < th) glo = mid + 1; else ghi = mid;
+  }
+  const bool giant = glo < tb.n_giant && tb.giant_key[glo] == th;
+  const bool mine = hs_probe_part(th, giant, tabs.q_first + ql / (uint32_t)L, tabs.n_parts) == tabs.part;
+  flag[ql] = mine ? 1u : 0u;
+  if (!mine) {
+    qstart[ql] = 0;
+    qcount[ql] = 0;
+    nslices[ql] = 0;
+    if (cand_out) cand_out[ql] = 0;
+    if (qbucket) qbucket[ql] = nb_total;
+  }
+}
+hipError_t hs_launch_part_owned(const hs_tables_dev& tabs, const int32_t* d_qints, uint32_t nq, int K, int L,
+                                uint32_t nb_total, uint32_t* d_flag, uint32_t* d_qstart, uint32_t* d_qcount,
+                                uint32_t* d_nslices, uint64_t* d_cand_out, uint32_t* d_qbucket, hipStream_t s) {
+  if (!nq) return hipSuccess;
+  hs_part_owned_kernel<<<blocks_for((uint64_t)nq * L + 1), 256, 0, s>>>(tabs, d_qints, nq, K, L, nb_total, d_flag,
+                                                                          d_qstart, d_qcount, d_nslices, d_cand_out,
+                                                                          d_qbucket);
+  return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void hs_flagged_list_kernel(const uint32_t* __restrict__ flag,
+                                                              const uint32_t* __restrict__ pos, uint32_t n,
+                                                              uint32_t* __restrict__ list) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n && flag[i]) list[pos[i]] = i;
+}
+hipError_t hs_launch_flagged_list(const uint32_t* d_flag, const uint32_t* d_pos, uint32_t n, uint32_t* d_list,
+                                  hipStream_t s) {
+  if (!n) return hipSuccess;
+  hs_flagged_list_kernel<<<blocks_for(n), 256, 0, s>>>(d_flag, d_pos, n, d_list);
   return hipGetLastError();
 }
 
