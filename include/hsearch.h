@@ -178,10 +178,10 @@ typedef enum hs_option {
 HS_API hs_status hs_set_option(hs_handle* h, int option, int64_t value);
 /* Bucket partition -- unlike the options above this CHANGES what a query call returns.  With n_parts > 1 the
  * searches of this handle (hs_query*, not the self-joins) probe only the buckets that fall to `part` of
- * `n_parts` (a fixed function of the bucket's key fingerprint, the same on every handle with the same key
- * seed; for the few buckets of more than max(4096, n / 1024) members a function of the fingerprint AND of the
- * query's number in the call, so that a giant bucket's queries are shared among the parts instead of the bucket
- * landing on one of them): the loop over tables and buckets of motif_both_points.cpp:224-238 cut by BUCKET.
+ * `n_parts` (a fixed function of the probe's K bucket ints, the same on every handle; for the few buckets of
+ * more than max(4096, n / 1024) members a function of the bucket ints AND of the query's number in the call, so
+ * that a giant bucket's queries are shared among the parts instead of the bucket landing on one of them): the
+ * loop over tables and buckets of motif_both_points.cpp:224-238 cut by BUCKET.
  * Every (query, table) probe belongs to exactly one part -- provided every part is given the same queries in
  * the same order --, so the union over the parts of the hits is the full call's hits plus
  * later-table sightings of ids an earlier table of another part already had: hs_merge_first_table_dev (per

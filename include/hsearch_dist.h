@@ -119,8 +119,8 @@ HS_API void hs_assign_tables(const double* cost, uint32_t L, uint32_t world, uin
 /* ---- the BUCKET-partitioned layout ----------------------------------------------------------------
  * Index replicated as in hs_comm_query, but the ranks share the BUCKETS instead of the queries: every rank
  * answers ALL queries in the buckets that fall to it (hs_set_bucket_partition(h, rank, world), hsearch.h: a
- * function of the bucket's key fingerprint -- and of the query for the few giant buckets --, so the parts are
- * even whatever the tables look like), the tuples
+ * function of the probe's bucket ints -- and of the query for the few giant buckets --, so the parts are even
+ * whatever the tables look like), the tuples
  * are all-gathered and merged by the same first-seen rule as above.  Per rank 1/world of the probes, members
  * and (member, query) pairs, with every bucket meeting all the queries of the job at once -- the operand reuse
  * query blocks lose as the ranks multiply (motif_both_points.cpp:224-238's loops cut by bucket, not by query).
