@@ -78,27 +78,27 @@ enum { EV_FORK = 0, EV_JOIN = 1, EVX_COUNT = 2 };
 // both and compare), sizes a batch, or prints a diagnostic.  Fault injection (HS_TEST_SPLIT_ABOVE) exists only
 // in the test build of the library (-DHS_TEST_HOOKS: libhsearch_amd_hooks.so), never in libhsearch_amd.so.
 struct Knobs {
-  bool build_serial = false;       // HS_BUILD_SERIAL: no hash / sort overlap in the build (measurement)
+  bool build_serial = false;       // HS_OPT_BUILD_SERIAL: no hash / sort overlap in the build (measurement)
   int join_xcd_run = -1;           // HS_OPT_JOIN_XCD_RUN: chunks per XCD-local run of join items (0 off, -1 auto)
   bool no_probe_records = false;   // HS_OPT_PROBE_RECORDS = 0: the probe reads the directory arrays, not the records
   uint32_t join_chunk = 0;         // HS_OPT_JOIN_CHUNK: items per counter access of hs_join8x_kernel (0: by itself)
   bool build_debug = false;        // HS_BUILD_DEBUG: say when a table is sorted a second time
   bool cluster_timing = false;     // HS_CLUSTER_TIMING: phase times of hs_self_join_range on stderr
   bool debug_refine = false;       // HS_DEBUG_REFINE: survivor counts per batch on stderr
-  bool force_wide = false;         // HS_FORCE_WIDE: 8-column rows whatever the radius (k <= 25)
-  bool no_wide_by_radius = false;  // HS_NO_WIDE_BY_RADIUS: never choose 8-column rows by radius
-  bool no_refine8 = false;         // HS_NO_REFINE8: no 8-column refinement of the join's survivors
-  bool no_self_codes = false;      // HS_NO_SELF_CODES: self-join from embedded centres, not from codes
-  bool sort_hits = false;          // HS_SORT_HITS: order hits by the radix sort, not per query
-  bool sync_items = false;         // HS_SYNC_ITEMS: read the join's item count back before launching it
-  bool no_join_r = false;          // HS_NO_JOIN_R: every segment through the query-streaming join kernel
-  bool no_recognise = false;       // HS_NO_RECOGNISE: centres that are k-mers are not looked for (run_query)
-  bool force_join_r = false;       // HS_FORCE_JOIN_R: the query-resident kernel for its class whatever its share
-  bool build_sort = false;         // HS_BUILD_SORT: group a table's k-mers by sorting (fingerprint, id) pairs
+  bool force_wide = false;         // HS_OPT_WIDE_ROWS = 1: 8-column rows whatever the radius (k <= 25)
+  bool no_wide_by_radius = false;  // HS_OPT_WIDE_ROWS >= 2: never choose 8-column rows by radius
+  bool no_refine8 = false;         // HS_OPT_REFINE8 = 0: no 8-column refinement of the join's survivors
+  bool no_self_codes = false;      // HS_OPT_SELF_CODES = 0: self-join from embedded centres, not from codes
+  bool sort_hits = false;          // HS_OPT_SORT_HITS: order hits by the radix sort, not per query
+  bool sync_items = false;         // HS_OPT_SYNC_ITEMS: read the join's item count back before launching it
+  bool no_join_r = false;          // HS_OPT_JOIN_RESIDENT = 1: every segment through the query-streaming join kernel
+  bool no_recognise = false;       // HS_OPT_RECOGNISE_KMERS = 0: centres that are k-mers are not looked for (run_query)
+  bool force_join_r = false;       // HS_OPT_JOIN_RESIDENT = 2: the query-resident kernel for its class whatever its share
+  bool build_sort = false;         // HS_OPT_BUILD_GROUPING = 1: group a table's k-mers by sorting (fingerprint, id) pairs
                                    // (rocPRIM; rounds 1-2) instead of hs_group.hip's table + rank sort
-  int seg_mode = 0;                // HS_SEG_MODE=sparse|dense: 1 / 2; 0 = by the bucket : probe ratio
-  int sort_from_bit = 16;          // HS_SORT_FROM_BIT: lowest fingerprint bit the build's sort looks at
-  uint32_t query_batch = 0;        // HS_QUERY_BATCH: queries per batch (0: by L)
+  int seg_mode = 0;                // HS_OPT_SEG_MODE: 1 sparse / 2 dense; 0 = by the bucket : probe ratio
+  int sort_from_bit = 16;          // HS_OPT_SORT_FROM_BIT: lowest fingerprint bit the build's sort looks at
+  uint32_t query_batch = 0;        // HS_OPT_QUERY_BATCH: queries per batch (0: by L and the free HBM)
 #ifdef HS_TEST_HOOKS
   uint32_t test_split_above = 0;   // HS_TEST_SPLIT_ABOVE: batches above this size report a survivor overflow
   bool test_group_fallback = false;  // HS_TEST_GROUP_FALLBACK: the build's fingerprint table reports itself full
@@ -2182,7 +2182,7 @@ static hs_status query_batch(hs_handle* h, const double* d_centers, const uint8_
   // search (a k-mer probes the bucket it sits in).  Needs the int8 join with its thin-segment filter,
   // the only filters that work without per-query distance tables.
   // how the probes are grouped by bucket in front of the join: a counting sort over the bucket slots,
-  // or -- when those far outnumber the probes -- a sort of the probes (HS_SEG_MODE=dense|sparse forces one)
+  // or -- when those far outnumber the probes -- a sort of the probes (HS_OPT_SEG_MODE forces one)
   // (measured at the configs[2] shape, 10^6 queries x 32 tables against 1.3e8 bucket slots -- a ratio of 4:
   // 11.3 ms for the whole probe + segment chain with the sort, 15.0 with the counting sort)
   bool seg_sparse = (uint64_t)h->nb_total > 2ull * nql;
